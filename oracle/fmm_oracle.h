@@ -1,0 +1,142 @@
+/* fmm_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A plain-C restatement of the reference's LaplaceSphericalBEM FMM matvec path
+ * (barbagroup/fmm-bem-relaxed).  Every function cites the reference file:line it
+ * follows.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+ * may load this library; the product (fmm-bem-relaxed_amd/) never does.
+ *
+ * PARITY STATUS: the reference cannot be built in this image (it needs Boost,
+ * which is absent, and stand-in headers are not allowed), and its repository
+ * holds no golden vectors.  Per-element parity is therefore UNPINNED.  What IS
+ * pinned: the reference-run known answers recorded in SURVEY.md section 6
+ * (exact list statistics for r=6,8,9; FMM-vs-Direct error levels at p=5,8,10,12),
+ * checked by tests/test_oracle_known_answers.py, plus analytic identities.
+ */
+#ifndef FMM_ORACLE_H
+#define FMM_ORACLE_H
+
+#include <complex.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+#error "the oracle is plain C"
+#endif
+
+#define ORC_MAXK 32      /* max stored quadrature points per panel            */
+#define ORC_PMAX 20      /* max expansion order the stack buffers allow       */
+#define ORC_EPS 1e-12    /* kernel/LaplaceSpherical.hpp:30                     */
+
+typedef double complex cplx;
+
+enum { ORC_POTENTIAL = 0, ORC_NORMAL_DERIV = 1 };
+
+/* kernel/LaplaceSphericalBEM.hpp:38-118 (Panel), flattened */
+typedef struct {
+  double v[3][3];          /* vertices                                         */
+  double c[3];             /* centroid                                         */
+  double n[3];             /* unit normal                                      */
+  double area;
+  const double (*q)[3];    /* stored quadrature points (nq of them; storage owned by the ctx) */
+  int bc;                  /* ORC_POTENTIAL / ORC_NORMAL_DERIV                 */
+} orc_panel;
+
+/* include/tree/Octree.hpp:201-269 (box_data), plus derived geometry */
+typedef struct {
+  uint32_t key;            /* marker-bit Morton key, leaf bit stripped         */
+  uint32_t parent;
+  uint32_t cb, ce;         /* children (box ids) or bodies (tree ids) if leaf  */
+  int leaf;
+  int level;
+  double center[3];
+  double side;             /* side_length()                                    */
+  uint32_t bb, be;         /* body range in tree order (all boxes)             */
+} orc_box;
+
+typedef struct { int first, second; } orc_pair;
+
+typedef struct orc_ctx {
+  /* inputs */
+  int n;                   /* panels                                           */
+  int K;                   /* quadrature key as the user gave it               */
+  int nq;                  /* actual number of stored quadrature points        */
+  double qw[ORC_MAXK];     /* weights of the K rule                            */
+  double theta;
+  unsigned ncrit;
+  orc_panel *panels;       /* ORIGINAL order                                   */
+  double *quad;            /* n * nq * 3 quadrature point storage              */
+  /* tree */
+  double pmin[3], cell[3];
+  int nboxes, nlevels;     /* nlevels = Octree::levels()                       */
+  orc_box *boxes;
+  uint32_t *perm;          /* tree index -> original index (Body::number())    */
+  uint32_t *code;          /* Morton code per tree index                       */
+  int *level_offset;       /* nlevels+1 entries                                */
+  /* lists: executor/EvalInteractionLazySparse.hpp:37-47 */
+  orc_pair *p2p; int n_p2p;        /* (source leaf, target leaf)               */
+  orc_pair *lr;  int n_lr;         /* (source box, target box)                 */
+  int *p2m; int n_p2m;
+  orc_pair *m2m; int n_m2m;        /* (child, parent) in reference order       */
+  orc_pair *l2l; int n_l2l;        /* (parent, child) in reference order       */
+  int *l2p; int n_l2p;
+  int n_l2l_skipped;       /* parent->child edges the reference's lazy rule omits
+                              although the parent holds a local expansion      */
+  /* LR list regrouped by target (canonical, race-free order) */
+  int *lr_ptr, *lr_src;    /* nboxes+1, n_lr                                   */
+  /* near matrix, CSR, rows/cols in tree order: executor/EvalP2P.hpp:47-98    */
+  int64_t *row_ptr; uint32_t *col; double *val; int64_t nnz;
+  /* expansions (allocated for pcap) */
+  int pcap;
+  cplx *M, *L;             /* [box][2][pcap*(pcap+1)/2]                        */
+} orc_ctx;
+
+/* precomputed tables of LaplaceSpherical (kernel/LaplaceSpherical.hpp:87-117) */
+typedef struct {
+  int P;
+  double *prefactor;       /* 4P^2 */
+  double *Anm;             /* 4P^2 */
+  cplx *Cnm;               /* P^4  */
+} orc_tables;
+
+/* ---- geometry.c ---- */
+int  orc_quadrature(int key, double pts[][3], double *w);   /* returns #points, -1 bad key */
+void orc_panel_init(orc_panel *p, const double v[9], int bc, int nq, const double pts[][3], double *qstore);
+long orc_unit_sphere(int recursions, double *verts_out);    /* verts_out may be NULL: returns N */
+double orc_eval_G(const orc_panel *s, const double t[3], int nq, const double *w);
+double orc_eval_dGdn(const orc_panel *s, const double t[3], int nq, const double *w);
+double orc_kernel(const orc_ctx *c, const orc_panel *t, const orc_panel *s);
+void orc_semi_analytical(double *G, double *dGdn, const double y0[3], const double y1[3],
+                         const double y2[3], const double x[3], int same);
+
+/* ---- tree.c ---- */
+orc_ctx *orc_create(int n, const double *verts, const uint8_t *bc, int K, double theta,
+                    unsigned ncrit);
+void orc_destroy(orc_ctx *c);
+void orc_stats(const orc_ctx *c, int64_t out[16]);
+
+/* ---- expansions.c ---- */
+orc_tables *orc_tables_create(int P);
+void orc_tables_destroy(orc_tables *t);
+void orc_cart2sph(double *r, double *theta, double *phi, const double d[3]);
+void orc_eval_multipole(const orc_tables *t, double rho, double alpha, double beta,
+                        cplx *Ynm, cplx *YnmTheta);
+void orc_eval_local(const orc_tables *t, double rho, double alpha, double beta,
+                    cplx *Ynm, cplx *YnmTheta);
+void orc_p2m_panel(const orc_tables *t, const orc_panel *src, int nq, const double *qw,
+                   double charge, const double center[3], cplx *M0, cplx *M1);
+void orc_m2m(const orc_tables *t, const cplx *Ms, cplx *Mt, const double tr[3]);
+void orc_m2l(const orc_tables *t, const cplx *Ms, cplx *Lt, const double tr[3]);
+void orc_l2l(const orc_tables *t, const cplx *Ls, cplx *Lt, const double tr[3]);
+void orc_l2p_panel(const orc_tables *t, const cplx *L0, const cplx *L1, const double center[3],
+                   const orc_panel *tgt, double *result);
+
+/* ---- matvec.c ---- */
+int  orc_build_near(orc_ctx *c);
+int  orc_matvec(orc_ctx *c, int P, const double *x, double *y, int flags, double stage_s[8]);
+void orc_direct(const orc_ctx *c, const double *x, double *y, int row_begin, int row_end);
+void orc_near_only(const orc_ctx *c, const double *x, double *y);
+
+#define ORC_FLAG_FAITHFUL 1   /* both expansions, serial SpMV/M2M/L2L like the reference */
+#define ORC_FLAG_TARGET_RANGE 2
+
+#endif
