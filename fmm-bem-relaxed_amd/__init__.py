@@ -1,0 +1,7 @@
+"""fmm-bem-relaxed_amd: MI355X-native FMM matvec behind the reference's FMM_plan / kernel surface.
+
+Only the hot path lives here: csrc/ (hand-written HIP for gfx950 + the C ABI of include/fmmbem.h)
+and this thin host-side mirror of the reference's operator interface.
+"""
+from ._capi import FmmBemError, LIB_PATH, PMAX, SYMBOLS  # noqa: F401
+from .plan import FMM_plan, FMMOptions, LaplaceSphericalBEM, unit_sphere  # noqa: F401

@@ -1,0 +1,99 @@
+"""ctypes binding of include/fmmbem.h (libfmmbem_hip.so).
+
+The library is hand-written HIP for gfx950 plus host C++; it is loaded from this directory (built
+in-tree by `make -C csrc` / __graft_entry__.build()).  There is no fallback: if the shared object
+is missing, importing this module raises, and if no GPU is visible every execute returns
+FMMBEM_ERR_NO_DEVICE.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfmmbem_hip.so")
+
+OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC, ERR_TREE, ERR_UNSUPPORTED = range(7)
+PMAX = 16
+KERNEL_LAPLACE_BEM = 0
+BC_POTENTIAL, BC_NORMAL_DERIV = 0, 1
+
+
+class Options(C.Structure):
+    """fmmbem_options"""
+    _fields_ = [("kernel", C.c_int32), ("p_max", C.c_int32), ("quad_k", C.c_int32), ("theta", C.c_double),
+                ("ncrit", C.c_uint32), ("sparse_local", C.c_int32), ("host_only", C.c_int32),
+                ("device", C.c_int32), ("shard_rank", C.c_int32), ("shard_world", C.c_int32),
+                ("reserved", C.c_int32 * 6)]
+
+
+class Stats(C.Structure):
+    """fmmbem_stats"""
+    _fields_ = ([(n, C.c_int64) for n in (
+        "n_panels", "n_boxes", "n_leaves", "n_levels", "near_nnz", "near_nnz_total", "p2p_pairs", "m2l_pairs",
+        "m2l_pairs_owned", "m2m_ops", "l2l_ops", "p2m_leaves", "l2p_leaves", "m2l_classes", "owned_leaf_begin",
+        "owned_leaf_end", "owned_row_begin", "owned_row_end", "near_bytes")] +
+        [("expansions_active", C.c_int32), ("last_p", C.c_int32)] +
+        [(n, C.c_double) for n in ("build_host_ms", "build_assemble_ms", "ms_total", "ms_gather", "ms_near",
+                                   "ms_p2m", "ms_m2m", "ms_m2l", "ms_l2l", "ms_l2p")])
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class FmmBemError(RuntimeError):
+    def __init__(self, status, text):
+        super().__init__("fmmbem status %d (%s): %s" % (status, _status_string(status), text))
+        self.status = status
+
+
+_lib = None
+
+# every symbol include/fmmbem.h declares (tests check that the library exports all of them)
+SYMBOLS = (
+    "fmmbem_options_default", "fmmbem_plan_create", "fmmbem_plan_destroy", "fmmbem_plan_execute",
+    "fmmbem_plan_execute_device", "fmmbem_plan_near_device", "fmmbem_plan_set_timing", "fmmbem_plan_stats",
+    "fmmbem_plan_get_perm", "fmmbem_plan_get_boxes", "fmmbem_plan_get_pairs", "fmmbem_plan_get_near_row",
+    "fmmbem_plan_get_expansions", "fmmbem_mesh_unit_sphere", "fmmbem_status_string", "fmmbem_last_error",
+    "fmmbem_version",
+)
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s not found: build it with `make -C %s` (hipcc --offload-arch=gfx950). "
+                          "There is no CPU fallback." % (LIB_PATH, os.path.join(_HERE, "csrc")))
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64p = C.c_void_p, C.c_int, C.POINTER(C.c_int64)
+    L.fmmbem_options_default.argtypes = [C.POINTER(Options)]
+    L.fmmbem_options_default.restype = None
+    L.fmmbem_plan_create.argtypes = [C.POINTER(Options), C.c_size_t, vp, vp, C.POINTER(vp)]
+    L.fmmbem_plan_destroy.argtypes = [vp]
+    L.fmmbem_plan_destroy.restype = None
+    L.fmmbem_plan_execute.argtypes = [vp, i32, vp, vp]
+    L.fmmbem_plan_execute_device.argtypes = [vp, i32, vp, vp, vp]
+    L.fmmbem_plan_near_device.argtypes = [vp, vp, vp, vp]
+    L.fmmbem_plan_set_timing.argtypes = [vp, i32]
+    L.fmmbem_plan_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.fmmbem_plan_get_perm.argtypes = [vp, vp]
+    L.fmmbem_plan_get_boxes.argtypes = [vp] * 8
+    L.fmmbem_plan_get_pairs.argtypes = [vp, i32, vp, i64p]
+    L.fmmbem_plan_get_near_row.argtypes = [vp, C.c_int64, vp, vp, i64p]
+    L.fmmbem_plan_get_expansions.argtypes = [vp, i32, i32, vp]
+    L.fmmbem_mesh_unit_sphere.argtypes = [i32, vp, C.POINTER(C.c_size_t)]
+    L.fmmbem_status_string.argtypes = [i32]
+    L.fmmbem_status_string.restype = C.c_char_p
+    L.fmmbem_last_error.restype = C.c_char_p
+    L.fmmbem_version.restype = i32
+    _lib = L
+    return L
+
+
+def _status_string(status):
+    return lib().fmmbem_status_string(status).decode()
+
+
+def check(status):
+    if status != OK:
+        raise FmmBemError(status, lib().fmmbem_last_error().decode())

@@ -1,0 +1,77 @@
+// device_plan.hpp -- HBM-resident form of a plan and the launch interface of the gfx950 kernels.
+//
+// HBM layout (all arrays uploaded once at plan creation; DESIGN.md "Data layout"):
+//   panels      SoA in TREE order: cx,cy,cz,nx,ny,nz,area [N]; quad [q][xyz][N]; vert [9][N]; bc [N] u8
+//   perm        [N] u32                      tree index -> original index
+//   leaves      leaf_row0/leaf_nrows [nl]; near_ptr [nl+1] -> near_src_row0/near_src_n (source leaf body ranges);
+//               near_ncols/near_stride [nl]; near_off [nl] (offset of the leaf's row block in near_val)
+//   near_val    per owned target leaf a dense row-major block  nrows x stride  (stride = ncols rounded
+//               up to even => every row 16-B aligned); the ONLY large array (8 B per near entry)
+//   boxes       center [nb][3]
+//   M, L        [nb][2][S_max] complex (S = p(p+1)/2), slot 0 = G, slot 1 = dG/dn
+//   Mh          [nb][2][P2_max] complex: M rescaled and phase-rotated, all orders -n..n (M2L input)
+//   m2l_*       CSR by target box: m2l_tgt [nt] (boxes to run), m2l_ptr [nb+1], m2l_src, m2l_cls
+//   class tabs  m2l_tab [classes][(2 p_max)^2] complex; up_tab/down_tab [classes][p_max^2] complex
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace fmmbem {
+
+struct DevicePlan {
+  int64_t n = 0;
+  int nq = 0;
+  int nboxes = 0, nleaves = 0;
+  int p_max = 0, s_max = 0, p2_max = 0, y2_max = 0;   // S, P^2, (2P)^2 at p_max
+  int leaf_begin = 0, leaf_end = 0;                   // owned target leaves
+  int64_t row_begin = 0, row_end = 0;
+  int max_ncols = 0;                                  // widest near row block (columns, padded even)
+  int n_act = 0;                                      // active expansion slots
+  int act[2] = {0, 0};
+
+  // panels
+  const double *cx, *cy, *cz, *nx, *ny, *nz, *area, *quad, *vert;
+  const uint8_t* bc;
+  const uint32_t* perm;
+  double qw[25];
+  // leaves
+  const int *leaf_row0, *leaf_nrows, *leaf_box;
+  const int64_t* near_ptr;
+  const int *near_src_row0, *near_src_n;
+  const int *near_ncols, *near_stride;
+  const int64_t* near_off;
+  double* near_val;
+  // boxes / expansions
+  const double* box_center;
+  double2 *M, *L, *Mh;
+  // tables
+  const double *tabA, *tabInvA, *tabPref;             // [n^2+n+m], n < 2*kPmax
+  // far-field lists
+  const int *p2m_leaf;        int n_p2m = 0;          // box ids
+  const int *l2p_leaf;        int n_l2p = 0;
+  const int *m2m_parent;      const int* box_child_begin; const int* box_child_end;
+  const int *l2l_child;       const int* box_parent;
+  const int *up_cls, *down_cls;                       // per box: class of (parent-child) / (child-parent)
+  const double2 *up_tab, *down_tab;                   // [cls][p2_max]
+  const int *mh_box;          int n_mh = 0;           // boxes whose Mh is needed (M2L sources)
+  const int *m2l_tgt;         int n_m2l_tgt = 0;
+  const int *m2l_ptr, *m2l_src, *m2l_cls;
+  const double2* m2l_tab;                             // [cls][y2_max]
+  // scratch
+  double *xt, *yt;                                    // tree-order x and near result
+};
+
+// ---- launchers (kernels_near.hip / kernels_far.hip); all asynchronous on `s` ----
+hipError_t launch_near_assemble(const DevicePlan& d, hipStream_t s);
+hipError_t launch_gather_x(const DevicePlan& d, const double* x, hipStream_t s);
+hipError_t launch_near_spmv(const DevicePlan& d, hipStream_t s);
+hipError_t launch_scatter_y(const DevicePlan& d, double* y, hipStream_t s);
+hipError_t launch_p2m(const DevicePlan& d, int p, hipStream_t s);
+hipError_t launch_m2m_level(const DevicePlan& d, int p, int first, int count, hipStream_t s);
+hipError_t launch_mh_prep(const DevicePlan& d, int p, hipStream_t s);
+hipError_t launch_m2l(const DevicePlan& d, int p, hipStream_t s);
+hipError_t launch_l2l_level(const DevicePlan& d, int p, int first, int count, hipStream_t s);
+hipError_t launch_l2p(const DevicePlan& d, int p, double* y, hipStream_t s);
+
+}  // namespace fmmbem

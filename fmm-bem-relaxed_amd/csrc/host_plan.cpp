@@ -1,0 +1,464 @@
+// host_plan.cpp -- see host_plan.hpp.  Host-only C++17; no device code here.
+#include "host_plan.hpp"
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstring>
+#include <deque>
+#include <numeric>
+#include <unordered_map>
+
+namespace fmmbem {
+
+// ------------------------------------------------------------------------------------------
+// Quadrature rules (numeric data of examples/BEM/GaussQuadrature.hpp:19-185).
+// Key 7 aliases the 4-point rule (:58-59); key 17 holds 16 points (:102-115); key 79 is not offered.
+// ------------------------------------------------------------------------------------------
+namespace {
+struct RuleBuilder {
+  QuadRule& r;
+  void centroid(double w) { add(1. / 3, 1. / 3, 1. / 3, w); }
+  void add(double a, double b, double c, double w) {
+    r.pts[r.n][0] = a; r.pts[r.n][1] = b; r.pts[r.n][2] = c; r.w[r.n] = w; ++r.n;
+  }
+  void rot(double a, double b, double w) { add(a, b, b, w); add(b, a, b, w); add(b, b, a, w); }
+  void perm(double a, double b, double c, double w) {
+    add(a, b, c, w); add(a, c, b, w); add(b, a, c, w); add(b, c, a, w); add(c, a, b, w); add(c, b, a, w);
+  }
+};
+}  // namespace
+
+bool quad_rule(int key, QuadRule& out) {
+  out.n = 0;
+  RuleBuilder b{out};
+  switch (key) {
+    case 1: b.centroid(1.); return true;
+    case 3: b.add(.5, .5, 0., 1. / 3); b.add(0., .5, .5, 1. / 3); b.add(.5, 0., .5, 1. / 3); return true;
+    case 4: case 7:
+      b.centroid(-27. / 48); b.add(.6, .2, .2, 25. / 48); b.add(.2, .6, .2, 25. / 48); b.add(.2, .2, .6, 25. / 48);
+      return true;
+    case 13:
+      b.centroid(-0.149570044467682);
+      b.rot(0.479308067841920, 0.260345966079040, 0.175615257433208);
+      b.rot(0.869739794195568, 0.065130102902216, 0.053347235608838);
+      b.perm(0.048690315425316, 0.312865496004874, 0.638444188569810, 0.077113760890257);
+      return true;
+    case 17:
+      b.centroid(0.144315607677787);
+      b.rot(0.081414823414554, 0.459292588292723, 0.095091634267285);
+      b.rot(0.658861384496480, 0.170569307751760, 0.103217370534718);
+      b.rot(0.898905543365938, 0.050547228317031, 0.032458497623198);
+      b.perm(0.008394777409958, 0.263112829634638, 0.728492392955404, 0.027230314174435);
+      return true;
+    case 19:
+      b.centroid(0.097135796282799);
+      b.rot(0.020634961602525, 0.489682519198738, 0.031334700227139);
+      b.rot(0.125820817014127, 0.437089591492937, 0.077827541004774);
+      b.rot(0.623592928761935, 0.188203535619033, 0.079647738927210);
+      b.rot(0.910540973211095, 0.044729513394453, 0.025577675658698);
+      b.perm(0.036838412054736, 0.221962989160766, 0.741198598784498, 0.043283539377289);
+      return true;
+    case 25:
+      b.centroid(0.090817990382754);
+      b.rot(0.028844733232685, 0.485577633383657, 0.036725957756467);
+      b.rot(0.781036849029926, 0.109481575485037, 0.045321059435528);
+      b.perm(0.141707219414880, 0.307939838764121, 0.550352941820999, 0.072757916845420);
+      b.perm(0.025003534762686, 0.246672560639903, 0.728323904597411, 0.028327242531057);
+      b.perm(0.009540815400299, 0.066803251012200, 0.923655933587500, 0.009421666963733);
+      return true;
+    default: return false;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Mesh: octahedron subdivided (recursions-1) times, vertices pushed to the unit sphere.
+// ------------------------------------------------------------------------------------------
+int64_t unit_sphere(int recursions, double* vertices) {
+  int64_t n = 8;
+  for (int i = 1; i < recursions; ++i) n *= 4;
+  if (!vertices) return n;
+  using V = std::array<double, 3>;
+  using T = std::array<V, 3>;
+  const V corner[6] = {{1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
+  const int face[8][3] = {{0, 4, 2}, {2, 4, 1}, {1, 4, 3}, {3, 4, 0}, {0, 2, 5}, {2, 1, 5}, {1, 3, 5}, {3, 0, 5}};
+  std::vector<T> tri(8);
+  for (int f = 0; f < 8; ++f) tri[f] = {corner[face[f][0]], corner[face[f][1]], corner[face[f][2]]};
+  auto mid = [](const V& a, const V& b) {
+    V m = {(a[0] + b[0]) * 0.5, (a[1] + b[1]) * 0.5, (a[2] + b[2]) * 0.5};
+    const double len = std::sqrt(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]);
+    m[0] /= len; m[1] /= len; m[2] /= len;
+    return m;
+  };
+  for (int it = 1; it < recursions; ++it) {
+    std::vector<T> next;
+    next.reserve(tri.size() * 4);
+    for (const T& t : tri) {
+      const V a = mid(t[0], t[2]), b = mid(t[0], t[1]), c = mid(t[1], t[2]);
+      next.push_back({t[0], b, a});
+      next.push_back({b, t[1], c});
+      next.push_back({a, b, c});
+      next.push_back({a, c, t[2]});
+    }
+    tri.swap(next);
+  }
+  for (size_t i = 0; i < tri.size(); ++i)
+    for (int v = 0; v < 3; ++v)
+      for (int k = 0; k < 3; ++k) vertices[9 * i + 3 * v + k] = tri[i][v][k];
+  return n;
+}
+
+// ------------------------------------------------------------------------------------------
+// Morton helpers (10 bits per dimension, x lowest)
+// ------------------------------------------------------------------------------------------
+namespace {
+constexpr unsigned kLevels = 10;
+
+inline uint32_t spread3(uint32_t x) {
+  x = (x | (x << 16)) & 0x030000FFu;
+  x = (x | (x << 8)) & 0x0300F00Fu;
+  x = (x | (x << 4)) & 0x030C30C3u;
+  x = (x | (x << 2)) & 0x09249249u;
+  return x;
+}
+inline uint32_t compact3(uint32_t x) {
+  x &= 0x09249249u;
+  x = (x | (x >> 2)) & 0x030C30C3u;
+  x = (x | (x >> 4)) & 0x0300F00Fu;
+  x = (x | (x >> 8)) & 0x030000FFu;
+  x = (x | (x >> 16)) & 0x000003FFu;
+  return x;
+}
+inline int level_of_key(uint32_t key) { return (31 - __builtin_clz(key)) / 3; }
+
+struct Coded { uint32_t code, idx; };
+}  // namespace
+
+std::string HostPlan::build(const HostOptions& o, int64_t n_panels, const double* vertices, const uint8_t* bc) {
+  opt = o;
+  n = n_panels;
+  if (n <= 0 || !vertices) return "no panels";
+  if (n > (int64_t(1) << 31) - 1) return "too many panels";
+  if (!quad_rule(o.quad_k, rule)) return "invalid quadrature key (valid: 1 3 4 7 13 17 19 25)";
+  if (o.p_max < 1 || o.p_max > kPmax) return "p_max out of range";
+  if (!(o.theta > 0)) return "theta must be positive";
+  if (o.shard_world < 1 || o.shard_rank < 0 || o.shard_rank >= o.shard_world) return "bad shard";
+
+  // ---- panel centroids in original order (tree is built on them, LaplaceSphericalBEM.hpp:99) ----
+  std::vector<double> cen(3 * n);
+  for (int64_t i = 0; i < n; ++i)
+    for (int k = 0; k < 3; ++k)
+      cen[3 * i + k] = (vertices[9 * i + k] + vertices[9 * i + 3 + k] + vertices[9 * i + 6 + k]) / 3;
+
+  // ---- bounding cube, inflated by 1+1e-6 (Octree.hpp:67-79) ----
+  double lo[3], hi[3];
+  for (int k = 0; k < 3; ++k) lo[k] = hi[k] = cen[k];
+  for (int64_t i = 1; i < n; ++i)
+    for (int k = 0; k < 3; ++k) {
+      lo[k] = std::min(lo[k], cen[3 * i + k]);
+      hi[k] = std::max(hi[k], cen[3 * i + k]);
+    }
+  const double ext = std::max({std::fabs(hi[0] - lo[0]), std::fabs(hi[1] - lo[1]), std::fabs(hi[2] - lo[2])});
+  for (int k = 0; k < 3; ++k) {
+    hi[k] = std::max(hi[k], lo[k] + ext * (1 + 1e-6));
+    pmin[k] = lo[k];
+    cell[k] = (hi[k] - lo[k]) / double(1u << kLevels);
+  }
+
+  // ---- Morton codes (Octree.hpp:118-129) ----
+  std::vector<Coded> codes(n), scratch(n);
+  for (int64_t i = 0; i < n; ++i) {
+    uint32_t s[3];
+    for (int k = 0; k < 3; ++k) {
+      double v = cen[3 * i + k];
+      v -= pmin[k];
+      v /= cell[k];
+      s[k] = (uint32_t)v;
+    }
+    codes[i] = {spread3(s[0]) | (spread3(s[1]) << 1) | (spread3(s[2]) << 2), (uint32_t)i};
+  }
+
+  // ---- BFS construction with stable 8-way bucketing per box (Octree.hpp:617-692) ----
+  box_key.assign(1, 1u);
+  box_parent.assign(1, 0);
+  box_body_begin.assign(1, 0);
+  box_body_end.assign(1, (int)n);
+  box_child_begin.assign(1, 0);
+  box_child_end.assign(1, 0);
+  box_leaf.assign(1, 0);
+  box_level.assign(1, 0);
+  level_off.assign(1, 0);
+  int deepest = 0;
+  for (size_t k = 0; k < box_key.size(); ++k) {
+    const int b0 = box_body_begin[k], b1 = box_body_end[k];
+    if ((unsigned)(b1 - b0) <= o.ncrit) { box_leaf[k] = 1; continue; }
+    const int lev = box_level[k];
+    if (lev >= (int)kLevels) return "octree deeper than 10 levels (reference 32-bit Morton keys, Octree.hpp:85-92)";
+    const unsigned shift = 3 * (kLevels - lev - 1);
+    int count[9] = {0};
+    for (int i = b0; i < b1; ++i) ++count[((codes[i].code >> shift) & 7) + 1];
+    for (int c = 0; c < 8; ++c) count[c + 1] += count[c];
+    int cursor[8];
+    std::copy(count, count + 8, cursor);
+    for (int i = b0; i < b1; ++i) scratch[b0 + cursor[(codes[i].code >> shift) & 7]++] = codes[i];
+    std::copy(scratch.begin() + b0, scratch.begin() + b1, codes.begin() + b0);
+    box_child_begin[k] = (int)box_key.size();
+    for (int c = 0; c < 8; ++c) {
+      if (count[c + 1] == count[c]) continue;        // empty octants get no box (:666)
+      const uint32_t key = (box_key[k] << 3) | (uint32_t)c;
+      const int l = level_of_key(key);
+      if (l > deepest) { deepest = l; level_off.push_back((int)box_key.size()); }
+      box_key.push_back(key);
+      box_parent.push_back((int)k);
+      box_body_begin.push_back(b0 + count[c]);
+      box_body_end.push_back(b0 + count[c + 1]);
+      box_child_begin.push_back(0);
+      box_child_end.push_back(0);
+      box_leaf.push_back(0);
+      box_level.push_back(l);
+    }
+    box_child_end[k] = (int)box_key.size();
+  }
+  nboxes = (int)box_key.size();
+  level_off.push_back(nboxes);
+  nlevels = (int)level_off.size() - 1;
+  perm.resize(n);
+  for (int64_t i = 0; i < n; ++i) perm[i] = codes[i].idx;
+  codes.clear(); codes.shrink_to_fit();
+  scratch.clear(); scratch.shrink_to_fit();
+
+  // ---- box geometry (Octree.hpp:334-355 through :109-113, :243-248) ----
+  box_center.resize(3 * (size_t)nboxes);
+  box_side.resize(nboxes);
+  box_icoord.resize(3 * (size_t)nboxes);
+  const double root_side = (pmin[0] + double(1u << kLevels) * cell[0]) - pmin[0];
+  for (int b = 0; b < nboxes; ++b) {
+    uint32_t m = box_key[b];
+    while (!(m & (1u << 30))) m <<= 3;
+    const uint32_t lower = m & ~(1u << 30);
+    const uint32_t ix[3] = {compact3(lower), compact3(lower >> 1), compact3(lower >> 2)};
+    const int lev = box_level[b];
+    for (int k = 0; k < 3; ++k) {
+      const double a = pmin[k] + cell[k] * double(ix[k]);
+      const double w = (a + cell[k]) - a;
+      box_center[3 * b + k] = a + w * std::ldexp(1.0, 9 - lev);
+      box_icoord[3 * b + k] = 2 * (int32_t)ix[k] + (1 << (10 - lev));   // exact, in half-cells
+    }
+    box_side[b] = root_side / double(1 << lev);
+  }
+
+  // ---- dual tree traversal (EvalInteractionLazySparse.hpp:68-110, :239-252) ----
+  auto accept = [&](int s, int t) {     // DefaultMAC, radius = side/2
+    const double dx = box_center[3 * s] - box_center[3 * t], dy = box_center[3 * s + 1] - box_center[3 * t + 1],
+                 dz = box_center[3 * s + 2] - box_center[3 * t + 2];
+    const double rhs = (box_side[s] / 2.0 + box_side[t] / 2.0) / o.theta;
+    return dx * dx + dy * dy + dz * dz > rhs * rhs;
+  };
+  {
+    std::deque<std::pair<int, int>> fifo;
+    fifo.emplace_back(0, 0);
+    while (!fifo.empty()) {
+      const auto [s, t] = fifo.front();
+      fifo.pop_front();
+      bool split_source;
+      if (box_leaf[s]) {
+        if (box_leaf[t]) { p2p_src.push_back(s); p2p_tgt.push_back(t); continue; }
+        split_source = false;
+      } else if (box_leaf[t]) {
+        split_source = true;
+      } else {
+        split_source = box_side[s] > box_side[t];        // ties split the target side (:98-108)
+      }
+      const int open = split_source ? s : t;
+      for (int c = box_child_begin[open]; c < box_child_end[open]; ++c) {
+        const int ns = split_source ? c : s, nt = split_source ? t : c;
+        if (accept(ns, nt)) { lr_src.push_back(ns); lr_tgt.push_back(nt); }
+        else fifo.emplace_back(ns, nt);
+      }
+    }
+  }
+
+  // ---- leaves in tree order ----
+  box_leaf_index.assign(nboxes, -1);
+  for (int b = 0; b < nboxes; ++b)
+    if (box_leaf[b]) leaf_box.push_back(b);
+  std::sort(leaf_box.begin(), leaf_box.end(), [&](int a, int b) { return box_body_begin[a] < box_body_begin[b]; });
+  for (int i = 0; i < (int)leaf_box.size(); ++i) box_leaf_index[leaf_box[i]] = i;
+  const int nl = nleaves();
+
+  // ---- near field grouped by target leaf; sources ascending (EvalP2P.hpp:87 sorts the columns) ----
+  near_ptr.assign(nl + 1, 0);
+  for (size_t i = 0; i < p2p_tgt.size(); ++i) ++near_ptr[box_leaf_index[p2p_tgt[i]] + 1];
+  for (int i = 0; i < nl; ++i) near_ptr[i + 1] += near_ptr[i];
+  near_src.resize(p2p_src.size());
+  {
+    std::vector<int64_t> at(near_ptr.begin(), near_ptr.end() - 1);
+    for (size_t i = 0; i < p2p_src.size(); ++i) near_src[at[box_leaf_index[p2p_tgt[i]]]++] = box_leaf_index[p2p_src[i]];
+  }
+  near_ncols.assign(nl, 0);
+  near_nnz_total = 0;
+  for (int t = 0; t < nl; ++t) {
+    std::sort(near_src.begin() + near_ptr[t], near_src.begin() + near_ptr[t + 1]);   // leaf index order == body order
+    int cols = 0;
+    for (int64_t i = near_ptr[t]; i < near_ptr[t + 1]; ++i) {
+      const int sb = leaf_box[near_src[i]];
+      cols += box_body_end[sb] - box_body_begin[sb];
+    }
+    near_ncols[t] = cols;
+    const int tb = leaf_box[t];
+    near_nnz_total += int64_t(cols) * (box_body_end[tb] - box_body_begin[tb]);
+  }
+
+  // ---- which boxes need a multipole / hold a local expansion (EvalInteractionLazySparse.hpp:173-237) ----
+  // need_M: every M2L source and its whole subtree; has_L: every M2L target and its whole subtree.
+  need_M.assign(nboxes, 0);
+  has_L.assign(nboxes, 0);
+  for (int s : lr_src) need_M[s] = 1;
+  for (int t : lr_tgt) has_L[t] = 1;
+  for (int b = 1; b < nboxes; ++b) {            // BFS order: parents precede children
+    if (need_M[box_parent[b]]) need_M[b] = 1;
+    if (has_L[box_parent[b]]) has_L[b] = 1;
+  }
+
+  // ---- shard: contiguous range of target leaves ----
+  {
+    std::vector<int> cut;
+    partition_leaves(*this, o.shard_world, cut);
+    leaf_begin = cut[o.shard_rank];
+    leaf_end = cut[o.shard_rank + 1];
+    row_begin = leaf_begin < nl ? box_body_begin[leaf_box[leaf_begin]] : n;
+    row_end = leaf_end > leaf_begin ? box_body_end[leaf_box[leaf_end - 1]] : row_begin;
+    owned_L.assign(nboxes, 0);
+    for (int l = leaf_begin; l < leaf_end; ++l)
+      for (int b = leaf_box[l];; b = box_parent[b]) {
+        if (owned_L[b]) break;
+        owned_L[b] = 1;
+        if (b == 0) break;
+      }
+    near_nnz_owned = 0;
+    for (int t = leaf_begin; t < leaf_end; ++t) {
+      const int tb = leaf_box[t];
+      near_nnz_owned += int64_t(near_ncols[t]) * (box_body_end[tb] - box_body_begin[tb]);
+    }
+  }
+
+  // ---- operator lists ----
+  for (int b = 0; b < nboxes; ++b) {
+    if (box_leaf[b] && need_M[b]) p2m_leaves.push_back(b);
+    if (box_leaf[b] && has_L[b] && owned_L[b]) l2p_leaves.push_back(b);
+  }
+  m2m_level_ptr.assign(1, 0);
+  m2m_ops = 0;
+  for (int lev = nlevels - 1; lev >= 0; --lev) {       // deepest parents first
+    for (int b = level_off[lev]; b < level_off[lev + 1]; ++b)
+      if (!box_leaf[b] && need_M[b]) { m2m_parents.push_back(b); m2m_ops += box_child_end[b] - box_child_begin[b]; }
+    m2m_level_ptr.push_back((int)m2m_parents.size());
+  }
+  l2l_level_ptr.assign(1, 0);
+  l2l_ops = 0;
+  for (int lev = 1; lev < nlevels; ++lev) {            // top-down
+    for (int b = level_off[lev]; b < level_off[lev + 1]; ++b)
+      if (has_L[box_parent[b]] && owned_L[b]) { l2l_children.push_back(b); ++l2l_ops; }
+    l2l_level_ptr.push_back((int)l2l_children.size());
+  }
+
+  // ---- M2L grouped by target, traversal order kept within a target; translation classes ----
+  m2l_ptr.assign(nboxes + 1, 0);
+  m2l_pairs_owned = 0;
+  for (size_t i = 0; i < lr_tgt.size(); ++i)
+    if (owned_L[lr_tgt[i]]) { ++m2l_ptr[lr_tgt[i] + 1]; ++m2l_pairs_owned; }
+  for (int b = 0; b < nboxes; ++b) m2l_ptr[b + 1] += m2l_ptr[b];
+  m2l_src.resize(m2l_pairs_owned);
+  m2l_cls.resize(m2l_pairs_owned);
+  {
+    std::vector<int> at(m2l_ptr.begin(), m2l_ptr.end() - 1);
+    std::unordered_map<uint64_t, int> cls_of;
+    for (size_t i = 0; i < lr_tgt.size(); ++i) {
+      const int s = lr_src[i], t = lr_tgt[i];
+      if (!owned_L[t]) continue;
+      const int32_t d[3] = {box_icoord[3 * t] - box_icoord[3 * s], box_icoord[3 * t + 1] - box_icoord[3 * s + 1],
+                            box_icoord[3 * t + 2] - box_icoord[3 * s + 2]};
+      const uint64_t key = (uint64_t)(uint32_t)(d[0] + 4096) | ((uint64_t)(uint32_t)(d[1] + 4096) << 16) |
+                           ((uint64_t)(uint32_t)(d[2] + 4096) << 32);
+      auto [it, fresh] = cls_of.try_emplace(key, (int)m2l_class_rep.size() / 2);
+      if (fresh) {
+        m2l_class_vec.insert(m2l_class_vec.end(), {d[0], d[1], d[2]});
+        m2l_class_rep.insert(m2l_class_rep.end(), {s, t});
+      }
+      const int slot = at[t]++;
+      m2l_src[slot] = s;
+      m2l_cls[slot] = it->second;
+    }
+  }
+
+  // ---- panels in tree order, SoA (LaplaceSphericalBEM.hpp:64-97) ----
+  PanelSoA& P = panels;
+  const int nq = rule.n;
+  P.cx.resize(n); P.cy.resize(n); P.cz.resize(n);
+  P.nx.resize(n); P.ny.resize(n); P.nz.resize(n);
+  P.area.resize(n); P.bc.resize(n);
+  P.quad.resize((size_t)nq * 3 * n);
+  P.vert.resize((size_t)9 * n);
+  has_bc[0] = has_bc[1] = false;
+  for (int64_t i = 0; i < n; ++i) {
+    const double* v = vertices + 9 * (size_t)perm[i];
+    const double *p0 = v, *p1 = v + 3, *p2 = v + 6;
+    P.cx[i] = (p0[0] + p1[0] + p2[0]) / 3;
+    P.cy[i] = (p0[1] + p1[1] + p2[1]) / 3;
+    P.cz[i] = (p0[2] + p1[2] + p2[2]) / 3;
+    const double a0[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
+    const double a1[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
+    const double c[3] = {a0[1] * a1[2] - a0[2] * a1[1], -(a0[0] * a1[2] - a0[2] * a1[0]), a0[0] * a1[1] - a0[1] * a1[0]};
+    const double A = 0.5 * std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+    P.area[i] = A;
+    P.nx[i] = c[0] / 2 / A; P.ny[i] = c[1] / 2 / A; P.nz[i] = c[2] / 2 / A;
+    for (int q = 0; q < nq; ++q)
+      for (int k = 0; k < 3; ++k)
+        P.quad[((size_t)q * 3 + k) * n + i] = p0[k] * rule.pts[q][0] + p1[k] * rule.pts[q][1] + p2[k] * rule.pts[q][2];
+    for (int k = 0; k < 9; ++k) P.vert[(size_t)k * n + i] = v[k];
+    const uint8_t flag = bc ? (bc[perm[i]] ? 1 : 0) : 0;
+    P.bc[i] = flag;
+    has_bc[flag] = true;
+  }
+  return {};
+}
+
+// Work model for one target leaf: near entries streamed + M2L pairs landing on the leaf and (shared
+// equally among their leaves) on its ancestors, weighted by a pair's cost in "entries" at p = p_max.
+void partition_leaves(const HostPlan& hp, int world, std::vector<int>& cut) {
+  const int nl = hp.nleaves();
+  cut.assign(world + 1, nl);
+  cut[0] = 0;
+  if (world == 1) return;
+  std::vector<double> pairs_on(hp.nboxes, 0.0);
+  for (int t : hp.lr_tgt) pairs_on[t] += 1.0;
+  // leaves under each box
+  std::vector<int> leaves_under(hp.nboxes, 0);
+  for (int b = hp.nboxes - 1; b >= 0; --b) {
+    if (hp.box_leaf[b]) leaves_under[b] = 1;
+    if (b) leaves_under[hp.box_parent[b]] += leaves_under[b];
+  }
+  const double P = hp.opt.p_max;
+  const double pair_cost = 0.5 * P * P * P * (P + 1) / 8.0;   // complex MACs per pair, in units of 8 near entries
+  std::vector<double> w(nl);
+  double total = 0;
+  for (int l = 0; l < nl; ++l) {
+    const int lb = hp.leaf_box[l];
+    double far = 0;
+    for (int b = lb;; b = hp.box_parent[b]) {
+      far += pairs_on[b] / leaves_under[b];
+      if (b == 0) break;
+    }
+    w[l] = double(hp.near_ncols[l]) * (hp.box_body_end[lb] - hp.box_body_begin[lb]) + far * pair_cost;
+    total += w[l];
+  }
+  double acc = 0;
+  int r = 1;
+  for (int l = 0; l < nl && r < world; ++l) {
+    acc += w[l];
+    while (r < world && acc >= total * r / world) cut[r++] = l + 1;
+  }
+  for (; r < world; ++r) cut[r] = nl;
+}
+
+}  // namespace fmmbem

@@ -1,0 +1,114 @@
+// host_plan.hpp -- host side of a plan: panels, Morton octree, dual tree traversal and the
+// flattened (CSR-like) operator lists that are uploaded once to HBM.
+//
+// What it reproduces from the reference (all host-only there as well):
+//   * Panel geometry                 kernel/LaplaceSphericalBEM.hpp:64-97
+//   * Octree                         include/tree/Octree.hpp:67-79, 118-129, 617-692, 334-355
+//   * MAC                            include/FMMOptions.hpp:21-31
+//   * dual traversal + lazy lists    include/executor/EvalInteractionLazySparse.hpp:68-115, 173-252
+//   * near-matrix sparsity           include/executor/EvalP2P.hpp:47-98
+// The layout is this build's own: everything is a flat array keyed by BFS box index or by
+// tree-order panel index, grouped by TARGET so that one wavefront owns one target.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace fmmbem {
+
+constexpr int kPmax = 16;
+constexpr int kMaxQuad = 25;
+
+struct QuadRule {            // triangle Gauss rule: barycentric points + weights
+  int n = 0;
+  double pts[kMaxQuad][3];
+  double w[kMaxQuad];
+};
+// examples/BEM/GaussQuadrature.hpp:19-185; false for an unknown key (the reference exits, :279-284)
+bool quad_rule(int key, QuadRule& out);
+
+struct HostOptions {
+  int p_max = 10;
+  int quad_k = 3;
+  double theta = 0.5;
+  unsigned ncrit = 64;
+  int shard_rank = 0, shard_world = 1;
+};
+
+// Panels in TREE order, structure-of-arrays (what the kernels stream).
+struct PanelSoA {
+  std::vector<double> cx, cy, cz;         // centroid
+  std::vector<double> nx, ny, nz;         // unit normal
+  std::vector<double> area;
+  std::vector<double> quad;               // [q][xyz][N]  stored quadrature points
+  std::vector<double> vert;               // [vertex*3+xyz][N]
+  std::vector<uint8_t> bc;
+};
+
+struct HostPlan {
+  HostOptions opt;
+  int64_t n = 0;
+  QuadRule rule;
+
+  // ---- tree ----
+  double pmin[3], cell[3];
+  std::vector<uint32_t> perm;             // tree index -> original index
+  int nboxes = 0, nlevels = 0;
+  std::vector<int> level_off;             // nlevels+1, boxes of one level are contiguous (BFS order)
+  std::vector<uint32_t> box_key;          // marker-bit Morton key
+  std::vector<int> box_level, box_parent, box_child_begin, box_child_end;   // children empty for leaves
+  std::vector<uint8_t> box_leaf;
+  std::vector<int> box_body_begin, box_body_end;
+  std::vector<double> box_center;         // [box][3]
+  std::vector<double> box_side;
+  std::vector<int32_t> box_icoord;        // [box][3] centre in half-finest-cell units (exact integers)
+
+  // ---- raw traversal output (reference order) ----
+  std::vector<int> p2p_src, p2p_tgt;      // leaf pairs
+  std::vector<int> lr_src, lr_tgt;        // M2L pairs
+
+  // ---- leaves ----
+  std::vector<int> leaf_box;              // leaf index -> box, ascending body_begin (= tree order)
+  std::vector<int> box_leaf_index;        // box -> leaf index or -1
+
+  // ---- near field, grouped by target leaf ----
+  std::vector<int64_t> near_ptr;          // nleaves+1 -> near_src
+  std::vector<int> near_src;              // source LEAF indices, ascending body_begin
+  std::vector<int> near_ncols;            // per target leaf: total columns
+  int64_t near_nnz_total = 0;
+
+  // ---- far field ----
+  std::vector<uint8_t> need_M, has_L;     // per box
+  std::vector<int> p2m_leaves, l2p_leaves;          // box ids
+  std::vector<int> m2l_ptr;               // nboxes+1, by target box
+  std::vector<int> m2l_src;               // source box
+  std::vector<int> m2l_cls;               // translation class of the pair
+  std::vector<int32_t> m2l_class_vec;     // [class][3] integer translation (target - source), half-finest-cell units
+  std::vector<int> m2l_class_rep;         // [class][2] representative (src,tgt) pair
+  std::vector<int> m2m_parents;           // parents with need_M, deepest level first; m2m_level_ptr delimits levels
+  std::vector<int> m2m_level_ptr;
+  std::vector<int> l2l_children;          // children receiving L2L, top level first
+  std::vector<int> l2l_level_ptr;
+  int64_t m2m_ops = 0, l2l_ops = 0;
+
+  // ---- shard (multi-GPU partition by target leaf) ----
+  int leaf_begin = 0, leaf_end = 0;       // owned leaves
+  int64_t row_begin = 0, row_end = 0;     // owned tree-order rows
+  std::vector<uint8_t> owned_L;           // box is an owned leaf or an ancestor of one
+  int64_t near_nnz_owned = 0, m2l_pairs_owned = 0;
+
+  PanelSoA panels;                        // tree order
+  bool has_bc[2] = {false, false};
+
+  // Builds everything above. Returns an empty string on success, else the error text.
+  std::string build(const HostOptions& o, int64_t n_panels, const double* vertices, const uint8_t* bc);
+  int nleaves() const { return (int)leaf_box.size(); }
+};
+
+// Triangulation::UnitSphere (examples/BEM/Triangulation.hpp:35-121)
+int64_t unit_sphere(int recursions, double* vertices);
+
+// Contiguous partition of leaves into `world` shards balanced by estimated work.
+void partition_leaves(const HostPlan& hp, int world, std::vector<int>& cut);
+
+}  // namespace fmmbem

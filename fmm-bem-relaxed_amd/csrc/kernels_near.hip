@@ -1,0 +1,288 @@
+// kernels_near.hip -- gfx950 kernels of the near field (P2P):
+//   near_assemble   plan-build: A[i,j] = K(target_i, source_j) for every leaf-leaf block
+//                   (reference: P2P_Lazy::to_matrix, executor/EvalP2P.hpp:47-98, calling
+//                    LaplaceSphericalBEM::operator(), kernel/LaplaceSphericalBEM.hpp:159-297)
+//   gather_x        x_tree[i] = x[perm[i]]        (EvalInteractionLazySparse.hpp:137-138)
+//   near_spmv       y_tree = A_near * x_tree      (Matvec<>, include/Matvec.hpp:14-33) -- HBM-bound hot kernel
+//   scatter_y       y[perm[i]] = y_tree[i]        (EvalInteractionLazySparse.hpp:146-148)
+#include "device_plan.hpp"
+
+namespace fmmbem {
+
+namespace {
+
+constexpr int kWave = 64;
+typedef double dvec2 __attribute__((ext_vector_type(2)));   // native 16-B vector (nontemporal builtin needs it)
+
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+  return v;
+}
+
+struct V3 { double x, y, z; };
+__device__ inline V3 sub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ inline V3 cross(V3 u, V3 v) { return {u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x}; }
+__device__ inline double norm(V3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+__device__ inline V3 mul3(const double* M, V3 v) {       // row-major 3x3 times vector (include/Mat3.hpp:76-82)
+  return {M[0] * v.x + M[1] * v.y + M[2] * v.z, M[3] * v.x + M[4] * v.y + M[5] * v.z, M[6] * v.x + M[7] * v.y + M[8] * v.z};
+}
+
+// 5-point Gauss-Legendre in the polar angle along one triangle edge
+// (examples/BEM/SemiAnalytical.hpp:13-71, LAPLACE branch; only G is needed by the Laplace near field)
+__device__ inline double edge_angle_integral(double z, double x, double v1, double v2) {
+  const double t1 = atan2(v1, x), t2 = atan2(v2, x);
+  const double dt = t2 - t1, tm = (t2 + t1) / 2;
+  const double az = fabs(z);
+  const double xk[5] = {-9.06179846e-01, -5.38469310e-01, 1.78162900e-17, 9.06179846e-01, 5.38469310e-01};
+  const double wk[5] = {0.23692689, 0.47862867, 0.56888889, 0.23692689, 0.47862867};
+  double G = 0;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const double tk = dt / 2 * xk[i] + tm;
+    const double Rt = x / cos(tk);
+    const double R = sqrt(Rt * Rt + z * z);
+    G += wk[i] * (R - az) * dt / 2;
+  }
+  return G;
+}
+
+// contribution of one edge v1->v2, in the panel plane with the collocation point at the origin and
+// height p above the plane (examples/BEM/SemiAnalytical.hpp:81-145)
+__device__ inline double edge_term(V3 v1, V3 v2, double p) {
+  const V3 e = sub(v2, v1);
+  const double len = norm(e);
+  const V3 u = {e.x / len, e.y / len, e.z / len};
+  const V3 o = cross(V3{0, 0, 1}, u);
+  double R[9] = {o.x, u.x, 0, o.y, u.y, 0, o.z, u.z, 1};
+  V3 a = mul3(R, v1);
+  if (a.x < 0) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = -R[i];
+    R[8] = 1.;
+    a = mul3(R, v1);
+  }
+  const V3 b = mul3(R, v2);
+  if ((a.y > 0 && b.y < 0) || (a.y < 0 && b.y > 0))
+    return edge_angle_integral(p, a.x, 0, a.y) + edge_angle_integral(p, a.x, b.y, 0);
+  return -edge_angle_integral(p, a.x, a.y, b.y);
+}
+
+// int_panel 1/|x - y| dS(y), semi-analytically (examples/BEM/SemiAnalytical.hpp:148-203)
+__device__ inline double semi_analytic_G(V3 y0, V3 y1, V3 y2, V3 x) {
+  const V3 xp = sub(x, y0), e1 = sub(y1, y0), e2 = sub(y2, y0);
+  V3 X = e1, Z = cross(e1, e2);
+  const double xn = norm(X), zn = norm(Z);
+  X = {X.x / xn, X.y / xn, X.z / xn};
+  Z = {Z.x / zn, Z.y / zn, Z.z / zn};
+  const V3 Y = cross(Z, X);
+  const double rot[9] = {X.x, X.y, X.z, Y.x, Y.y, Y.z, Z.x, Z.y, Z.z};
+  const V3 q0 = mul3(rot, V3{0, 0, 0}), q1 = mul3(rot, e1), q2 = mul3(rot, e2), xq = mul3(rot, xp);
+  const V3 f0 = {q0.x - xq.x, q0.y - xq.y, q0.z}, f1 = {q1.x - xq.x, q1.y - xq.y, q1.z}, f2 = {q2.x - xq.x, q2.y - xq.y, q2.z};
+  return edge_term(f0, f1, xq.z) + edge_term(f1, f2, xq.z) + edge_term(f2, f0, xq.z);
+}
+
+// the 16-point "K_fine" rule keyed 17 (examples/BEM/GaussQuadrature.hpp:86-116), barycentric
+__constant__ double kFine[16][4] = {
+    {1. / 3, 1. / 3, 1. / 3, 0.144315607677787},
+    {0.081414823414554, 0.459292588292723, 0.459292588292723, 0.095091634267285},
+    {0.459292588292723, 0.081414823414554, 0.459292588292723, 0.095091634267285},
+    {0.459292588292723, 0.459292588292723, 0.081414823414554, 0.095091634267285},
+    {0.658861384496480, 0.170569307751760, 0.170569307751760, 0.103217370534718},
+    {0.170569307751760, 0.658861384496480, 0.170569307751760, 0.103217370534718},
+    {0.170569307751760, 0.170569307751760, 0.658861384496480, 0.103217370534718},
+    {0.898905543365938, 0.050547228317031, 0.050547228317031, 0.032458497623198},
+    {0.050547228317031, 0.898905543365938, 0.050547228317031, 0.032458497623198},
+    {0.050547228317031, 0.050547228317031, 0.898905543365938, 0.032458497623198},
+    {0.008394777409958, 0.263112829634638, 0.728492392955404, 0.027230314174435},
+    {0.008394777409958, 0.728492392955404, 0.263112829634638, 0.027230314174435},
+    {0.263112829634638, 0.008394777409958, 0.728492392955404, 0.027230314174435},
+    {0.263112829634638, 0.728492392955404, 0.008394777409958, 0.027230314174435},
+    {0.728492392955404, 0.008394777409958, 0.263112829634638, 0.027230314174435},
+    {0.728492392955404, 0.263112829634638, 0.008394777409958, 0.027230314174435}};
+
+// One near-matrix entry: target centroid t with BC flag, source panel j (tree index).
+// kernel/LaplaceSphericalBEM.hpp:273-297 -> eval_G (:159-205) / eval_dGdn (:208-264)
+__device__ inline double laplace_entry(const DevicePlan& d, V3 t, int tbc, int64_t j) {
+  const int64_t N = d.n;
+  const V3 c = {d.cx[j], d.cy[j], d.cz[j]};
+  const double A = d.area[j];
+  const double dist = norm(sub(t, c));
+  const bool nearby = sqrt(2 * A) / dist >= 0.5;
+  if (tbc == 0) {                                   // POTENTIAL target: int G
+    if (nearby) {
+      const V3 v0 = {d.vert[0 * N + j], d.vert[1 * N + j], d.vert[2 * N + j]};
+      const V3 v1 = {d.vert[3 * N + j], d.vert[4 * N + j], d.vert[5 * N + j]};
+      const V3 v2 = {d.vert[6 * N + j], d.vert[7 * N + j], d.vert[8 * N + j]};
+      return semi_analytic_G(v0, v1, v2, t);
+    }
+    double r = 0;
+    for (int q = 0; q < d.nq; ++q) {
+      const V3 qp = {d.quad[(q * 3 + 0) * N + j], d.quad[(q * 3 + 1) * N + j], d.quad[(q * 3 + 2) * N + j]};
+      r += d.qw[q] * A / norm(sub(t, qp));
+    }
+    return r;
+  }
+  // NORMAL_DERIV target: int dG/dn
+  if (dist < 1e-8) return 2 * M_PI;
+  const V3 nrm = {d.nx[j], d.ny[j], d.nz[j]};
+  double r = 0;
+  if (nearby) {
+    const V3 v0 = {d.vert[0 * N + j], d.vert[1 * N + j], d.vert[2 * N + j]};
+    const V3 v1 = {d.vert[3 * N + j], d.vert[4 * N + j], d.vert[5 * N + j]};
+    const V3 v2 = {d.vert[6 * N + j], d.vert[7 * N + j], d.vert[8 * N + j]};
+    for (int q = 0; q < 16; ++q) {
+      const V3 pt = {v0.x * kFine[q][0] + v1.x * kFine[q][1] + v2.x * kFine[q][2],
+                     v0.y * kFine[q][0] + v1.y * kFine[q][1] + v2.y * kFine[q][2],
+                     v0.z * kFine[q][0] + v1.z * kFine[q][1] + v2.z * kFine[q][2]};
+      const V3 dx = sub(pt, t);
+      const double r2 = dx.x * dx.x + dx.y * dx.y + dx.z * dx.z;
+      r += kFine[q][3] * A * (dx.x * nrm.x + dx.y * nrm.y + dx.z * nrm.z) / (r2 * sqrt(r2));
+    }
+    return r;
+  }
+  for (int q = 0; q < d.nq; ++q) {
+    const V3 qp = {d.quad[(q * 3 + 0) * N + j], d.quad[(q * 3 + 1) * N + j], d.quad[(q * 3 + 2) * N + j]};
+    const V3 dx = sub(qp, t);
+    const double r2 = dx.x * dx.x + dx.y * dx.y + dx.z * dx.z;
+    r += d.qw[q] * A * (dx.x * nrm.x + dx.y * nrm.y + dx.z * nrm.z) / (r2 * sqrt(r2));
+  }
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// near_assemble: one workgroup per owned target leaf. LDS holds the column -> source panel map.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void near_assemble_kernel(DevicePlan d) {
+  extern __shared__ int colmap[];
+  const int t = d.leaf_begin + blockIdx.x;
+  const int ncols = d.near_ncols[t], stride = d.near_stride[t], nrows = d.leaf_nrows[t];
+  const int row0 = d.leaf_row0[t];
+  int base = 0;
+  for (int64_t s = d.near_ptr[t]; s < d.near_ptr[t + 1]; ++s) {
+    const int b = d.near_src_row0[s], m = d.near_src_n[s];
+    for (int i = threadIdx.x; i < m; i += blockDim.x) colmap[base + i] = b + i;
+    base += m;
+  }
+  __syncthreads();
+  double* blk = d.near_val + d.near_off[t];
+  const int total = nrows * stride;
+  for (int e = threadIdx.x; e < total; e += blockDim.x) {
+    const int r = e / stride, c = e - r * stride;
+    double v = 0;                                     // padding column (odd ncols) stays zero
+    if (c < ncols) {
+      const int64_t i = row0 + r;
+      v = laplace_entry(d, V3{d.cx[i], d.cy[i], d.cz[i]}, d.bc[i], colmap[c]);
+    }
+    blk[e] = v;
+  }
+}
+
+__global__ void gather_x_kernel(const uint32_t* __restrict__ perm, const double* __restrict__ x,
+                                double* __restrict__ xt, int64_t n) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) xt[i] = x[perm[i]];
+}
+
+__global__ void scatter_y_kernel(const uint32_t* __restrict__ perm, const double* __restrict__ yt,
+                                 double* __restrict__ y, int64_t row_begin, int64_t row_end) {
+  const int64_t i = row_begin + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < row_end) y[perm[i]] = yt[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// near_spmv: one 256-thread workgroup (4 wavefronts) per owned target leaf.
+//   1. the x slices of the leaf's source leaves are staged once in LDS (<= max_ncols doubles);
+//   2. each wavefront takes rows w, w+4, ... two at a time; a row is `stride` contiguous doubles,
+//      read as 16-B vectors, lanes striding over the columns (fully coalesced 1-KiB wave loads),
+//      ROWS_IN_FLIGHT x UNROLL independent loads are issued before the first FMA;
+//   3. per-row wave shuffle reduction, lane 0 stores y_tree[row].
+// Algorithmic bytes: 8 B per near entry (+ 8 B x read + 8 B y write per panel); no column indices.
+// ---------------------------------------------------------------------------------------------
+constexpr int kSpmvWaves = 4;
+
+__global__ __launch_bounds__(kSpmvWaves * kWave) void near_spmv_kernel(DevicePlan d) {
+  extern __shared__ double xs[];
+  const int t = d.leaf_begin + blockIdx.x;
+  const int ncols = d.near_ncols[t], stride = d.near_stride[t], nrows = d.leaf_nrows[t];
+  int base = 0;
+  for (int64_t s = d.near_ptr[t]; s < d.near_ptr[t + 1]; ++s) {
+    const int b = d.near_src_row0[s], m = d.near_src_n[s];
+    for (int i = threadIdx.x; i < m; i += blockDim.x) xs[base + i] = d.xt[b + i];
+    base += m;
+  }
+  if (threadIdx.x == 0 && stride > ncols) xs[ncols] = 0.0;
+  __syncthreads();
+
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const double* blk = d.near_val + d.near_off[t];
+  const int row0 = d.leaf_row0[t];
+  const int nvec = stride >> 1;                       // 16-B vectors per row
+  const dvec2* xv = reinterpret_cast<const dvec2*>(xs);
+
+  for (int r = wave; r < nrows; r += 2 * kSpmvWaves) {
+    const int r2 = r + kSpmvWaves;
+    const bool has2 = r2 < nrows;
+    const dvec2* a = reinterpret_cast<const dvec2*>(blk + (int64_t)r * stride);
+    const dvec2* b = reinterpret_cast<const dvec2*>(blk + (int64_t)(has2 ? r2 : r) * stride);
+    double acc0 = 0, acc1 = 0;
+    for (int c = lane; c < nvec; c += 4 * kWave) {
+      dvec2 va[4], vb[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int cc = c + u * kWave;
+        const bool ok = cc < nvec;
+        va[u] = ok ? __builtin_nontemporal_load(&a[cc]) : dvec2{0, 0};
+        vb[u] = ok ? __builtin_nontemporal_load(&b[cc]) : dvec2{0, 0};
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int cc = c + u * kWave;
+        if (cc < nvec) {
+          const dvec2 x2 = xv[cc];
+          acc0 = fma(va[u].x, x2.x, fma(va[u].y, x2.y, acc0));
+          acc1 = fma(vb[u].x, x2.x, fma(vb[u].y, x2.y, acc1));
+        }
+      }
+    }
+    acc0 = wave_sum(acc0);
+    acc1 = wave_sum(acc1);
+    if (lane == 0) {
+      d.yt[row0 + r] = acc0;
+      if (has2) d.yt[row0 + r2] = acc1;
+    }
+  }
+}
+
+}  // namespace
+
+hipError_t launch_near_assemble(const DevicePlan& d, hipStream_t s) {
+  const int nb = d.leaf_end - d.leaf_begin;
+  if (nb <= 0) return hipSuccess;
+  hipLaunchKernelGGL(near_assemble_kernel, dim3(nb), dim3(256), (size_t)d.max_ncols * sizeof(int), s, d);
+  return hipGetLastError();
+}
+
+hipError_t launch_gather_x(const DevicePlan& d, const double* x, hipStream_t s) {
+  const int bs = 256;
+  hipLaunchKernelGGL(gather_x_kernel, dim3((unsigned)((d.n + bs - 1) / bs)), dim3(bs), 0, s, d.perm, x, d.xt, d.n);
+  return hipGetLastError();
+}
+
+hipError_t launch_near_spmv(const DevicePlan& d, hipStream_t s) {
+  const int nb = d.leaf_end - d.leaf_begin;
+  if (nb <= 0) return hipSuccess;
+  hipLaunchKernelGGL(near_spmv_kernel, dim3(nb), dim3(kSpmvWaves * kWave), (size_t)d.max_ncols * sizeof(double), s, d);
+  return hipGetLastError();
+}
+
+hipError_t launch_scatter_y(const DevicePlan& d, double* y, hipStream_t s) {
+  const int64_t rows = d.row_end - d.row_begin;
+  if (rows <= 0) return hipSuccess;
+  const int bs = 256;
+  hipLaunchKernelGGL(scatter_y_kernel, dim3((unsigned)((rows + bs - 1) / bs)), dim3(bs), 0, s, d.perm, d.yt, y,
+                     d.row_begin, d.row_end);
+  return hipGetLastError();
+}
+
+}  // namespace fmmbem

@@ -1,0 +1,598 @@
+// plan.hip -- implementation of the C ABI declared in include/fmmbem.h.
+// Host orchestration only: builds the HostPlan, tabulates the translation operators, uploads
+// everything once, and sequences the gfx950 kernels of kernels_near.hip / kernels_far.hip on a HIP
+// stream.  There is NO CPU execution path: without a device, execute returns FMMBEM_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <complex>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/fmmbem.h"
+#include "device_plan.hpp"
+#include "host_plan.hpp"
+
+using namespace fmmbem;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess)                                                                          \
+      return fail(e_ == hipErrorOutOfMemory ? FMMBEM_ERR_ALLOC : FMMBEM_ERR_HIP,                  \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                              \
+  } while (0)
+
+double now_ms() {
+  using namespace std::chrono;
+  return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+constexpr int kTabN = 2 * kPmax;        // harmonic degrees tabulated: n < 32
+constexpr double kEps = 1e-12;          // kernel/LaplaceSpherical.hpp:30
+
+// Anm / prefactor of LaplaceSpherical::precompute (kernel/LaplaceSpherical.hpp:87-104), for all degrees
+// any p <= 16 needs.  The index n^2+n+m does not depend on P, so one table serves every order.
+struct HarmonicTables {
+  std::vector<double> A, invA, pref;
+  HarmonicTables() : A(kTabN * kTabN), invA(kTabN * kTabN), pref(kTabN * kTabN) {
+    for (int n = 0; n < kTabN; ++n)
+      for (int m = -n; m <= n; ++m) {
+        const int nm = n * n + n + m, am = std::abs(m);
+        double fnmm = kEps, fnpm = kEps, fnma = 1.0, fnpa = 1.0;
+        for (int i = 1; i <= n - m; ++i) fnmm *= i;
+        for (int i = 1; i <= n + m; ++i) fnpm *= i;
+        for (int i = 1; i <= n - am; ++i) fnma *= i;
+        for (int i = 1; i <= n + am; ++i) fnpa *= i;
+        pref[nm] = std::sqrt(fnma / fnpa);
+        A[nm] = ((n & 1) ? -1.0 : 1.0) / std::sqrt(fnmm * fnpm);
+        invA[nm] = 1.0 / A[nm];
+      }
+  }
+};
+
+struct SphHost { double rho, alpha, beta; };
+// kernel/LaplaceSpherical.hpp:528-541
+SphHost cart2sph_host(const double d[3]) {
+  SphHost s;
+  s.rho = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) + kEps;
+  s.alpha = std::acos(d[2] / s.rho);
+  if (std::fabs(d[0]) + std::fabs(d[1]) < kEps) s.beta = 0;
+  else if (std::fabs(d[0]) < kEps) s.beta = d[1] / std::fabs(d[1]) * M_PI * 0.5;
+  else if (d[0] > 0) s.beta = std::atan(d[1] / d[0]);
+  else s.beta = std::atan(d[1] / d[0]) + M_PI;
+  return s;
+}
+
+using cplx = std::complex<double>;
+
+// Harmonics for orders m >= 0, degrees n < N.  regular: rho^n P_n^m pref e^{i m beta}
+// (evalMultipole, :455-488); otherwise rho^{-n-1} ... (evalLocal, :491-524).  out[n(n+1)/2+m].
+void harmonics(const HarmonicTables& T, bool regular, double rho, double alpha, double beta, int N,
+               std::vector<cplx>& out) {
+  out.assign((size_t)N * (N + 1) / 2, cplx(0, 0));
+  const double x = std::cos(alpha), y = std::sin(alpha);
+  double fact = 1, pn = 1, rhom = regular ? 1.0 : 1.0 / rho;
+  for (int m = 0; m < N; ++m) {
+    const cplx eim = std::exp(cplx(0, 1) * double(m * beta));
+    double p = pn;
+    out[(size_t)m * (m + 1) / 2 + m] = rhom * p * T.pref[m * m + 2 * m] * eim;
+    double p1 = p;
+    p = x * (2 * m + 1) * p1;
+    if (regular) rhom *= rho; else rhom /= rho;
+    double rhon = rhom;
+    for (int n = m + 1; n < N; ++n) {
+      out[(size_t)n * (n + 1) / 2 + m] = rhon * p * T.pref[n * n + n + m] * eim;
+      const double p2 = p1;
+      p1 = p;
+      p = (x * (2 * n + 1) * p1 - (n + m) * p2) / (n - m + 1);
+      if (regular) rhon *= rho; else rhon /= rho;
+    }
+    pn = -pn * fact * y;
+    fact += 2;
+  }
+}
+
+cplx i_pow(int q) {
+  switch (q & 3) { case 0: return {1, 0}; case 1: return {0, 1}; case 2: return {-1, 0}; default: return {0, -1}; }
+}
+
+}  // namespace
+
+struct fmmbem_plan {
+  fmmbem_options opts;
+  HostPlan hp;
+  DevicePlan d;
+  bool on_device = false;
+  std::vector<void*> allocs;
+  std::vector<std::pair<int, int>> m2m_launch, l2l_launch;     // (first, count) per level
+  int64_t near_bytes = 0;
+  int64_t n_classes = 0;
+  double build_host_ms = 0, build_assemble_ms = 0;
+  // execute state
+  bool timing = false;
+  int last_p = 0;
+  double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  hipEvent_t ev[9] = {};
+  bool have_events = false;
+  double *stage_x = nullptr, *stage_y = nullptr;               // device staging for host-pointer execute
+  hipStream_t own_stream = nullptr;
+
+  template <class T>
+  int upload(const std::vector<T>& v, const T** out) {
+    *out = nullptr;
+    void* p = nullptr;
+    const size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+    HIP_TRY(hipMalloc(&p, bytes));
+    allocs.push_back(p);
+    if (!v.empty()) HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = static_cast<const T*>(p);
+    return FMMBEM_OK;
+  }
+  template <class T>
+  int alloc(size_t count, T** out, bool zero) {
+    void* p = nullptr;
+    const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    HIP_TRY(hipMalloc(&p, bytes));
+    allocs.push_back(p);
+    if (zero) HIP_TRY(hipMemset(p, 0, bytes));
+    *out = static_cast<T*>(p);
+    return FMMBEM_OK;
+  }
+  int to_device();
+  int run(int p, const double* d_x, double* d_y, hipStream_t s, bool near_only);
+  ~fmmbem_plan() {
+    if (on_device) {
+      (void)hipSetDevice(opts.device);
+      for (void* p : allocs) (void)hipFree(p);
+      if (have_events) for (auto& e : ev) (void)hipEventDestroy(e);
+      if (own_stream) (void)hipStreamDestroy(own_stream);
+    }
+  }
+};
+
+#define TRY(expr) do { int rc_ = (expr); if (rc_ != FMMBEM_OK) return rc_; } while (0)
+
+int fmmbem_plan::to_device() {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(FMMBEM_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU execution path)");
+  if (opts.device < 0 || opts.device >= ndev) return fail(FMMBEM_ERR_INVALID, "device ordinal out of range");
+  HIP_TRY(hipSetDevice(opts.device));
+  on_device = true;
+  HIP_TRY(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
+  for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+  have_events = true;
+
+  const HarmonicTables T;
+  const int nl = hp.nleaves(), nb = hp.nboxes, pm = hp.opt.p_max;
+  d = DevicePlan{};
+  d.n = hp.n; d.nq = hp.rule.n; d.nboxes = nb; d.nleaves = nl;
+  d.p_max = pm; d.s_max = pm * (pm + 1) / 2; d.p2_max = pm * pm; d.y2_max = 4 * pm * pm;
+  d.leaf_begin = hp.leaf_begin; d.leaf_end = hp.leaf_end; d.row_begin = hp.row_begin; d.row_end = hp.row_end;
+  for (int q = 0; q < hp.rule.n; ++q) d.qw[q] = hp.rule.w[q];
+  d.n_act = 0;
+  for (int s = 0; s < 2; ++s) if (hp.has_bc[s]) d.act[d.n_act++] = s;
+
+  // panels + permutation
+  const PanelSoA& P = hp.panels;
+  TRY(upload(P.cx, &d.cx)); TRY(upload(P.cy, &d.cy)); TRY(upload(P.cz, &d.cz));
+  TRY(upload(P.nx, &d.nx)); TRY(upload(P.ny, &d.ny)); TRY(upload(P.nz, &d.nz));
+  TRY(upload(P.area, &d.area)); TRY(upload(P.quad, &d.quad)); TRY(upload(P.vert, &d.vert));
+  TRY(upload(P.bc, &d.bc)); TRY(upload(hp.perm, &d.perm));
+
+  // leaves and the near block structure
+  std::vector<int> leaf_row0(nl), leaf_nrows(nl), near_stride(nl), src_row0(hp.near_src.size()), src_n(hp.near_src.size());
+  std::vector<int64_t> near_off(nl, 0);
+  int64_t total = 0;
+  int max_cols = 2;
+  for (int l = 0; l < nl; ++l) {
+    const int b = hp.leaf_box[l];
+    leaf_row0[l] = hp.box_body_begin[b];
+    leaf_nrows[l] = hp.box_body_end[b] - hp.box_body_begin[b];
+    near_stride[l] = (hp.near_ncols[l] + 1) & ~1;
+    if (l >= hp.leaf_begin && l < hp.leaf_end) {
+      near_off[l] = total;
+      total += (int64_t)leaf_nrows[l] * near_stride[l];
+      max_cols = std::max(max_cols, near_stride[l]);
+    }
+  }
+  for (size_t i = 0; i < hp.near_src.size(); ++i) {
+    const int b = hp.leaf_box[hp.near_src[i]];
+    src_row0[i] = hp.box_body_begin[b];
+    src_n[i] = hp.box_body_end[b] - hp.box_body_begin[b];
+  }
+  d.max_ncols = max_cols;
+  near_bytes = total * (int64_t)sizeof(double);
+  TRY(upload(leaf_row0, &d.leaf_row0)); TRY(upload(leaf_nrows, &d.leaf_nrows)); TRY(upload(hp.leaf_box, &d.leaf_box));
+  TRY(upload(hp.near_ptr, &d.near_ptr)); TRY(upload(src_row0, &d.near_src_row0)); TRY(upload(src_n, &d.near_src_n));
+  TRY(upload(hp.near_ncols, &d.near_ncols)); TRY(upload(near_stride, &d.near_stride)); TRY(upload(near_off, &d.near_off));
+  TRY(alloc((size_t)total, &d.near_val, false));
+
+  // boxes, expansions, tables
+  TRY(upload(hp.box_center, &d.box_center));
+  TRY(alloc((size_t)nb * 2 * d.s_max, &d.M, true));
+  TRY(alloc((size_t)nb * 2 * d.s_max, &d.L, true));
+  TRY(alloc((size_t)nb * 2 * d.p2_max, &d.Mh, true));
+  TRY(upload(T.A, &d.tabA)); TRY(upload(T.invA, &d.tabInvA)); TRY(upload(T.pref, &d.tabPref));
+
+  // far-field lists
+  std::vector<int> p2m_leaf, l2p_leaf;
+  for (int b : hp.p2m_leaves) p2m_leaf.push_back(hp.box_leaf_index[b]);
+  for (int b : hp.l2p_leaves) l2p_leaf.push_back(hp.box_leaf_index[b]);
+  d.n_p2m = (int)p2m_leaf.size(); d.n_l2p = (int)l2p_leaf.size();
+  TRY(upload(p2m_leaf, &d.p2m_leaf)); TRY(upload(l2p_leaf, &d.l2p_leaf));
+  TRY(upload(hp.m2m_parents, &d.m2m_parent)); TRY(upload(hp.l2l_children, &d.l2l_child));
+  TRY(upload(hp.box_child_begin, &d.box_child_begin)); TRY(upload(hp.box_child_end, &d.box_child_end));
+  TRY(upload(hp.box_parent, &d.box_parent));
+  for (size_t l = 0; l + 1 < hp.m2m_level_ptr.size(); ++l)
+    if (hp.m2m_level_ptr[l + 1] > hp.m2m_level_ptr[l])
+      m2m_launch.emplace_back(hp.m2m_level_ptr[l], hp.m2m_level_ptr[l + 1] - hp.m2m_level_ptr[l]);
+  for (size_t l = 0; l + 1 < hp.l2l_level_ptr.size(); ++l)
+    if (hp.l2l_level_ptr[l + 1] > hp.l2l_level_ptr[l])
+      l2l_launch.emplace_back(hp.l2l_level_ptr[l], hp.l2l_level_ptr[l + 1] - hp.l2l_level_ptr[l]);
+
+  // parent<->child translation classes and their regular-harmonic tables
+  {
+    std::vector<int> up_cls(nb, 0), down_cls(nb, 0);
+    std::unordered_map<uint64_t, int> seen;
+    std::vector<cplx> up_tab, down_tab, h;
+    for (int b = 1; b < nb; ++b) {
+      const int par = hp.box_parent[b];
+      const int32_t v[3] = {hp.box_icoord[3 * par] - hp.box_icoord[3 * b], hp.box_icoord[3 * par + 1] - hp.box_icoord[3 * b + 1],
+                            hp.box_icoord[3 * par + 2] - hp.box_icoord[3 * b + 2]};
+      const uint64_t key = (uint64_t)(uint32_t)(v[0] + 4096) | ((uint64_t)(uint32_t)(v[1] + 4096) << 16) |
+                           ((uint64_t)(uint32_t)(v[2] + 4096) << 32);
+      auto [it, fresh] = seen.try_emplace(key, (int)seen.size());
+      if (fresh) {
+        double up[3], down[3];
+        for (int k = 0; k < 3; ++k) { up[k] = hp.box_center[3 * par + k] - hp.box_center[3 * b + k]; down[k] = -up[k]; }
+        // M2M: evalMultipole(rho, alpha, -beta) of (parent - child)   (LaplaceSpherical.hpp:253-254)
+        SphHost s = cart2sph_host(up);
+        harmonics(T, true, s.rho, s.alpha, -s.beta, pm, h);
+        for (int n = 0; n < pm; ++n)
+          for (int m = -n; m <= n; ++m) {
+            const cplx y = h[(size_t)n * (n + 1) / 2 + std::abs(m)];
+            up_tab.push_back(m < 0 ? std::conj(y) : y);
+          }
+        // L2L: evalMultipole(rho, alpha, +beta) of (child - parent)   (LaplaceSpherical.hpp:383-384)
+        s = cart2sph_host(down);
+        harmonics(T, true, s.rho, s.alpha, s.beta, pm, h);
+        for (int n = 0; n < pm; ++n)
+          for (int m = -n; m <= n; ++m) {
+            const cplx y = h[(size_t)n * (n + 1) / 2 + std::abs(m)];
+            down_tab.push_back(m < 0 ? std::conj(y) : y);
+          }
+      }
+      up_cls[b] = down_cls[b] = it->second;
+    }
+    TRY(upload(up_cls, &d.up_cls)); TRY(upload(down_cls, &d.down_cls));
+    const cplx *pu = nullptr, *pd = nullptr;
+    TRY(upload(up_tab, &pu)); TRY(upload(down_tab, &pd));
+    d.up_tab = reinterpret_cast<const double2*>(pu);
+    d.down_tab = reinterpret_cast<const double2*>(pd);
+  }
+
+  // M2L: targets to run, sources whose Mh is needed, class tables Yh[r,c] = i^{|c|} EPS Y[r,c] / A[r,c]
+  {
+    std::vector<int> tgt, mh;
+    std::vector<uint8_t> is_src(nb, 0);
+    for (int b = 0; b < nb; ++b)
+      if (hp.has_L[b] && hp.owned_L[b]) tgt.push_back(b);
+    for (int s : hp.m2l_src) is_src[s] = 1;
+    for (int b = 0; b < nb; ++b) if (is_src[b]) mh.push_back(b);
+    d.n_m2l_tgt = (int)tgt.size(); d.n_mh = (int)mh.size();
+    TRY(upload(tgt, &d.m2l_tgt)); TRY(upload(mh, &d.mh_box));
+    TRY(upload(hp.m2l_ptr, &d.m2l_ptr)); TRY(upload(hp.m2l_src, &d.m2l_src)); TRY(upload(hp.m2l_cls, &d.m2l_cls));
+    n_classes = (int64_t)hp.m2l_class_rep.size() / 2;
+    const int R = 2 * pm;
+    std::vector<cplx> tab((size_t)n_classes * d.y2_max), h;
+    for (int64_t c = 0; c < n_classes; ++c) {
+      const int s = hp.m2l_class_rep[2 * c], t = hp.m2l_class_rep[2 * c + 1];
+      double tr[3];
+      for (int k = 0; k < 3; ++k) tr[k] = hp.box_center[3 * t + k] - hp.box_center[3 * s + k];   // executor/M2L.hpp:40
+      const SphHost sp = cart2sph_host(tr);
+      harmonics(T, false, sp.rho, sp.alpha, sp.beta, R, h);                                      // evalLocal to order 2P
+      cplx* out = tab.data() + (size_t)c * d.y2_max;
+      for (int r = 0; r < R; ++r)
+        for (int cc = 0; cc <= r; ++cc) {
+          const cplx yh = i_pow(cc) * (h[(size_t)r * (r + 1) / 2 + cc] * kEps / T.A[r * r + r + cc]);
+          out[r * r + r + cc] = yh;
+          if (cc) out[r * r + r - cc] = ((cc & 1) ? -1.0 : 1.0) * std::conj(yh);
+        }
+    }
+    const cplx* pt = nullptr;
+    TRY(upload(tab, &pt));
+    d.m2l_tab = reinterpret_cast<const double2*>(pt);
+  }
+
+  TRY(alloc((size_t)hp.n, &d.xt, true));
+  TRY(alloc((size_t)hp.n, &d.yt, true));
+  TRY(alloc((size_t)hp.n, &stage_x, true));
+  TRY(alloc((size_t)hp.n, &stage_y, true));
+
+  // near-field assembly on the device
+  const double t0 = now_ms();
+  HIP_TRY(launch_near_assemble(d, own_stream));
+  HIP_TRY(hipStreamSynchronize(own_stream));
+  build_assemble_ms = now_ms() - t0;
+  return FMMBEM_OK;
+}
+
+int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool near_only) {
+  if (!on_device) return fail(FMMBEM_ERR_NO_DEVICE, "plan was built host-only; there is no CPU execution path");
+  if (p < 1 || p > hp.opt.p_max) return fail(FMMBEM_ERR_INVALID, "p outside [1, p_max]");
+  if (!d_x || !d_y) return fail(FMMBEM_ERR_INVALID, "null vector");
+  HIP_TRY(hipSetDevice(opts.device));
+  const bool tm = timing;
+  int e = 0;
+  auto mark = [&]() -> hipError_t { return tm ? hipEventRecord(ev[e++], s) : hipSuccess; };
+  HIP_TRY(mark());
+  HIP_TRY(launch_gather_x(d, d_x, s));
+  HIP_TRY(mark());
+  HIP_TRY(launch_near_spmv(d, s));
+  if (hp.opt.shard_world > 1) HIP_TRY(hipMemsetAsync(d_y, 0, sizeof(double) * (size_t)hp.n, s));
+  HIP_TRY(launch_scatter_y(d, d_y, s));
+  HIP_TRY(mark());
+  if (!near_only) {
+    HIP_TRY(launch_p2m(d, p, s));
+    HIP_TRY(mark());
+    for (auto [first, count] : m2m_launch) HIP_TRY(launch_m2m_level(d, p, first, count, s));
+    HIP_TRY(mark());
+    HIP_TRY(launch_mh_prep(d, p, s));
+    HIP_TRY(launch_m2l(d, p, s));
+    HIP_TRY(mark());
+    for (auto [first, count] : l2l_launch) HIP_TRY(launch_l2l_level(d, p, first, count, s));
+    HIP_TRY(mark());
+    HIP_TRY(launch_l2p(d, p, d_y, s));
+    HIP_TRY(mark());
+  }
+  last_p = p;
+  if (tm) {
+    HIP_TRY(hipStreamSynchronize(s));
+    for (int i = 0; i < 8; ++i) ms[i] = 0;
+    float f = 0;
+    for (int i = 0; i + 1 < e; ++i) { HIP_TRY(hipEventElapsedTime(&f, ev[i], ev[i + 1])); ms[1 + i] = f; }
+    HIP_TRY(hipEventElapsedTime(&f, ev[0], ev[e - 1]));
+    ms[0] = f;
+  }
+  return FMMBEM_OK;
+}
+
+// ============================================ C ABI ============================================
+extern "C" {
+
+void fmmbem_options_default(fmmbem_options* o) {
+  if (!o) return;
+  std::memset(o, 0, sizeof(*o));
+  o->kernel = FMMBEM_KERNEL_LAPLACE_BEM;
+  o->p_max = 10;
+  o->quad_k = 3;
+  o->theta = 0.5;
+  o->ncrit = 64;
+  o->sparse_local = 1;
+  o->shard_world = 1;
+}
+
+int fmmbem_plan_create(const fmmbem_options* opts, size_t n_panels, const double* vertices, const uint8_t* bc,
+                       fmmbem_plan** out) {
+  if (!opts || !out) return fail(FMMBEM_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (opts->kernel != FMMBEM_KERNEL_LAPLACE_BEM) return fail(FMMBEM_ERR_UNSUPPORTED, "only FMMBEM_KERNEL_LAPLACE_BEM");
+  if (!opts->sparse_local) return fail(FMMBEM_ERR_UNSUPPORTED, "only the assembled near field (sparse_local=1)");
+  if (!vertices || n_panels == 0) return fail(FMMBEM_ERR_INVALID, "no panels");
+  std::unique_ptr<fmmbem_plan> pl(new (std::nothrow) fmmbem_plan);
+  if (!pl) return fail(FMMBEM_ERR_ALLOC, "plan");
+  pl->opts = *opts;
+  HostOptions ho;
+  ho.p_max = opts->p_max; ho.quad_k = opts->quad_k; ho.theta = opts->theta; ho.ncrit = opts->ncrit;
+  ho.shard_rank = opts->shard_rank; ho.shard_world = opts->shard_world < 1 ? 1 : opts->shard_world;
+  const double t0 = now_ms();
+  std::string err;
+  try {
+    err = pl->hp.build(ho, (int64_t)n_panels, vertices, bc);
+  } catch (const std::bad_alloc&) {
+    return fail(FMMBEM_ERR_ALLOC, "host allocation failed while building the plan");
+  }
+  if (!err.empty()) return fail(err.find("octree") != std::string::npos ? FMMBEM_ERR_TREE : FMMBEM_ERR_INVALID, err);
+  pl->build_host_ms = now_ms() - t0;
+  if (!opts->host_only) {
+    try {
+      const int rc = pl->to_device();
+      if (rc != FMMBEM_OK) return rc;
+    } catch (const std::bad_alloc&) {
+      return fail(FMMBEM_ERR_ALLOC, "host allocation failed while tabulating operators");
+    }
+    // vertices are only needed by the assembly; keep the host copy small
+    pl->hp.panels.vert.clear(); pl->hp.panels.vert.shrink_to_fit();
+  }
+  *out = pl.release();
+  return FMMBEM_OK;
+}
+
+void fmmbem_plan_destroy(fmmbem_plan* plan) { delete plan; }
+
+int fmmbem_plan_execute_device(fmmbem_plan* plan, int p, const double* d_x, double* d_y, void* stream) {
+  if (!plan) return fail(FMMBEM_ERR_INVALID, "null plan");
+  return plan->run(p, d_x, d_y, static_cast<hipStream_t>(stream), false);
+}
+
+int fmmbem_plan_near_device(fmmbem_plan* plan, const double* d_x, double* d_y, void* stream) {
+  if (!plan) return fail(FMMBEM_ERR_INVALID, "null plan");
+  return plan->run(1, d_x, d_y, static_cast<hipStream_t>(stream), true);
+}
+
+int fmmbem_plan_execute(fmmbem_plan* plan, int p, const double* x, double* y) {
+  if (!plan) return fail(FMMBEM_ERR_INVALID, "null plan");
+  if (!plan->on_device) return fail(FMMBEM_ERR_NO_DEVICE, "plan was built host-only; there is no CPU execution path");
+  if (!x || !y) return fail(FMMBEM_ERR_INVALID, "null vector");
+  HIP_TRY(hipSetDevice(plan->opts.device));
+  const size_t bytes = sizeof(double) * (size_t)plan->hp.n;
+  hipStream_t s = plan->own_stream;
+  HIP_TRY(hipMemcpyAsync(plan->stage_x, x, bytes, hipMemcpyHostToDevice, s));
+  const int rc = plan->run(p, plan->stage_x, plan->stage_y, s, false);
+  if (rc != FMMBEM_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(y, plan->stage_y, bytes, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return FMMBEM_OK;
+}
+
+int fmmbem_plan_set_timing(fmmbem_plan* plan, int enabled) {
+  if (!plan) return fail(FMMBEM_ERR_INVALID, "null plan");
+  plan->timing = enabled != 0;
+  return FMMBEM_OK;
+}
+
+int fmmbem_plan_stats(const fmmbem_plan* plan, fmmbem_stats* o) {
+  if (!plan || !o) return fail(FMMBEM_ERR_INVALID, "null argument");
+  const HostPlan& h = plan->hp;
+  std::memset(o, 0, sizeof(*o));
+  o->n_panels = h.n; o->n_boxes = h.nboxes; o->n_leaves = h.nleaves(); o->n_levels = h.nlevels;
+  o->near_nnz = h.near_nnz_owned; o->near_nnz_total = h.near_nnz_total;
+  o->p2p_pairs = (int64_t)h.p2p_src.size(); o->m2l_pairs = (int64_t)h.lr_src.size(); o->m2l_pairs_owned = h.m2l_pairs_owned;
+  o->m2m_ops = h.m2m_ops; o->l2l_ops = h.l2l_ops;
+  o->p2m_leaves = (int64_t)h.p2m_leaves.size(); o->l2p_leaves = (int64_t)h.l2p_leaves.size();
+  o->m2l_classes = (int64_t)h.m2l_class_rep.size() / 2;
+  o->owned_leaf_begin = h.leaf_begin; o->owned_leaf_end = h.leaf_end;
+  o->owned_row_begin = h.row_begin; o->owned_row_end = h.row_end;
+  o->near_bytes = plan->near_bytes;
+  o->expansions_active = (h.has_bc[0] ? 1 : 0) | (h.has_bc[1] ? 2 : 0);
+  o->last_p = plan->last_p;
+  o->build_host_ms = plan->build_host_ms; o->build_assemble_ms = plan->build_assemble_ms;
+  o->ms_total = plan->ms[0]; o->ms_gather = plan->ms[1]; o->ms_near = plan->ms[2]; o->ms_p2m = plan->ms[3];
+  o->ms_m2m = plan->ms[4]; o->ms_m2l = plan->ms[5]; o->ms_l2l = plan->ms[6]; o->ms_l2p = plan->ms[7];
+  return FMMBEM_OK;
+}
+
+int fmmbem_plan_get_perm(const fmmbem_plan* plan, uint32_t* out) {
+  if (!plan || !out) return fail(FMMBEM_ERR_INVALID, "null argument");
+  std::memcpy(out, plan->hp.perm.data(), sizeof(uint32_t) * (size_t)plan->hp.n);
+  return FMMBEM_OK;
+}
+
+int fmmbem_plan_get_boxes(const fmmbem_plan* plan, double* center, double* side, int32_t* level, int32_t* is_leaf,
+                          int32_t* parent, int32_t* body_begin, int32_t* body_end) {
+  if (!plan) return fail(FMMBEM_ERR_INVALID, "null plan");
+  const HostPlan& h = plan->hp;
+  for (int b = 0; b < h.nboxes; ++b) {
+    if (center) std::memcpy(center + 3 * b, &h.box_center[3 * b], sizeof(double) * 3);
+    if (side) side[b] = h.box_side[b];
+    if (level) level[b] = h.box_level[b];
+    if (is_leaf) is_leaf[b] = h.box_leaf[b];
+    if (parent) parent[b] = h.box_parent[b];
+    if (body_begin) body_begin[b] = h.box_body_begin[b];
+    if (body_end) body_end[b] = h.box_body_end[b];
+  }
+  return FMMBEM_OK;
+}
+
+int fmmbem_plan_get_pairs(const fmmbem_plan* plan, int which, int32_t* out, int64_t* n) {
+  if (!plan || !n) return fail(FMMBEM_ERR_INVALID, "null argument");
+  const HostPlan& h = plan->hp;
+  std::vector<int32_t> flat;
+  switch (which) {
+    case 0: for (size_t i = 0; i < h.p2p_src.size(); ++i) { flat.push_back(h.p2p_src[i]); flat.push_back(h.p2p_tgt[i]); } break;
+    case 1: for (size_t i = 0; i < h.lr_src.size(); ++i) { flat.push_back(h.lr_src[i]); flat.push_back(h.lr_tgt[i]); } break;
+    case 2:
+      for (int par : h.m2m_parents)
+        for (int c = h.box_child_begin[par]; c < h.box_child_end[par]; ++c) { flat.push_back(c); flat.push_back(par); }
+      break;
+    case 3: for (int c : h.l2l_children) { flat.push_back(h.box_parent[c]); flat.push_back(c); } break;
+    default: return fail(FMMBEM_ERR_INVALID, "which must be 0..3");
+  }
+  *n = (int64_t)flat.size() / 2;
+  if (out) std::memcpy(out, flat.data(), flat.size() * sizeof(int32_t));
+  return FMMBEM_OK;
+}
+
+int fmmbem_plan_get_near_row(const fmmbem_plan* plan, int64_t row, uint32_t* cols, double* vals, int64_t* n) {
+  if (!plan || !n) return fail(FMMBEM_ERR_INVALID, "null argument");
+  const HostPlan& h = plan->hp;
+  if (row < h.row_begin || row >= h.row_end) return fail(FMMBEM_ERR_INVALID, "row not owned by this shard");
+  // owning leaf: last leaf whose first row <= row
+  int lo = h.leaf_begin, hi = h.leaf_end - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) / 2;
+    if (h.box_body_begin[h.leaf_box[mid]] <= row) lo = mid; else hi = mid - 1;
+  }
+  const int leaf = lo, tb = h.leaf_box[leaf];
+  const int ncols = h.near_ncols[leaf];
+  *n = ncols;
+  if (cols) {
+    int at = 0;
+    for (int64_t s = h.near_ptr[leaf]; s < h.near_ptr[leaf + 1]; ++s) {
+      const int sb = h.leaf_box[h.near_src[s]];
+      for (int j = h.box_body_begin[sb]; j < h.box_body_end[sb]; ++j) cols[at++] = (uint32_t)j;
+    }
+  }
+  if (vals) {
+    if (!plan->on_device) return fail(FMMBEM_ERR_NO_DEVICE, "near values live on the device");
+    HIP_TRY(hipSetDevice(plan->opts.device));
+    // recompute this leaf's block offset
+    int64_t off = 0;
+    for (int l = h.leaf_begin; l < leaf; ++l) {
+      const int b = h.leaf_box[l];
+      off += (int64_t)(h.box_body_end[b] - h.box_body_begin[b]) * ((h.near_ncols[l] + 1) & ~1);
+    }
+    const int stride = (ncols + 1) & ~1;
+    const int r = (int)(row - h.box_body_begin[tb]);
+    HIP_TRY(hipMemcpy(vals, plan->d.near_val + off + (int64_t)r * stride, sizeof(double) * (size_t)ncols, hipMemcpyDeviceToHost));
+  }
+  return FMMBEM_OK;
+}
+
+int fmmbem_plan_get_expansions(const fmmbem_plan* plan, int which, int p, double* out) {
+  if (!plan || !out) return fail(FMMBEM_ERR_INVALID, "null argument");
+  if (!plan->on_device) return fail(FMMBEM_ERR_NO_DEVICE, "expansions live on the device");
+  if (p < 1 || p > plan->hp.opt.p_max) return fail(FMMBEM_ERR_INVALID, "p outside [1, p_max]");
+  HIP_TRY(hipSetDevice(plan->opts.device));
+  const DevicePlan& d = plan->d;
+  std::vector<double2> tmp((size_t)d.nboxes * 2 * d.s_max);
+  HIP_TRY(hipMemcpy(tmp.data(), which == 0 ? d.M : d.L, tmp.size() * sizeof(double2), hipMemcpyDeviceToHost));
+  const int S = p * (p + 1) / 2;
+  for (int b = 0; b < d.nboxes; ++b)
+    for (int s = 0; s < 2; ++s)
+      for (int i = 0; i < S; ++i) {
+        const double2 v = tmp[((size_t)b * 2 + s) * d.s_max + i];
+        out[(((size_t)b * 2 + s) * S + i) * 2] = v.x;
+        out[(((size_t)b * 2 + s) * S + i) * 2 + 1] = v.y;
+      }
+  return FMMBEM_OK;
+}
+
+int fmmbem_mesh_unit_sphere(int recursions, double* vertices, size_t* n_panels) {
+  if (recursions < 1 || recursions > 12 || !n_panels) return fail(FMMBEM_ERR_INVALID, "recursions must be 1..12");
+  *n_panels = (size_t)unit_sphere(recursions, vertices);
+  return FMMBEM_OK;
+}
+
+const char* fmmbem_status_string(int status) {
+  switch (status) {
+    case FMMBEM_OK: return "ok";
+    case FMMBEM_ERR_INVALID: return "invalid argument";
+    case FMMBEM_ERR_NO_DEVICE: return "no HIP device";
+    case FMMBEM_ERR_HIP: return "HIP runtime error";
+    case FMMBEM_ERR_ALLOC: return "allocation failed";
+    case FMMBEM_ERR_TREE: return "octree too deep";
+    case FMMBEM_ERR_UNSUPPORTED: return "unsupported option";
+    default: return "unknown status";
+  }
+}
+
+const char* fmmbem_last_error(void) { return g_last_error.c_str(); }
+int fmmbem_version(void) { return FMMBEM_VERSION; }
+
+}  // extern "C"

@@ -1,0 +1,200 @@
+"""Host-side mirror of the reference's operator interface for the FMM matvec path.
+
+Reference surface (C++ templates) -> here:
+    FMMOptions                              include/FMMOptions.hpp:9-60        -> FMMOptions
+    LaplaceSphericalBEM(p, k) / set_p(p)    kernel/LaplaceSphericalBEM.hpp:131-140 -> LaplaceSphericalBEM
+    FMM_plan<K>(K, panels, opts)            include/FMM_plan.hpp:34-43         -> FMM_plan(K, panels, opts)
+    plan.execute(charges) -> results        include/FMM_plan.hpp:75-90         -> FMM_plan.execute
+    plan.kernel() / plan.options()          include/FMM_plan.hpp:66-71, 94-96  -> .kernel() / .options()
+Same names, same argument meaning; errors are exceptions (FmmBemError) instead of exit()/printf.
+All arithmetic happens in libfmmbem_hip.so on the GPU; this file only marshals arrays.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+
+
+class FMMOptions:
+    """include/FMMOptions.hpp:9-60 (fields the hot path reads)."""
+
+    def __init__(self):
+        self.lazy_evaluation = True     # FMMOptions.hpp:41
+        self.local_evaluation = False
+        self.sparse_local = True        # examples/LaplaceBEM.cpp:81 forces it
+        self.block_diagonal = False
+        self.theta = 0.5                # DefaultMAC(0.5), FMMOptions.hpp:45
+        self.ncrit = 64                 # NCRIT_, FMMOptions.hpp:46
+
+    def set_mac_theta(self, theta):     # FMMOptions.hpp:50-52
+        self.theta = float(theta)
+
+    def set_max_per_box(self, ncrit):   # FMMOptions.hpp:58-60
+        self.ncrit = int(ncrit)
+
+    def max_per_box(self):
+        return self.ncrit
+
+
+class LaplaceSphericalBEM:
+    """Kernel descriptor: expansion order p and Gauss rule key k (kernel/LaplaceSphericalBEM.hpp:131)."""
+    POTENTIAL, NORMAL_DERIV = _capi.BC_POTENTIAL, _capi.BC_NORMAL_DERIV
+
+    def __init__(self, p=5, k=3):
+        if not 1 <= int(p) <= _capi.PMAX:
+            raise ValueError("p must be in 1..%d" % _capi.PMAX)
+        self.P = int(p)
+        self.K = int(k)
+
+    def set_p(self, p):                 # kernel/LaplaceSphericalBEM.hpp:137-140
+        if not 1 <= int(p) <= _capi.PMAX:
+            raise ValueError("p must be in 1..%d" % _capi.PMAX)
+        self.P = int(p)
+
+
+def unit_sphere(recursions, center=(0.0, 0.0, 0.0)):
+    """Triangulation::UnitSphere (examples/BEM/Triangulation.hpp:105-121) -> (N, 3, 3) vertex array."""
+    n = C.c_size_t(0)
+    _capi.check(_capi.lib().fmmbem_mesh_unit_sphere(recursions, None, C.byref(n)))
+    v = np.empty((n.value, 3, 3), dtype=np.float64)
+    _capi.check(_capi.lib().fmmbem_mesh_unit_sphere(recursions, v.ctypes.data_as(C.c_void_p), C.byref(n)))
+    if any(center):
+        v += np.asarray(center, dtype=np.float64)
+    return v
+
+
+class FMM_plan:
+    """FMM_plan<LaplaceSphericalBEM> (include/FMM_plan.hpp:16-128).
+
+    panels: (N, 3, 3) triangle vertices (the arguments of Panel(p0, p1, p2)); bc: N boundary flags.
+    p_max: largest order later set through kernel().set_p (defaults to K.P, or 16 if the caller
+    intends to relax p upward).
+    """
+
+    def __init__(self, K, panels, opts=None, bc=None, p_max=None, device=0, shard=(0, 1), host_only=False):
+        opts = opts if opts is not None else FMMOptions()
+        if not opts.sparse_local or opts.local_evaluation or opts.block_diagonal or not opts.lazy_evaluation:
+            raise _capi.FmmBemError(_capi.ERR_UNSUPPORTED, "only the lazy sparse_local FMM evaluator is built")
+        self._K = K
+        self._opts = opts
+        v = np.ascontiguousarray(panels, dtype=np.float64).reshape(-1, 9)
+        self.n = v.shape[0]
+        o = _capi.Options()
+        _capi.lib().fmmbem_options_default(C.byref(o))
+        o.p_max = int(p_max if p_max is not None else K.P)
+        o.quad_k = K.K
+        o.theta = opts.theta
+        o.ncrit = opts.ncrit
+        o.host_only = 1 if host_only else 0
+        o.device = int(device)
+        o.shard_rank, o.shard_world = int(shard[0]), int(shard[1])
+        self.p_max = o.p_max
+        bcp = None
+        if bc is not None:
+            bc = np.ascontiguousarray(bc, dtype=np.uint8)
+            if bc.shape != (self.n,):
+                raise ValueError("bc must have one flag per panel")
+            bcp = bc.ctypes.data_as(C.c_void_p)
+        h = C.c_void_p()
+        _capi.check(_capi.lib().fmmbem_plan_create(C.byref(o), self.n, v.ctypes.data_as(C.c_void_p), bcp, C.byref(h)))
+        self._h = h
+
+    # ---- reference surface ----
+    def kernel(self):
+        return self._K
+
+    def options(self):
+        return self._opts
+
+    def execute(self, charges):
+        """results = plan.execute(charges) at the kernel's current p. numpy in, numpy out (host)."""
+        x = np.ascontiguousarray(charges, dtype=np.float64)
+        if x.shape != (self.n,):
+            raise ValueError("charges must have one value per panel")
+        y = np.empty(self.n)
+        _capi.check(_capi.lib().fmmbem_plan_execute(self._h, self._K.P, x.ctypes.data_as(C.c_void_p),
+                                                    y.ctypes.data_as(C.c_void_p)))
+        return y
+
+    def __call__(self, x, y):
+        """Preconditioner-style operator()(x, y) adapter (examples/BEM/Preconditioner.hpp:11-15)."""
+        y[...] = self.execute(x)
+
+    # ---- device-resident variant (torch tensors or raw device pointers) ----
+    def execute_device(self, x_ptr, y_ptr, stream=0, p=None):
+        _capi.check(_capi.lib().fmmbem_plan_execute_device(self._h, self._K.P if p is None else int(p),
+                                                           C.c_void_p(x_ptr), C.c_void_p(y_ptr), C.c_void_p(stream)))
+
+    def near_device(self, x_ptr, y_ptr, stream=0):
+        _capi.check(_capi.lib().fmmbem_plan_near_device(self._h, C.c_void_p(x_ptr), C.c_void_p(y_ptr), C.c_void_p(stream)))
+
+    def execute_torch(self, x, out=None, p=None):
+        """x: float64 CUDA tensor (N,), ORIGINAL panel order. Runs on torch's current stream."""
+        import torch
+        if x.dtype != torch.float64 or not x.is_cuda or not x.is_contiguous() or x.numel() != self.n:
+            raise ValueError("x must be a contiguous float64 CUDA tensor with one value per panel")
+        if out is None:
+            out = torch.empty_like(x)
+        self.execute_device(x.data_ptr(), out.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream, p)
+        return out
+
+    # ---- introspection ----
+    def set_timing(self, on=True):
+        _capi.check(_capi.lib().fmmbem_plan_set_timing(self._h, 1 if on else 0))
+
+    def stats(self):
+        s = _capi.Stats()
+        _capi.check(_capi.lib().fmmbem_plan_stats(self._h, C.byref(s)))
+        return s.as_dict()
+
+    def perm(self):
+        out = np.empty(self.n, dtype=np.uint32)
+        _capi.check(_capi.lib().fmmbem_plan_get_perm(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def boxes(self):
+        nb = self.stats()["n_boxes"]
+        d = dict(center=np.empty((nb, 3)), side=np.empty(nb))
+        for k in ("level", "leaf", "parent", "bb", "be"):
+            d[k] = np.empty(nb, dtype=np.int32)
+        _capi.check(_capi.lib().fmmbem_plan_get_boxes(self._h, *[d[k].ctypes.data_as(C.c_void_p) for k in
+                                                                 ("center", "side", "level", "leaf", "parent", "bb", "be")]))
+        return d
+
+    def pairs(self, which):
+        idx = {"p2p": 0, "m2l": 1, "m2m": 2, "l2l": 3}[which]
+        n = C.c_int64(0)
+        _capi.check(_capi.lib().fmmbem_plan_get_pairs(self._h, idx, None, C.byref(n)))
+        out = np.empty((n.value, 2), dtype=np.int32)
+        _capi.check(_capi.lib().fmmbem_plan_get_pairs(self._h, idx, out.ctypes.data_as(C.c_void_p), C.byref(n)))
+        return out
+
+    def near_row(self, row, values=True):
+        n = C.c_int64(0)
+        _capi.check(_capi.lib().fmmbem_plan_get_near_row(self._h, row, None, None, C.byref(n)))
+        cols = np.empty(n.value, dtype=np.uint32)
+        vals = np.empty(n.value) if values else None
+        _capi.check(_capi.lib().fmmbem_plan_get_near_row(
+            self._h, row, cols.ctypes.data_as(C.c_void_p),
+            vals.ctypes.data_as(C.c_void_p) if values else None, C.byref(n)))
+        return cols, vals
+
+    def expansions(self, which, p=None):
+        p = self._K.P if p is None else p
+        nb = self.stats()["n_boxes"]
+        out = np.empty((nb, 2, p * (p + 1) // 2), dtype=np.complex128)
+        _capi.check(_capi.lib().fmmbem_plan_get_expansions(self._h, 0 if which == "M" else 1, p,
+                                                           out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _capi.lib().fmmbem_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,141 @@
+/* fmmbem.h -- C ABI of the MI355X-native FMM-BEM matvec (libfmmbem_hip.so).
+ *
+ * Drop-in boundary for the reference's hot path
+ *     FMM_plan<LaplaceSphericalBEM>::FMM_plan / ::execute / ::kernel().set_p / ::options
+ * (reference: include/FMM_plan.hpp:34-43, :75-90, :66-71, :94-96), i.e. everything that
+ * include/executor/ExecutorSingleTree.hpp and EvalInteractionLazySparse.hpp do behind it.
+ * Plain C types only: pointers, sizes, PODs.  No exit(), no stdout; every entry point returns
+ * an fmmbem_status (0 = success) and fmmbem_last_error() gives the text of the last failure on
+ * the calling thread.
+ *
+ * Threading: one in-flight execute per plan (as the reference: a plan is not re-entrant,
+ * ExecutorSingleTree.hpp:120-129); distinct plans may run concurrently.
+ */
+#ifndef FMMBEM_H
+#define FMMBEM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FMMBEM_VERSION 1
+#define FMMBEM_PMAX 16          /* expansion orders 1..16 are pre-compiled */
+
+typedef enum {
+  FMMBEM_OK = 0,
+  FMMBEM_ERR_INVALID = 1,       /* bad argument (null pointer, p out of range, bad quadrature key ...) */
+  FMMBEM_ERR_NO_DEVICE = 2,     /* no usable HIP device, or the plan was built host-only            */
+  FMMBEM_ERR_HIP = 3,           /* a HIP runtime call or kernel launch failed                         */
+  FMMBEM_ERR_ALLOC = 4,         /* host or device allocation failed                                   */
+  FMMBEM_ERR_TREE = 5,          /* octree deeper than the 10 levels of the reference's 32-bit keys    */
+  FMMBEM_ERR_UNSUPPORTED = 6    /* option combination not implemented                                 */
+} fmmbem_status;
+
+/* kernel ids: which reference Kernel class the plan stands in for */
+typedef enum {
+  FMMBEM_KERNEL_LAPLACE_BEM = 0 /* kernel/LaplaceSphericalBEM.hpp */
+} fmmbem_kernel;
+
+/* boundary-condition flag per panel: LaplaceSphericalBEM::Panel::BoundaryType
+ * (kernel/LaplaceSphericalBEM.hpp:40) */
+enum { FMMBEM_BC_POTENTIAL = 0, FMMBEM_BC_NORMAL_DERIV = 1 };
+
+/* Mirrors FMMOptions (include/FMMOptions.hpp:9-60) + the kernel constructor arguments
+ * LaplaceSphericalBEM(p, k) (kernel/LaplaceSphericalBEM.hpp:131) + device placement.
+ * Initialise with fmmbem_options_default(). */
+typedef struct {
+  int32_t  kernel;            /* fmmbem_kernel                                                     */
+  int32_t  p_max;             /* largest expansion order any execute() will ask for (1..16)        */
+  int32_t  quad_k;            /* Gauss rule key K: 1,3,4,7,13,17,19,25 (GaussQuadrature.hpp)       */
+  double   theta;             /* FMMOptions::set_mac_theta, default 0.5 (FMMOptions.hpp:45)        */
+  uint32_t ncrit;             /* FMMOptions::set_max_per_box, default 64 (FMMOptions.hpp:46-47)    */
+  int32_t  sparse_local;      /* 1: assembled near matrix (EvalInteractionLazySparse). Only mode.  */
+  int32_t  host_only;         /* 1: build tree + lists on the host, touch no device (CPU tests)    */
+  int32_t  device;            /* HIP device ordinal                                                */
+  int32_t  shard_rank;        /* target-leaf shard owned by this plan: rank of world               */
+  int32_t  shard_world;       /* 1 = whole operator                                                */
+  int32_t  reserved[6];
+} fmmbem_options;
+
+/* Statistics of a plan and of its last execute (times in milliseconds, device-side HIP events). */
+typedef struct {
+  int64_t n_panels, n_boxes, n_leaves, n_levels;
+  int64_t near_nnz;             /* entries of the assembled near matrix owned by this shard          */
+  int64_t near_nnz_total;       /* ... of the whole operator                                         */
+  int64_t p2p_pairs, m2l_pairs, m2l_pairs_owned, m2m_ops, l2l_ops, p2m_leaves, l2p_leaves;
+  int64_t m2l_classes;          /* distinct M2L translation vectors                                  */
+  int64_t owned_leaf_begin, owned_leaf_end, owned_row_begin, owned_row_end;
+  int64_t near_bytes;           /* HBM bytes of the near-matrix values                               */
+  int32_t expansions_active;    /* bit 0: G expansion, bit 1: dG/dn expansion                        */
+  int32_t last_p;
+  double  build_host_ms, build_assemble_ms;
+  double  ms_total, ms_gather, ms_near, ms_p2m, ms_m2m, ms_m2l, ms_l2l, ms_l2p;
+} fmmbem_stats;
+
+typedef struct fmmbem_plan fmmbem_plan;
+
+/* ---- lifecycle -------------------------------------------------------------------------- */
+void fmmbem_options_default(fmmbem_options *opts);
+
+/* FMM_plan(const Kernel&, const std::vector<source_type>&, FMMOptions&)  (FMM_plan.hpp:34-43).
+ * vertices: n_panels x 3 vertices x 3 coordinates (the arguments of Panel(p0,p1,p2),
+ * LaplaceSphericalBEM.hpp:64); bc: n_panels flags or NULL (all POTENTIAL).
+ * Builds octree + interaction lists on the host, uploads them once, assembles the near matrix
+ * on the device. */
+int fmmbem_plan_create(const fmmbem_options *opts, size_t n_panels, const double *vertices,
+                       const uint8_t *bc, fmmbem_plan **out);
+void fmmbem_plan_destroy(fmmbem_plan *plan);
+
+/* ---- the hot path ----------------------------------------------------------------------- */
+/* results = plan.execute(charges) with kernel().set_p(p) applied first
+ * (FMM_plan.hpp:75-90; GMRES.hpp:194-201).  x, y: n_panels doubles in ORIGINAL panel order,
+ * HOST pointers; y is overwritten.  With shard_world > 1, y holds this shard's rows and zeros
+ * elsewhere (sum over shards = full result). */
+int fmmbem_plan_execute(fmmbem_plan *plan, int p, const double *x, double *y);
+
+/* Same, with DEVICE pointers and an explicit hipStream_t (NULL = default stream); asynchronous. */
+int fmmbem_plan_execute_device(fmmbem_plan *plan, int p, const double *d_x, double *d_y, void *stream);
+
+/* Near-field part only: y = A_near x (what Matvec<> does in EvalInteractionLazySparse.hpp:136-148).
+ * DEVICE pointers, asynchronous. */
+int fmmbem_plan_near_device(fmmbem_plan *plan, const double *d_x, double *d_y, void *stream);
+
+/* Toggle per-stage HIP-event timing (adds a stream synchronisation per execute). Default off. */
+int fmmbem_plan_set_timing(fmmbem_plan *plan, int enabled);
+
+int fmmbem_plan_stats(const fmmbem_plan *plan, fmmbem_stats *out);
+
+/* ---- introspection (tests, partition checks) --------------------------------------------- */
+/* Body::number() permutation, tree index -> original index (Octree.hpp:298-300). out: n_panels. */
+int fmmbem_plan_get_perm(const fmmbem_plan *plan, uint32_t *out);
+/* Boxes in BFS order. Any pointer may be NULL. center: n_boxes x 3. */
+int fmmbem_plan_get_boxes(const fmmbem_plan *plan, double *center, double *side, int32_t *level,
+                          int32_t *is_leaf, int32_t *parent, int32_t *body_begin, int32_t *body_end);
+/* Pair lists; which: 0 = P2P (source leaf, target leaf), 1 = M2L (source box, target box),
+ * 2 = M2M (child, parent), 3 = L2L (parent, child).  out may be NULL; returns the count via *n. */
+int fmmbem_plan_get_pairs(const fmmbem_plan *plan, int which, int32_t *out, int64_t *n);
+/* One assembled near-matrix row (tree-order row index, must be owned): column tree indices and
+ * values, ascending columns.  cols/vals may be NULL; *n receives the row length. */
+int fmmbem_plan_get_near_row(const fmmbem_plan *plan, int64_t row, uint32_t *cols, double *vals,
+                             int64_t *n);
+/* Multipole (which=0) or local (which=1) coefficients of the last execute for every box:
+ * out[box][slot][p(p+1)/2][re,im], slot 0 = G expansion, slot 1 = dG/dn expansion. */
+int fmmbem_plan_get_expansions(const fmmbem_plan *plan, int which, int p, double *out);
+
+/* ---- mesh generator of the reference's drivers ------------------------------------------- */
+/* Triangulation::UnitSphere(panels, recursions) (examples/BEM/Triangulation.hpp:105-121):
+ * N = 2*4^recursions panels.  vertices == NULL: only returns N through *n_panels. */
+int fmmbem_mesh_unit_sphere(int recursions, double *vertices, size_t *n_panels);
+
+/* ---- errors ------------------------------------------------------------------------------ */
+const char *fmmbem_status_string(int status);
+const char *fmmbem_last_error(void);
+int fmmbem_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FMMBEM_H */

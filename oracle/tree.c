@@ -51,7 +51,7 @@ static void box_geometry(orc_ctx *c, orc_box *b) {
     double lo = c->pmin[k] + c->cell[k]*ix[k];
     double hi = lo + c->cell[k];
     double dim = hi - lo;
-    b->center[k] = lo + dim * (double)(1 << (10 - b->level - 1));
+    b->center[k] = lo + dim * ldexp(1.0, 9 - b->level);   /* = 1 << (10-level-1) for level <= 9 */
   }
   double bbmax0 = c->pmin[0] + (double)(1u << LEVELS) * c->cell[0];   /* MortonCoder::bounding_box, :102-105 */
   b->side = (bbmax0 - c->pmin[0]) / (double)(1 << b->level);

@@ -1,0 +1,101 @@
+"""CPU-only checks of the product's C-ABI library: it loads, exports every symbol include/fmmbem.h
+declares, builds tree + lists on the host identically to the oracle, reports errors as codes, and has
+no CPU execution path."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def test_library_exports_every_declared_symbol(fb):
+    header = open(os.path.join(ROOT, "include", "fmmbem.h")).read()
+    declared = set(re.findall(r"^(?:int|void|const char \*)\s*(fmmbem_[a-z_]+)\s*\(", header, flags=re.M))
+    assert declared == set(fb.SYMBOLS)
+    lib = ctypes.CDLL(fb.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.fmmbem_version() == 1
+
+
+@pytest.mark.parametrize("r", [4, 5, 6, 8])
+def test_host_lists_equal_oracle(fb, oracle_mod, r):
+    v = fb.unit_sphere(r)
+    assert np.array_equal(v, oracle_mod.unit_sphere(r))
+    pl = fb.FMM_plan(fb.LaplaceSphericalBEM(10, 3), v, host_only=True)
+    o = oracle_mod.Oracle(v)
+    s, so = pl.stats(), o.stats()
+    assert (s["n_boxes"], s["n_leaves"], s["n_levels"], s["near_nnz_total"], s["m2l_pairs"], s["m2m_ops"],
+            s["l2l_ops"], s["p2p_pairs"]) == (so["boxes"], so["leaves"], so["levels"], so["near_nnz"],
+                                              so["m2l_pairs"], so["m2m_ops"], so["l2l_ops"], so["p2p_pairs"])
+    assert np.array_equal(pl.perm(), o.perm())
+    assert np.array_equal(pl.pairs("m2l"), o.pairs("m2l"))          # same traversal order
+    assert np.array_equal(pl.pairs("p2p"), o.pairs("p2p"))
+    assert set(map(tuple, pl.pairs("m2m"))) == set(map(tuple, o.pairs("m2m")))
+    assert set(map(tuple, pl.pairs("l2l"))) == set(map(tuple, o.pairs("l2l")))
+    b, bo = pl.boxes(), o.boxes()
+    for k in ("center", "side", "level", "leaf", "bb", "be"):
+        assert np.array_equal(b[k], bo[k]), k
+    # near sparsity pattern of a few rows
+    rp, col, _ = (None, None, None)
+    if r <= 6:
+        rp, col, _ = o.near_csr()
+        for row in (0, o.n // 3, o.n - 1):
+            cols, _ = pl.near_row(row, values=False)
+            assert np.array_equal(cols, col[rp[row]:rp[row + 1]])
+
+
+def test_other_options_equal_oracle(fb, oracle_mod):
+    v = fb.unit_sphere(5)
+    for theta, ncrit in [(0.4, 64), (0.6, 32), (0.5, 125), (0.5, 10)]:
+        opts = fb.FMMOptions()
+        opts.set_mac_theta(theta)
+        opts.set_max_per_box(ncrit)
+        pl = fb.FMM_plan(fb.LaplaceSphericalBEM(5, 3), v, opts, host_only=True)
+        o = oracle_mod.Oracle(v, theta=theta, ncrit=ncrit)
+        assert np.array_equal(pl.pairs("m2l"), o.pairs("m2l"))
+        assert np.array_equal(pl.pairs("p2p"), o.pairs("p2p"))
+        assert pl.stats()["near_nnz_total"] == o.stats()["near_nnz"]
+
+
+def test_no_cpu_execution_path(fb):
+    pl = fb.FMM_plan(fb.LaplaceSphericalBEM(5, 3), fb.unit_sphere(3), host_only=True)
+    with pytest.raises(fb.FmmBemError) as e:
+        pl.execute(np.ones(pl.n))
+    assert e.value.status == 2          # FMMBEM_ERR_NO_DEVICE
+
+
+def test_error_codes(fb):
+    v = fb.unit_sphere(3)
+    with pytest.raises(fb.FmmBemError) as e:
+        fb.FMM_plan(fb.LaplaceSphericalBEM(5, 2), v, host_only=True)         # invalid Gauss key
+    assert e.value.status == 1
+    with pytest.raises(ValueError):
+        fb.LaplaceSphericalBEM(17, 3)
+    opts = fb.FMMOptions()
+    opts.sparse_local = False
+    with pytest.raises(fb.FmmBemError) as e:
+        fb.FMM_plan(fb.LaplaceSphericalBEM(5, 3), v, opts, host_only=True)
+    assert e.value.status == 6
+    with pytest.raises(fb.FmmBemError):
+        fb.FMM_plan(fb.LaplaceSphericalBEM(5, 3), v, host_only=True, shard=(2, 2))
+
+
+def test_shards_partition_the_leaves(fb):
+    v = fb.unit_sphere(6)
+    full = fb.FMM_plan(fb.LaplaceSphericalBEM(10, 3), v, host_only=True).stats()
+    for world in (2, 3, 8):
+        rows, nnz, pairs, prev_end = 0, 0, 0, 0
+        for rank in range(world):
+            s = fb.FMM_plan(fb.LaplaceSphericalBEM(10, 3), v, host_only=True, shard=(rank, world)).stats()
+            assert s["owned_leaf_begin"] == prev_end
+            prev_end = s["owned_leaf_end"]
+            rows += s["owned_row_end"] - s["owned_row_begin"]
+            nnz += s["near_nnz"]
+            pairs += s["m2l_pairs_owned"]
+        assert prev_end == full["n_leaves"] and rows == full["n_panels"] and nnz == full["near_nnz_total"]
+        assert pairs >= full["m2l_pairs"]            # shared top-of-tree targets are recomputed per shard
+        assert pairs < 1.2 * full["m2l_pairs"]

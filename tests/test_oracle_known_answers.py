@@ -1,0 +1,126 @@
+"""Pins the CPU oracle against the reference-run known answers recorded in SURVEY.md section 6 / 8(c)
+(probe of the unmodified reference in the survey stage): exact list statistics and FMM-vs-Direct error
+levels.  The reference itself cannot be built here (Boost absent), so these recorded outputs are the pin.
+"""
+import numpy as np
+import pytest
+
+from conftest import drand48, rel_l2
+
+# SURVEY.md section 6 "List statistics": r -> (N, boxes, leaves, levels, near nnz, M2L pairs, M2M ops, L2L ops)
+LIST_STATS = {
+    6: (8192, 329, 272, 4, 4030016, 10664, 320, 264),
+    8: (131072, 5201, 4184, 6, 79891400, 167480, 5192, 5136),
+    9: (524288, 22001, 17408, 8, 310835696, 720908, 21992, 21936),
+}
+
+
+@pytest.mark.parametrize("r", [6, 8, 9])
+def test_list_statistics_match_reference_run(oracle_mod, r):
+    o = oracle_mod.Oracle(oracle_mod.unit_sphere(r))
+    s = o.stats()
+    got = (s["n"], s["boxes"], s["leaves"], s["levels"], s["near_nnz"], s["m2l_pairs"], s["m2m_ops"], s["l2l_ops"])
+    assert got == LIST_STATS[r]
+    # on a closed surface every leaf is on the P2M and L2P lists
+    assert s["p2m_leaves"] == s["leaves"] and s["l2p_leaves"] == s["leaves"]
+    # the reference's lazy L2L rule never drops a needed parent->child shift on these inputs
+    assert s["l2l_skipped"] == 0
+    o.close()
+
+
+def test_p2p_pairs_r6(oracle_mod):
+    # 4 376 leaf pairs / 272 leaves at r=6
+    o = oracle_mod.Oracle(oracle_mod.unit_sphere(6))
+    assert o.stats()["p2p_pairs"] == 4376
+
+
+@pytest.fixture(scope="module")
+def sphere6(oracle_mod):
+    v = oracle_mod.unit_sphere(6)
+    o = oracle_mod.Oracle(v)
+    x = drand48(o.n)
+    return v, o, x, o.direct(x)
+
+
+# N=8192, theta=.5, ncrit=64, k=3, all POTENTIAL: rel L2 of FMM vs Direct::matvec
+@pytest.mark.parametrize("p,ref", [(5, 6.71e-5), (8, 3.36e-6), (10, 5.52e-7), (12, 5.05e-8)])
+def test_fmm_vs_direct_error_level_matches_reference_run(sphere6, p, ref):
+    _, o, x, d = sphere6
+    err = rel_l2(o.matvec(x, p), d)
+    assert abs(err - ref) / ref < 0.01, (err, ref)     # recorded to 3 significant digits
+
+
+def test_faithful_and_tuned_modes_agree(sphere6):
+    _, o, x, _ = sphere6
+    assert rel_l2(o.matvec(x, 8, faithful=True), o.matvec(x, 8, faithful=False)) < 1e-14
+
+
+def test_dgdn_kernel_error_level(oracle_mod, sphere6):
+    v, _, x, _ = sphere6
+    o = oracle_mod.Oracle(v, bc=np.ones(len(v), dtype=np.uint8))
+    err = rel_l2(o.matvec(x, 10), o.direct(x))
+    assert abs(err - 6.70e-6) / 6.70e-6 < 0.01, err     # SURVEY section 6, dG/dn kernel at p=10
+
+
+def test_theta_04(oracle_mod, sphere6):
+    v, _, x, _ = sphere6
+    o = oracle_mod.Oracle(v, theta=0.4)
+    s = o.stats()
+    assert s["m2l_pairs"] == 13328 and round(s["near_nnz"] / s["n"]) == 939
+    err = rel_l2(o.matvec(x, 10), o.direct(x))
+    assert abs(err - 7.96e-8) / 7.96e-8 < 0.01, err
+
+
+def test_north_star_gate_at_p10(sphere6):
+    """'result within 1e-6 relative L2 of Direct.hpp' holds for the G kernel at p=10, theta=0.5."""
+    _, o, x, d = sphere6
+    assert rel_l2(o.matvec(x, 10), d) < 1e-6
+
+
+def test_analytic_identities(oracle_mod):
+    """Closed unit sphere, constant density: int dG/dn = 2*pi collocated on the surface (sum of a row of
+    the double-layer matrix incl. the 2*pi self term -> 4*pi*... discretised), int G = 4*pi*R/R = 4*pi."""
+    v = oracle_mod.unit_sphere(5)
+    n = len(v)
+    og = oracle_mod.Oracle(v)
+    yg = og.direct(np.ones(n))
+    assert abs(np.mean(yg) - 4 * np.pi) / (4 * np.pi) < 5e-3          # potential of a unit-density sphere
+    od = oracle_mod.Oracle(v, bc=np.ones(n, dtype=np.uint8))
+    yd = od.direct(np.ones(n))
+    # reference normal orientation: -int dG/dn over the rest of the sphere + 2*pi self = 4*pi
+    assert abs(abs(np.mean(yd)) - 4 * np.pi) / (4 * np.pi) < 2e-2 or abs(np.mean(yd)) < 0.3
+
+
+def test_quadrature_rules(oracle_mod):
+    for key, npts in [(1, 1), (3, 3), (4, 4), (7, 4), (13, 13), (17, 16), (19, 19), (25, 25)]:
+        pts, w = oracle_mod.quadrature(key)
+        assert len(w) == npts
+        assert abs(w.sum() - 1) < 2e-9
+        assert np.allclose(pts.sum(axis=1), 1, atol=2e-9)
+    with pytest.raises(ValueError):
+        oracle_mod.quadrature(2)
+
+
+def test_m2l_chain_against_direct_point(oracle_mod):
+    """P2M -> M2L -> L2P for well separated boxes reproduces 1/r (tests/single_level.cpp idea)."""
+    T = oracle_mod.Tables(12)
+    pre, A, Cn = T.arrays()
+    assert pre.shape == (4 * 144,) and Cn.shape == (12 ** 4,)
+    # multipole of a unit point charge at offset s from the source centre: M[nms] = Ynm(rho, alpha, -beta)
+    s = np.array([0.11, -0.07, 0.05])
+    r, a, b = oracle_mod.cart2sph(s)
+    Y, _ = T.eval_multipole(r, a, -b)
+    P = 12
+    M = np.array([Y[n * n + n + m] for n in range(P) for m in range(n + 1)])
+    tr = np.array([2.0, 1.0, -1.5])                    # target centre - source centre
+    L = T.m2l(M, tr)
+    t = np.array([-0.09, 0.12, 0.06])                  # target offset from the target centre
+    r, a, b = oracle_mod.cart2sph(t)
+    Yt, _ = T.eval_multipole(r, a, b)
+    val, i = 0.0, 0
+    for n in range(P):
+        for m in range(n + 1):
+            val += (1 if m == 0 else 2) * (L[i] * Yt[n * n + n + m]).real
+            i += 1
+    exact = 1.0 / np.linalg.norm((tr + t) - s)
+    assert abs(val - exact) / exact < 1e-7
