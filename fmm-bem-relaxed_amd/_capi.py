@@ -64,6 +64,14 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise ImportError("%s not found: build it with `make -C %s` (hipcc --offload-arch=gfx950). "
                           "There is no CPU fallback." % (LIB_PATH, os.path.join(_HERE, "csrc")))
+    # One HIP runtime per process: torch ships its own libamdhip64.so (SONAME libamdhip64.so.7). Loading
+    # torch FIRST makes our NEEDED "libamdhip64.so.7" resolve to that already-loaded copy, so device
+    # pointers of torch tensors and torch streams are valid inside this library.  (Loaded the other way
+    # round the process ends up with two runtimes and torch then reports "No HIP GPUs are available".)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i32, i64p = C.c_void_p, C.c_int, C.POINTER(C.c_int64)
     L.fmmbem_options_default.argtypes = [C.POINTER(Options)]

@@ -322,7 +322,7 @@ __global__ __launch_bounds__(M2LShape<P>::THREADS) void m2l_kernel(DevicePlan d)
     if (valid) {
 #pragma unroll
       for (int n = 0; n < P; ++n) {
-        const double2* row = Yt + (c0 + n * (2 * j + 1) + n * n + n);
+        const double2* row = Yt + (c0 + n * (2 * j + 1) + n * n);   // (j+n)^2 + (j+n) - k
 #pragma unroll
         for (int m = -n; m <= n; ++m) cfma(acc, mh[n * n + n + m], row[m]);
       }

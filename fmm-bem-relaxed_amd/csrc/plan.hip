@@ -259,7 +259,7 @@ int fmmbem_plan::to_device() {
       auto [it, fresh] = seen.try_emplace(key, (int)seen.size());
       if (fresh) {
         double up[3], down[3];
-        for (int k = 0; k < 3; ++k) { up[k] = hp.box_center[3 * par + k] - hp.box_center[3 * b + k]; down[k] = -up[k]; }
+        for (int k = 0; k < 3; ++k) { up[k] = 0.5 * hp.cell[k] * double(v[k]); down[k] = -up[k]; }
         // M2M: evalMultipole(rho, alpha, -beta) of (parent - child)   (LaplaceSpherical.hpp:253-254)
         SphHost s = cart2sph_host(up);
         harmonics(T, true, s.rho, s.alpha, -s.beta, pm, h);
@@ -301,9 +301,11 @@ int fmmbem_plan::to_device() {
     const int R = 2 * pm;
     std::vector<cplx> tab((size_t)n_classes * d.y2_max), h;
     for (int64_t c = 0; c < n_classes; ++c) {
-      const int s = hp.m2l_class_rep[2 * c], t = hp.m2l_class_rep[2 * c + 1];
+      // translation = c_target - c_source (executor/M2L.hpp:40), rebuilt from the exact integer class
+      // vector (half-cell units) so that the table does not depend on which pair was seen first
+      // (shards of one operator must produce bit-identical rows).
       double tr[3];
-      for (int k = 0; k < 3; ++k) tr[k] = hp.box_center[3 * t + k] - hp.box_center[3 * s + k];   // executor/M2L.hpp:40
+      for (int k = 0; k < 3; ++k) tr[k] = 0.5 * hp.cell[k] * double(hp.m2l_class_vec[3 * c + k]);
       const SphHost sp = cart2sph_host(tr);
       harmonics(T, false, sp.rho, sp.alpha, sp.beta, R, h);                                      // evalLocal to order 2P
       cplx* out = tab.data() + (size_t)c * d.y2_max;

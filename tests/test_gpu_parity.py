@@ -30,6 +30,7 @@ def case6(fb, oracle_mod):
 def test_extension_is_loaded(fb):
     import os
     assert os.path.exists(fb.LIB_PATH)
+    fb.unit_sphere(1)                                  # first call loads the shared object
     maps = open("/proc/self/maps").read()
     assert "libfmmbem_hip.so" in maps
 
