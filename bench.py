@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- FMM matvecs/s of the LaplaceBEM operator on MI355X, with the P2P roofline and a CPU baseline.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched through
+torch.distributed.run (one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
+
+  step      one FMM matvec  y = A x  (near-field block SpMV + P2M/M2M/M2L/L2L/L2P at p=10), x and y
+            resident in HBM, result replicated on every rank (one all-reduce per matvec when N > 1)
+  workload  BASELINE.json metric "LaplaceBEM sphere N=1e6 p=10": two disjoint unit spheres, each
+            Triangulation::UnitSphere(recursions=9), N = 1 048 576 panels,
+            k=3, theta=0.5, ncrit=64, all panels POTENTIAL (first-kind operator, int G)
+  value     matvecs/s of the whole job (K matvecs / max-over-ranks wall time)
+  roofline  the HBM-bound P2P kernel (near_spmv): algorithmic bytes per launch / mean launch duration
+            measured with HIP events on the launch stream during the timed steps
+  cpu_baseline  the oracle ("port" of the reference's OpenMP path, faithful structure) timed on this box's
+            host cores on a bounded sample: one sphere r=8 (N=131 072 = 1/8 of the workload), p=10,
+            extrapolated by O(N) to the full workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_PEAK_TFLOPS = 78.6      # MI355X FP64 vector peak (AMD datasheet); the guide lists no FP64 figure
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--recursions", type=int, default=9, help="UnitSphere recursions per sphere")
+    ap.add_argument("--spheres", type=int, default=2)
+    ap.add_argument("--p", type=int, default=10)
+    ap.add_argument("--theta", type=float, default=0.5)
+    ap.add_argument("--ncrit", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-accuracy", action="store_true")
+    ap.add_argument("--cpu-recursions", type=int, default=8)
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """Oracle (faithful mode) on the host cores; bounded sample, see module docstring."""
+    import numpy as np
+    from oracle import oracle as O
+    r = args.cpu_recursions
+    v = O.unit_sphere(r)
+    o = O.Oracle(v, K=3, theta=args.theta, ncrit=args.ncrit)
+    t0 = time.time()
+    o.build_near()
+    build_s = time.time() - t0
+    x = np.random.default_rng(0).random(o.n)
+    o.matvec(x, args.p, faithful=True)                       # warm-up
+    times = []
+    for _ in range(3):                                       # tests/scaling.cpp:44-54 times 3 executes
+        t0 = time.time()
+        o.matvec(x, args.p, faithful=True)
+        times.append(time.time() - t0)
+    t = sum(times) / len(times)
+    n_full = args.spheres * 2 * 4 ** args.recursions
+    scale = n_full / o.n
+    return {
+        "value": 1.0 / (t * scale), "unit": "matvecs/s", "cores": O.num_threads(), "kind": "port",
+        "sample": "oracle faithful mode, UnitSphere(r=%d) N=%d p=%d: %.3f s/matvec (mean of 3 after 1 warm-up, "
+                  "near-matrix build %.1f s not counted), scaled x1/%.0f by O(N) to N=%d"
+                  % (r, o.n, args.p, t, build_s, scale, n_full),
+        "sample_s_per_matvec": t,
+    }
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import fmm_bem_relaxed_amd as fb
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU execution path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    # ---- workload: `spheres` disjoint unit spheres, centres 3 apart on the x axis ----
+    parts = [fb.unit_sphere(args.recursions, center=(3.0 * i, 0.0, 0.0)) for i in range(args.spheres)]
+    v = np.concatenate(parts) if len(parts) > 1 else parts[0]
+    n = len(v)
+    K = fb.LaplaceSphericalBEM(args.p, 3)
+    opts = fb.FMMOptions()
+    opts.set_mac_theta(args.theta)
+    opts.set_max_per_box(args.ncrit)
+    t0 = time.time()
+    op = fb.ShardedFMM(K, v, opts, device=local_rank)
+    build_s = time.time() - t0
+    plan = op.plan
+
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    x = torch.rand(n, dtype=torch.float64, generator=g).to(dev)
+    y = torch.empty_like(x)
+
+    def step():
+        plan.execute_torch(x, out=y)
+        if world > 1:
+            dist.all_reduce(y)
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    plan.set_timing(True)                                    # HIP events around each kernel, no added syncs
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    st = plan.stats()
+    plan.set_timing(False)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = elapsed / args.steps * 1e3
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the P2P kernel on this rank's shard (SURVEY.md section 8d "Algorithmic bytes, P2P") ----
+    rows = st["owned_row_end"] - st["owned_row_begin"]
+    p2p_bytes = st["near_nnz"] * 8 + n * 8 + rows * 8
+    near_ms = st["ms_near"]
+    p2p_gbs = p2p_bytes / (near_ms * 1e-3) / 1e9 if near_ms > 0 else 0.0
+    traffic = None
+    try:                                                     # PMC traffic comes from a separate rocprofv3 --pmc pass
+        prof = json.load(open(os.path.join(ROOT, "profiles", "pmc_near_spmv.json")))
+        if prof.get("n_panels") == n and prof.get("n_gpus") == world:
+            traffic = prof.get("hbm_bytes_per_launch")
+    except Exception:
+        pass
+    P = args.p
+    m2l_flops = st["m2l_pairs_owned"] * 8.0 * (P * (P + 1) // 2) * P * P       # 4 FMAs = 8 flop per complex MAC
+    m2l_tflops = m2l_flops / (st["ms_m2l"] * 1e-3) / 1e12 if st["ms_m2l"] > 0 else 0.0
+
+    out = {
+        "metric": "FMM matvecs/s (LaplaceBEM sphere N=1e6 p=10) + achieved HBM GB/s on P2P",
+        "value": args.steps / elapsed, "unit": "matvecs/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "LaplaceSphericalBEM, %d disjoint UnitSphere(r=%d), N=%d panels, p=%d, k=3, theta=%g, "
+                               "ncrit=%d, all POTENTIAL; target leaves sharded over %d GPU(s), 1 all-reduce of y per matvec"
+                               % (args.spheres, args.recursions, n, P, args.theta, args.ncrit, world),
+                   "n_panels": n, "p": P, "near_nnz": st["near_nnz_total"], "m2l_pairs": st["m2l_pairs"],
+                   "boxes": st["n_boxes"], "leaves": st["n_leaves"]},
+        "roofline": {"kernel": "near_spmv (P2P)", "bound": "hbm", "achieved": p2p_gbs, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": p2p_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": p2p_bytes, "launch_ms": near_ms,
+                     "timed_launches": st["timed_executes"]},
+        "roofline_m2l": {"kernel": "m2l", "bound": "fp64 vector FMA", "achieved": m2l_tflops, "peak": FP64_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": m2l_tflops / FP64_PEAK_TFLOPS,
+                         "algorithmic_flops_per_launch": m2l_flops, "launch_ms": st["ms_m2l"]},
+        "stage_ms": {k[3:]: st[k] for k in ("ms_total", "ms_gather", "ms_near", "ms_scatter", "ms_p2m", "ms_m2m",
+                                            "ms_mh", "ms_m2l", "ms_l2l", "ms_l2p")},
+        "plan_build_s": build_s, "near_assemble_s": st["build_assemble_ms"] * 1e-3,
+        "host_lists_s": st["build_host_ms"] * 1e-3,
+    }
+
+    if world == 1 and not args.no_accuracy:
+        # north_star gate at full size: relative L2 vs the O(N^2) Direct sum on a 256-target sample (oracle as checker)
+        from oracle import oracle as O
+        o = O.Oracle(v, K=3, theta=args.theta, ncrit=args.ncrit)
+        xs = x.cpu().numpy()
+        lo = n // 3
+        d = o.direct(xs, rows=(lo, lo + 256))
+        ys = y.cpu().numpy()[lo:lo + 256]
+        out["rel_l2_vs_direct_sample"] = float(np.linalg.norm(ys - d) / np.linalg.norm(d))
+        o.close()
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args)
+        out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

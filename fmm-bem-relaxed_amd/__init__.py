@@ -5,3 +5,11 @@ and this thin host-side mirror of the reference's operator interface.
 """
 from ._capi import FmmBemError, LIB_PATH, PMAX, SYMBOLS  # noqa: F401
 from .plan import FMM_plan, FMMOptions, LaplaceSphericalBEM, unit_sphere  # noqa: F401
+
+
+def __getattr__(name):
+    # torch is only needed for the multi-GPU wrapper; import it lazily
+    if name == "ShardedFMM":
+        from .distributed import ShardedFMM
+        return ShardedFMM
+    raise AttributeError(name)

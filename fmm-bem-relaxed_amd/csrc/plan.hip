@@ -125,9 +125,10 @@ struct fmmbem_plan {
   // execute state
   bool timing = false;
   int last_p = 0;
-  double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  hipEvent_t ev[9] = {};
-  bool have_events = false;
+  static constexpr int kStages = 9, kRing = 64;                // gather spmv scatter p2m m2m mh m2l l2l l2p
+  std::vector<hipEvent_t> ev;                                  // kRing sets of kStages+1 events
+  int ev_marks[kRing] = {};                                    // events actually recorded in each set
+  int64_t ev_count = 0;                                        // executes recorded since timing was enabled
   double *stage_x = nullptr, *stage_y = nullptr;               // device staging for host-pointer execute
   hipStream_t own_stream = nullptr;
 
@@ -158,7 +159,7 @@ struct fmmbem_plan {
     if (on_device) {
       (void)hipSetDevice(opts.device);
       for (void* p : allocs) (void)hipFree(p);
-      if (have_events) for (auto& e : ev) (void)hipEventDestroy(e);
+      for (auto& e : ev) (void)hipEventDestroy(e);
       if (own_stream) (void)hipStreamDestroy(own_stream);
     }
   }
@@ -174,8 +175,8 @@ int fmmbem_plan::to_device() {
   HIP_TRY(hipSetDevice(opts.device));
   on_device = true;
   HIP_TRY(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
+  ev.assign((size_t)kRing * (kStages + 1), nullptr);
   for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
-  have_events = true;
 
   const HarmonicTables T;
   const int nl = hp.nleaves(), nb = hp.nboxes, pm = hp.opt.p_max;
@@ -340,12 +341,14 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
   if (!d_x || !d_y) return fail(FMMBEM_ERR_INVALID, "null vector");
   HIP_TRY(hipSetDevice(opts.device));
   const bool tm = timing;
+  hipEvent_t* set = tm ? &ev[(size_t)(ev_count % kRing) * (kStages + 1)] : nullptr;
   int e = 0;
-  auto mark = [&]() -> hipError_t { return tm ? hipEventRecord(ev[e++], s) : hipSuccess; };
+  auto mark = [&]() -> hipError_t { return tm ? hipEventRecord(set[e++], s) : hipSuccess; };
   HIP_TRY(mark());
   HIP_TRY(launch_gather_x(d, d_x, s));
   HIP_TRY(mark());
   HIP_TRY(launch_near_spmv(d, s));
+  HIP_TRY(mark());
   if (hp.opt.shard_world > 1) HIP_TRY(hipMemsetAsync(d_y, 0, sizeof(double) * (size_t)hp.n, s));
   HIP_TRY(launch_scatter_y(d, d_y, s));
   HIP_TRY(mark());
@@ -355,6 +358,7 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
     for (auto [first, count] : m2m_launch) HIP_TRY(launch_m2m_level(d, p, first, count, s));
     HIP_TRY(mark());
     HIP_TRY(launch_mh_prep(d, p, s));
+    HIP_TRY(mark());
     HIP_TRY(launch_m2l(d, p, s));
     HIP_TRY(mark());
     for (auto [first, count] : l2l_launch) HIP_TRY(launch_l2l_level(d, p, first, count, s));
@@ -363,14 +367,7 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
     HIP_TRY(mark());
   }
   last_p = p;
-  if (tm) {
-    HIP_TRY(hipStreamSynchronize(s));
-    for (int i = 0; i < 8; ++i) ms[i] = 0;
-    float f = 0;
-    for (int i = 0; i + 1 < e; ++i) { HIP_TRY(hipEventElapsedTime(&f, ev[i], ev[i + 1])); ms[1 + i] = f; }
-    HIP_TRY(hipEventElapsedTime(&f, ev[0], ev[e - 1]));
-    ms[0] = f;
-  }
+  if (tm) { ev_marks[ev_count % kRing] = e; ++ev_count; }
   return FMMBEM_OK;
 }
 
@@ -454,7 +451,8 @@ int fmmbem_plan_execute(fmmbem_plan* plan, int p, const double* x, double* y) {
 
 int fmmbem_plan_set_timing(fmmbem_plan* plan, int enabled) {
   if (!plan) return fail(FMMBEM_ERR_INVALID, "null plan");
-  plan->timing = enabled != 0;
+  plan->timing = enabled != 0 && plan->on_device;
+  plan->ev_count = 0;
   return FMMBEM_OK;
 }
 
@@ -474,8 +472,33 @@ int fmmbem_plan_stats(const fmmbem_plan* plan, fmmbem_stats* o) {
   o->expansions_active = (h.has_bc[0] ? 1 : 0) | (h.has_bc[1] ? 2 : 0);
   o->last_p = plan->last_p;
   o->build_host_ms = plan->build_host_ms; o->build_assemble_ms = plan->build_assemble_ms;
-  o->ms_total = plan->ms[0]; o->ms_gather = plan->ms[1]; o->ms_near = plan->ms[2]; o->ms_p2m = plan->ms[3];
-  o->ms_m2m = plan->ms[4]; o->ms_m2l = plan->ms[5]; o->ms_l2l = plan->ms[6]; o->ms_l2p = plan->ms[7];
+  if (plan->on_device && plan->ev_count > 0) {
+    // mean stage times over the recorded executes (waits for the newest recorded event)
+    constexpr int NS = fmmbem_plan::kStages, NR = fmmbem_plan::kRing;
+    const int64_t have = plan->ev_count < NR ? plan->ev_count : NR;
+    double sum[NS + 1] = {0};
+    int64_t used = 0;
+    HIP_TRY(hipSetDevice(plan->opts.device));
+    for (int64_t i = 0; i < have; ++i) {
+      const int64_t slot = (plan->ev_count - 1 - i) % NR;
+      const hipEvent_t* set = &plan->ev[(size_t)slot * (NS + 1)];
+      const int marks = plan->ev_marks[slot];
+      if (marks < 2) continue;
+      HIP_TRY(hipEventSynchronize(set[marks - 1]));
+      float f = 0;
+      for (int k = 0; k + 1 < marks; ++k) { HIP_TRY(hipEventElapsedTime(&f, set[k], set[k + 1])); sum[k] += f; }
+      HIP_TRY(hipEventElapsedTime(&f, set[0], set[marks - 1]));
+      sum[NS] += f;
+      ++used;
+    }
+    if (used) {
+      const double inv = 1.0 / double(used);
+      o->ms_gather = sum[0] * inv; o->ms_near = sum[1] * inv; o->ms_scatter = sum[2] * inv; o->ms_p2m = sum[3] * inv;
+      o->ms_m2m = sum[4] * inv; o->ms_mh = sum[5] * inv; o->ms_m2l = sum[6] * inv; o->ms_l2l = sum[7] * inv;
+      o->ms_l2p = sum[8] * inv; o->ms_total = sum[NS] * inv;
+      o->timed_executes = used;
+    }
+  }
   return FMMBEM_OK;
 }
 

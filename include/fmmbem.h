@@ -72,7 +72,9 @@ typedef struct {
   int32_t expansions_active;    /* bit 0: G expansion, bit 1: dG/dn expansion                        */
   int32_t last_p;
   double  build_host_ms, build_assemble_ms;
-  double  ms_total, ms_gather, ms_near, ms_p2m, ms_m2m, ms_m2l, ms_l2l, ms_l2p;
+  /* per-stage device times: MEAN over the executes recorded since timing was (re)enabled */
+  double  ms_total, ms_gather, ms_near, ms_scatter, ms_p2m, ms_m2m, ms_mh, ms_m2l, ms_l2l, ms_l2p;
+  int64_t timed_executes;       /* how many executes the means cover                                 */
 } fmmbem_stats;
 
 typedef struct fmmbem_plan fmmbem_plan;
@@ -103,7 +105,10 @@ int fmmbem_plan_execute_device(fmmbem_plan *plan, int p, const double *d_x, doub
  * DEVICE pointers, asynchronous. */
 int fmmbem_plan_near_device(fmmbem_plan *plan, const double *d_x, double *d_y, void *stream);
 
-/* Toggle per-stage HIP-event timing (adds a stream synchronisation per execute). Default off. */
+/* Toggle per-stage HIP-event timing.  While enabled every execute records HIP events around each
+ * kernel on the stream it runs on (no synchronisation is added); fmmbem_plan_stats() waits for the
+ * recorded events and reports the mean stage times of up to the last 64 executes.  Enabling resets
+ * the record.  Default off. */
 int fmmbem_plan_set_timing(fmmbem_plan *plan, int enabled);
 
 int fmmbem_plan_stats(const fmmbem_plan *plan, fmmbem_stats *out);

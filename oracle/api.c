@@ -69,3 +69,10 @@ void orc_get_tables(const orc_tables *t, double *prefactor, double *Anm, double 
   if (Anm) memcpy(Anm, t->Anm, sizeof(double)*4*P*P);
   if (Cnm) memcpy(Cnm, t->Cnm, sizeof(cplx)*(size_t)P*P*P*P);
 }
+
+#ifdef _OPENMP
+#include <omp.h>
+int orc_num_threads(void) { return omp_get_max_threads(); }
+#else
+int orc_num_threads(void) { return 1; }
+#endif

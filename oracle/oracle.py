@@ -68,12 +68,18 @@ def lib():
         L.orc_semi_analytical.argtypes = [vp, vp, vp, vp, vp, vp, i32]
         L.orc_quadrature.argtypes = [i32, vp, vp]
         L.orc_quadrature.restype = i32
+        L.orc_num_threads.restype = i32
         _LIB = L
     return _LIB
 
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def num_threads():
+    """OpenMP threads the oracle's parallel stages use."""
+    return lib().orc_num_threads()
 
 
 def unit_sphere(recursions, center=(0.0, 0.0, 0.0)):

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 output directories into the small files committed under profiles/.
+
+  python tools/prof_summary.py kernel-stats <dir> <out.md>        (from --kernel-trace --stats)
+  python tools/prof_summary.py pmc <fetch_dir> <write_dir> <out.json> <n_panels> <n_gpus>
+PMC units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and
+WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming
+read, so the read side of the streaming near_spmv kernel is doubled.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def short(name):
+    name = name.replace("fmmbem::(anonymous namespace)::", "").replace("void ", "")
+    return name.split("(")[0]
+
+
+def kernel_stats(d, out):
+    f = glob.glob(os.path.join(d, "**", "*_kernel_stats.csv"), recursive=True)[0]
+    rows = list(csv.DictReader(open(f)))
+    with open(out, "w") as o:
+        o.write("| kernel | calls | avg us | min us | max us | % of GPU time |\n|---|---|---|---|---|---|\n")
+        for r in rows:
+            o.write("| %s | %s | %.1f | %.1f | %.1f | %s |\n" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3,
+                                                              float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"]))
+    print(open(out).read())
+
+
+def pmc_mean(d, counter):
+    f = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)[0]
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == counter:
+            agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    return {k: (sum(v) / len(v), len(v)) for k, v in agg.items()}
+
+
+def pmc(fetch_dir, write_dir, out, n_panels, n_gpus):
+    fe, wr = pmc_mean(fetch_dir, "FETCH_SIZE"), pmc_mean(write_dir, "WRITE_SIZE")
+    res = {"n_panels": int(n_panels), "n_gpus": int(n_gpus), "kernels": {}}
+    for k in sorted(set(fe) | set(wr)):
+        f_kib, nf = fe.get(k, (0.0, 0))
+        w_kib, nw = wr.get(k, (0.0, 0))
+        res["kernels"][k] = {"FETCH_SIZE_KiB_raw": f_kib, "WRITE_SIZE_KiB": w_kib, "dispatches": max(nf, nw)}
+    ns = res["kernels"].get("near_spmv_kernel")
+    if ns:
+        # gfx950: FETCH_SIZE counts 64 B per 128-B request of a wide streaming read -> x2 (guide, HBM section)
+        res["hbm_bytes_per_launch"] = (2.0 * ns["FETCH_SIZE_KiB_raw"] + ns["WRITE_SIZE_KiB"]) * 1024.0
+        res["note"] = "near_spmv_kernel: (2*FETCH_SIZE + WRITE_SIZE) KiB, separate --pmc passes"
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "kernel-stats":
+        kernel_stats(sys.argv[2], sys.argv[3])
+    else:
+        pmc(*sys.argv[2:7])
