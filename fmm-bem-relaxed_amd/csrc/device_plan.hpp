@@ -3,13 +3,14 @@
 // HBM layout (all arrays uploaded once at plan creation; DESIGN.md "Data layout"):
 //   panels      SoA in TREE order: cx,cy,cz,nx,ny,nz,area [N]; quad [q][xyz][N]; vert [9][N]; bc [N] u8
 //   perm        [N] u32                      tree index -> original index
-//   leaves      leaf_row0/leaf_nrows [nl]; near_ptr [nl+1] -> near_src_row0/near_src_n (source leaf body ranges);
+//   leaves      leaf_row0/leaf_nrows [nl]; near_ptr [nl+1] -> near_run_row0/near_run_off (runs of consecutive
+//               source rows: adjacent source leaves are merged; off = first column of the run);
 //               near_ncols/near_stride [nl]; near_off [nl] (offset of the leaf's row block in near_val)
 //   near_val    per owned target leaf a dense row-major block  nrows x stride  (stride = ncols rounded
 //               up to even => every row 16-B aligned); the ONLY large array (8 B per near entry)
 //   boxes       center [nb][3]
 //   M, L        [nb][2][S_max] complex (S = p(p+1)/2), slot 0 = G, slot 1 = dG/dn
-//   Mh          [nb][2][P2_max] complex: M rescaled and phase-rotated, all orders -n..n (M2L input)
+//   Mh          [nb][2][S_max] complex: M rescaled and phase-rotated (orders m >= 0), the M2L input
 //   m2l_*       CSR by target box: m2l_tgt [nt] (boxes to run), m2l_ptr [nb+1], m2l_src, m2l_cls
 //   class tabs  m2l_tab [classes][(2 p_max)^2] complex; up_tab/down_tab [classes][p_max^2] complex
 #pragma once
@@ -27,6 +28,7 @@ struct DevicePlan {
   int leaf_begin = 0, leaf_end = 0;                   // owned target leaves
   int64_t row_begin = 0, row_end = 0;
   int max_ncols = 0;                                  // widest near row block (columns, padded even)
+  int max_runs = 0;                                   // most source runs of any owned target leaf
   int n_act = 0;                                      // active expansion slots
   int act[2] = {0, 0};
 
@@ -38,7 +40,7 @@ struct DevicePlan {
   // leaves
   const int *leaf_row0, *leaf_nrows, *leaf_box;
   const int64_t* near_ptr;
-  const int *near_src_row0, *near_src_n;
+  const int *near_run_row0, *near_run_off;            // runs of consecutive source rows: first row, column offset
   const int *near_ncols, *near_stride;
   const int64_t* near_off;
   double* near_val;
@@ -58,6 +60,9 @@ struct DevicePlan {
   const int *m2l_tgt;         int n_m2l_tgt = 0;
   const int *m2l_ptr, *m2l_src, *m2l_cls;
   const double2* m2l_tab;                             // [cls][y2_max]
+  const int *m2l_lane;                                // [p-1][192] lane -> output map (m2l_layout.hpp)
+  const int *m2l_scat;                                // per p: table index -> LDS slot
+  int m2l_scat_off[16];                               // offset of order p's scatter map in m2l_scat
   // scratch
   double *xt, *yt;                                    // tree-order x and near result
 };

@@ -1,11 +1,11 @@
-// kernels_far.hip -- gfx950 kernels of the far field, one instantiation per expansion order
-// p = 1..16 (the solver's per-iteration relaxation of p only selects among them).
+// kernels_far.hip -- gfx950 kernels of the far field except M2L (kernels_m2l.hip); the expansion order p
+// is a launch argument (the solver's per-iteration relaxation of p).
 //
 //   p2m        LaplaceSphericalBEM::P2M            kernel/LaplaceSphericalBEM.hpp:307-352
 //   m2m_level  LaplaceSpherical::M2M               kernel/LaplaceSpherical.hpp:245-285
 //   mh_prep    source-side rescaling of M for M2L  (folds Anm and the i^{|k-m|-|k|-|m|} phase of Cnm,
 //                                                   kernel/LaplaceSpherical.hpp:106-116)
-//   m2l        LaplaceSpherical::M2L + evalLocal   kernel/LaplaceSpherical.hpp:296-329, 491-524
+//   (m2l       lives in kernels_m2l.hip)
 //   l2l_level  LaplaceSpherical::L2L               kernel/LaplaceSpherical.hpp:378-411
 //   l2p        LaplaceSphericalBEM::L2P            kernel/LaplaceSphericalBEM.hpp:448-476
 //
@@ -248,90 +248,20 @@ __global__ __launch_bounds__(kWave) void m2m_kernel(DevicePlan d, const int P, i
 }
 
 // ---------------------------------------------------------------------------------------------
-// mh_prep: Mh[n,m] = i^{-|m|} A[n,m] Mt[n,m] for all orders -n..n of every M2L source box.
+// mh_prep: Mh[n,m] = i^{-m} A[n,m] M[n,m] for the stored orders m >= 0 of every M2L source box
+// (negative orders follow from Mh[n,-m] = (-1)^m conj(Mh[n,m]) inside the M2L kernel).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kWave) void mh_prep_kernel(DevicePlan d, const int P) {
-  const int P2 = P * P;
+  const int S = P * (P + 1) / 2;
   const int box = d.mh_box[blockIdx.x];
   const int slot = d.act[blockIdx.y];
   const double2* M = d.M + ((size_t)box * 2 + slot) * d.s_max;
-  double2* Mh = d.Mh + ((size_t)box * 2 + slot) * d.p2_max;
-  for (int nm = threadIdx.x; nm < P2; nm += kWave) {
-    int n = 0;
-    while ((n + 1) * (n + 1) <= nm) ++n;
-    const int m = nm - n * n - n;
-    const int am = m < 0 ? -m : m;
-    double2 v = M[n * (n + 1) / 2 + am];
-    if (m < 0) v = cconj(v);
-    const double a = d.tabA[nm];
-    Mh[nm] = mul_i_pow(double2{v.x * a, v.y * a}, -am);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// M2L: the FP64-FMA-bound hot kernel.  One wavefront (or team of wavefronts) per target box.
-// Per source in the target's list: copy the translation's Yh table (2P)^2 complex from its class
-// table (L2-resident) into the wavefront's LDS region, then every lane (one (j,k) output) runs
-//     acc += Mh[n,m] * Yh[(j+n)^2 + (j+n) + m - k]        for n < P, |m| <= n
-// with Mh wave-uniform (scalar loads) and Yh a per-lane LDS read at base(j,k,n) + m.
-// ---------------------------------------------------------------------------------------------
-// When S = P(P+1)/2 exceeds 64 (P >= 11) a TEAM of ceil(S/64) wavefronts shares one target box (one
-// output per lane throughout), otherwise a workgroup carries kM2LTargets independent wavefronts.
-constexpr int kM2LTargets = 4;
-template <int P> struct M2LShape {
-  static constexpr int S = P * (P + 1) / 2, Y2 = 4 * P * P;
-  static constexpr int TEAM = (S + kWave - 1) / kWave;
-  static constexpr int TARGETS = TEAM == 1 ? kM2LTargets : 1;
-  static constexpr int THREADS = TEAM * TARGETS * kWave;
-};
-
-template <int P>
-__global__ __launch_bounds__(M2LShape<P>::THREADS) void m2l_kernel(DevicePlan d) {
-  using Sh = M2LShape<P>;
-  constexpr int S = Sh::S, Y2 = Sh::Y2, TEAM = Sh::TEAM, TARGETS = Sh::TARGETS;
-  __shared__ double2 Yall[TARGETS][Y2];
-  const int lane = threadIdx.x & (kWave - 1);
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-  const int ti = blockIdx.x * TARGETS + (TEAM == 1 ? wave : 0);
-  if (ti >= d.n_m2l_tgt) return;                       // TEAM==1: whole wavefront; TEAM>1: whole workgroup
-  const int tgt = d.m2l_tgt[ti];
-  const int slot = d.act[blockIdx.y];
-  double2* Yt = Yall[TEAM == 1 ? wave : 0];
-  const int tid = TEAM == 1 ? lane : (int)threadIdx.x;  // index within the team
-  const int idx = tid;                                  // this lane's output coefficient
-  const bool valid = idx < S;
-  const int j = valid ? kJK.j[idx] : 0, k = valid ? kJK.k[idx] : 0;
-  const int c0 = j * j + j - k;
-  double2 acc = {0, 0};
-
-  const int pb = d.m2l_ptr[tgt], pe = d.m2l_ptr[tgt + 1];
-  for (int pi = pb; pi < pe; ++pi) {
-    const int src = __builtin_amdgcn_readfirstlane(d.m2l_src[pi]);
-    const int cls = __builtin_amdgcn_readfirstlane(d.m2l_cls[pi]);
-    const double2* tab = d.m2l_tab + (size_t)cls * d.y2_max;
-    if (TEAM == 1) __builtin_amdgcn_wave_barrier(); else __syncthreads();
-    for (int i = tid; i < Y2; i += TEAM * kWave) Yt[i] = tab[i];
-    if (TEAM == 1) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    } else {
-      __syncthreads();
-    }
-    const double2* __restrict__ mh = d.Mh + ((size_t)src * 2 + slot) * d.p2_max;
-    if (valid) {
-#pragma unroll
-      for (int n = 0; n < P; ++n) {
-        const double2* row = Yt + (c0 + n * (2 * j + 1) + n * n);   // (j+n)^2 + (j+n) - k
-#pragma unroll
-        for (int m = -n; m <= n; ++m) cfma(acc, mh[n * n + n + m], row[m]);
-      }
-    }
-  }
-  if (valid) {
-    double2* L = d.L + ((size_t)tgt * 2 + slot) * d.s_max;
-    const double f = oddeven(j) * d.tabA[j * j + j + k];
-    L[idx] = mul_i_pow(double2{acc.x * f, acc.y * f}, -k);
+  double2* Mh = d.Mh + ((size_t)box * 2 + slot) * d.s_max;
+  for (int idx = threadIdx.x; idx < S; idx += kWave) {
+    const int n = kJK.j[idx], m = kJK.k[idx];
+    const double2 v = M[idx];
+    const double a = d.tabA[n * n + n + m];
+    Mh[idx] = mul_i_pow(double2{v.x * a, v.y * a}, -m);
   }
 }
 
@@ -441,19 +371,6 @@ __global__ __launch_bounds__(kWave) void l2p_kernel(DevicePlan d, const int P, d
   }
 }
 
-#define FMMBEM_DISPATCH_P(p, ...)                                                                     \
-  switch (p) {                                                                                         \
-    case 1: { constexpr int PP = 1; __VA_ARGS__; } break;   case 2: { constexpr int PP = 2; __VA_ARGS__; } break;    \
-    case 3: { constexpr int PP = 3; __VA_ARGS__; } break;   case 4: { constexpr int PP = 4; __VA_ARGS__; } break;    \
-    case 5: { constexpr int PP = 5; __VA_ARGS__; } break;   case 6: { constexpr int PP = 6; __VA_ARGS__; } break;    \
-    case 7: { constexpr int PP = 7; __VA_ARGS__; } break;   case 8: { constexpr int PP = 8; __VA_ARGS__; } break;    \
-    case 9: { constexpr int PP = 9; __VA_ARGS__; } break;   case 10: { constexpr int PP = 10; __VA_ARGS__; } break;  \
-    case 11: { constexpr int PP = 11; __VA_ARGS__; } break; case 12: { constexpr int PP = 12; __VA_ARGS__; } break;  \
-    case 13: { constexpr int PP = 13; __VA_ARGS__; } break; case 14: { constexpr int PP = 14; __VA_ARGS__; } break;  \
-    case 15: { constexpr int PP = 15; __VA_ARGS__; } break; case 16: { constexpr int PP = 16; __VA_ARGS__; } break;  \
-    default: return hipErrorInvalidValue;                                                              \
-  }
-
 hipError_t upload_constants_once() {
   static hipError_t st = [] {
     const JK t = make_jk();
@@ -494,18 +411,10 @@ hipError_t launch_m2m_level(const DevicePlan& d, int p, int first, int count, hi
 }
 
 hipError_t launch_mh_prep(const DevicePlan& d, int p, hipStream_t s) {
+  if (hipError_t e = upload_constants_once(); e != hipSuccess) return e;
   if (d.n_mh <= 0) return hipSuccess;
   if (p < 1 || p > kPmaxDev) return hipErrorInvalidValue;
   hipLaunchKernelGGL(mh_prep_kernel, dim3(d.n_mh, d.n_act), dim3(kWave), 0, s, d, p);
-  return hipGetLastError();
-}
-
-hipError_t launch_m2l(const DevicePlan& d, int p, hipStream_t s) {
-  if (hipError_t e = upload_constants_once(); e != hipSuccess) return e;
-  if (d.n_m2l_tgt <= 0) return hipSuccess;
-  FMMBEM_DISPATCH_P(p, hipLaunchKernelGGL((m2l_kernel<PP>),
-                                          dim3((d.n_m2l_tgt + M2LShape<PP>::TARGETS - 1) / M2LShape<PP>::TARGETS, d.n_act),
-                                          dim3(M2LShape<PP>::THREADS), 0, s, d))
   return hipGetLastError();
 }
 

@@ -150,20 +150,44 @@ __device__ inline double laplace_entry(const DevicePlan& d, V3 t, int tbc, int64
   return r;
 }
 
+// Column staging shared by near_assemble and near_spmv.  The columns of a target leaf's row block are
+// the rows of its source leaves in ascending order; adjacent source leaves were merged on the host into
+// runs (first row, first column).  All run descriptors are fetched with ONE parallel load, then every
+// thread locates its column's run by a binary search in LDS -- two dependent global-memory latencies per
+// workgroup instead of two per source leaf.
+struct Runs { int* row0; int* off; int n; };
+__device__ inline Runs load_runs(const DevicePlan& d, int t, int* lds_row0, int* lds_off) {
+  const int64_t rb = d.near_ptr[t];
+  const int nruns = (int)(d.near_ptr[t + 1] - rb);
+  for (int i = threadIdx.x; i < nruns; i += blockDim.x) {
+    lds_row0[i] = d.near_run_row0[rb + i];
+    lds_off[i] = d.near_run_off[rb + i];
+  }
+  __syncthreads();
+  return {lds_row0, lds_off, nruns};
+}
+__device__ inline int column_to_row(const Runs& r, int c) {
+  int lo = 0, hi = r.n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (r.off[mid] <= c) lo = mid; else hi = mid - 1;
+  }
+  return r.row0[lo] + (c - r.off[lo]);
+}
+
 // ---------------------------------------------------------------------------------------------
-// near_assemble: one workgroup per owned target leaf. LDS holds the column -> source panel map.
+// near_assemble: one workgroup per owned target leaf, one thread per matrix entry (grid-stride).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void near_assemble_kernel(DevicePlan d) {
-  extern __shared__ int colmap[];
+  extern __shared__ int lds_i[];
+  int* colmap = lds_i;                               // [max_ncols]
+  int* run_row0 = lds_i + d.max_ncols;               // [max_runs]
+  int* run_off = run_row0 + d.max_runs;              // [max_runs]
   const int t = d.leaf_begin + blockIdx.x;
   const int ncols = d.near_ncols[t], stride = d.near_stride[t], nrows = d.leaf_nrows[t];
   const int row0 = d.leaf_row0[t];
-  int base = 0;
-  for (int64_t s = d.near_ptr[t]; s < d.near_ptr[t + 1]; ++s) {
-    const int b = d.near_src_row0[s], m = d.near_src_n[s];
-    for (int i = threadIdx.x; i < m; i += blockDim.x) colmap[base + i] = b + i;
-    base += m;
-  }
+  const Runs runs = load_runs(d, t, run_row0, run_off);
+  for (int c = threadIdx.x; c < ncols; c += blockDim.x) colmap[c] = column_to_row(runs, c);
   __syncthreads();
   double* blk = d.near_val + d.near_off[t];
   const int total = nrows * stride;
@@ -192,25 +216,25 @@ __global__ void scatter_y_kernel(const uint32_t* __restrict__ perm, const double
 
 // ---------------------------------------------------------------------------------------------
 // near_spmv: one 256-thread workgroup (4 wavefronts) per owned target leaf.
-//   1. the x slices of the leaf's source leaves are staged once in LDS (<= max_ncols doubles);
-//   2. each wavefront takes rows w, w+4, ... two at a time; a row is `stride` contiguous doubles,
-//      read as 16-B vectors, lanes striding over the columns (fully coalesced 1-KiB wave loads),
-//      ROWS_IN_FLIGHT x UNROLL independent loads are issued before the first FMA;
+//   1. the x values of the leaf's columns are staged once in LDS (<= max_ncols doubles), see load_runs;
+//   2. each wavefront takes kRows rows at a time (rows w, w+4, w+8, w+12 ...); a row is `stride`
+//      contiguous doubles read as 16-B vectors, lanes striding over the columns (fully coalesced 1-KiB
+//      wave loads); all kRows x kVecs loads of a batch are issued before the first FMA, so a wavefront
+//      keeps up to 16 KiB in flight and a typical leaf (~20-30 rows x ~500-600 columns) needs only one or
+//      two batches per wavefront;
 //   3. per-row wave shuffle reduction, lane 0 stores y_tree[row].
 // Algorithmic bytes: 8 B per near entry (+ 8 B x read + 8 B y write per panel); no column indices.
 // ---------------------------------------------------------------------------------------------
-constexpr int kSpmvWaves = 4;
+constexpr int kSpmvWaves = 4, kRows = 4, kVecs = 4;
 
 __global__ __launch_bounds__(kSpmvWaves * kWave) void near_spmv_kernel(DevicePlan d) {
-  extern __shared__ double xs[];
+  extern __shared__ double xs[];                      // [max_ncols] doubles, then the run descriptors
+  int* run_row0 = reinterpret_cast<int*>(xs + d.max_ncols);
+  int* run_off = run_row0 + d.max_runs;
   const int t = d.leaf_begin + blockIdx.x;
   const int ncols = d.near_ncols[t], stride = d.near_stride[t], nrows = d.leaf_nrows[t];
-  int base = 0;
-  for (int64_t s = d.near_ptr[t]; s < d.near_ptr[t + 1]; ++s) {
-    const int b = d.near_src_row0[s], m = d.near_src_n[s];
-    for (int i = threadIdx.x; i < m; i += blockDim.x) xs[base + i] = d.xt[b + i];
-    base += m;
-  }
+  const Runs runs = load_runs(d, t, run_row0, run_off);
+  for (int c = threadIdx.x; c < ncols; c += blockDim.x) xs[c] = d.xt[column_to_row(runs, c)];
   if (threadIdx.x == 0 && stride > ncols) xs[ncols] = 0.0;
   __syncthreads();
 
@@ -220,36 +244,42 @@ __global__ __launch_bounds__(kSpmvWaves * kWave) void near_spmv_kernel(DevicePla
   const int nvec = stride >> 1;                       // 16-B vectors per row
   const dvec2* xv = reinterpret_cast<const dvec2*>(xs);
 
-  for (int r = wave; r < nrows; r += 2 * kSpmvWaves) {
-    const int r2 = r + kSpmvWaves;
-    const bool has2 = r2 < nrows;
-    const dvec2* a = reinterpret_cast<const dvec2*>(blk + (int64_t)r * stride);
-    const dvec2* b = reinterpret_cast<const dvec2*>(blk + (int64_t)(has2 ? r2 : r) * stride);
-    double acc0 = 0, acc1 = 0;
-    for (int c = lane; c < nvec; c += 4 * kWave) {
-      dvec2 va[4], vb[4];
+  for (int r = wave; r < nrows; r += kRows * kSpmvWaves) {
+    const dvec2* row[kRows];
+    double acc[kRows];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+    for (int i = 0; i < kRows; ++i) {
+      const int ri = r + i * kSpmvWaves;
+      row[i] = reinterpret_cast<const dvec2*>(blk + (int64_t)(ri < nrows ? ri : r) * stride);
+      acc[i] = 0;
+    }
+    for (int c = lane; c < nvec; c += kVecs * kWave) {
+      dvec2 v[kRows][kVecs];
+#pragma unroll
+      for (int u = 0; u < kVecs; ++u) {
         const int cc = c + u * kWave;
         const bool ok = cc < nvec;
-        va[u] = ok ? __builtin_nontemporal_load(&a[cc]) : dvec2{0, 0};
-        vb[u] = ok ? __builtin_nontemporal_load(&b[cc]) : dvec2{0, 0};
+#pragma unroll
+        for (int i = 0; i < kRows; ++i) v[i][u] = ok ? __builtin_nontemporal_load(&row[i][cc]) : dvec2{0, 0};
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < kVecs; ++u) {
         const int cc = c + u * kWave;
         if (cc < nvec) {
           const dvec2 x2 = xv[cc];
-          acc0 = fma(va[u].x, x2.x, fma(va[u].y, x2.y, acc0));
-          acc1 = fma(vb[u].x, x2.x, fma(vb[u].y, x2.y, acc1));
+#pragma unroll
+          for (int i = 0; i < kRows; ++i) acc[i] = fma(v[i][u].x, x2.x, fma(v[i][u].y, x2.y, acc[i]));
         }
       }
     }
-    acc0 = wave_sum(acc0);
-    acc1 = wave_sum(acc1);
+#pragma unroll
+    for (int i = 0; i < kRows; ++i) acc[i] = wave_sum(acc[i]);
     if (lane == 0) {
-      d.yt[row0 + r] = acc0;
-      if (has2) d.yt[row0 + r2] = acc1;
+#pragma unroll
+      for (int i = 0; i < kRows; ++i) {
+        const int ri = r + i * kSpmvWaves;
+        if (ri < nrows) d.yt[row0 + ri] = acc[i];
+      }
     }
   }
 }
@@ -259,7 +289,7 @@ __global__ __launch_bounds__(kSpmvWaves * kWave) void near_spmv_kernel(DevicePla
 hipError_t launch_near_assemble(const DevicePlan& d, hipStream_t s) {
   const int nb = d.leaf_end - d.leaf_begin;
   if (nb <= 0) return hipSuccess;
-  hipLaunchKernelGGL(near_assemble_kernel, dim3(nb), dim3(256), (size_t)d.max_ncols * sizeof(int), s, d);
+  hipLaunchKernelGGL(near_assemble_kernel, dim3(nb), dim3(256), ((size_t)d.max_ncols + 2 * (size_t)d.max_runs) * sizeof(int), s, d);
   return hipGetLastError();
 }
 
@@ -272,7 +302,8 @@ hipError_t launch_gather_x(const DevicePlan& d, const double* x, hipStream_t s) 
 hipError_t launch_near_spmv(const DevicePlan& d, hipStream_t s) {
   const int nb = d.leaf_end - d.leaf_begin;
   if (nb <= 0) return hipSuccess;
-  hipLaunchKernelGGL(near_spmv_kernel, dim3(nb), dim3(kSpmvWaves * kWave), (size_t)d.max_ncols * sizeof(double), s, d);
+  hipLaunchKernelGGL(near_spmv_kernel, dim3(nb), dim3(kSpmvWaves * kWave),
+                     (size_t)d.max_ncols * sizeof(double) + 2 * (size_t)d.max_runs * sizeof(int), s, d);
   return hipGetLastError();
 }
 

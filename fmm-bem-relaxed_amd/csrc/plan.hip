@@ -16,6 +16,7 @@
 #include "../../include/fmmbem.h"
 #include "device_plan.hpp"
 #include "host_plan.hpp"
+#include "m2l_layout.hpp"
 
 using namespace fmmbem;
 
@@ -196,30 +197,39 @@ int fmmbem_plan::to_device() {
   TRY(upload(P.bc, &d.bc)); TRY(upload(hp.perm, &d.perm));
 
   // leaves and the near block structure
-  std::vector<int> leaf_row0(nl), leaf_nrows(nl), near_stride(nl), src_row0(hp.near_src.size()), src_n(hp.near_src.size());
-  std::vector<int64_t> near_off(nl, 0);
+  std::vector<int> leaf_row0(nl), leaf_nrows(nl), near_stride(nl), run_row0, run_off;
+  std::vector<int64_t> near_off(nl, 0), run_ptr(nl + 1, 0);
   int64_t total = 0;
-  int max_cols = 2;
+  int max_cols = 2, max_runs = 1;
   for (int l = 0; l < nl; ++l) {
     const int b = hp.leaf_box[l];
     leaf_row0[l] = hp.box_body_begin[b];
     leaf_nrows[l] = hp.box_body_end[b] - hp.box_body_begin[b];
     near_stride[l] = (hp.near_ncols[l] + 1) & ~1;
+    // source leaves are ascending; leaves with consecutive indices own adjacent rows -> one run
+    int col = 0, runs = 0;
+    for (int64_t i = hp.near_ptr[l]; i < hp.near_ptr[l + 1]; ++i) {
+      const int sl = hp.near_src[i], sb = hp.leaf_box[sl];
+      if (i == hp.near_ptr[l] || hp.near_src[i - 1] + 1 != sl) {
+        run_row0.push_back(hp.box_body_begin[sb]);
+        run_off.push_back(col);
+        ++runs;
+      }
+      col += hp.box_body_end[sb] - hp.box_body_begin[sb];
+    }
+    run_ptr[l + 1] = (int64_t)run_row0.size();
     if (l >= hp.leaf_begin && l < hp.leaf_end) {
       near_off[l] = total;
       total += (int64_t)leaf_nrows[l] * near_stride[l];
       max_cols = std::max(max_cols, near_stride[l]);
+      max_runs = std::max(max_runs, runs);
     }
   }
-  for (size_t i = 0; i < hp.near_src.size(); ++i) {
-    const int b = hp.leaf_box[hp.near_src[i]];
-    src_row0[i] = hp.box_body_begin[b];
-    src_n[i] = hp.box_body_end[b] - hp.box_body_begin[b];
-  }
+  d.max_runs = max_runs;
   d.max_ncols = max_cols;
   near_bytes = total * (int64_t)sizeof(double);
   TRY(upload(leaf_row0, &d.leaf_row0)); TRY(upload(leaf_nrows, &d.leaf_nrows)); TRY(upload(hp.leaf_box, &d.leaf_box));
-  TRY(upload(hp.near_ptr, &d.near_ptr)); TRY(upload(src_row0, &d.near_src_row0)); TRY(upload(src_n, &d.near_src_n));
+  TRY(upload(run_ptr, &d.near_ptr)); TRY(upload(run_row0, &d.near_run_row0)); TRY(upload(run_off, &d.near_run_off));
   TRY(upload(hp.near_ncols, &d.near_ncols)); TRY(upload(near_stride, &d.near_stride)); TRY(upload(near_off, &d.near_off));
   TRY(alloc((size_t)total, &d.near_val, false));
 
@@ -227,7 +237,7 @@ int fmmbem_plan::to_device() {
   TRY(upload(hp.box_center, &d.box_center));
   TRY(alloc((size_t)nb * 2 * d.s_max, &d.M, true));
   TRY(alloc((size_t)nb * 2 * d.s_max, &d.L, true));
-  TRY(alloc((size_t)nb * 2 * d.p2_max, &d.Mh, true));
+  TRY(alloc((size_t)nb * 2 * d.s_max, &d.Mh, true));
   TRY(upload(T.A, &d.tabA)); TRY(upload(T.invA, &d.tabInvA)); TRY(upload(T.pref, &d.tabPref));
 
   // far-field lists
@@ -320,6 +330,16 @@ int fmmbem_plan::to_device() {
     const cplx* pt = nullptr;
     TRY(upload(tab, &pt));
     d.m2l_tab = reinterpret_cast<const double2*>(pt);
+    // lane -> output maps and table -> LDS scatter maps of the M2L kernel, every order up to p_max
+    std::vector<int32_t> lanes, scat, one;
+    for (int p = 1; p <= kPmax; ++p) {
+      if (!m2l_lane_map(p, one)) return fail(FMMBEM_ERR_INVALID, "internal: M2L lane dealing failed");
+      lanes.insert(lanes.end(), one.begin(), one.end());
+      m2l_scatter_map(p, one);
+      d.m2l_scat_off[p - 1] = (int)scat.size();
+      scat.insert(scat.end(), one.begin(), one.end());
+    }
+    TRY(upload(lanes, &d.m2l_lane)); TRY(upload(scat, &d.m2l_scat));
   }
 
   TRY(alloc((size_t)hp.n, &d.xt, true));
