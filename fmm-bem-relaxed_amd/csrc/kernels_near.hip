@@ -155,6 +155,7 @@ __device__ inline double laplace_entry(const DevicePlan& d, V3 t, int tbc, int64
 // runs (first row, first column).  All run descriptors are fetched with ONE parallel load, then every
 // thread locates its column's run by a binary search in LDS -- two dependent global-memory latencies per
 // workgroup instead of two per source leaf.
+constexpr int kAsmChunk = 4096;                      // columns mapped in LDS at a time
 struct Runs { int* row0; int* off; int n; };
 __device__ inline Runs load_runs(const DevicePlan& d, int t, int* lds_row0, int* lds_off) {
   const int64_t rb = d.near_ptr[t];
@@ -176,29 +177,35 @@ __device__ inline int column_to_row(const Runs& r, int c) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// near_assemble: one workgroup per owned target leaf, one thread per matrix entry (grid-stride).
+// near_assemble: workgroups stride over the owned target leaves, one thread per matrix entry.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void near_assemble_kernel(DevicePlan d) {
   extern __shared__ int lds_i[];
-  int* colmap = lds_i;                               // [max_ncols]
-  int* run_row0 = lds_i + d.max_ncols;               // [max_runs]
+  int* colmap = lds_i;                               // [kAsmChunk]
+  int* run_row0 = lds_i + kAsmChunk;                 // [max_runs]
   int* run_off = run_row0 + d.max_runs;              // [max_runs]
-  const int t = d.leaf_begin + blockIdx.x;
-  const int ncols = d.near_ncols[t], stride = d.near_stride[t], nrows = d.leaf_nrows[t];
-  const int row0 = d.leaf_row0[t];
-  const Runs runs = load_runs(d, t, run_row0, run_off);
-  for (int c = threadIdx.x; c < ncols; c += blockDim.x) colmap[c] = column_to_row(runs, c);
-  __syncthreads();
-  double* blk = d.near_val + d.near_off[t];
-  const int total = nrows * stride;
-  for (int e = threadIdx.x; e < total; e += blockDim.x) {
-    const int r = e / stride, c = e - r * stride;
-    double v = 0;                                     // padding column (odd ncols) stays zero
-    if (c < ncols) {
-      const int64_t i = row0 + r;
-      v = laplace_entry(d, V3{d.cx[i], d.cy[i], d.cz[i]}, d.bc[i], colmap[c]);
+  for (int t = d.leaf_begin + blockIdx.x; t < d.leaf_end; t += gridDim.x) {
+    const int ncols = d.near_ncols[t], stride = d.near_stride[t], nrows = d.leaf_nrows[t];
+    const int row0 = d.leaf_row0[t];
+    const Runs runs = load_runs(d, t, run_row0, run_off);
+    double* blk = d.near_val + d.near_off[t];
+    for (int c0 = 0; c0 < stride; c0 += kAsmChunk) {
+      const int cw = stride - c0 < kAsmChunk ? stride - c0 : kAsmChunk;
+      if (c0) __syncthreads();
+      for (int c = threadIdx.x; c < cw; c += blockDim.x) colmap[c] = c0 + c < ncols ? column_to_row(runs, c0 + c) : -1;
+      __syncthreads();
+      const int total = nrows * cw;
+      for (int e = threadIdx.x; e < total; e += blockDim.x) {
+        const int r = e / cw, c = e - r * cw;
+        double v = 0;                                 // padding column (odd ncols) stays zero
+        if (colmap[c] >= 0) {
+          const int64_t i = row0 + r;
+          v = laplace_entry(d, V3{d.cx[i], d.cy[i], d.cz[i]}, d.bc[i], colmap[c]);
+        }
+        blk[(int64_t)r * stride + c0 + c] = v;
+      }
     }
-    blk[e] = v;
+    __syncthreads();
   }
 }
 
@@ -225,62 +232,73 @@ __global__ void scatter_y_kernel(const uint32_t* __restrict__ perm, const double
 //   3. per-row wave shuffle reduction, lane 0 stores y_tree[row].
 // Algorithmic bytes: 8 B per near entry (+ 8 B x read + 8 B y write per panel); no column indices.
 // ---------------------------------------------------------------------------------------------
-constexpr int kSpmvWaves = 4, kRows = 4, kVecs = 4;
+constexpr int kSpmvWaves = 4, kVecs = 4;
+constexpr int kSpmvChunk = 2048;                     // columns of x staged in LDS at a time (16 KiB)
 
+template <int kRows, bool NT>
 __global__ __launch_bounds__(kSpmvWaves * kWave) void near_spmv_kernel(DevicePlan d) {
-  extern __shared__ double xs[];                      // [max_ncols] doubles, then the run descriptors
-  int* run_row0 = reinterpret_cast<int*>(xs + d.max_ncols);
+  extern __shared__ double xs[];                      // [kSpmvChunk] doubles, then the run descriptors
+  int* run_row0 = reinterpret_cast<int*>(xs + kSpmvChunk);
   int* run_off = run_row0 + d.max_runs;
-  const int t = d.leaf_begin + blockIdx.x;
-  const int ncols = d.near_ncols[t], stride = d.near_stride[t], nrows = d.leaf_nrows[t];
-  const Runs runs = load_runs(d, t, run_row0, run_off);
-  for (int c = threadIdx.x; c < ncols; c += blockDim.x) xs[c] = d.xt[column_to_row(runs, c)];
-  if (threadIdx.x == 0 && stride > ncols) xs[ncols] = 0.0;
-  __syncthreads();
-
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-  const double* blk = d.near_val + d.near_off[t];
-  const int row0 = d.leaf_row0[t];
-  const int nvec = stride >> 1;                       // 16-B vectors per row
   const dvec2* xv = reinterpret_cast<const dvec2*>(xs);
 
-  for (int r = wave; r < nrows; r += kRows * kSpmvWaves) {
-    const dvec2* row[kRows];
-    double acc[kRows];
+  // Persistent workgroups (grid = a few per CU) striding over the owned target leaves: a leaf is only
+  // ~75 KB of matrix, and one short-lived workgroup per leaf leaves the CUs mostly empty (measured: 3.5
+  // resident wavefronts per CU, launch-rate bound).
+  for (int t = d.leaf_begin + blockIdx.x; t < d.leaf_end; t += gridDim.x) {
+    const int ncols = d.near_ncols[t], stride = d.near_stride[t], nrows = d.leaf_nrows[t];
+    const Runs runs = load_runs(d, t, run_row0, run_off);
+    const double* blk = d.near_val + d.near_off[t];
+    const int row0 = d.leaf_row0[t];
+    // the x slice is staged kSpmvChunk columns at a time: a few coarse leaves of an adaptive tree see
+    // >10^4 columns, and sizing the LDS for them would leave one workgroup per CU
+    for (int c0 = 0; c0 < stride; c0 += kSpmvChunk) {
+      const int cw = stride - c0 < kSpmvChunk ? stride - c0 : kSpmvChunk;
+      if (c0) __syncthreads();
+      for (int c = threadIdx.x; c < cw; c += blockDim.x) xs[c] = c0 + c < ncols ? d.xt[column_to_row(runs, c0 + c)] : 0.0;
+      __syncthreads();
+      const int nvec = cw >> 1;                       // 16-B vectors of this chunk per row
+      for (int r = wave; r < nrows; r += kRows * kSpmvWaves) {
+        const dvec2* row[kRows];
+        double acc[kRows];
 #pragma unroll
-    for (int i = 0; i < kRows; ++i) {
-      const int ri = r + i * kSpmvWaves;
-      row[i] = reinterpret_cast<const dvec2*>(blk + (int64_t)(ri < nrows ? ri : r) * stride);
-      acc[i] = 0;
-    }
-    for (int c = lane; c < nvec; c += kVecs * kWave) {
-      dvec2 v[kRows][kVecs];
+        for (int i = 0; i < kRows; ++i) {
+          const int ri = r + i * kSpmvWaves;
+          row[i] = reinterpret_cast<const dvec2*>(blk + (int64_t)(ri < nrows ? ri : r) * stride + c0);
+          acc[i] = 0;
+        }
+        for (int c = lane; c < nvec; c += kVecs * kWave) {
+          dvec2 v[kRows][kVecs];
 #pragma unroll
-      for (int u = 0; u < kVecs; ++u) {
-        const int cc = c + u * kWave;
-        const bool ok = cc < nvec;
+          for (int u = 0; u < kVecs; ++u) {
+            const int cc = c + u * kWave;
+            const bool ok = cc < nvec;
 #pragma unroll
-        for (int i = 0; i < kRows; ++i) v[i][u] = ok ? __builtin_nontemporal_load(&row[i][cc]) : dvec2{0, 0};
-      }
+            for (int i = 0; i < kRows; ++i) v[i][u] = ok ? (NT ? __builtin_nontemporal_load(&row[i][cc]) : row[i][cc]) : dvec2{0, 0};
+          }
 #pragma unroll
-      for (int u = 0; u < kVecs; ++u) {
-        const int cc = c + u * kWave;
-        if (cc < nvec) {
-          const dvec2 x2 = xv[cc];
+          for (int u = 0; u < kVecs; ++u) {
+            const int cc = c + u * kWave;
+            if (cc < nvec) {
+              const dvec2 x2 = xv[cc];
 #pragma unroll
-          for (int i = 0; i < kRows; ++i) acc[i] = fma(v[i][u].x, x2.x, fma(v[i][u].y, x2.y, acc[i]));
+              for (int i = 0; i < kRows; ++i) acc[i] = fma(v[i][u].x, x2.x, fma(v[i][u].y, x2.y, acc[i]));
+            }
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < kRows; ++i) acc[i] = wave_sum(acc[i]);
+        if (lane == 0) {
+#pragma unroll
+          for (int i = 0; i < kRows; ++i) {
+            const int ri = r + i * kSpmvWaves;
+            if (ri < nrows) d.yt[row0 + ri] = c0 ? d.yt[row0 + ri] + acc[i] : acc[i];
+          }
         }
       }
     }
-#pragma unroll
-    for (int i = 0; i < kRows; ++i) acc[i] = wave_sum(acc[i]);
-    if (lane == 0) {
-#pragma unroll
-      for (int i = 0; i < kRows; ++i) {
-        const int ri = r + i * kSpmvWaves;
-        if (ri < nrows) d.yt[row0 + ri] = acc[i];
-      }
-    }
+    __syncthreads();                                  // xs / run descriptors are rewritten for the next leaf
   }
 }
 
@@ -289,7 +307,8 @@ __global__ __launch_bounds__(kSpmvWaves * kWave) void near_spmv_kernel(DevicePla
 hipError_t launch_near_assemble(const DevicePlan& d, hipStream_t s) {
   const int nb = d.leaf_end - d.leaf_begin;
   if (nb <= 0) return hipSuccess;
-  hipLaunchKernelGGL(near_assemble_kernel, dim3(nb), dim3(256), ((size_t)d.max_ncols + 2 * (size_t)d.max_runs) * sizeof(int), s, d);
+  hipLaunchKernelGGL(near_assemble_kernel, dim3(nb < 256 * 8 ? nb : 256 * 8), dim3(256),
+                     ((size_t)kAsmChunk + 2 * (size_t)d.max_runs) * sizeof(int), s, d);
   return hipGetLastError();
 }
 
@@ -302,8 +321,17 @@ hipError_t launch_gather_x(const DevicePlan& d, const double* x, hipStream_t s) 
 hipError_t launch_near_spmv(const DevicePlan& d, hipStream_t s) {
   const int nb = d.leaf_end - d.leaf_begin;
   if (nb <= 0) return hipSuccess;
-  hipLaunchKernelGGL(near_spmv_kernel, dim3(nb), dim3(kSpmvWaves * kWave),
-                     (size_t)d.max_ncols * sizeof(double) + 2 * (size_t)d.max_runs * sizeof(int), s, d);
+  const size_t lds = (size_t)kSpmvChunk * sizeof(double) + 2 * (size_t)d.max_runs * sizeof(int);
+  const int per_cu = d.debug_mode % 10 ? d.debug_mode % 10 : 6;
+  const dim3 g(nb < 256 * per_cu ? nb : 256 * per_cu), b(kSpmvWaves * kWave);
+  switch (d.debug_mode / 10) {
+    case 1: hipLaunchKernelGGL((near_spmv_kernel<4, false>), g, b, lds, s, d); break;
+    case 2: hipLaunchKernelGGL((near_spmv_kernel<2, true>), g, b, lds, s, d); break;
+    case 3: hipLaunchKernelGGL((near_spmv_kernel<2, false>), g, b, lds, s, d); break;
+    case 4: hipLaunchKernelGGL((near_spmv_kernel<1, true>), g, b, lds, s, d); break;
+    case 5: hipLaunchKernelGGL((near_spmv_kernel<8, true>), g, b, lds, s, d); break;
+    default: hipLaunchKernelGGL((near_spmv_kernel<4, true>), g, b, lds, s, d); break;
+  }
   return hipGetLastError();
 }
 

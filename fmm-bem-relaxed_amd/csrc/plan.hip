@@ -8,6 +8,7 @@
 #include <cmath>
 #include <complex>
 #include <cstring>
+#include <cstdlib>
 #include <memory>
 #include <string>
 #include <unordered_map>
@@ -226,6 +227,7 @@ int fmmbem_plan::to_device() {
     }
   }
   d.max_runs = max_runs;
+  if (const char* dbg = getenv("FMMBEM_DEBUG_MODE")) d.debug_mode = atoi(dbg);
   d.max_ncols = max_cols;
   near_bytes = total * (int64_t)sizeof(double);
   TRY(upload(leaf_row0, &d.leaf_row0)); TRY(upload(leaf_nrows, &d.leaf_nrows)); TRY(upload(hp.leaf_box, &d.leaf_box));
