@@ -57,6 +57,11 @@ struct DevicePlan {
   const int *l2l_child;       const int* box_parent;
   const int *up_cls, *down_cls;                       // per box: class of (parent-child) / (child-parent)
   const double2 *up_tab, *down_tab;                   // [cls][p2_max]
+  // M2M / L2L as sparse operators in ELL form (shift_ops.hpp), rows = stored coefficient index at p_max
+  const uint16_t *up_src, *up_y, *down_src, *down_y;
+  const double *up_real, *down_real;
+  const int *up_len, *down_cnt;
+  int up_maxlen = 0, down_maxlen = 0;
   const int *mh_box;          int n_mh = 0;           // boxes whose Mh is needed (M2L sources)
   const int *m2l_tgt;         int n_m2l_tgt = 0;
   const int *m2l_ptr, *m2l_src, *m2l_cls;

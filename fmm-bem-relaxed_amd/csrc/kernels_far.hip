@@ -43,17 +43,7 @@ JK make_jk() {
   return t;
 }
 
-__device__ inline double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
-  return v;
-}
 __device__ inline double2 cmul(double2 a, double2 b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
-__device__ inline double2 cconj(double2 a) { return {a.x, -a.y}; }
-__device__ inline void cfma(double2& acc, double2 a, double2 b) {     // acc += a*b
-  acc.x = fma(a.x, b.x, acc.x); acc.x = fma(-a.y, b.y, acc.x);
-  acc.y = fma(a.x, b.y, acc.y); acc.y = fma(a.y, b.x, acc.y);
-}
 __device__ inline double2 mul_i_pow(double2 a, int q) {              // a * i^q
   switch (q & 3) {
     case 0: return a;
@@ -62,7 +52,6 @@ __device__ inline double2 mul_i_pow(double2 a, int q) {              // a * i^q
     default: return {a.y, -a.x};
   }
 }
-__device__ inline int oddeven(int n) { return (n & 1) ? -1 : 1; }
 
 // Spherical coordinates of d as the reference's cart2sph produces them
 // (kernel/LaplaceSpherical.hpp:528-541): rho = |d| + EPS, alpha = acos(z/rho); the azimuth is kept as
@@ -81,169 +70,170 @@ __device__ inline Sph cart2sph(double dx, double dy, double dz) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// P2M: one wavefront per source leaf and expansion slot; lane = panel, NQ quadrature points advanced
-// in lock-step through the Legendre / rho^n / e^{im beta} recurrences of evalMultipole(rho,alpha,-beta)
-// (kernel/LaplaceSpherical.hpp:455-488); each coefficient is reduced over the wavefront by shuffles.
+// P2M: one wavefront per source leaf (workgroups stride over the leaves).  Lane = one quadrature point of
+// one panel; every lane runs the Legendre / rho^n / e^{-im beta} recurrences of evalMultipole(rho,alpha,-beta)
+// (kernel/LaplaceSpherical.hpp:455-488) for its point and drops its weighted harmonic for coefficient row r
+// into an LDS tile [row][lane]; after kP2MBand rows the tile is reduced along the lanes (two lanes per row,
+// conflict-free 16-B reads) and added to the leaf's accumulator.  No per-coefficient wave shuffles.
 // ---------------------------------------------------------------------------------------------
-template <int NQ, int slot>
-__global__ __launch_bounds__(kWave) void p2m_kernel(DevicePlan d, const int P) {
-  const int S = P * (P + 1) / 2;
-  __shared__ double2 acc[kSmax];
-  const int lane = threadIdx.x;
-  const int leaf = d.p2m_leaf[blockIdx.x];
-  const int box = d.leaf_box[leaf];
-  const int row0 = d.leaf_row0[leaf], nrows = d.leaf_nrows[leaf];
-  const double c0 = d.box_center[3 * box], c1 = d.box_center[3 * box + 1], c2 = d.box_center[3 * box + 2];
-  for (int i = lane; i < S; i += kWave) acc[i] = {0, 0};
-  const int64_t N = d.n;
+constexpr int kP2MBand = 16;                          // rows per LDS tile (16.6 KiB): 4 lanes reduce one row
 
-  for (int chunk = 0; chunk < nrows; chunk += kWave) {
-    const int64_t i = row0 + chunk + lane;
-    const bool live = (chunk + lane < nrows) && (d.bc[i] == slot);
-    const double wpanel = live ? d.xt[i] * d.area[i] : 0.0;
-    const double n0 = live ? d.nx[i] : 0, n1 = live ? d.ny[i] : 0, n2 = live ? d.nz[i] : 0;
-    for (int q0 = 0; q0 < d.nq; q0 += NQ) {
-      Sph s[NQ];
-      double wq[NQ];
+template <int slot>
+__global__ __launch_bounds__(kWave) void p2m_kernel(DevicePlan d, const int P) {
+  __shared__ double2 tile[kP2MBand][kWave + 1];
+  __shared__ double2 acc[kSmax];
+  __shared__ int rowidx[kP2MBand];
+  const int S = P * (P + 1) / 2;
+  const int lane = threadIdx.x;
+  const int64_t N = d.n;
+  const int nq = d.nq;
+  for (int li = blockIdx.x; li < d.n_p2m; li += gridDim.x) {
+    const int leaf = d.p2m_leaf[li];
+    const int box = d.leaf_box[leaf];
+    const int row0 = d.leaf_row0[leaf], npts = d.leaf_nrows[leaf] * nq;
+    const double c0 = d.box_center[3 * box], c1 = d.box_center[3 * box + 1], c2 = d.box_center[3 * box + 2];
+    for (int i = lane; i < S; i += kWave) acc[i] = {0, 0};
+    int inband = 0;
+    auto flush = [&]() {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      constexpr int kPer = kWave / kP2MBand, kCols = kWave / kPer;      // lanes per row, columns per lane
+      const int r = lane & (kP2MBand - 1), part = lane / kP2MBand;
+      double sr = 0, si = 0;
+      if (r < inband) {
+        const double2* rowp = &tile[r][part * kCols];
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const bool on = live && (q0 + q < d.nq);
-        const int qq = on ? q0 + q : 0;
-        const double dx = on ? d.quad[(qq * 3 + 0) * N + i] - c0 : 0.3;
-        const double dy = on ? d.quad[(qq * 3 + 1) * N + i] - c1 : 0.4;
-        const double dz = on ? d.quad[(qq * 3 + 2) * N + i] - c2 : 0.5;
-        s[q] = cart2sph(dx, dy, dz);
-        wq[q] = on ? wpanel * d.qw[qq] : 0.0;
+        for (int k = 0; k < kCols; ++k) { sr += rowp[k].x; si += rowp[k].y; }
       }
-      double pn[NQ], rhom[NQ], er[NQ], ei[NQ];
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) { pn[q] = 1; rhom[q] = 1; er[q] = 1; ei[q] = 0; }
-      double fact = 1;
+      for (int off = kP2MBand; off < kWave; off <<= 1) {
+        sr += __shfl_xor(sr, off, kWave);
+        si += __shfl_xor(si, off, kWave);
+      }
+      if (part == 0 && r < inband) { double2& a = acc[rowidx[r]]; a.x += sr; a.y += si; }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      inband = 0;
+    };
+    for (int chunk = 0; chunk < npts; chunk += kWave) {
+      const int pt = chunk + lane;
+      const int panel = pt / nq, q = pt - panel * nq;
+      const int64_t i = row0 + panel;
+      const bool live = pt < npts && d.bc[i] == slot;
+      const double wq = live ? d.xt[i] * d.area[i] * d.qw[q] : 0.0;
+      const double n0 = live ? d.nx[i] : 0, n1 = live ? d.ny[i] : 0, n2 = live ? d.nz[i] : 0;
+      const Sph s = cart2sph(live ? d.quad[(q * 3 + 0) * N + i] - c0 : 0.3, live ? d.quad[(q * 3 + 1) * N + i] - c1 : 0.4,
+                             live ? d.quad[(q * 3 + 2) * N + i] - c2 : 0.5);
+      double pn = 1, rhom = 1, er = 1, ei = 0, fact = 1;
 #pragma nounroll
       for (int m = 0; m < P; ++m) {
-        double p[NQ], p1[NQ], rhon[NQ];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) { p[q] = pn[q]; p1[q] = p[q]; rhon[q] = rhom[q]; }
+        double p = pn, p1 = p, rhon = rhom;
 #pragma nounroll
         for (int n = m; n < P; ++n) {
           const double pref = d.tabPref[n * n + n + m];
-          double vr = 0, vi = 0;
-#pragma unroll
-          for (int q = 0; q < NQ; ++q) {
-            // Ynm[n,m] at (rho, alpha, -beta): rho^n P_n^m(cos a) pref e^{-i m beta}
-            const double mag = rhon[q] * p[q] * pref;
-            const double yr = mag * er[q], yi = -mag * ei[q];
-            // advance the Legendre recurrence (p -> P_{n+1}^m), keeping P_n^m in pcur
-            const double pcur = p[q];
-            double pnext;
-            if (n == m) pnext = s[q].ca * (2 * m + 1) * pcur;
-            else pnext = (s[q].ca * (2 * n + 1) * pcur - (n + m) * p1[q]) / (double)(n - m + 1);
-            if (slot == 0) {                          // source BC POTENTIAL: G moments (:326)
-              vr = fma(wq[q], yr, vr); vi = fma(wq[q], yi, vi);
-            } else {                                  // NORMAL_DERIV: (n . grad)(rho^n Ynm) (:331-343)
-              double tmag;                            // YnmTheta magnitude
-              if (n == m) tmag = rhon[q] * (pnext - (m + 1) * s[q].ca * pcur) / s[q].sa * pref;
-              else tmag = rhon[q] * ((n - m + 1) * pnext - (n + 1) * s[q].ca * pcur) / s[q].sa * pref;
-              const double tr = tmag * er[q], ti = -tmag * ei[q];
-              const double rho = s[q].rho, sa = s[q].sa, ca = s[q].ca, cb = s[q].cb, sb = s[q].sb;
-              const double brr = (double)n / rho * yr, bri = (double)n / rho * yi;       // d/d rho
-              const double ber = (double)m * yi, bei = -(double)m * yr;                  // -i m Ynm
-              const double gxr = sa * cb * brr + ca * cb / rho * tr - sb / rho / sa * ber;
-              const double gxi = sa * cb * bri + ca * cb / rho * ti - sb / rho / sa * bei;
-              const double gyr = sa * sb * brr + ca * sb / rho * tr + cb / rho / sa * ber;
-              const double gyi = sa * sb * bri + ca * sb / rho * ti + cb / rho / sa * bei;
-              const double gzr = ca * brr - sa / rho * tr;
-              const double gzi = ca * bri - sa / rho * ti;
-              vr += wq[q] * (n0 * gxr + n1 * gyr + n2 * gzr);
-              vi += wq[q] * (n0 * gxi + n1 * gyi + n2 * gzi);
-            }
-            p1[q] = pcur; p[q] = pnext;
-            rhon[q] *= s[q].rho;
+          // Ynm[n,m] at (rho, alpha, -beta): rho^n P_n^m(cos a) pref e^{-i m beta}
+          const double mag = rhon * p * pref;
+          const double yr = mag * er, yi = -mag * ei;
+          const double pcur = p;
+          double pnext;                               // Legendre recurrence, P_{n+1}^m
+          if (n == m) pnext = s.ca * (2 * m + 1) * pcur;
+          else pnext = (s.ca * (2 * n + 1) * pcur - (n + m) * p1) / (double)(n - m + 1);
+          double vr, vi;
+          if (slot == 0) {                            // source BC POTENTIAL: G moments (LaplaceSphericalBEM.hpp:326)
+            vr = wq * yr; vi = wq * yi;
+          } else {                                    // NORMAL_DERIV: (n . grad)(rho^n Ynm) (:331-343)
+            double tmag;                              // YnmTheta magnitude
+            if (n == m) tmag = rhon * (pnext - (m + 1) * s.ca * pcur) / s.sa * pref;
+            else tmag = rhon * ((n - m + 1) * pnext - (n + 1) * s.ca * pcur) / s.sa * pref;
+            const double tr = tmag * er, ti = -tmag * ei;
+            const double rho = s.rho, sa = s.sa, ca = s.ca, cb = s.cb, sb = s.sb;
+            const double brr = (double)n / rho * yr, bri = (double)n / rho * yi;       // d/d rho
+            const double ber = (double)m * yi, bei = -(double)m * yr;                  // -i m Ynm
+            const double gxr = sa * cb * brr + ca * cb / rho * tr - sb / rho / sa * ber;
+            const double gxi = sa * cb * bri + ca * cb / rho * ti - sb / rho / sa * bei;
+            const double gyr = sa * sb * brr + ca * sb / rho * tr + cb / rho / sa * ber;
+            const double gyi = sa * sb * bri + ca * sb / rho * ti + cb / rho / sa * bei;
+            const double gzr = ca * brr - sa / rho * tr;
+            const double gzi = ca * bri - sa / rho * ti;
+            vr = wq * (n0 * gxr + n1 * gyr + n2 * gzr);
+            vi = wq * (n0 * gxi + n1 * gyi + n2 * gzi);
           }
-          vr = wave_sum(vr);
-          vi = wave_sum(vi);
-          if (lane == 0) { double2& a = acc[n * (n + 1) / 2 + m]; a.x += vr; a.y += vi; }
+          tile[inband][lane] = {vr, vi};
+          if (lane == 0) rowidx[inband] = n * (n + 1) / 2 + m;
+          if (++inband == kP2MBand) flush();
+          p1 = pcur; p = pnext;
+          rhon *= s.rho;
         }
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          pn[q] = -pn[q] * fact * s[q].sa;
-          rhom[q] *= s[q].rho;
-          const double nr = er[q] * s[q].cb - ei[q] * s[q].sb, ni = er[q] * s[q].sb + ei[q] * s[q].cb;
-          er[q] = nr; ei[q] = ni;
-        }
+        pn = -pn * fact * s.sa;
+        rhom *= s.rho;
+        const double nr = er * s.cb - ei * s.sb, ni = er * s.sb + ei * s.cb;
+        er = nr; ei = ni;
         fact += 2;
       }
+      if (inband) flush();
     }
+    double2* M = d.M + ((size_t)box * 2 + slot) * d.s_max;
+    for (int i = lane; i < S; i += kWave) M[i] = acc[i];
+    __builtin_amdgcn_wave_barrier();
   }
-  __syncthreads();
-  double2* M = d.M + ((size_t)box * 2 + slot) * d.s_max;
-  for (int i = lane; i < S; i += kWave) M[i] = acc[i];
 }
 
 // ---------------------------------------------------------------------------------------------
-// M2M, one tree level per launch: one wavefront per parent box and slot, children in turn.
-// The regular harmonics of the parent-child translation come from a per-class table.
+// M2M, one tree level per launch.  A workgroup = kShiftWaves wavefronts takes one parent box; wavefront w
+// translates child w (children are the <= 8 occupied octants) with the precomputed sparse operator
+// (shift_ops.hpp): lanes = output rows, ELL term lists read coalesced, the child's M and the class's
+// regular harmonics in LDS.  The per-child results are combined in child order (the reference's order,
+// EvalInteractionLazySparse.hpp:185-190) and stored -- a parent's M has no other contribution.
+// Workgroups stride over the level's parents.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kWave) void m2m_kernel(DevicePlan d, const int P, int first) {
-  const int S = P * (P + 1) / 2, P2 = P * P;
-  constexpr int SLOTS = (kSmax + kWave - 1) / kWave;
-  __shared__ double2 Ms[kSmax];
-  __shared__ double2 Y[kPmaxDev * kPmaxDev];
-  const int lane = threadIdx.x;
-  const int parent = d.m2m_parent[first + blockIdx.x];
+constexpr int kShiftWaves = 8;
+
+__global__ __launch_bounds__(kShiftWaves * kWave) void m2m_kernel(DevicePlan d, const int P, int first, int count) {
+  extern __shared__ double2 lds2[];
+  const int S = P * (P + 1) / 2, P2 = P * P, SM = d.s_max;
+  const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+  double2* Ms = lds2 + (size_t)w * (S + P2);          // this wavefront's child multipole
+  double2* Y = Ms + S;                                // ... and its translation harmonics
+  double2* part = lds2 + (size_t)kShiftWaves * (S + P2) + (size_t)w * S;
   const int slot = d.act[blockIdx.y];
-  const double* A = d.tabA;
-  const double* iA = d.tabInvA;
-  double2 acc[SLOTS];
-#pragma unroll
-  for (int s = 0; s < SLOTS; ++s) acc[s] = {0, 0};
-  for (int c = d.box_child_begin[parent]; c < d.box_child_end[parent]; ++c) {
-    __syncthreads();
-    const double2* src = d.M + ((size_t)c * 2 + slot) * d.s_max;
-    const double2* tab = d.up_tab + (size_t)d.up_cls[c] * d.p2_max;
-    for (int i = lane; i < S; i += kWave) Ms[i] = src[i];
-    for (int i = lane; i < P2; i += kWave) Y[i] = tab[i];
-    __syncthreads();
-#pragma unroll
-    for (int s = 0; s < SLOTS; ++s) {
-      const int idx = lane + s * kWave;
-      if (idx >= S) continue;
-      const int j = kJK.j[idx], k = kJK.k[idx];
-      const int jk = j * j + j + k;
-      double2 sum = {0, 0};
-      for (int n = 0; n <= j; ++n) {
-        const int mhi = (k - 1 < n) ? k - 1 : n;
-        for (int m = -n; m <= mhi; ++m) {
-          if (j - n >= k - m) {
-            const int jnkm = (j - n) * (j - n) + j - n + k - m;
-            const int jnkms = (j - n) * (j - n + 1) / 2 + k - m;
-            const int nm = n * n + n + m;
-            const double ph = (m < 0 && (m & 1)) ? -1.0 : 1.0;               // i^{m-|m|}
-            const double coef = ph * oddeven(n) * A[nm] * A[jnkm] * iA[jk];
-            const double2 t = cmul(Ms[jnkms], Y[nm]);
-            sum.x = fma(t.x, coef, sum.x); sum.y = fma(t.y, coef, sum.y);
-          }
+  for (int it = blockIdx.x; it < count; it += gridDim.x) {
+    const int parent = d.m2m_parent[first + it];
+    const int cb = d.box_child_begin[parent], nchild = d.box_child_end[parent] - cb;
+    if (w < nchild) {
+      const int c = cb + w;
+      const double2* src = d.M + ((size_t)c * 2 + slot) * SM;
+      const double2* tab = d.up_tab + (size_t)d.up_cls[c] * d.p2_max;
+      for (int i = lane; i < S; i += kWave) Ms[i] = src[i];
+      for (int i = lane; i < P2; i += kWave) Y[i] = tab[i];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      for (int idx = lane; idx < S; idx += kWave) {
+        const int len = d.up_len[idx];
+        double2 acc = {0, 0};
+        for (int i = 0; i < len; ++i) {
+          const size_t e = (size_t)i * SM + idx;
+          const unsigned sc = d.up_src[e];
+          double2 v = Ms[sc & 0x7fff];
+          if (sc & 0x8000) v.y = -v.y;
+          const double2 t = cmul(v, Y[d.up_y[e]]);
+          const double r = d.up_real[e];
+          acc.x = fma(t.x, r, acc.x); acc.y = fma(t.y, r, acc.y);
         }
-        for (int m = k; m <= n; ++m) {
-          if (j - n >= m - k) {
-            const int jnkm = (j - n) * (j - n) + j - n + k - m;
-            const int jnkms = (j - n) * (j - n + 1) / 2 - k + m;
-            const int nm = n * n + n + m;
-            const double coef = oddeven(k + n + m) * A[nm] * A[jnkm] * iA[jk];
-            const double2 t = cmul(cconj(Ms[jnkms]), Y[nm]);
-            sum.x = fma(t.x, coef, sum.x); sum.y = fma(t.y, coef, sum.y);
-          }
-        }
+        part[idx] = acc;
       }
-      acc[s].x = fma(sum.x, kEps, acc[s].x);
-      acc[s].y = fma(sum.y, kEps, acc[s].y);
     }
-  }
-  double2* dst = d.M + ((size_t)parent * 2 + slot) * d.s_max;
-#pragma unroll
-  for (int s = 0; s < SLOTS; ++s) {
-    const int idx = lane + s * kWave;
-    if (idx < S) dst[idx] = acc[s];
+    __syncthreads();
+    double2* dst = d.M + ((size_t)parent * 2 + slot) * SM;
+    const double2* parts = lds2 + (size_t)kShiftWaves * (S + P2);
+    for (int idx = threadIdx.x; idx < S; idx += blockDim.x) {
+      double2 sum = {0, 0};
+      for (int c = 0; c < nchild; ++c) { sum.x += parts[(size_t)c * S + idx].x; sum.y += parts[(size_t)c * S + idx].y; }
+      dst[idx] = sum;
+    }
+    __syncthreads();
   }
 }
 
@@ -266,57 +256,44 @@ __global__ __launch_bounds__(kWave) void mh_prep_kernel(DevicePlan d, const int 
 }
 
 // ---------------------------------------------------------------------------------------------
-// L2L, one tree level per launch: one wavefront per child box and slot: L[child] += shift(L[parent]).
+// L2L, one tree level per launch: L[child] += shift(L[parent]).  One wavefront per child box (kShiftWaves
+// independent children per workgroup), same sparse-operator scheme as M2M; the terms usable at order p are
+// a prefix of each row's list (down_cnt).  Workgroups stride over the level's children.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kWave) void l2l_kernel(DevicePlan d, const int P, int first) {
-  const int S = P * (P + 1) / 2, P2 = P * P;
-  constexpr int SLOTS = (kSmax + kWave - 1) / kWave;
-  __shared__ double2 Ls[kSmax];
-  __shared__ double2 Y[kPmaxDev * kPmaxDev];
-  const int lane = threadIdx.x;
-  const int child = d.l2l_child[first + blockIdx.x];
-  const int parent = d.box_parent[child];
+__global__ __launch_bounds__(kShiftWaves * kWave) void l2l_kernel(DevicePlan d, const int P, int first, int count) {
+  extern __shared__ double2 lds2[];
+  const int S = P * (P + 1) / 2, P2 = P * P, SM = d.s_max;
+  const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+  double2* Ls = lds2 + (size_t)w * (S + P2);
+  double2* Y = Ls + S;
   const int slot = d.act[blockIdx.y];
-  const double* A = d.tabA;
-  const double* iA = d.tabInvA;
-  const double2* src = d.L + ((size_t)parent * 2 + slot) * d.s_max;
-  const double2* tab = d.down_tab + (size_t)d.down_cls[child] * d.p2_max;
-  for (int i = lane; i < S; i += kWave) Ls[i] = src[i];
-  for (int i = lane; i < P2; i += kWave) Y[i] = tab[i];
-  __syncthreads();
-  double2* dst = d.L + ((size_t)child * 2 + slot) * d.s_max;
-#pragma unroll
-  for (int s = 0; s < SLOTS; ++s) {
-    const int idx = lane + s * kWave;
-    if (idx >= S) continue;
-    const int j = kJK.j[idx], k = kJK.k[idx];
-    const int jk = j * j + j + k;
-    double2 sum = {0, 0};
-    for (int n = j; n < P; ++n) {
-      for (int m = j + k - n; m < 0; ++m) {
-        const int jnkm = (n - j) * (n - j) + n - j + m - k;
-        const int nm = n * n + n - m;
-        const int nms = n * (n + 1) / 2 - m;
-        const double coef = oddeven(k) * A[jnkm] * A[jk] * iA[nm];
-        const double2 t = cmul(cconj(Ls[nms]), Y[jnkm]);
-        sum.x = fma(t.x, coef, sum.x); sum.y = fma(t.y, coef, sum.y);
+  const int* cnt = d.down_cnt + (size_t)(P - 1) * SM;
+  for (int it = blockIdx.x * kShiftWaves + w; it < count; it += gridDim.x * kShiftWaves) {
+    const int child = d.l2l_child[first + it];
+    const int parent = d.box_parent[child];
+    const double2* src = d.L + ((size_t)parent * 2 + slot) * SM;
+    const double2* tab = d.down_tab + (size_t)d.down_cls[child] * d.p2_max;
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < S; i += kWave) Ls[i] = src[i];
+    for (int i = lane; i < P2; i += kWave) Y[i] = tab[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double2* dst = d.L + ((size_t)child * 2 + slot) * SM;
+    for (int idx = lane; idx < S; idx += kWave) {
+      const int len = cnt[idx];
+      double2 acc = dst[idx];
+      for (int i = 0; i < len; ++i) {
+        const size_t e = (size_t)i * SM + idx;
+        const unsigned sc = d.down_src[e];
+        double2 v = Ls[sc & 0x7fff];
+        if (sc & 0x8000) v.y = -v.y;
+        const double2 t = cmul(v, Y[d.down_y[e]]);
+        const double r = d.down_real[e];
+        acc.x = fma(t.x, r, acc.x); acc.y = fma(t.y, r, acc.y);
       }
-      for (int m = 0; m <= n; ++m) {
-        const int dmk = m - k, admk = dmk < 0 ? -dmk : dmk;
-        if (n - j >= admk) {
-          const int jnkm = (n - j) * (n - j) + n - j + m - k;
-          const int nm = n * n + n + m;
-          const int nms = n * (n + 1) / 2 + m;
-          const double ph = (dmk < 0 && (dmk & 1)) ? -1.0 : 1.0;             // i^{m-k-|m-k|}
-          const double coef = ph * A[jnkm] * A[jk] * iA[nm];
-          const double2 t = cmul(Ls[nms], Y[jnkm]);
-          sum.x = fma(t.x, coef, sum.x); sum.y = fma(t.y, coef, sum.y);
-        }
-      }
+      dst[idx] = acc;
     }
-    double2 cur = dst[idx];
-    cur.x = fma(sum.x, kEps, cur.x); cur.y = fma(sum.y, kEps, cur.y);
-    dst[idx] = cur;
   }
 }
 
@@ -328,9 +305,11 @@ __global__ __launch_bounds__(kWave) void l2p_kernel(DevicePlan d, const int P, d
   const int S = P * (P + 1) / 2;
   __shared__ double2 Ls[2][kSmax];
   const int lane = threadIdx.x;
-  const int leaf = d.l2p_leaf[blockIdx.x];
+  for (int li = blockIdx.x; li < d.n_l2p; li += gridDim.x) {
+  const int leaf = d.l2p_leaf[li];
   const int box = d.leaf_box[leaf];
   const int row0 = d.leaf_row0[leaf], nrows = d.leaf_nrows[leaf];
+  __syncthreads();
   for (int s = 0; s < 2; ++s) {
     const double2* src = d.L + ((size_t)box * 2 + s) * d.s_max;
     for (int i = lane; i < S; i += kWave) Ls[s][i] = src[i];
@@ -369,12 +348,17 @@ __global__ __launch_bounds__(kWave) void l2p_kernel(DevicePlan d, const int P, d
     const uint32_t o = d.perm[i];
     y[o] += tb ? -r : r;
   }
+  }
 }
 
 hipError_t upload_constants_once() {
   static hipError_t st = [] {
     const JK t = make_jk();
-    return hipMemcpyToSymbol(HIP_SYMBOL(kJK), &t, sizeof(t));
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(kJK), &t, sizeof(t));
+    // M2M at p = 16 needs a little over 64 KiB of dynamic LDS
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(m2m_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(l2l_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    return e;
   }();
   return st;
 }
@@ -385,19 +369,10 @@ hipError_t launch_p2m(const DevicePlan& d, int p, hipStream_t s) {
   if (hipError_t e = upload_constants_once(); e != hipSuccess) return e;
   if (d.n_p2m <= 0) return hipSuccess;
   if (p < 1 || p > kPmaxDev) return hipErrorInvalidValue;
-  const dim3 g(d.n_p2m), b(kWave);
+  const dim3 g(d.n_p2m < 256 * 16 ? d.n_p2m : 256 * 16), b(kWave);
   for (int a = 0; a < d.n_act; ++a) {
-    const int slot = d.act[a];
-    if (d.nq == 3) {
-      if (slot == 0) hipLaunchKernelGGL((p2m_kernel<3, 0>), g, b, 0, s, d, p);
-      else hipLaunchKernelGGL((p2m_kernel<3, 1>), g, b, 0, s, d, p);
-    } else if (d.nq == 4) {
-      if (slot == 0) hipLaunchKernelGGL((p2m_kernel<4, 0>), g, b, 0, s, d, p);
-      else hipLaunchKernelGGL((p2m_kernel<4, 1>), g, b, 0, s, d, p);
-    } else {
-      if (slot == 0) hipLaunchKernelGGL((p2m_kernel<1, 0>), g, b, 0, s, d, p);
-      else hipLaunchKernelGGL((p2m_kernel<1, 1>), g, b, 0, s, d, p);
-    }
+    if (d.act[a] == 0) hipLaunchKernelGGL((p2m_kernel<0>), g, b, 0, s, d, p);
+    else hipLaunchKernelGGL((p2m_kernel<1>), g, b, 0, s, d, p);
   }
   return hipGetLastError();
 }
@@ -406,7 +381,11 @@ hipError_t launch_m2m_level(const DevicePlan& d, int p, int first, int count, hi
   if (hipError_t e = upload_constants_once(); e != hipSuccess) return e;
   if (count <= 0) return hipSuccess;
   if (p < 1 || p > kPmaxDev) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(m2m_kernel, dim3(count, d.n_act), dim3(kWave), 0, s, d, p, first);
+  {
+    const size_t S = (size_t)p * (p + 1) / 2, P2 = (size_t)p * p;
+    const size_t lds = (kShiftWaves * (S + P2) + kShiftWaves * S) * sizeof(double2);
+    hipLaunchKernelGGL(m2m_kernel, dim3(count < 1024 ? count : 1024, d.n_act), dim3(kShiftWaves * kWave), lds, s, d, p, first, count);
+  }
   return hipGetLastError();
 }
 
@@ -422,14 +401,19 @@ hipError_t launch_l2l_level(const DevicePlan& d, int p, int first, int count, hi
   if (hipError_t e = upload_constants_once(); e != hipSuccess) return e;
   if (count <= 0) return hipSuccess;
   if (p < 1 || p > kPmaxDev) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(l2l_kernel, dim3(count, d.n_act), dim3(kWave), 0, s, d, p, first);
+  {
+    const size_t S = (size_t)p * (p + 1) / 2, P2 = (size_t)p * p;
+    const size_t lds = kShiftWaves * (S + P2) * sizeof(double2);
+    const int blocks = (count + kShiftWaves - 1) / kShiftWaves;
+    hipLaunchKernelGGL(l2l_kernel, dim3(blocks < 1024 ? blocks : 1024, d.n_act), dim3(kShiftWaves * kWave), lds, s, d, p, first, count);
+  }
   return hipGetLastError();
 }
 
 hipError_t launch_l2p(const DevicePlan& d, int p, double* y, hipStream_t s) {
   if (d.n_l2p <= 0) return hipSuccess;
   if (p < 1 || p > kPmaxDev) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(l2p_kernel, dim3(d.n_l2p), dim3(kWave), 0, s, d, p, y);
+  hipLaunchKernelGGL(l2p_kernel, dim3(d.n_l2p < 256 * 32 ? d.n_l2p : 256 * 32), dim3(kWave), 0, s, d, p, y);
   return hipGetLastError();
 }
 

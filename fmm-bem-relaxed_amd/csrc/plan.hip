@@ -18,6 +18,7 @@
 #include "device_plan.hpp"
 #include "host_plan.hpp"
 #include "m2l_layout.hpp"
+#include "shift_ops.hpp"
 
 using namespace fmmbem;
 
@@ -297,6 +298,12 @@ int fmmbem_plan::to_device() {
     TRY(upload(up_tab, &pu)); TRY(upload(down_tab, &pd));
     d.up_tab = reinterpret_cast<const double2*>(pu);
     d.down_tab = reinterpret_cast<const double2*>(pd);
+    const ShiftOps ops = build_shift_ops(pm, T.A, kEps);
+    d.up_maxlen = ops.up_maxlen; d.down_maxlen = ops.down_maxlen;
+    TRY(upload(ops.up_src, &d.up_src)); TRY(upload(ops.up_y, &d.up_y)); TRY(upload(ops.up_real, &d.up_real));
+    TRY(upload(ops.up_len, &d.up_len));
+    TRY(upload(ops.down_src, &d.down_src)); TRY(upload(ops.down_y, &d.down_y)); TRY(upload(ops.down_real, &d.down_real));
+    TRY(upload(ops.down_cnt, &d.down_cnt));
   }
 
   // M2L: targets to run, sources whose Mh is needed, class tables Yh[r,c] = i^{|c|} EPS Y[r,c] / A[r,c]
