@@ -18,6 +18,8 @@
 #include "device_plan.hpp"
 #include "m2l_layout.hpp"
 
+#include <type_traits>
+
 namespace fmmbem {
 
 namespace {
@@ -27,13 +29,28 @@ struct C2 { double x, y; };
 typedef __attribute__((address_space(4))) C2 ConstC2;      // complex value in the constant address space
 constexpr int kM2LTargets = 4;         // independent single-wavefront targets per workgroup when TEAM == 1
 
-template <int P> struct Shape {
+constexpr int isqrt_cut(int P, int i, int NS) {          // round(P * sqrt(i / NS)) without <cmath>
+  int best = 0;
+  for (int c = 0; c <= P; ++c) {
+    const long a = (long)c * c * NS - (long)P * P * i, b = (long)best * best * NS - (long)P * P * i;
+    if ((a < 0 ? -a : a) < (b < 0 ? -b : b)) best = c;
+  }
+  return best;
+}
+
+template <int P, int NS_> struct Shape {
   static constexpr int S = P * (P + 1) / 2, Y2 = 4 * P * P;
-  static constexpr int TEAM = m2l_team(P);
-  static constexpr int TARGETS = TEAM == 1 ? kM2LTargets : 1;
-  static constexpr int THREADS = TEAM * TARGETS * kWave;
+  static constexpr int TEAM = m2l_team(P);               // wavefronts needed to give every output a lane
+  // The (n,m) terms of every output can additionally be split between NS wavefronts (contiguous n ranges
+  // of about P^2/NS terms each) that share one LDS image: NS times the wavefronts per CU for the same
+  // LDS, which is what hides the scalar-load latency of Mh.
+  static constexpr int NS = NS_;
+  static constexpr int cut(int i) { return i <= 0 ? 0 : (i >= NS ? P : isqrt_cut(P, i, NS)); }
+  static constexpr int WAVES = TEAM * NS;
+  static constexpr int TARGETS = WAVES == 1 ? kM2LTargets : 1;
+  static constexpr int THREADS = WAVES * TARGETS * kWave;
   static constexpr int R = m2l_stride(P), C0 = m2l_col0(P), SLOTS = m2l_lds_slots(P);
-  static constexpr int NLOAD = (Y2 + TEAM * kWave - 1) / (TEAM * kWave);   // table entries copied per lane
+  static constexpr int NLOAD = (Y2 + WAVES * kWave - 1) / (WAVES * kWave);   // table entries copied per lane
 };
 
 __device__ inline void cfma(double2& acc, double2 a, double2 b) {     // acc += a*b
@@ -49,22 +66,26 @@ __device__ inline double2 mul_i_pow(double2 a, int q) {              // a * i^q
   }
 }
 
-template <int P>
-__global__ __launch_bounds__(Shape<P>::THREADS) void m2l_kernel(DevicePlan d) {
-  using Sh = Shape<P>;
+template <int P, int NS_>
+__global__ __launch_bounds__((Shape<P, NS_>::THREADS)) void m2l_kernel(DevicePlan d) {
+  using Sh = Shape<P, NS_>;
   constexpr int Y2 = Sh::Y2, TEAM = Sh::TEAM, TARGETS = Sh::TARGETS, R = Sh::R, NLOAD = Sh::NLOAD;
+  constexpr int NS = Sh::NS, WAVES = Sh::WAVES;
   __shared__ double2 Yall[TARGETS][Sh::SLOTS];
+  __shared__ double2 Comb[NS == 1 ? 1 : (NS - 1) * TEAM * kWave];   // partial sums of the other n-ranges
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-  const int ti = blockIdx.x * TARGETS + (TEAM == 1 ? wave : 0);
-  if (ti >= d.n_m2l_tgt) return;                       // TEAM==1: whole wavefront; TEAM>1: whole workgroup
+  const int ti = blockIdx.x * TARGETS + (WAVES == 1 ? wave : 0);
+  if (ti >= d.n_m2l_tgt) return;                       // WAVES==1: whole wavefront; else: whole workgroup
   const int tgt = d.m2l_tgt[ti];
   const int slot = d.act[blockIdx.y];
-  double2* Yt = Yall[TEAM == 1 ? wave : 0];
-  const int tid = TEAM == 1 ? lane : (int)threadIdx.x;  // index within the team
+  double2* Yt = Yall[WAVES == 1 ? wave : 0];
+  const int tid = WAVES == 1 ? lane : (int)threadIdx.x;  // index within the team (table copy)
+  const int npart = WAVES == 1 ? 0 : wave % NS;          // which n-range this wavefront sums
+  const int otid = WAVES == 1 ? lane : (wave / NS) * kWave + lane;   // index in the lane -> output map
 
   // this lane's output (conflict-free dealing, m2l_layout.hpp)
-  const int packed = d.m2l_lane[(P - 1) * kM2LMaxThreads + tid];
+  const int packed = d.m2l_lane[(P - 1) * kM2LMaxThreads + otid];
   const bool valid = packed >= 0;
   const int j = valid ? (packed & 0xff) : 0, k = valid ? ((packed >> 8) & 0xff) : 0, idx = valid ? (packed >> 16) : 0;
   const double2* ybase = Yt + (j * R - k + Sh::C0);
@@ -77,7 +98,7 @@ __global__ __launch_bounds__(Shape<P>::THREADS) void m2l_kernel(DevicePlan d) {
   const int* scat = d.m2l_scat + d.m2l_scat_off[P - 1];
 #define FMMBEM_REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 #define DECL(u)                                                                   \
-  const int i##u = tid + u * TEAM * kWave;                                        \
+  const int i##u = tid + u * WAVES * kWave;                                       \
   const int src##u = (u < NLOAD && i##u < Y2) ? i##u : 0;                         \
   const int dst##u = (u < NLOAD && i##u < Y2) ? scat[i##u] : -1;                  \
   double2 pre##u = {0, 0};
@@ -100,9 +121,9 @@ __global__ __launch_bounds__(Shape<P>::THREADS) void m2l_kernel(DevicePlan d) {
     const int src = __builtin_amdgcn_readfirstlane(d.m2l_src[pi]);
     const int pn = pi + 1 < pe ? pi + 1 : pi;          // last iteration re-reads its own table (harmless)
     const int cls_next = __builtin_amdgcn_readfirstlane(d.m2l_cls[pn]);
-    if (TEAM == 1) __builtin_amdgcn_wave_barrier(); else __syncthreads();     // previous source's reads are done
+    if (WAVES == 1) __builtin_amdgcn_wave_barrier(); else __syncthreads();    // previous source's reads are done
     FMMBEM_REP8(STORE)
-    if (TEAM == 1) {
+    if (WAVES == 1) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -128,9 +149,10 @@ __global__ __launch_bounds__(Shape<P>::THREADS) void m2l_kernel(DevicePlan d) {
         asm volatile("" ::"v"(touch.x), "v"(touch.y));
       }
     }
-    if (valid) {
+    auto mac_range = [&](auto lo_c, auto hi_c) {
+      constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
 #pragma unroll
-      for (int n = 0; n < P; ++n) {
+      for (int n = LO; n < HI; ++n) {
 #pragma unroll
         for (int m = -n; m <= n; ++m) {
           const int am = m < 0 ? -m : m;
@@ -140,12 +162,26 @@ __global__ __launch_bounds__(Shape<P>::THREADS) void m2l_kernel(DevicePlan d) {
           cfma(acc, double2{ar, ai}, ybase[n * R + m]);
         }
       }
+    };
+    if (valid) {
+      if (npart == 0) mac_range(std::integral_constant<int, 0>{}, std::integral_constant<int, Sh::cut(1)>{});
+      if (NS > 1 && npart == 1) mac_range(std::integral_constant<int, Sh::cut(1)>{}, std::integral_constant<int, Sh::cut(2)>{});
+      if (NS > 2 && npart == 2) mac_range(std::integral_constant<int, Sh::cut(2)>{}, std::integral_constant<int, Sh::cut(3)>{});
+      if (NS > 3 && npart == 3) mac_range(std::integral_constant<int, Sh::cut(3)>{}, std::integral_constant<int, Sh::cut(4)>{});
     }
   }
 #undef LOAD
 #undef STORE
 #undef FMMBEM_REP8
-  if (valid) {
+  if (NS > 1) {                                        // fold the other n-ranges into the first, fixed order
+    if (npart > 0) Comb[(npart - 1) * TEAM * kWave + otid] = acc;
+    __syncthreads();
+    if (npart == 0) {
+#pragma unroll
+      for (int q = 0; q < NS - 1; ++q) { acc.x += Comb[q * TEAM * kWave + otid].x; acc.y += Comb[q * TEAM * kWave + otid].y; }
+    }
+  }
+  if (valid && npart == 0) {
     double2* L = d.L + ((size_t)tgt * 2 + slot) * d.s_max;
     const double f = ((j & 1) ? -1.0 : 1.0) * d.tabA[j * j + j + k];
     L[idx] = mul_i_pow(double2{acc.x * f, acc.y * f}, -k);
@@ -169,9 +205,13 @@ __global__ __launch_bounds__(Shape<P>::THREADS) void m2l_kernel(DevicePlan d) {
 
 hipError_t launch_m2l(const DevicePlan& d, int p, hipStream_t s) {
   if (d.n_m2l_tgt <= 0) return hipSuccess;
-  FMMBEM_DISPATCH_P(p, hipLaunchKernelGGL((m2l_kernel<PP>),
-                                          dim3((d.n_m2l_tgt + Shape<PP>::TARGETS - 1) / Shape<PP>::TARGETS, d.n_act),
-                                          dim3(Shape<PP>::THREADS), 0, s, d))
+#define LAUNCH(NSV)                                                                                        \
+  hipLaunchKernelGGL((m2l_kernel<PP, NSV>),                                                                \
+                     dim3((d.n_m2l_tgt + Shape<PP, NSV>::TARGETS - 1) / Shape<PP, NSV>::TARGETS, d.n_act),  \
+                     dim3(Shape<PP, NSV>::THREADS), 0, s, d)
+  // NS = 2 measured best at p = 10 on MI355X (N = 1M: NS 1/2/3/4 -> 3.24 / 2.37 / 2.47 / 2.57 ms)
+  FMMBEM_DISPATCH_P(p, if (PP < 6) { LAUNCH(1); } else { LAUNCH(2); })
+#undef LAUNCH
   return hipGetLastError();
 }
 

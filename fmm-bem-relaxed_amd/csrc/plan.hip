@@ -129,11 +129,16 @@ struct fmmbem_plan {
   bool timing = false;
   int last_p = 0;
   static constexpr int kStages = 9, kRing = 64;                // gather spmv scatter p2m m2m mh m2l l2l l2p
-  std::vector<hipEvent_t> ev;                                  // kRing sets of kStages+1 events
-  int ev_marks[kRing] = {};                                    // events actually recorded in each set
+  std::vector<hipEvent_t> ev;                                  // kRing sets of 2*kStages events (begin, end)
+  unsigned ev_mask[kRing] = {};                                // stages actually recorded in each set
+  // Near field on its own stream beside M2L: measured +4% matvecs/s at N=1M (M2L fills the wavefront slots
+  // first and the streaming kernel is starved: 1.0 -> 3.6 ms), so it is off unless FMMBEM_OVERLAP_NEAR=1.
+  bool overlap_near = false;
   int64_t ev_count = 0;                                        // executes recorded since timing was enabled
   double *stage_x = nullptr, *stage_y = nullptr;               // device staging for host-pointer execute
   hipStream_t own_stream = nullptr;
+  hipStream_t near_stream = nullptr;                          // the HBM-bound near field runs beside the far field
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
   template <class T>
   int upload(const std::vector<T>& v, const T** out) {
@@ -164,6 +169,9 @@ struct fmmbem_plan {
       for (void* p : allocs) (void)hipFree(p);
       for (auto& e : ev) (void)hipEventDestroy(e);
       if (own_stream) (void)hipStreamDestroy(own_stream);
+      if (near_stream) (void)hipStreamDestroy(near_stream);
+      if (ev_fork) (void)hipEventDestroy(ev_fork);
+      if (ev_join) (void)hipEventDestroy(ev_join);
     }
   }
 };
@@ -178,7 +186,10 @@ int fmmbem_plan::to_device() {
   HIP_TRY(hipSetDevice(opts.device));
   on_device = true;
   HIP_TRY(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
-  ev.assign((size_t)kRing * (kStages + 1), nullptr);
+  HIP_TRY(hipStreamCreateWithFlags(&near_stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+  ev.assign((size_t)kRing * 2 * kStages, nullptr);
   for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
 
   const HarmonicTables T;
@@ -229,6 +240,7 @@ int fmmbem_plan::to_device() {
   }
   d.max_runs = max_runs;
   if (const char* dbg = getenv("FMMBEM_DEBUG_MODE")) d.debug_mode = atoi(dbg);
+  if (const char* ov = getenv("FMMBEM_OVERLAP_NEAR")) overlap_near = atoi(ov) != 0;
   d.max_ncols = max_cols;
   near_bytes = total * (int64_t)sizeof(double);
   TRY(upload(leaf_row0, &d.leaf_row0)); TRY(upload(leaf_nrows, &d.leaf_nrows)); TRY(upload(hp.leaf_box, &d.leaf_box));
@@ -370,33 +382,62 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
   if (!d_x || !d_y) return fail(FMMBEM_ERR_INVALID, "null vector");
   HIP_TRY(hipSetDevice(opts.device));
   const bool tm = timing;
-  hipEvent_t* set = tm ? &ev[(size_t)(ev_count % kRing) * (kStages + 1)] : nullptr;
-  int e = 0;
-  auto mark = [&]() -> hipError_t { return tm ? hipEventRecord(set[e++], s) : hipSuccess; };
-  HIP_TRY(mark());
+  const int64_t ring = ev_count % kRing;
+  hipEvent_t* set = tm ? &ev[(size_t)ring * 2 * kStages] : nullptr;
+  unsigned mask = 0;
+  // stage i runs on stream st: begin/end events bracket exactly that kernel (or level sequence)
+  auto begin = [&](int i, hipStream_t st) -> hipError_t { return tm ? hipEventRecord(set[2 * i], st) : hipSuccess; };
+  auto end = [&](int i, hipStream_t st) -> hipError_t {
+    mask |= 1u << i;
+    return tm ? hipEventRecord(set[2 * i + 1], st) : hipSuccess;
+  };
+  // Stage order of the reference (EvalInteractionLazySparse.hpp:120-168): near-field SpMV, then P2M, M2M,
+  // M2L, L2L, L2P.  The near field only meets the far field in y, so it is launched on a second stream next
+  // to M2L (an HBM-bound kernel beside an FMA-bound one); the two are joined before L2P adds into y.
+  const bool overlap = overlap_near && !near_only;
+  HIP_TRY(begin(0, s));
   HIP_TRY(launch_gather_x(d, d_x, s));
-  HIP_TRY(mark());
-  HIP_TRY(launch_near_spmv(d, s));
-  HIP_TRY(mark());
-  if (hp.opt.shard_world > 1) HIP_TRY(hipMemsetAsync(d_y, 0, sizeof(double) * (size_t)hp.n, s));
-  HIP_TRY(launch_scatter_y(d, d_y, s));
-  HIP_TRY(mark());
+  HIP_TRY(end(0, s));
+  auto near_field = [&](hipStream_t ns) -> int {
+    HIP_TRY(begin(1, ns));
+    HIP_TRY(launch_near_spmv(d, ns));
+    HIP_TRY(end(1, ns));
+    HIP_TRY(begin(2, ns));
+    if (hp.opt.shard_world > 1) HIP_TRY(hipMemsetAsync(d_y, 0, sizeof(double) * (size_t)hp.n, ns));
+    HIP_TRY(launch_scatter_y(d, d_y, ns));
+    HIP_TRY(end(2, ns));
+    return FMMBEM_OK;
+  };
+  if (!overlap) TRY(near_field(s));
   if (!near_only) {
+    HIP_TRY(begin(3, s));
     HIP_TRY(launch_p2m(d, p, s));
-    HIP_TRY(mark());
+    HIP_TRY(end(3, s));
+    HIP_TRY(begin(4, s));
     for (auto [first, count] : m2m_launch) HIP_TRY(launch_m2m_level(d, p, first, count, s));
-    HIP_TRY(mark());
+    HIP_TRY(end(4, s));
+    HIP_TRY(begin(5, s));
     HIP_TRY(launch_mh_prep(d, p, s));
-    HIP_TRY(mark());
+    HIP_TRY(end(5, s));
+    if (overlap) {                                     // fork: the near field streams HBM while M2L saturates the FMA pipes
+      HIP_TRY(hipEventRecord(ev_fork, s));
+      HIP_TRY(hipStreamWaitEvent(near_stream, ev_fork, 0));
+      TRY(near_field(near_stream));
+      HIP_TRY(hipEventRecord(ev_join, near_stream));
+    }
+    HIP_TRY(begin(6, s));
     HIP_TRY(launch_m2l(d, p, s));
-    HIP_TRY(mark());
+    HIP_TRY(end(6, s));
+    HIP_TRY(begin(7, s));
     for (auto [first, count] : l2l_launch) HIP_TRY(launch_l2l_level(d, p, first, count, s));
-    HIP_TRY(mark());
+    HIP_TRY(end(7, s));
+    if (overlap) HIP_TRY(hipStreamWaitEvent(s, ev_join, 0));
+    HIP_TRY(begin(8, s));
     HIP_TRY(launch_l2p(d, p, d_y, s));
-    HIP_TRY(mark());
+    HIP_TRY(end(8, s));
   }
   last_p = p;
-  if (tm) { ev_marks[ev_count % kRing] = e; ++ev_count; }
+  if (tm) { ev_mask[ring] = mask; ++ev_count; }
   return FMMBEM_OK;
 }
 
@@ -502,7 +543,7 @@ int fmmbem_plan_stats(const fmmbem_plan* plan, fmmbem_stats* o) {
   o->last_p = plan->last_p;
   o->build_host_ms = plan->build_host_ms; o->build_assemble_ms = plan->build_assemble_ms;
   if (plan->on_device && plan->ev_count > 0) {
-    // mean stage times over the recorded executes (waits for the newest recorded event)
+    // mean stage times over the recorded executes (waits for the recorded events)
     constexpr int NS = fmmbem_plan::kStages, NR = fmmbem_plan::kRing;
     const int64_t have = plan->ev_count < NR ? plan->ev_count : NR;
     double sum[NS + 1] = {0};
@@ -510,13 +551,19 @@ int fmmbem_plan_stats(const fmmbem_plan* plan, fmmbem_stats* o) {
     HIP_TRY(hipSetDevice(plan->opts.device));
     for (int64_t i = 0; i < have; ++i) {
       const int64_t slot = (plan->ev_count - 1 - i) % NR;
-      const hipEvent_t* set = &plan->ev[(size_t)slot * (NS + 1)];
-      const int marks = plan->ev_marks[slot];
-      if (marks < 2) continue;
-      HIP_TRY(hipEventSynchronize(set[marks - 1]));
+      const hipEvent_t* set = &plan->ev[(size_t)slot * 2 * NS];
+      const unsigned mask = plan->ev_mask[slot];
+      int last = -1;
+      for (int k = 0; k < NS; ++k) if (mask & (1u << k)) last = k;
+      if (last < 0) continue;
       float f = 0;
-      for (int k = 0; k + 1 < marks; ++k) { HIP_TRY(hipEventElapsedTime(&f, set[k], set[k + 1])); sum[k] += f; }
-      HIP_TRY(hipEventElapsedTime(&f, set[0], set[marks - 1]));
+      for (int k = 0; k < NS; ++k) {
+        if (!(mask & (1u << k))) continue;
+        HIP_TRY(hipEventSynchronize(set[2 * k + 1]));
+        HIP_TRY(hipEventElapsedTime(&f, set[2 * k], set[2 * k + 1]));
+        sum[k] += f;
+      }
+      HIP_TRY(hipEventElapsedTime(&f, set[0], set[2 * last + 1]));      // both on the caller's stream
       sum[NS] += f;
       ++used;
     }
