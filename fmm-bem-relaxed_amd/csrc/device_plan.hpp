@@ -28,7 +28,6 @@ struct DevicePlan {
   int leaf_begin = 0, leaf_end = 0;                   // owned target leaves
   int64_t row_begin = 0, row_end = 0;
   int max_ncols = 0;                                  // widest near row block (columns, padded even)
-  int debug_mode = 0;
   int max_runs = 0;                                   // most source runs of any owned target leaf
   int n_act = 0;                                      // active expansion slots
   int act[2] = {0, 0};

@@ -239,7 +239,6 @@ int fmmbem_plan::to_device() {
     }
   }
   d.max_runs = max_runs;
-  if (const char* dbg = getenv("FMMBEM_DEBUG_MODE")) d.debug_mode = atoi(dbg);
   if (const char* ov = getenv("FMMBEM_OVERLAP_NEAR")) overlap_near = atoi(ov) != 0;
   d.max_ncols = max_cols;
   near_bytes = total * (int64_t)sizeof(double);

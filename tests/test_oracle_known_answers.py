@@ -7,12 +7,15 @@ import pytest
 
 from conftest import drand48, rel_l2
 
-# SURVEY.md section 6 "List statistics": r -> (N, boxes, leaves, levels, near nnz, M2L pairs, M2M ops, L2L ops)
-LIST_STATS = {
-    6: (8192, 329, 272, 4, 4030016, 10664, 320, 264),
-    8: (131072, 5201, 4184, 6, 79891400, 167480, 5192, 5136),
-    9: (524288, 22001, 17408, 8, 310835696, 720908, 21992, 21936),
-}
+import json
+import os
+
+from conftest import ROOT
+
+# reference-run values recorded from SURVEY.md section 6 / 8(c), see the file's _provenance
+KNOWN = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_known_answers.json")))
+_KEYS = ("n", "boxes", "leaves", "levels", "near_nnz", "m2l_pairs", "m2m_ops", "l2l_ops")
+LIST_STATS = {int(r): tuple(d[k] for k in _KEYS) for r, d in KNOWN["list_statistics"].items()}
 
 
 @pytest.mark.parametrize("r", [6, 8, 9])
@@ -43,7 +46,7 @@ def sphere6(oracle_mod):
 
 
 # N=8192, theta=.5, ncrit=64, k=3, all POTENTIAL: rel L2 of FMM vs Direct::matvec
-@pytest.mark.parametrize("p,ref", [(5, 6.71e-5), (8, 3.36e-6), (10, 5.52e-7), (12, 5.05e-8)])
+@pytest.mark.parametrize("p,ref", [(int(p), e) for p, e in KNOWN["fmm_vs_direct_rel_l2_r6"].items()])
 def test_fmm_vs_direct_error_level_matches_reference_run(sphere6, p, ref):
     _, o, x, d = sphere6
     err = rel_l2(o.matvec(x, p), d)

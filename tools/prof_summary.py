@@ -47,7 +47,7 @@ def pmc(fetch_dir, write_dir, out, n_panels, n_gpus):
         f_kib, nf = fe.get(k, (0.0, 0))
         w_kib, nw = wr.get(k, (0.0, 0))
         res["kernels"][k] = {"FETCH_SIZE_KiB_raw": f_kib, "WRITE_SIZE_KiB": w_kib, "dispatches": max(nf, nw)}
-    ns = res["kernels"].get("near_spmv_kernel")
+    ns = next((v for k, v in res["kernels"].items() if k.startswith("near_spmv_kernel")), None)
     if ns:
         # gfx950: FETCH_SIZE counts 64 B per 128-B request of a wide streaming read -> x2 (guide, HBM section)
         res["hbm_bytes_per_launch"] = (2.0 * ns["FETCH_SIZE_KiB_raw"] + ns["WRITE_SIZE_KiB"]) * 1024.0
