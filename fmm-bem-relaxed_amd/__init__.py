@@ -12,4 +12,7 @@ def __getattr__(name):
     if name == "ShardedFMM":
         from .distributed import ShardedFMM
         return ShardedFMM
+    if name in ("SolverOptions", "gmres", "laplace_bem_first_kind"):
+        from . import solver
+        return getattr(solver, name)
     raise AttributeError(name)

@@ -1,0 +1,137 @@
+"""The caller of the hot path: restarted GMRES with per-iteration relaxation of the FMM order p.
+
+Mirrors examples/BEM/SolverOptions.hpp:11-39 (SolverOptions, predict_p) and examples/BEM/GMRES.hpp:143-252
+(GMRES with modified Gram-Schmidt and Givens rotations, p chosen from the current residual before every
+matvec).  Krylov vectors live in HBM as torch tensors; the matvec is FMM_plan.execute_torch (HIP kernels);
+per iteration ONE device->host transfer brings the new Hessenberg column to the host for the O(R) Givens
+update.  The vector algebra (dot/axpy/norm) is torch plumbing around the operator, not part of the hot path.
+"""
+import math
+
+import torch
+
+
+class SolverOptions:
+    """examples/BEM/SolverOptions.hpp:11-39."""
+    SIMONCINI, BOURAS = 0, 1
+
+    def __init__(self, residual=1e-5, max_iters=500, max_p=16, restart=None, variable_p=True, p_min=5):
+        self.residual = residual
+        self.max_iters = max_iters
+        self.restart = max_iters if restart is None else restart     # LaplaceBEM.cpp:162-163
+        self.max_p = max_p
+        self.p_min = p_min
+        self.variable_p = variable_p
+        self.relax_type = SolverOptions.BOURAS
+
+    def predict_p(self, eps):
+        """SolverOptions.hpp:25-38: Bouras-Fraysse  p = min(ceil(-log2(min(tol / min(eps, 1), 1))), max_p)."""
+        if not self.variable_p:
+            return self.max_p
+        if self.relax_type == SolverOptions.BOURAS:
+            alpha = 1.0 / min(eps, 1.0)
+            nu = min(alpha * self.residual, 1.0)
+            return min(int(math.ceil(-math.log2(nu))) & 0xFFFFFFFF, self.max_p)     # (unsigned)ceil(...)
+        return min(int(math.ceil(-math.log2(eps))) & 0xFFFFFFFF, self.max_p)
+
+
+def _generate_plane_rotation(dx, dy):          # GMRES.hpp:88-105
+    if dy == 0.0:
+        return 1.0, 0.0
+    if abs(dy) > abs(dx):
+        tmp = dx / dy
+        sn = 1.0 / math.sqrt(1.0 + tmp * tmp)
+        return tmp * sn, sn
+    tmp = dy / dx
+    cs = 1.0 / math.sqrt(1.0 + tmp * tmp)
+    return cs, tmp * cs
+
+
+def gmres(MV, x, b, opts, M=None, log=None):
+    """GMRES(MV, x, b, opts[, M]) of examples/BEM/GMRES.hpp:143-252.
+
+    MV: object with execute_torch(tensor)->tensor (or execute) and kernel().set_p(p);
+    x, b: float64 CUDA tensors (x is updated in place and returned); M: optional callable z = M(v).
+    log: optional list receiving (iteration, p, |residual|) per inner iteration.
+    Returns (x, iterations, |residual|)."""
+    execute = getattr(MV, "execute_torch", None) or MV.execute
+    K = MV.kernel()
+    R, n = opts.restart, x.numel()
+    V = torch.empty((R + 1, n), dtype=x.dtype, device=x.device)
+    H = [[0.0] * R for _ in range(R + 1)]
+    cs, sn, s = [0.0] * R, [0.0] * R, [0.0] * (R + 1)
+    normb = float(torch.linalg.vector_norm(b))
+    it, resid = 0, 0.0
+    while True:                                           # outer (restart) loop, :166
+        w = execute(x)                                    # at the kernel's current p
+        w = w - b
+        beta = float(torch.linalg.vector_norm(w))
+        V[0] = w * (-1.0 / beta)
+        s[0] = beta
+        i = -1
+        resid = s[0] / normb
+        while True:                                       # inner loop, :186
+            i += 1
+            it += 1
+            p = max(1, opts.predict_p(abs(resid)))        # :195
+            K.set_p(p)
+            z = V[i] if M is None else M(V[i])
+            w = execute(z).clone()
+            hcol = torch.empty(i + 2, dtype=x.dtype, device=x.device)
+            for k in range(i + 1):                        # modified Gram-Schmidt, :203-208
+                hk = torch.dot(w, V[k])
+                hcol[k] = hk
+                w -= hk * V[k]
+            hn = torch.linalg.vector_norm(w)
+            hcol[i + 1] = hn
+            V[i + 1] = w / hn
+            col = hcol.tolist()                           # the one sync of the iteration
+            for k in range(i + 2):
+                H[k][i] = col[k]
+            for k in range(i):                            # PlaneRotation, :108-117
+                t = cs[k] * H[k][i] + sn[k] * H[k + 1][i]
+                H[k + 1][i] = -sn[k] * H[k][i] + cs[k] * H[k + 1][i]
+                H[k][i] = t
+            cs[i], sn[i] = _generate_plane_rotation(H[i][i], H[i + 1][i])
+            t = cs[i] * H[i][i] + sn[i] * H[i + 1][i]
+            H[i + 1][i] = -sn[i] * H[i][i] + cs[i] * H[i + 1][i]
+            H[i][i] = t
+            s[i + 1] = -sn[i] * s[i]
+            s[i] = cs[i] * s[i]
+            resid = s[i + 1] / normb
+            if log is not None:
+                log.append((it, p, abs(resid)))
+            if abs(resid) < opts.residual:
+                break
+            if not (i + 1 < R and i + 1 <= opts.max_iters and abs(resid) > opts.residual):
+                break
+        y = s[:i + 1]
+        for j in range(i, -1, -1):                        # back substitution, :228-234
+            y[j] /= H[j][j]
+            for k in range(j - 1, -1, -1):
+                y[k] -= H[k][j] * y[j]
+        for j in range(i + 1):                            # x += y_j M(V_j), :237-241
+            x += y[j] * (V[j] if M is None else M(V[j]))
+        if not (abs(resid) > opts.residual and it < opts.max_iters):
+            break
+    return x, it, abs(resid)
+
+
+def laplace_bem_first_kind(fb, panels, p=12, k=3, tol=1e-5, theta=0.5, ncrit=64, max_iters=500, device=0, log=None):
+    """The solve of examples/LaplaceBEM.cpp:168-291 (first-kind equation, identity preconditioner):
+    b = A_flipped-BC * 1 (:218-232), x0 = 0, GMRES with relaxed p (max_p = p). Returns (x, iterations, residual)."""
+    import numpy as np
+    opts = fb.FMMOptions()
+    opts.set_mac_theta(theta)
+    opts.set_max_per_box(ncrit)
+    K = fb.LaplaceSphericalBEM(p, k)
+    n = len(panels)
+    plan = fb.FMM_plan(K, panels, opts, p_max=p, device=device)
+    rhs_plan = fb.FMM_plan(fb.LaplaceSphericalBEM(p, k), panels, opts, bc=np.ones(n, dtype=np.uint8), p_max=p, device=device)
+    dev = torch.device("cuda", device)
+    ones = torch.ones(n, dtype=torch.float64, device=dev)
+    b = rhs_plan.execute_torch(ones)
+    rhs_plan.close()
+    x = torch.zeros(n, dtype=torch.float64, device=dev)
+    so = SolverOptions(residual=tol, max_iters=max_iters, max_p=p)
+    return gmres(plan, x, b, so, log=log)

@@ -1,0 +1,50 @@
+"""The caller of the path: SolverOptions::predict_p and the relaxed GMRES."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+KNOWN = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_known_answers.json")))
+
+
+def test_predict_p_bouras(fb):
+    so = fb.SolverOptions(residual=1e-5, max_p=12)
+    # tol=1e-5, max_p=12: p=12 while |r| > 2.4e-2 ... p=4 at |r| ~ 1e-4
+    assert so.predict_p(1.0) == 12 and so.predict_p(0.5) == 12 and so.predict_p(0.03) == 12
+    assert so.predict_p(1e-4) == 4
+    for eps in (1.0, 0.3, 1e-2, 1e-3, 1e-4, 3e-5, 1e-5):
+        expect = min(int(math.ceil(-math.log2(min((1.0 / min(eps, 1.0)) * 1e-5, 1.0)))), 12)
+        assert so.predict_p(eps) == expect
+    so.variable_p = False
+    assert so.predict_p(1e-4) == 12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tol,key,iters", [(1e-5, "tol_1e-5", 6), (1e-10, "tol_1e-10", 34)])
+def test_relaxed_gmres_reproduces_reference_schedule(fb, tol, key, iters):
+    """LaplaceBEM -recursions 6 -p 12 -theta 0.5: the reference prints the p of every
+    iteration but the last; the data-dependent schedule, the iteration count and the errors must come out the same."""
+    log = []
+    x, it, res = fb.laplace_bem_first_kind(fb, fb.unit_sphere(6), p=12, k=3, tol=tol, log=log)
+    ps = [p for _, p, _ in log]
+    ref = KNOWN["gmres_p_schedule_r6_maxp12"][key]
+    assert res < tol
+    if tol == 1e-5:
+        assert it == iters and ps[:-1] == ref                 # exact reproduction
+    else:
+        # 34 inexact matvecs deep the residual sits within rounding of a 2^-k threshold of predict_p a few times
+        # (e.g. 6.4e-9 at iteration 23): allow +-1 there, +-1 iteration in total
+        assert abs(it - iters) <= 1
+        m = min(len(ref), len(ps) - 1)
+        assert all(abs(a - b) <= 1 for a, b in zip(ps[:m], ref[:m]))
+        assert sum(a == b for a, b in zip(ps[:m], ref[:m])) >= m - 4
+        assert ps[:23] == ref[:23]
+    xs = x.cpu().numpy()
+    err = np.linalg.norm(xs - 1.0) / np.sqrt(len(xs))         # analytic solution sigma = 1 (LaplaceBEM.cpp:356-357)
+    assert err < 5e-3
+    if tol == 1e-10:
+        assert abs(err - 3.1e-3) / 3.1e-3 < 0.05              # relative error vs sigma = 1: 3.1e-3
