@@ -76,6 +76,7 @@ struct DevicePlan {
 hipError_t launch_near_assemble(const DevicePlan& d, hipStream_t s);
 hipError_t launch_gather_x(const DevicePlan& d, const double* x, hipStream_t s);
 hipError_t launch_near_spmv(const DevicePlan& d, hipStream_t s);
+hipError_t launch_near_matfree(const DevicePlan& d, hipStream_t s);
 hipError_t launch_scatter_y(const DevicePlan& d, double* y, hipStream_t s);
 hipError_t launch_p2m(const DevicePlan& d, int p, hipStream_t s);
 hipError_t launch_m2m_level(const DevicePlan& d, int p, int first, int count, hipStream_t s);

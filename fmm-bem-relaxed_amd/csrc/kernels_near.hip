@@ -209,6 +209,47 @@ __global__ __launch_bounds__(256) void near_assemble_kernel(DevicePlan d) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// near_matfree: the matrix-free near field of EvalInteractionLazy (sparse_local = false):
+//   r_i += sum_j K(t_i, s_j) c_j  recomputed every matvec (executor/EvalInteractionLazy.hpp:239-252 ->
+//   executor/P2P.hpp:20-36 -> Direct::eval asymmetric, include/Direct.hpp:99-125).
+// Same decomposition as near_spmv (persistent workgroups over target leaves, source columns staged in LDS
+// chunks, one wavefront per row, shuffle reduction) with the panel integral evaluated in place of a load.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void near_matfree_kernel(DevicePlan d) {
+  extern __shared__ double lds_d[];
+  double* xs = lds_d;                                          // [kAsmChunk]
+  int* colmap = reinterpret_cast<int*>(xs + kAsmChunk);        // [kAsmChunk]
+  int* run_row0 = colmap + kAsmChunk;
+  int* run_off = run_row0 + d.max_runs;
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, nwaves = blockDim.x / kWave;
+  for (int t = d.leaf_begin + blockIdx.x; t < d.leaf_end; t += gridDim.x) {
+    const int ncols = d.near_ncols[t], nrows = d.leaf_nrows[t];
+    const int row0 = d.leaf_row0[t];
+    const Runs runs = load_runs(d, t, run_row0, run_off);
+    for (int c0 = 0; c0 < ncols; c0 += kAsmChunk) {
+      const int cw = ncols - c0 < kAsmChunk ? ncols - c0 : kAsmChunk;
+      if (c0) __syncthreads();
+      for (int c = threadIdx.x; c < cw; c += blockDim.x) {
+        const int j = column_to_row(runs, c0 + c);
+        colmap[c] = j;
+        xs[c] = d.xt[j];
+      }
+      __syncthreads();
+      for (int r = wave; r < nrows; r += nwaves) {
+        const int64_t i = row0 + r;
+        const V3 tc = {d.cx[i], d.cy[i], d.cz[i]};
+        const int tbc = d.bc[i];
+        double acc = 0;
+        for (int c = lane; c < cw; c += kWave) acc = fma(laplace_entry(d, tc, tbc, colmap[c]), xs[c], acc);
+        acc = wave_sum(acc);
+        if (lane == 0) d.yt[i] = c0 ? d.yt[i] + acc : acc;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 __global__ void gather_x_kernel(const uint32_t* __restrict__ perm, const double* __restrict__ x,
                                 double* __restrict__ xt, int64_t n) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -309,6 +350,14 @@ hipError_t launch_near_assemble(const DevicePlan& d, hipStream_t s) {
   if (nb <= 0) return hipSuccess;
   hipLaunchKernelGGL(near_assemble_kernel, dim3(nb < 256 * 8 ? nb : 256 * 8), dim3(256),
                      ((size_t)kAsmChunk + 2 * (size_t)d.max_runs) * sizeof(int), s, d);
+  return hipGetLastError();
+}
+
+hipError_t launch_near_matfree(const DevicePlan& d, hipStream_t s) {
+  const int nb = d.leaf_end - d.leaf_begin;
+  if (nb <= 0) return hipSuccess;
+  const size_t lds = (size_t)kAsmChunk * (sizeof(double) + sizeof(int)) + 2 * (size_t)d.max_runs * sizeof(int);
+  hipLaunchKernelGGL(near_matfree_kernel, dim3(nb < 256 * 8 ? nb : 256 * 8), dim3(256), lds, s, d);
   return hipGetLastError();
 }
 

@@ -245,7 +245,8 @@ int fmmbem_plan::to_device() {
   TRY(upload(leaf_row0, &d.leaf_row0)); TRY(upload(leaf_nrows, &d.leaf_nrows)); TRY(upload(hp.leaf_box, &d.leaf_box));
   TRY(upload(run_ptr, &d.near_ptr)); TRY(upload(run_row0, &d.near_run_row0)); TRY(upload(run_off, &d.near_run_off));
   TRY(upload(hp.near_ncols, &d.near_ncols)); TRY(upload(near_stride, &d.near_stride)); TRY(upload(near_off, &d.near_off));
-  TRY(alloc((size_t)total, &d.near_val, false));
+  if (opts.sparse_local) TRY(alloc((size_t)total, &d.near_val, false));   // matrix-free mode keeps no matrix
+  else { d.near_val = nullptr; near_bytes = 0; }
 
   // boxes, expansions, tables
   TRY(upload(hp.box_center, &d.box_center));
@@ -369,8 +370,10 @@ int fmmbem_plan::to_device() {
 
   // near-field assembly on the device
   const double t0 = now_ms();
-  HIP_TRY(launch_near_assemble(d, own_stream));
-  HIP_TRY(hipStreamSynchronize(own_stream));
+  if (opts.sparse_local) {
+    HIP_TRY(launch_near_assemble(d, own_stream));
+    HIP_TRY(hipStreamSynchronize(own_stream));
+  }
   build_assemble_ms = now_ms() - t0;
   return FMMBEM_OK;
 }
@@ -399,7 +402,7 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
   HIP_TRY(end(0, s));
   auto near_field = [&](hipStream_t ns) -> int {
     HIP_TRY(begin(1, ns));
-    HIP_TRY(launch_near_spmv(d, ns));
+    if (opts.sparse_local) HIP_TRY(launch_near_spmv(d, ns)); else HIP_TRY(launch_near_matfree(d, ns));
     HIP_TRY(end(1, ns));
     HIP_TRY(begin(2, ns));
     if (hp.opt.shard_world > 1) HIP_TRY(hipMemsetAsync(d_y, 0, sizeof(double) * (size_t)hp.n, ns));
@@ -460,7 +463,6 @@ int fmmbem_plan_create(const fmmbem_options* opts, size_t n_panels, const double
   if (!opts || !out) return fail(FMMBEM_ERR_INVALID, "null argument");
   *out = nullptr;
   if (opts->kernel != FMMBEM_KERNEL_LAPLACE_BEM) return fail(FMMBEM_ERR_UNSUPPORTED, "only FMMBEM_KERNEL_LAPLACE_BEM");
-  if (!opts->sparse_local) return fail(FMMBEM_ERR_UNSUPPORTED, "only the assembled near field (sparse_local=1)");
   if (!vertices || n_panels == 0) return fail(FMMBEM_ERR_INVALID, "no panels");
   std::unique_ptr<fmmbem_plan> pl(new (std::nothrow) fmmbem_plan);
   if (!pl) return fail(FMMBEM_ERR_ALLOC, "plan");
@@ -484,7 +486,7 @@ int fmmbem_plan_create(const fmmbem_options* opts, size_t n_panels, const double
     } catch (const std::bad_alloc&) {
       return fail(FMMBEM_ERR_ALLOC, "host allocation failed while tabulating operators");
     }
-    // vertices are only needed by the assembly; keep the host copy small
+    // vertices are only needed on the device; keep the host copy small
     pl->hp.panels.vert.clear(); pl->hp.panels.vert.shrink_to_fit();
   }
   *out = pl.release();
@@ -640,6 +642,7 @@ int fmmbem_plan_get_near_row(const fmmbem_plan* plan, int64_t row, uint32_t* col
   }
   if (vals) {
     if (!plan->on_device) return fail(FMMBEM_ERR_NO_DEVICE, "near values live on the device");
+    if (!plan->opts.sparse_local) return fail(FMMBEM_ERR_INVALID, "matrix-free plan holds no near matrix");
     HIP_TRY(hipSetDevice(plan->opts.device));
     // recompute this leaf's block offset
     int64_t off = 0;

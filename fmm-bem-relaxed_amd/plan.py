@@ -74,8 +74,8 @@ class FMM_plan:
 
     def __init__(self, K, panels, opts=None, bc=None, p_max=None, device=0, shard=(0, 1), host_only=False):
         opts = opts if opts is not None else FMMOptions()
-        if not opts.sparse_local or opts.local_evaluation or opts.block_diagonal or not opts.lazy_evaluation:
-            raise _capi.FmmBemError(_capi.ERR_UNSUPPORTED, "only the lazy sparse_local FMM evaluator is built")
+        if opts.local_evaluation or opts.block_diagonal or not opts.lazy_evaluation:
+            raise _capi.FmmBemError(_capi.ERR_UNSUPPORTED, "only the lazy FMM evaluators (sparse or matrix-free near field) are built")
         self._K = K
         self._opts = opts
         v = np.ascontiguousarray(panels, dtype=np.float64).reshape(-1, 9)
@@ -86,6 +86,7 @@ class FMM_plan:
         o.quad_k = K.K
         o.theta = opts.theta
         o.ncrit = opts.ncrit
+        o.sparse_local = 1 if opts.sparse_local else 0
         o.host_only = 1 if host_only else 0
         o.device = int(device)
         o.shard_rank, o.shard_world = int(shard[0]), int(shard[1])

@@ -52,7 +52,9 @@ typedef struct {
   int32_t  quad_k;            /* Gauss rule key K: 1,3,4,7,13,17,19,25 (GaussQuadrature.hpp)       */
   double   theta;             /* FMMOptions::set_mac_theta, default 0.5 (FMMOptions.hpp:45)        */
   uint32_t ncrit;             /* FMMOptions::set_max_per_box, default 64 (FMMOptions.hpp:46-47)    */
-  int32_t  sparse_local;      /* 1: assembled near matrix (EvalInteractionLazySparse). Only mode.  */
+  int32_t  sparse_local;      /* 1: assembled near matrix (EvalInteractionLazySparse, what the BEM
+                               *    drivers select); 0: matrix-free near field recomputed every
+                               *    matvec (EvalInteractionLazy, `-disable_sparse`)                  */
   int32_t  host_only;         /* 1: build tree + lists on the host, touch no device (CPU tests)    */
   int32_t  device;            /* HIP device ordinal                                                */
   int32_t  shard_rank;        /* target-leaf shard owned by this plan: rank of world               */

@@ -99,10 +99,10 @@ class FMM_plan<LaplaceSphericalBEM> {
     o.quad_k = (int)K.K;
     o.theta = opts.theta;
     o.ncrit = opts.NCRIT_;
-    o.sparse_local = 1;   // examples/LaplaceBEM.cpp:81 always selects the sparse near field
+    o.sparse_local = opts.sparse_local ? 1 : 0;   // examples/LaplaceBEM.cpp:81 sets it; FMMOptions defaults to false
     o.device = device;
     if (!opts.lazy_evaluation || opts.local_evaluation || opts.block_diagonal || opts.evaluator != FMMOptions::FMM)
-      throw fmmbem::Error(FMMBEM_ERR_UNSUPPORTED, "only the lazy sparse_local FMM evaluator is built");
+      throw fmmbem::Error(FMMBEM_ERR_UNSUPPORTED, "only the lazy FMM evaluators are built");
     fmmbem::check(fmmbem_plan_create(&o, n_, v.data(), bc.data(), &plan_));
   }
   ~FMM_plan() { fmmbem_plan_destroy(plan_); }

@@ -76,7 +76,7 @@ def test_error_codes(fb):
     with pytest.raises(ValueError):
         fb.LaplaceSphericalBEM(17, 3)
     opts = fb.FMMOptions()
-    opts.sparse_local = False
+    opts.local_evaluation = True          # preconditioner-only evaluators are not built
     with pytest.raises(fb.FmmBemError) as e:
         fb.FMM_plan(fb.LaplaceSphericalBEM(5, 3), v, opts, host_only=True)
     assert e.value.status == 6

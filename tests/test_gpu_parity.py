@@ -206,3 +206,21 @@ def test_larger_case_r8_properties(fb, oracle_mod):
     rows = (1000, 1256)
     d = o.direct(x, rows=rows)
     assert rel_l2(y[rows[0]:rows[1]], d) < 2e-6
+
+
+@pytest.mark.parametrize("bc_val", [0, 1])
+def test_matrix_free_near_field(fb, oracle_mod, bc_val):
+    """sparse_local = false: EvalInteractionLazy recomputes the panel integrals every matvec."""
+    v = fb.unit_sphere(5)
+    n = len(v)
+    bc = np.full(n, bc_val, dtype=np.uint8)
+    opts = fb.FMMOptions()
+    opts.sparse_local = False
+    K = fb.LaplaceSphericalBEM(10, 3)
+    pl = fb.FMM_plan(K, v, opts, bc=bc)
+    assert pl.stats()["near_bytes"] == 0
+    x = drand48(n, seed=5)
+    y = pl.execute(x)
+    assert rel_l2(y, oracle_mod.Oracle(v, bc=bc).matvec(x, 10)) <= TOL_MATVEC
+    dense = fb.FMM_plan(K, v, bc=bc).execute(x)
+    assert rel_l2(y, dense) <= 1e-14
