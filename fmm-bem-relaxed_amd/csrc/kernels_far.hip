@@ -35,6 +35,7 @@ constexpr double kEps = 1e-12;                         // kernel/LaplaceSpherica
 // stored index -> (j,k), up to p = 16
 struct JK { unsigned char j[136], k[136]; };
 __constant__ JK kJK;
+__constant__ double kRecip[40];                        // 1/k, k = 1..39 (Legendre recurrence denominators)
 JK make_jk() {
   JK t;
   int i = 0;
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(kWave) void p2m_kernel(DevicePlan d, const int P) {
           const double pcur = p;
           double pnext;                               // Legendre recurrence, P_{n+1}^m
           if (n == m) pnext = s.ca * (2 * m + 1) * pcur;
-          else pnext = (s.ca * (2 * n + 1) * pcur - (n + m) * p1) / (double)(n - m + 1);
+          else pnext = (s.ca * (2 * n + 1) * pcur - (n + m) * p1) * kRecip[n - m + 1];
           double vr, vi;
           if (slot == 0) {                            // source BC POTENTIAL: G moments (LaplaceSphericalBEM.hpp:326)
             vr = wq * yr; vi = wq * yi;
@@ -213,14 +214,21 @@ __global__ __launch_bounds__(kShiftWaves * kWave) void m2m_kernel(DevicePlan d, 
       for (int idx = lane; idx < S; idx += kWave) {
         const int len = d.up_len[idx];
         double2 acc = {0, 0};
-        for (int i = 0; i < len; ++i) {
-          const size_t e = (size_t)i * SM + idx;
-          const unsigned sc = d.up_src[e];
-          double2 v = Ms[sc & 0x7fff];
-          if (sc & 0x8000) v.y = -v.y;
-          const double2 t = cmul(v, Y[d.up_y[e]]);
-          const double r = d.up_real[e];
-          acc.x = fma(t.x, r, acc.x); acc.y = fma(t.y, r, acc.y);
+        for (int i = 0; i < len; i += 4) {              // four terms' operands in flight (rows are zero-padded)
+          unsigned sc[4], yi[4];
+          double r[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const size_t e = (size_t)(i + u) * SM + idx;
+            sc[u] = d.up_src[e]; yi[u] = d.up_y[e]; r[u] = d.up_real[e];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            double2 v = Ms[sc[u] & 0x7fff];
+            if (sc[u] & 0x8000) v.y = -v.y;
+            const double2 t = cmul(v, Y[yi[u]]);
+            acc.x = fma(t.x, r[u], acc.x); acc.y = fma(t.y, r[u], acc.y);
+          }
         }
         part[idx] = acc;
       }
@@ -283,14 +291,22 @@ __global__ __launch_bounds__(kShiftWaves * kWave) void l2l_kernel(DevicePlan d, 
     for (int idx = lane; idx < S; idx += kWave) {
       const int len = cnt[idx];
       double2 acc = dst[idx];
-      for (int i = 0; i < len; ++i) {
-        const size_t e = (size_t)i * SM + idx;
-        const unsigned sc = d.down_src[e];
-        double2 v = Ls[sc & 0x7fff];
-        if (sc & 0x8000) v.y = -v.y;
-        const double2 t = cmul(v, Y[d.down_y[e]]);
-        const double r = d.down_real[e];
-        acc.x = fma(t.x, r, acc.x); acc.y = fma(t.y, r, acc.y);
+      for (int i = 0; i < len; i += 4) {                // four terms' operands in flight
+        unsigned sc[4], yi[4];
+        double r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const size_t e = (size_t)(i + u) * SM + idx;
+          const bool on = i + u < len;                    // a row's usable terms at order p are a prefix
+          sc[u] = on ? d.down_src[e] : 0; yi[u] = on ? d.down_y[e] : 0; r[u] = on ? d.down_real[e] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          double2 v = Ls[sc[u] & 0x7fff];
+          if (sc[u] & 0x8000) v.y = -v.y;
+          const double2 t = cmul(v, Y[yi[u]]);
+          acc.x = fma(t.x, r[u], acc.x); acc.y = fma(t.y, r[u], acc.y);
+        }
       }
       dst[idx] = acc;
     }
@@ -335,7 +351,7 @@ __global__ __launch_bounds__(kWave) void l2p_kernel(DevicePlan d, const int P, d
         r += w * (Lc.x * (mag * er) - Lc.y * (mag * ei));        // Re(L * Ynm), Ynm = mag e^{+i m beta}
         const double pcur = p;
         if (n == m) p = s.ca * (2 * m + 1) * pcur;
-        else p = (s.ca * (2 * n + 1) * pcur - (n + m) * p1) / (double)(n - m + 1);
+        else p = (s.ca * (2 * n + 1) * pcur - (n + m) * p1) * kRecip[n - m + 1];
         p1 = pcur;
         rhon *= s.rho;
       }
@@ -355,6 +371,10 @@ hipError_t upload_constants_once() {
   static hipError_t st = [] {
     const JK t = make_jk();
     hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(kJK), &t, sizeof(t));
+    double recip[40];
+    recip[0] = 0;
+    for (int k = 1; k < 40; ++k) recip[k] = 1.0 / k;
+    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(kRecip), recip, sizeof(recip));
     // M2M at p = 16 needs a little over 64 KiB of dynamic LDS
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(m2m_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(l2l_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
@@ -411,6 +431,7 @@ hipError_t launch_l2l_level(const DevicePlan& d, int p, int first, int count, hi
 }
 
 hipError_t launch_l2p(const DevicePlan& d, int p, double* y, hipStream_t s) {
+  if (hipError_t e = upload_constants_once(); e != hipSuccess) return e;
   if (d.n_l2p <= 0) return hipSuccess;
   if (p < 1 || p > kPmaxDev) return hipErrorInvalidValue;
   hipLaunchKernelGGL(l2p_kernel, dim3(d.n_l2p < 256 * 32 ? d.n_l2p : 256 * 32), dim3(kWave), 0, s, d, p, y);

@@ -368,6 +368,11 @@ int fmmbem_plan::to_device() {
   TRY(alloc((size_t)hp.n, &stage_x, true));
   TRY(alloc((size_t)hp.n, &stage_y, true));
 
+  // The zero-fills above ran on the NULL stream, which the plan's non-blocking streams do not wait for:
+  // drain it before anything else touches those buffers (a late memset of x_tree / staging vectors would
+  // otherwise race with the first execute).
+  HIP_TRY(hipDeviceSynchronize());
+
   // near-field assembly on the device
   const double t0 = now_ms();
   if (opts.sparse_local) {

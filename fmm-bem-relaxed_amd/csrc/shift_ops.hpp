@@ -71,6 +71,7 @@ inline ShiftOps build_shift_ops(int P, const std::vector<double>& A, double eps)
                   std::vector<uint16_t>& y, std::vector<double>& real) {
     maxlen = 0;
     for (auto& r : rows) maxlen = (int)r.size() > maxlen ? (int)r.size() : maxlen;
+    maxlen = (maxlen + 3) & ~3;                          // kernels consume terms four at a time; padding terms are zeros
     src.assign((size_t)maxlen * o.S, 0);
     y.assign((size_t)maxlen * o.S, 0);
     real.assign((size_t)maxlen * o.S, 0.0);
