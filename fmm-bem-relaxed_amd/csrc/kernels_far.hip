@@ -70,6 +70,22 @@ __device__ inline Sph cart2sph(double dx, double dy, double dz) {
   return s;
 }
 
+// Per-step constants of the harmonic recurrences, in the m-major order the loops below visit (n,m):
+// pref = sqrt((n-m)!/(n+m)!), and the Legendre step P_{n+1}^m = c1 x P_n^m - c2 P_{n-1}^m with
+// c1 = (2n+1)/(n-m+1), c2 = (n+m)/(n-m+1)  (c1 = 2m+1, c2 = 0 on the diagonal n = m).
+// Kept in LDS: fetched as wave-uniform scalar loads from global memory they cost one SMEM round trip
+// per step (measured: 51 % of the P2M wave cycles were s_waitcnt).
+__device__ inline void fill_step_tables(const DevicePlan& d, int P, int lane, double* sPref, double* sC1, double* sC2) {
+  int t = 0;
+  for (int m = 0; m < P; ++m)
+    for (int n = m; n < P; ++n, ++t)
+      if ((t & (kWave - 1)) == lane) {
+        sPref[t] = d.tabPref[n * n + n + m];
+        sC1[t] = n == m ? (double)(2 * m + 1) : (double)(2 * n + 1) * kRecip[n - m + 1];
+        sC2[t] = n == m ? 0.0 : (double)(n + m) * kRecip[n - m + 1];
+      }
+}
+
 // ---------------------------------------------------------------------------------------------
 // P2M: one wavefront per source leaf (workgroups stride over the leaves).  Lane = one quadrature point of
 // one panel; every lane runs the Legendre / rho^n / e^{-im beta} recurrences of evalMultipole(rho,alpha,-beta)
@@ -77,17 +93,20 @@ __device__ inline Sph cart2sph(double dx, double dy, double dz) {
 // into an LDS tile [row][lane]; after kP2MBand rows the tile is reduced along the lanes (two lanes per row,
 // conflict-free 16-B reads) and added to the leaf's accumulator.  No per-coefficient wave shuffles.
 // ---------------------------------------------------------------------------------------------
-constexpr int kP2MBand = 16;                          // rows per LDS tile (16.6 KiB): 4 lanes reduce one row
+constexpr int kP2MBand = 8;                           // rows per LDS tile (8.3 KiB): 8 lanes reduce one row
 
 template <int slot>
 __global__ __launch_bounds__(kWave) void p2m_kernel(DevicePlan d, const int P) {
   __shared__ double2 tile[kP2MBand][kWave + 1];
   __shared__ double2 acc[kSmax];
   __shared__ int rowidx[kP2MBand];
+  __shared__ double sPref[kSmax], sC1[kSmax], sC2[kSmax];
   const int S = P * (P + 1) / 2;
   const int lane = threadIdx.x;
   const int64_t N = d.n;
   const int nq = d.nq;
+  fill_step_tables(d, P, lane, sPref, sC1, sC2);
+  __syncthreads();
   for (int li = blockIdx.x; li < d.n_p2m; li += gridDim.x) {
     const int leaf = d.p2m_leaf[li];
     const int box = d.leaf_box[leaf];
@@ -128,19 +147,18 @@ __global__ __launch_bounds__(kWave) void p2m_kernel(DevicePlan d, const int P) {
       const Sph s = cart2sph(live ? d.quad[(q * 3 + 0) * N + i] - c0 : 0.3, live ? d.quad[(q * 3 + 1) * N + i] - c1 : 0.4,
                              live ? d.quad[(q * 3 + 2) * N + i] - c2 : 0.5);
       double pn = 1, rhom = 1, er = 1, ei = 0, fact = 1;
+      int step = 0;
 #pragma nounroll
       for (int m = 0; m < P; ++m) {
         double p = pn, p1 = p, rhon = rhom;
 #pragma nounroll
-        for (int n = m; n < P; ++n) {
-          const double pref = d.tabPref[n * n + n + m];
+        for (int n = m; n < P; ++n, ++step) {
+          const double pref = sPref[step];
           // Ynm[n,m] at (rho, alpha, -beta): rho^n P_n^m(cos a) pref e^{-i m beta}
           const double mag = rhon * p * pref;
           const double yr = mag * er, yi = -mag * ei;
           const double pcur = p;
-          double pnext;                               // Legendre recurrence, P_{n+1}^m
-          if (n == m) pnext = s.ca * (2 * m + 1) * pcur;
-          else pnext = (s.ca * (2 * n + 1) * pcur - (n + m) * p1) * kRecip[n - m + 1];
+          const double pnext = sC1[step] * s.ca * pcur - sC2[step] * p1;   // Legendre recurrence, P_{n+1}^m
           double vr, vi;
           if (slot == 0) {                            // source BC POTENTIAL: G moments (LaplaceSphericalBEM.hpp:326)
             vr = wq * yr; vi = wq * yi;
@@ -320,7 +338,9 @@ __global__ __launch_bounds__(kShiftWaves * kWave) void l2l_kernel(DevicePlan d, 
 __global__ __launch_bounds__(kWave) void l2p_kernel(DevicePlan d, const int P, double* __restrict__ y) {
   const int S = P * (P + 1) / 2;
   __shared__ double2 Ls[2][kSmax];
+  __shared__ double sPref[kSmax], sC1[kSmax], sC2[kSmax];
   const int lane = threadIdx.x;
+  fill_step_tables(d, P, lane, sPref, sC1, sC2);
   for (int li = blockIdx.x; li < d.n_l2p; li += gridDim.x) {
   const int leaf = d.l2p_leaf[li];
   const int box = d.leaf_box[leaf];
@@ -340,18 +360,18 @@ __global__ __launch_bounds__(kWave) void l2p_kernel(DevicePlan d, const int P, d
     const Sph s = cart2sph(d.cx[i] - c0, d.cy[i] - c1, d.cz[i] - c2);
     double r = 0;
     double pn = 1, rhom = 1, er = 1, ei = 0, fact = 1;
+    int step = 0;
 #pragma nounroll
     for (int m = 0; m < P; ++m) {
       double p = pn, p1 = p, rhon = rhom;
       const double w = m == 0 ? 1.0 : 2.0;
 #pragma nounroll
-      for (int n = m; n < P; ++n) {
-        const double mag = rhon * p * d.tabPref[n * n + n + m];
+      for (int n = m; n < P; ++n, ++step) {
+        const double mag = rhon * p * sPref[step];
         const double2 Lc = Lt[n * (n + 1) / 2 + m];
         r += w * (Lc.x * (mag * er) - Lc.y * (mag * ei));        // Re(L * Ynm), Ynm = mag e^{+i m beta}
         const double pcur = p;
-        if (n == m) p = s.ca * (2 * m + 1) * pcur;
-        else p = (s.ca * (2 * n + 1) * pcur - (n + m) * p1) * kRecip[n - m + 1];
+        p = sC1[step] * s.ca * pcur - sC2[step] * p1;
         p1 = pcur;
         rhon *= s.rho;
       }
