@@ -95,19 +95,24 @@ __device__ inline void fill_step_tables(const DevicePlan& d, int P, int lane, do
 // ---------------------------------------------------------------------------------------------
 constexpr int kP2MBand = 8;                           // rows per LDS tile (8.3 KiB): 8 lanes reduce one row
 
+constexpr int kP2MWaves = 4;                          // independent leaves per workgroup (tables shared)
+
 template <int slot>
-__global__ __launch_bounds__(kWave) void p2m_kernel(DevicePlan d, const int P) {
-  __shared__ double2 tile[kP2MBand][kWave + 1];
-  __shared__ double2 acc[kSmax];
-  __shared__ int rowidx[kP2MBand];
+__global__ __launch_bounds__(kP2MWaves * kWave) void p2m_kernel(DevicePlan d, const int P) {
+  __shared__ double2 tile_all[kP2MWaves][kP2MBand][kWave + 1];
+  __shared__ double2 acc_all[kP2MWaves][kSmax];
+  __shared__ int rowidx_all[kP2MWaves][kP2MBand];
   __shared__ double sPref[kSmax], sC1[kSmax], sC2[kSmax];
   const int S = P * (P + 1) / 2;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  double2 (*tile)[kWave + 1] = tile_all[wave];
+  double2* acc = acc_all[wave];
+  int* rowidx = rowidx_all[wave];
   const int64_t N = d.n;
   const int nq = d.nq;
-  fill_step_tables(d, P, lane, sPref, sC1, sC2);
+  if (wave == 0) fill_step_tables(d, P, lane, sPref, sC1, sC2);
   __syncthreads();
-  for (int li = blockIdx.x; li < d.n_p2m; li += gridDim.x) {
+  for (int li = blockIdx.x * kP2MWaves + wave; li < d.n_p2m; li += gridDim.x * kP2MWaves) {
     const int leaf = d.p2m_leaf[li];
     const int box = d.leaf_box[leaf];
     const int row0 = d.leaf_row0[leaf], npts = d.leaf_nrows[leaf] * nq;
@@ -409,7 +414,8 @@ hipError_t launch_p2m(const DevicePlan& d, int p, hipStream_t s) {
   if (hipError_t e = upload_constants_once(); e != hipSuccess) return e;
   if (d.n_p2m <= 0) return hipSuccess;
   if (p < 1 || p > kPmaxDev) return hipErrorInvalidValue;
-  const dim3 g(d.n_p2m < 256 * 16 ? d.n_p2m : 256 * 16), b(kWave);
+  const int nblk = (d.n_p2m + kP2MWaves - 1) / kP2MWaves;
+  const dim3 g(nblk < 256 * 8 ? nblk : 256 * 8), b(kP2MWaves * kWave);
   for (int a = 0; a < d.n_act; ++a) {
     if (d.act[a] == 0) hipLaunchKernelGGL((p2m_kernel<0>), g, b, 0, s, d, p);
     else hipLaunchKernelGGL((p2m_kernel<1>), g, b, 0, s, d, p);
