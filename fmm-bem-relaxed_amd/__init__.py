@@ -4,7 +4,7 @@ Only the hot path lives here: csrc/ (hand-written HIP for gfx950 + the C ABI of 
 and this thin host-side mirror of the reference's operator interface.
 """
 from ._capi import FmmBemError, LIB_PATH, PMAX, SYMBOLS  # noqa: F401
-from .plan import FMM_plan, FMMOptions, LaplaceSphericalBEM, unit_sphere  # noqa: F401
+from .plan import FMM_plan, FMMOptions, LaplaceSphericalBEM, StokesSphericalBEM, unit_sphere  # noqa: F401
 
 
 def __getattr__(name):

@@ -9,7 +9,8 @@
 //   near_val    per owned target leaf a dense row-major block  nrows x stride  (stride = ncols rounded
 //               up to even => every row 16-B aligned); the ONLY large array (8 B per near entry)
 //   boxes       center [nb][3]
-//   M, L        [nb][2][S_max] complex (S = p(p+1)/2), slot 0 = G, slot 1 = dG/dn
+//   M, L        [nb][nslots][S_max] complex (S = p(p+1)/2); Laplace: slot 0 = G, slot 1 = dG/dn;
+//               Stokes: slots 0-3 = the four harmonic potentials (f0,f1,f2,f.x) of the velocity group
 //   Mh          [nb][2][S_max] complex: M rescaled and phase-rotated (orders m >= 0), the M2L input
 //   m2l_*       CSR by target box: m2l_tgt [nt] (boxes to run), m2l_ptr [nb+1], m2l_src, m2l_cls
 //   class tabs  m2l_tab [classes][(2 p_max)^2] complex; up_tab/down_tab [classes][p_max^2] complex
@@ -30,7 +31,13 @@ struct DevicePlan {
   int max_ncols = 0;                                  // widest near row block (columns, padded even)
   int max_runs = 0;                                   // most source runs of any owned target leaf
   int n_act = 0;                                      // active expansion slots
-  int act[2] = {0, 0};
+  int act[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int nslots = 2;                                     // expansions per box: Laplace 2 (G, dG/dn), Stokes 2 x 4
+  int kernel = 0;                                     // fmmbem_kernel
+  int dof = 1;                                        // unknowns per panel (Stokes: 3, interleaved)
+  double mu = 1.0;                                    // Stokes viscosity
+  int nqf = 0;                                        // Stokes near-regime rule K_fine: barycentric points + weight
+  double qf[25][4];
 
   // panels
   const double *cx, *cy, *cz, *nx, *ny, *nz, *area, *quad, *vert;
@@ -84,5 +91,8 @@ hipError_t launch_mh_prep(const DevicePlan& d, int p, hipStream_t s);
 hipError_t launch_m2l(const DevicePlan& d, int p, hipStream_t s);
 hipError_t launch_l2l_level(const DevicePlan& d, int p, int first, int count, hipStream_t s);
 hipError_t launch_l2p(const DevicePlan& d, int p, double* y, hipStream_t s);
+hipError_t launch_near_assemble_stokes(const DevicePlan& d, hipStream_t s);
+hipError_t launch_p2m_stokes(const DevicePlan& d, int p, hipStream_t s);
+hipError_t launch_l2p_stokes(const DevicePlan& d, int p, double* y, hipStream_t s);
 
 }  // namespace fmmbem

@@ -98,7 +98,7 @@ constexpr int kP2MBand = 8;                           // rows per LDS tile (8.3 
 constexpr int kP2MWaves = 4;                          // independent leaves per workgroup (tables shared)
 
 template <int slot>
-__global__ __launch_bounds__(kP2MWaves * kWave) void p2m_kernel(DevicePlan d, const int P) {
+__global__ __launch_bounds__(kP2MWaves * kWave) void p2m_kernel(DevicePlan d, const int P, const int wmode, const int out_slot) {
   __shared__ double2 tile_all[kP2MWaves][kP2MBand][kWave + 1];
   __shared__ double2 acc_all[kP2MWaves][kSmax];
   __shared__ int rowidx_all[kP2MWaves][kP2MBand];
@@ -146,8 +146,18 @@ __global__ __launch_bounds__(kP2MWaves * kWave) void p2m_kernel(DevicePlan d, co
       const int pt = chunk + lane;
       const int panel = pt / nq, q = pt - panel * nq;
       const int64_t i = row0 + panel;
-      const bool live = pt < npts && d.bc[i] == slot;
-      const double wq = live ? d.xt[i] * d.area[i] * d.qw[q] : 0.0;
+      // wmode 0: Laplace, charge * w * Area for panels whose BC feeds this slot (LaplaceSphericalBEM.hpp:323-344)
+      // wmode 1..3: Stokes f_e * w * Area; wmode 4: (f . x_q) * w * Area with the ABSOLUTE quadrature point
+      // (kernel/StokesSphericalBEM.hpp:417-431)
+      const bool live = pt < npts && (wmode ? true : d.bc[i] == slot);
+      double wq = 0.0;
+      if (live) {
+        const double aw = d.area[i] * d.qw[q];
+        if (wmode == 0) wq = d.xt[i] * aw;
+        else if (wmode < 4) wq = d.xt[3 * i + (wmode - 1)] * aw;
+        else wq = (d.xt[3 * i] * d.quad[(q * 3 + 0) * N + i] + d.xt[3 * i + 1] * d.quad[(q * 3 + 1) * N + i] +
+                   d.xt[3 * i + 2] * d.quad[(q * 3 + 2) * N + i]) * aw;
+      }
       const double n0 = live ? d.nx[i] : 0, n1 = live ? d.ny[i] : 0, n2 = live ? d.nz[i] : 0;
       const Sph s = cart2sph(live ? d.quad[(q * 3 + 0) * N + i] - c0 : 0.3, live ? d.quad[(q * 3 + 1) * N + i] - c1 : 0.4,
                              live ? d.quad[(q * 3 + 2) * N + i] - c2 : 0.5);
@@ -198,7 +208,7 @@ __global__ __launch_bounds__(kP2MWaves * kWave) void p2m_kernel(DevicePlan d, co
       }
       if (inband) flush();
     }
-    double2* M = d.M + ((size_t)box * 2 + slot) * d.s_max;
+    double2* M = d.M + ((size_t)box * d.nslots + out_slot) * d.s_max;
     for (int i = lane; i < S; i += kWave) M[i] = acc[i];
     __builtin_amdgcn_wave_barrier();
   }
@@ -227,7 +237,7 @@ __global__ __launch_bounds__(kShiftWaves * kWave) void m2m_kernel(DevicePlan d, 
     const int cb = d.box_child_begin[parent], nchild = d.box_child_end[parent] - cb;
     if (w < nchild) {
       const int c = cb + w;
-      const double2* src = d.M + ((size_t)c * 2 + slot) * SM;
+      const double2* src = d.M + ((size_t)c * d.nslots + slot) * SM;
       const double2* tab = d.up_tab + (size_t)d.up_cls[c] * d.p2_max;
       for (int i = lane; i < S; i += kWave) Ms[i] = src[i];
       for (int i = lane; i < P2; i += kWave) Y[i] = tab[i];
@@ -257,7 +267,7 @@ __global__ __launch_bounds__(kShiftWaves * kWave) void m2m_kernel(DevicePlan d, 
       }
     }
     __syncthreads();
-    double2* dst = d.M + ((size_t)parent * 2 + slot) * SM;
+    double2* dst = d.M + ((size_t)parent * d.nslots + slot) * SM;
     const double2* parts = lds2 + (size_t)kShiftWaves * (S + P2);
     for (int idx = threadIdx.x; idx < S; idx += blockDim.x) {
       double2 sum = {0, 0};
@@ -276,8 +286,8 @@ __global__ __launch_bounds__(kWave) void mh_prep_kernel(DevicePlan d, const int 
   const int S = P * (P + 1) / 2;
   const int box = d.mh_box[blockIdx.x];
   const int slot = d.act[blockIdx.y];
-  const double2* M = d.M + ((size_t)box * 2 + slot) * d.s_max;
-  double2* Mh = d.Mh + ((size_t)box * 2 + slot) * d.s_max;
+  const double2* M = d.M + ((size_t)box * d.nslots + slot) * d.s_max;
+  double2* Mh = d.Mh + ((size_t)box * d.nslots + slot) * d.s_max;
   for (int idx = threadIdx.x; idx < S; idx += kWave) {
     const int n = kJK.j[idx], m = kJK.k[idx];
     const double2 v = M[idx];
@@ -302,7 +312,7 @@ __global__ __launch_bounds__(kShiftWaves * kWave) void l2l_kernel(DevicePlan d, 
   for (int it = blockIdx.x * kShiftWaves + w; it < count; it += gridDim.x * kShiftWaves) {
     const int child = d.l2l_child[first + it];
     const int parent = d.box_parent[child];
-    const double2* src = d.L + ((size_t)parent * 2 + slot) * SM;
+    const double2* src = d.L + ((size_t)parent * d.nslots + slot) * SM;
     const double2* tab = d.down_tab + (size_t)d.down_cls[child] * d.p2_max;
     __builtin_amdgcn_wave_barrier();
     for (int i = lane; i < S; i += kWave) Ls[i] = src[i];
@@ -310,7 +320,7 @@ __global__ __launch_bounds__(kShiftWaves * kWave) void l2l_kernel(DevicePlan d, 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    double2* dst = d.L + ((size_t)child * 2 + slot) * SM;
+    double2* dst = d.L + ((size_t)child * d.nslots + slot) * SM;
     for (int idx = lane; idx < S; idx += kWave) {
       const int len = cnt[idx];
       double2 acc = dst[idx];
@@ -352,7 +362,7 @@ __global__ __launch_bounds__(kWave) void l2p_kernel(DevicePlan d, const int P, d
   const int row0 = d.leaf_row0[leaf], nrows = d.leaf_nrows[leaf];
   __syncthreads();
   for (int s = 0; s < 2; ++s) {
-    const double2* src = d.L + ((size_t)box * 2 + s) * d.s_max;
+    const double2* src = d.L + ((size_t)box * d.nslots + s) * d.s_max;
     for (int i = lane; i < S; i += kWave) Ls[s][i] = src[i];
   }
   __syncthreads();
@@ -392,6 +402,95 @@ __global__ __launch_bounds__(kWave) void l2p_kernel(DevicePlan d, const int P, d
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Stokes L2P: StokesSpherical::L2P (kernel/StokesSpherical.hpp:318-401) then the 1/(2 mu) of
+// StokesSphericalBEM::L2P (kernel/StokesSphericalBEM.hpp:512-522).  Lane = target panel; the leaf's four
+// harmonic potentials L[0..3] in LDS; per lane the potentials' values and spherical gradients are
+// accumulated along the same recurrence as the Laplace L2P (Ynm and its theta derivative), then
+//   u_k = phi_k - x_0 d_k phi_0 - x_1 d_k phi_1 - x_2 d_k phi_2 + d_k phi_3   (Tornberg-Greengard)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kWave) void l2p_stokes_kernel(DevicePlan d, const int P, double* __restrict__ y) {
+  const int S = P * (P + 1) / 2;
+  __shared__ double2 Ls[4][kSmax];
+  __shared__ double sPref[kSmax], sC1[kSmax], sC2[kSmax];
+  const int lane = threadIdx.x;
+  fill_step_tables(d, P, lane, sPref, sC1, sC2);
+  for (int li = blockIdx.x; li < d.n_l2p; li += gridDim.x) {
+    const int leaf = d.l2p_leaf[li];
+    const int box = d.leaf_box[leaf];
+    const int row0 = d.leaf_row0[leaf], nrows = d.leaf_nrows[leaf];
+    __syncthreads();
+    for (int e = 0; e < 4; ++e) {
+      const double2* src = d.L + ((size_t)box * d.nslots + e) * d.s_max;
+      for (int i = lane; i < S; i += kWave) Ls[e][i] = src[i];
+    }
+    __syncthreads();
+    const double c0 = d.box_center[3 * box], c1 = d.box_center[3 * box + 1], c2 = d.box_center[3 * box + 2];
+    for (int chunk = 0; chunk < nrows; chunk += kWave) {
+      if (chunk + lane >= nrows) break;
+      const int64_t i = row0 + chunk + lane;
+      const double tx = d.cx[i], ty = d.cy[i], tz = d.cz[i];
+      const Sph s = cart2sph(tx - c0, ty - c1, tz - c2);
+      double val[3] = {0, 0, 0};               // potentials phi_0..2 at the target
+      double g[4][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};   // (d/dr, d/dtheta, d/dphi-ish) of phi_0..3
+      double pn = 1, rhom = 1, er = 1, ei = 0, fact = 1;
+      int step = 0;
+#pragma nounroll
+      for (int m = 0; m < P; ++m) {
+        double p = pn, p1 = p, rhon = rhom;
+        const double w = m == 0 ? 1.0 : 2.0;
+#pragma nounroll
+        for (int n = m; n < P; ++n, ++step) {
+          const double pref = sPref[step];
+          const double mag = rhon * p * pref;
+          const double yr = mag * er, yi = mag * ei;                 // Ynm = mag e^{+i m beta}
+          const double pcur = p;
+          const double pnext = sC1[step] * s.ca * pcur - sC2[step] * p1;
+          double tmag;                                               // YnmTheta (LaplaceSpherical.hpp:471,482)
+          if (n == m) tmag = rhon * (pnext - (m + 1) * s.ca * pcur) / s.sa * pref;
+          else tmag = rhon * ((n - m + 1) * pnext - (n + 1) * s.ca * pcur) / s.sa * pref;
+          const double tr = tmag * er, ti = tmag * ei;
+          const double factor = 1. / s.rho * n;
+          const int idx = n * (n + 1) / 2 + m;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const double2 L = Ls[e][idx];
+            const double re = L.x * yr - L.y * yi;                   // Re(L Ynm)
+            if (e < 3) val[e] += w * re;
+            g[e][0] += w * re * factor;
+            g[e][1] += w * (L.x * tr - L.y * ti);                    // Re(L YnmTheta)
+            if (m) g[e][2] += 2 * (-(L.x * yi + L.y * yr)) * m;      // Re(L Ynm i) m
+          }
+          p1 = pcur; p = pnext;
+          rhon *= s.rho;
+        }
+        pn = -pn * fact * s.sa;
+        fact += 2;
+        rhom *= s.rho;
+        const double nr = er * s.cb - ei * s.sb, ni = er * s.sb + ei * s.cb;
+        er = nr; ei = ni;
+      }
+      // sph2cart (kernel/LaplaceSpherical.hpp:546-561) of each gradient, then the recombination
+      const double r = s.rho, st = s.sa, ct = s.ca, cp = s.cb, sp = s.sb;
+      double res[3] = {val[0], val[1], val[2]};
+      const double tgt[3] = {tx, ty, tz};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const double cx_ = st * cp * g[e][0] + ct * cp / r * g[e][1] - sp / r / st * g[e][2];
+        const double cy_ = st * sp * g[e][0] + ct * sp / r * g[e][1] + cp / r / st * g[e][2];
+        const double cz_ = ct * g[e][0] - st / r * g[e][1];
+        const double f = e < 3 ? -tgt[e] : 1.0;
+        res[0] += f * cx_; res[1] += f * cy_; res[2] += f * cz_;
+      }
+      const uint32_t o = d.perm[i];
+      const double sc = 1. / 2 / d.mu;
+      y[3 * (size_t)o] += sc * res[0];
+      y[3 * (size_t)o + 1] += sc * res[1];
+      y[3 * (size_t)o + 2] += sc * res[2];
+    }
+  }
+}
+
 hipError_t upload_constants_once() {
   static hipError_t st = [] {
     const JK t = make_jk();
@@ -417,8 +516,8 @@ hipError_t launch_p2m(const DevicePlan& d, int p, hipStream_t s) {
   const int nblk = (d.n_p2m + kP2MWaves - 1) / kP2MWaves;
   const dim3 g(nblk < 256 * 8 ? nblk : 256 * 8), b(kP2MWaves * kWave);
   for (int a = 0; a < d.n_act; ++a) {
-    if (d.act[a] == 0) hipLaunchKernelGGL((p2m_kernel<0>), g, b, 0, s, d, p);
-    else hipLaunchKernelGGL((p2m_kernel<1>), g, b, 0, s, d, p);
+    if (d.act[a] == 0) hipLaunchKernelGGL((p2m_kernel<0>), g, b, 0, s, d, p, 0, 0);
+    else hipLaunchKernelGGL((p2m_kernel<1>), g, b, 0, s, d, p, 0, 1);
   }
   return hipGetLastError();
 }
@@ -464,4 +563,24 @@ hipError_t launch_l2p(const DevicePlan& d, int p, double* y, hipStream_t s) {
   return hipGetLastError();
 }
 
+}  // namespace fmmbem
+
+namespace fmmbem {
+hipError_t launch_p2m_stokes(const DevicePlan& d, int p, hipStream_t s) {
+  if (hipError_t e = upload_constants_once(); e != hipSuccess) return e;
+  if (d.n_p2m <= 0) return hipSuccess;
+  if (p < 1 || p > kPmaxDev) return hipErrorInvalidValue;
+  const int nblk = (d.n_p2m + kP2MWaves - 1) / kP2MWaves;
+  const dim3 g(nblk < 256 * 8 ? nblk : 256 * 8), b(kP2MWaves * kWave);
+  for (int e = 0; e < 4; ++e) hipLaunchKernelGGL((p2m_kernel<0>), g, b, 0, s, d, p, e + 1, e);
+  return hipGetLastError();
+}
+
+hipError_t launch_l2p_stokes(const DevicePlan& d, int p, double* y, hipStream_t s) {
+  if (hipError_t e = upload_constants_once(); e != hipSuccess) return e;
+  if (d.n_l2p <= 0) return hipSuccess;
+  if (p < 1 || p > kPmaxDev) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(l2p_stokes_kernel, dim3(d.n_l2p < 256 * 32 ? d.n_l2p : 256 * 32), dim3(kWave), 0, s, d, p, y);
+  return hipGetLastError();
+}
 }  // namespace fmmbem

@@ -109,7 +109,7 @@ __global__ __launch_bounds__((Shape<P, NS_>::THREADS)) void m2l_kernel(DevicePla
 
   const int pb = d.m2l_ptr[tgt], pe = d.m2l_ptr[tgt + 1];
   if (pb == pe) {                                      // a box that only inherits from its parent: L = 0
-    if (valid) d.L[((size_t)tgt * 2 + slot) * d.s_max + idx] = {0, 0};
+    if (valid) d.L[((size_t)tgt * d.nslots + slot) * d.s_max + idx] = {0, 0};
     return;
   }
   {
@@ -138,12 +138,12 @@ __global__ __launch_bounds__((Shape<P, NS_>::THREADS)) void m2l_kernel(DevicePla
     // written by the preceding kernel and is immutable here: address it through the CONSTANT address space
     // so that the wave-uniform loads are always selected as scalar (SMEM) loads feeding SGPR operands.
     const ConstC2* mh = reinterpret_cast<const ConstC2*>(
-        reinterpret_cast<uintptr_t>(d.Mh + ((size_t)src * 2 + slot) * d.s_max));
+        reinterpret_cast<uintptr_t>(d.Mh + ((size_t)src * d.nslots + slot) * d.s_max));
     // Warm the L2 for the NEXT source's Mh (a random 880-B record of a >100 MB array): one 16-B vector load
     // per lane now turns next iteration's dependent scalar loads from HBM/MALL misses into L2 hits.
     {
       const int src_next = __builtin_amdgcn_readfirstlane(d.m2l_src[pn]);
-      const double2* nxt = d.Mh + ((size_t)src_next * 2 + slot) * d.s_max;
+      const double2* nxt = d.Mh + ((size_t)src_next * d.nslots + slot) * d.s_max;
       if (tid < Sh::S) {
         const double2 touch = nxt[tid];
         asm volatile("" ::"v"(touch.x), "v"(touch.y));
@@ -182,7 +182,7 @@ __global__ __launch_bounds__((Shape<P, NS_>::THREADS)) void m2l_kernel(DevicePla
     }
   }
   if (valid && npart == 0) {
-    double2* L = d.L + ((size_t)tgt * 2 + slot) * d.s_max;
+    double2* L = d.L + ((size_t)tgt * d.nslots + slot) * d.s_max;
     const double f = ((j & 1) ? -1.0 : 1.0) * d.tabA[j * j + j + k];
     L[idx] = mul_i_pow(double2{acc.x * f, acc.y * f}, -k);
   }

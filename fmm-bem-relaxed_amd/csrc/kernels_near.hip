@@ -210,6 +210,150 @@ __global__ __launch_bounds__(256) void near_assemble_kernel(DevicePlan d) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Stokes (velocity boundary condition): one near-matrix entry is the 3x3 block
+//   (1/2mu) int_source ( I/r + d d^T / r^3 ) dS,  d = target centroid - y
+// (kernel/StokesSphericalBEM.hpp:260-375).  Regimes: far -> the K stored Gauss points (:352-369);
+// near (sqrt(2A)/dist >= 0.5) -> the K_fine rule on the vertices (:302-321); self -> Fata's closed form.
+// ---------------------------------------------------------------------------------------------
+__device__ inline void stokeslet_point(double* res, double wA, V3 t, V3 pnt) {
+  const V3 dd = sub(t, pnt);
+  const double r2 = dd.x * dd.x + dd.y * dd.y + dd.z * dd.z;
+  double invR2 = 1. / r2;
+  if (r2 < 1e-8) invR2 = 0;
+  const double f = wA * invR2 * sqrt(invR2);
+  const double dv[3] = {dd.x, dd.y, dd.z};
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) res[3 * i + j] += f * ((i == j ? r2 : 0.0) + dv[i] * dv[j]);
+}
+
+// Self term: AnalyticalIntegral::FataAnalytical<STOKES>(y1,y2,y3,.,x = centroid, self = true, G)
+// (examples/BEM/FataAnalytical.hpp:414-690, self branch :535-539) + Integration<STOKES>::integrate (:273-341).
+// With the collocation point in the panel plane (et = 0) and chi left at {0,0,0} in the self branch, only
+// omega (three logarithms) and the rho-difference terms survive.
+__device__ inline void stokes_self(V3 y1, V3 y2, V3 y3, V3 x, double* IU) {
+  const double pi = M_PI;
+  const V3 v1 = sub(y2, y1), v3 = sub(y3, y1);
+  const double snrm = v1.x * v1.x + v1.y * v1.y + v1.z * v1.z, nrm = sqrt(snrm);
+  const double al = (v1.x * v3.x + v1.y * v3.y + v1.z * v3.z) / snrm;
+  V3 e2 = {v3.x - al * v1.x, v3.y - al * v1.y, v3.z - al * v1.z};
+  const double nrx = norm(e2);
+  const V3 e1 = {v1.x / nrm, v1.y / nrm, v1.z / nrm};
+  e2 = {e2.x / nrx, e2.y / nrx, e2.z / nrx};
+  const V3 e3 = {e1.y * e2.z - e2.y * e1.z, e1.z * e2.x - e2.z * e1.x, e1.x * e2.y - e2.x * e1.y};
+  const double bQ = v1.x * e1.x + v1.y * e1.y + v1.z * e1.z;
+  const double aQ = v3.x * e2.x + v3.y * e2.y + v3.z * e2.z;
+  const double cQ = v3.x * e1.x + v3.y * e1.y + v3.z * e1.z;
+  const double bmc = bQ - cQ, aQs = aQ * aQ;
+  const double th0 = acos(cQ / sqrt(cQ * cQ + aQs)), th1 = acos(bmc / sqrt(bmc * bmc + aQs));
+  const double alpha2 = pi - th1, alpha3 = pi + th0;
+  const double cs2 = cos(alpha2), sn2 = sin(alpha2), cs3 = cos(alpha3), sn3 = sin(alpha3);
+  const V3 r1 = sub(x, y1);
+  const double xi = r1.x * e1.x + r1.y * e1.y + r1.z * e1.z;
+  const double zt = r1.x * e2.x + r1.y * e2.y + r1.z * e2.z;
+  double q[3];
+  const double p11 = -xi, p12 = bQ - xi;
+  q[0] = -zt;
+  const double x3 = cQ + p11, z3 = aQ + q[0];
+  const double p22 = p12 * cs2 + q[0] * sn2, p23 = x3 * cs2 + z3 * sn2;
+  q[1] = q[0] * cs2 - p12 * sn2;
+  const double p31 = p11 * cs3 + q[0] * sn3, p33 = x3 * cs3 + z3 * sn3;
+  q[2] = q[0] * cs3 - p11 * sn3;
+  const double rho[3] = {sqrt(p11 * p11 + q[0] * q[0]), sqrt(p12 * p12 + q[0] * q[0]), sqrt(p33 * p33 + q[2] * q[2])};
+  const double omega = q[0] * log((p11 + rho[0]) / (p12 + rho[1])) + q[1] * log((p22 + rho[1]) / (p23 + rho[2])) +
+                       q[2] * log((p33 + rho[2]) / (p31 + rho[0]));
+  const double alpha[3] = {0., alpha2, alpha3};
+  const double rb[3] = {rho[0] - rho[1], rho[1] - rho[2], rho[2] - rho[0]};
+  double Ixx = 0, Izz = 0, Izx = 0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    Ixx += (rb[i] * sin(alpha[i])) * cos(alpha[i]);
+    Izz += (-rb[i] * cos(alpha[i])) * sin(alpha[i]);
+    Izx += (rb[i] * sin(alpha[i])) * sin(alpha[i]);
+  }
+  const double E[3][3] = {{e1.x, e1.y, e1.z}, {e2.x, e2.y, e2.z}, {e3.x, e3.y, e3.z}};
+  const double coef[3][3] = {{omega + Ixx, Izx, 0.0}, {Izx, omega + Izz, 0.0}, {0.0, 0.0, omega}};
+#pragma unroll
+  for (int i = 0; i < 9; ++i) IU[i] = 0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) IU[3 * i + j] += coef[a][b] * E[a][i] * E[b][j];
+}
+
+__device__ inline void stokes_entry(const DevicePlan& d, V3 t, int64_t j, double* out) {
+  const int64_t N = d.n;
+  const V3 c = {d.cx[j], d.cy[j], d.cz[j]};
+  const double A = d.area[j];
+  const double dist = norm(sub(t, c));
+#pragma unroll
+  for (int i = 0; i < 9; ++i) out[i] = 0;
+  if (sqrt(2 * A) / dist >= 0.5) {
+    const V3 v0 = {d.vert[0 * N + j], d.vert[1 * N + j], d.vert[2 * N + j]};
+    const V3 v1 = {d.vert[3 * N + j], d.vert[4 * N + j], d.vert[5 * N + j]};
+    const V3 v2 = {d.vert[6 * N + j], d.vert[7 * N + j], d.vert[8 * N + j]};
+    if (dist < 1e-8) {
+      stokes_self(v0, v1, v2, t, out);
+    } else {
+      for (int q = 0; q < d.nqf; ++q) {
+        const V3 pt = {v0.x * d.qf[q][0] + v1.x * d.qf[q][1] + v2.x * d.qf[q][2],
+                       v0.y * d.qf[q][0] + v1.y * d.qf[q][1] + v2.y * d.qf[q][2],
+                       v0.z * d.qf[q][0] + v1.z * d.qf[q][1] + v2.z * d.qf[q][2]};
+        stokeslet_point(out, d.qf[q][3] * A, t, pt);
+      }
+    }
+  } else {
+    for (int q = 0; q < d.nq; ++q) {
+      const V3 qp = {d.quad[(q * 3 + 0) * N + j], d.quad[(q * 3 + 1) * N + j], d.quad[(q * 3 + 2) * N + j]};
+      stokeslet_point(out, d.qw[q] * A, t, qp);
+    }
+  }
+  const double sc = 1. / 2 / d.mu;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) out[i] *= sc;
+}
+
+// one thread per (target panel, source panel) pair of the leaf block; writes its 3x3 block into the
+// 3 rows x 3 columns it occupies in the row-major block of unknowns
+__global__ __launch_bounds__(256) void near_assemble_stokes_kernel(DevicePlan d) {
+  extern __shared__ int lds_i[];
+  int* colmap = lds_i;                               // [kAsmChunk] panel columns
+  int* run_row0 = lds_i + kAsmChunk;
+  int* run_off = run_row0 + d.max_runs;
+  for (int t = d.leaf_begin + blockIdx.x; t < d.leaf_end; t += gridDim.x) {
+    const int ncols = d.near_ncols[t], stride = d.near_stride[t], nrows = d.leaf_nrows[t];
+    const int row0 = d.leaf_row0[t];
+    const Runs runs = load_runs(d, t, run_row0, run_off);
+    double* blk = d.near_val + d.near_off[t];
+    if (stride > 3 * ncols)                           // padding column (odd number of unknowns per row)
+      for (int r = threadIdx.x; r < 3 * nrows; r += blockDim.x) blk[(int64_t)r * stride + 3 * ncols] = 0.0;
+    for (int c0 = 0; c0 < ncols; c0 += kAsmChunk) {
+      const int cw = ncols - c0 < kAsmChunk ? ncols - c0 : kAsmChunk;
+      if (c0) __syncthreads();
+      for (int c = threadIdx.x; c < cw; c += blockDim.x) colmap[c] = column_to_row(runs, c0 + c);
+      __syncthreads();
+      const int total = nrows * cw;
+      for (int e = threadIdx.x; e < total; e += blockDim.x) {
+        const int r = e / cw, c = e - r * cw;
+        const int64_t i = row0 + r;
+        double m[9];
+        stokes_entry(d, V3{d.cx[i], d.cy[i], d.cz[i]}, colmap[c], m);
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int b = 0; b < 3; ++b) blk[(int64_t)(3 * r + a) * stride + 3 * (c0 + c) + b] = m[3 * a + b];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // near_matfree: the matrix-free near field of EvalInteractionLazy (sparse_local = false):
 //   r_i += sum_j K(t_i, s_j) c_j  recomputed every matvec (executor/EvalInteractionLazy.hpp:239-252 ->
 //   executor/P2P.hpp:20-36 -> Direct::eval asymmetric, include/Direct.hpp:99-125).
@@ -250,16 +394,17 @@ __global__ __launch_bounds__(256) void near_matfree_kernel(DevicePlan d) {
   }
 }
 
+// dof unknowns per panel, interleaved (Stokes: Vec<3,double> per panel); one thread per unknown
 __global__ void gather_x_kernel(const uint32_t* __restrict__ perm, const double* __restrict__ x,
-                                double* __restrict__ xt, int64_t n) {
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i < n) xt[i] = x[perm[i]];
+                                double* __restrict__ xt, int64_t n, int dof) {
+  const int64_t u = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (u < n * dof) { const int64_t i = u / dof; const int a = (int)(u - i * dof); xt[u] = x[(int64_t)perm[i] * dof + a]; }
 }
 
 __global__ void scatter_y_kernel(const uint32_t* __restrict__ perm, const double* __restrict__ yt,
-                                 double* __restrict__ y, int64_t row_begin, int64_t row_end) {
-  const int64_t i = row_begin + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i < row_end) y[perm[i]] = yt[i];
+                                 double* __restrict__ y, int64_t row_begin, int64_t row_end, int dof) {
+  const int64_t u = row_begin * dof + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (u < row_end * dof) { const int64_t i = u / dof; const int a = (int)(u - i * dof); y[(int64_t)perm[i] * dof + a] = yt[u]; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -288,16 +433,21 @@ __global__ __launch_bounds__(kSpmvWaves * kWave) void near_spmv_kernel(DevicePla
   // ~75 KB of matrix, and one short-lived workgroup per leaf leaves the CUs mostly empty (measured: 3.5
   // resident wavefronts per CU, launch-rate bound).
   for (int t = d.leaf_begin + blockIdx.x; t < d.leaf_end; t += gridDim.x) {
-    const int ncols = d.near_ncols[t], stride = d.near_stride[t], nrows = d.leaf_nrows[t];
+    // rows / columns counted in unknowns: dof per panel (Stokes: the 3x3 blocks are simply 3 rows x 3 columns)
+    const int dof = d.dof;
+    const int ncols = dof * d.near_ncols[t], stride = d.near_stride[t], nrows = dof * d.leaf_nrows[t];
     const Runs runs = load_runs(d, t, run_row0, run_off);
     const double* blk = d.near_val + d.near_off[t];
-    const int row0 = d.leaf_row0[t];
+    const int row0 = dof * d.leaf_row0[t];
     // the x slice is staged kSpmvChunk columns at a time: a few coarse leaves of an adaptive tree see
     // >10^4 columns, and sizing the LDS for them would leave one workgroup per CU
     for (int c0 = 0; c0 < stride; c0 += kSpmvChunk) {
       const int cw = stride - c0 < kSpmvChunk ? stride - c0 : kSpmvChunk;
       if (c0) __syncthreads();
-      for (int c = threadIdx.x; c < cw; c += blockDim.x) xs[c] = c0 + c < ncols ? d.xt[column_to_row(runs, c0 + c)] : 0.0;
+      for (int c = threadIdx.x; c < cw; c += blockDim.x) {
+        const int cc = c0 + c, pc = cc / dof;            // unknown -> panel column
+        xs[c] = cc < ncols ? d.xt[(int64_t)dof * column_to_row(runs, pc) + (cc - pc * dof)] : 0.0;
+      }
       __syncthreads();
       const int nvec = cw >> 1;                       // 16-B vectors of this chunk per row
       for (int r = wave; r < nrows; r += kRows * kSpmvWaves) {
@@ -353,6 +503,14 @@ hipError_t launch_near_assemble(const DevicePlan& d, hipStream_t s) {
   return hipGetLastError();
 }
 
+hipError_t launch_near_assemble_stokes(const DevicePlan& d, hipStream_t s) {
+  const int nb = d.leaf_end - d.leaf_begin;
+  if (nb <= 0) return hipSuccess;
+  hipLaunchKernelGGL(near_assemble_stokes_kernel, dim3(nb < 256 * 8 ? nb : 256 * 8), dim3(256),
+                     ((size_t)kAsmChunk + 2 * (size_t)d.max_runs) * sizeof(int), s, d);
+  return hipGetLastError();
+}
+
 hipError_t launch_near_matfree(const DevicePlan& d, hipStream_t s) {
   const int nb = d.leaf_end - d.leaf_begin;
   if (nb <= 0) return hipSuccess;
@@ -363,7 +521,7 @@ hipError_t launch_near_matfree(const DevicePlan& d, hipStream_t s) {
 
 hipError_t launch_gather_x(const DevicePlan& d, const double* x, hipStream_t s) {
   const int bs = 256;
-  hipLaunchKernelGGL(gather_x_kernel, dim3((unsigned)((d.n + bs - 1) / bs)), dim3(bs), 0, s, d.perm, x, d.xt, d.n);
+  hipLaunchKernelGGL(gather_x_kernel, dim3((unsigned)((d.n * d.dof + bs - 1) / bs)), dim3(bs), 0, s, d.perm, x, d.xt, d.n, d.dof);
   return hipGetLastError();
 }
 
@@ -379,11 +537,11 @@ hipError_t launch_near_spmv(const DevicePlan& d, hipStream_t s) {
 }
 
 hipError_t launch_scatter_y(const DevicePlan& d, double* y, hipStream_t s) {
-  const int64_t rows = d.row_end - d.row_begin;
+  const int64_t rows = (d.row_end - d.row_begin) * d.dof;
   if (rows <= 0) return hipSuccess;
   const int bs = 256;
   hipLaunchKernelGGL(scatter_y_kernel, dim3((unsigned)((rows + bs - 1) / bs)), dim3(bs), 0, s, d.perm, d.yt, y,
-                     d.row_begin, d.row_end);
+                     d.row_begin, d.row_end, d.dof);
   return hipGetLastError();
 }
 

@@ -199,8 +199,21 @@ int fmmbem_plan::to_device() {
   d.p_max = pm; d.s_max = pm * (pm + 1) / 2; d.p2_max = pm * pm; d.y2_max = 4 * pm * pm;
   d.leaf_begin = hp.leaf_begin; d.leaf_end = hp.leaf_end; d.row_begin = hp.row_begin; d.row_end = hp.row_end;
   for (int q = 0; q < hp.rule.n; ++q) d.qw[q] = hp.rule.w[q];
+  d.kernel = opts.kernel;
   d.n_act = 0;
-  for (int s = 0; s < 2; ++s) if (hp.has_bc[s]) d.act[d.n_act++] = s;
+  if (opts.kernel == FMMBEM_KERNEL_STOKES_BEM) {
+    // StokesSphericalBEM: M[2][4] per box (kernel/StokesSphericalBEM.hpp:143-153); the velocity group is live
+    d.dof = 3; d.nslots = 8; d.mu = opts.mu;
+    for (int s = 0; s < 4; ++s) d.act[d.n_act++] = s;
+    QuadRule fine;
+    if (!quad_rule(opts.quad_k_fine, fine)) return fail(FMMBEM_ERR_INVALID, "invalid K_fine (valid: 1 3 4 7 13 17 19 25)");
+    d.nqf = fine.n;
+    for (int q = 0; q < fine.n; ++q) { for (int k = 0; k < 3; ++k) d.qf[q][k] = fine.pts[q][k]; d.qf[q][3] = fine.w[q]; }
+  } else {
+    d.dof = 1; d.nslots = 2;
+    for (int s = 0; s < 2; ++s) if (hp.has_bc[s]) d.act[d.n_act++] = s;
+  }
+  const int dof = d.dof;
 
   // panels + permutation
   const PanelSoA& P = hp.panels;
@@ -218,7 +231,7 @@ int fmmbem_plan::to_device() {
     const int b = hp.leaf_box[l];
     leaf_row0[l] = hp.box_body_begin[b];
     leaf_nrows[l] = hp.box_body_end[b] - hp.box_body_begin[b];
-    near_stride[l] = (hp.near_ncols[l] + 1) & ~1;
+    near_stride[l] = (dof * hp.near_ncols[l] + 1) & ~1;      // in unknowns (dof per panel), rows 16-B aligned
     // source leaves are ascending; leaves with consecutive indices own adjacent rows -> one run
     int col = 0, runs = 0;
     for (int64_t i = hp.near_ptr[l]; i < hp.near_ptr[l + 1]; ++i) {
@@ -233,7 +246,7 @@ int fmmbem_plan::to_device() {
     run_ptr[l + 1] = (int64_t)run_row0.size();
     if (l >= hp.leaf_begin && l < hp.leaf_end) {
       near_off[l] = total;
-      total += (int64_t)leaf_nrows[l] * near_stride[l];
+      total += (int64_t)dof * leaf_nrows[l] * near_stride[l];
       max_cols = std::max(max_cols, near_stride[l]);
       max_runs = std::max(max_runs, runs);
     }
@@ -250,9 +263,9 @@ int fmmbem_plan::to_device() {
 
   // boxes, expansions, tables
   TRY(upload(hp.box_center, &d.box_center));
-  TRY(alloc((size_t)nb * 2 * d.s_max, &d.M, true));
-  TRY(alloc((size_t)nb * 2 * d.s_max, &d.L, true));
-  TRY(alloc((size_t)nb * 2 * d.s_max, &d.Mh, true));
+  TRY(alloc((size_t)nb * d.nslots * d.s_max, &d.M, true));
+  TRY(alloc((size_t)nb * d.nslots * d.s_max, &d.L, true));
+  TRY(alloc((size_t)nb * d.nslots * d.s_max, &d.Mh, true));
   TRY(upload(T.A, &d.tabA)); TRY(upload(T.invA, &d.tabInvA)); TRY(upload(T.pref, &d.tabPref));
 
   // far-field lists
@@ -363,10 +376,10 @@ int fmmbem_plan::to_device() {
     TRY(upload(lanes, &d.m2l_lane)); TRY(upload(scat, &d.m2l_scat));
   }
 
-  TRY(alloc((size_t)hp.n, &d.xt, true));
-  TRY(alloc((size_t)hp.n, &d.yt, true));
-  TRY(alloc((size_t)hp.n, &stage_x, true));
-  TRY(alloc((size_t)hp.n, &stage_y, true));
+  TRY(alloc((size_t)hp.n * dof, &d.xt, true));
+  TRY(alloc((size_t)hp.n * dof, &d.yt, true));
+  TRY(alloc((size_t)hp.n * dof, &stage_x, true));
+  TRY(alloc((size_t)hp.n * dof, &stage_y, true));
 
   // The zero-fills above ran on the NULL stream, which the plan's non-blocking streams do not wait for:
   // drain it before anything else touches those buffers (a late memset of x_tree / staging vectors would
@@ -376,7 +389,8 @@ int fmmbem_plan::to_device() {
   // near-field assembly on the device
   const double t0 = now_ms();
   if (opts.sparse_local) {
-    HIP_TRY(launch_near_assemble(d, own_stream));
+    if (opts.kernel == FMMBEM_KERNEL_STOKES_BEM) HIP_TRY(launch_near_assemble_stokes(d, own_stream));
+    else HIP_TRY(launch_near_assemble(d, own_stream));
     HIP_TRY(hipStreamSynchronize(own_stream));
   }
   build_assemble_ms = now_ms() - t0;
@@ -410,7 +424,7 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
     if (opts.sparse_local) HIP_TRY(launch_near_spmv(d, ns)); else HIP_TRY(launch_near_matfree(d, ns));
     HIP_TRY(end(1, ns));
     HIP_TRY(begin(2, ns));
-    if (hp.opt.shard_world > 1) HIP_TRY(hipMemsetAsync(d_y, 0, sizeof(double) * (size_t)hp.n, ns));
+    if (hp.opt.shard_world > 1) HIP_TRY(hipMemsetAsync(d_y, 0, sizeof(double) * (size_t)hp.n * d.dof, ns));
     HIP_TRY(launch_scatter_y(d, d_y, ns));
     HIP_TRY(end(2, ns));
     return FMMBEM_OK;
@@ -418,7 +432,7 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
   if (!overlap) TRY(near_field(s));
   if (!near_only) {
     HIP_TRY(begin(3, s));
-    HIP_TRY(launch_p2m(d, p, s));
+    if (d.kernel == FMMBEM_KERNEL_STOKES_BEM) HIP_TRY(launch_p2m_stokes(d, p, s)); else HIP_TRY(launch_p2m(d, p, s));
     HIP_TRY(end(3, s));
     HIP_TRY(begin(4, s));
     for (auto [first, count] : m2m_launch) HIP_TRY(launch_m2m_level(d, p, first, count, s));
@@ -440,7 +454,7 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
     HIP_TRY(end(7, s));
     if (overlap) HIP_TRY(hipStreamWaitEvent(s, ev_join, 0));
     HIP_TRY(begin(8, s));
-    HIP_TRY(launch_l2p(d, p, d_y, s));
+    if (d.kernel == FMMBEM_KERNEL_STOKES_BEM) HIP_TRY(launch_l2p_stokes(d, p, d_y, s)); else HIP_TRY(launch_l2p(d, p, d_y, s));
     HIP_TRY(end(8, s));
   }
   last_p = p;
@@ -467,7 +481,15 @@ int fmmbem_plan_create(const fmmbem_options* opts, size_t n_panels, const double
                        fmmbem_plan** out) {
   if (!opts || !out) return fail(FMMBEM_ERR_INVALID, "null argument");
   *out = nullptr;
-  if (opts->kernel != FMMBEM_KERNEL_LAPLACE_BEM) return fail(FMMBEM_ERR_UNSUPPORTED, "only FMMBEM_KERNEL_LAPLACE_BEM");
+  if (opts->kernel != FMMBEM_KERNEL_LAPLACE_BEM && opts->kernel != FMMBEM_KERNEL_STOKES_BEM)
+    return fail(FMMBEM_ERR_UNSUPPORTED, "unknown kernel id");
+  if (opts->kernel == FMMBEM_KERNEL_STOKES_BEM) {
+    if (!opts->sparse_local) return fail(FMMBEM_ERR_UNSUPPORTED, "Stokes: only the assembled near field (sparse_local=1)");
+    if (!(opts->mu > 0)) return fail(FMMBEM_ERR_INVALID, "Stokes: viscosity mu must be positive");
+    if (bc)
+      for (size_t i = 0; i < n_panels; ++i)
+        if (bc[i]) return fail(FMMBEM_ERR_UNSUPPORTED, "Stokes: only VELOCITY panels (the traction far field of the reference is not reproducible)");
+  }
   if (!vertices || n_panels == 0) return fail(FMMBEM_ERR_INVALID, "no panels");
   std::unique_ptr<fmmbem_plan> pl(new (std::nothrow) fmmbem_plan);
   if (!pl) return fail(FMMBEM_ERR_ALLOC, "plan");
@@ -515,7 +537,7 @@ int fmmbem_plan_execute(fmmbem_plan* plan, int p, const double* x, double* y) {
   if (!plan->on_device) return fail(FMMBEM_ERR_NO_DEVICE, "plan was built host-only; there is no CPU execution path");
   if (!x || !y) return fail(FMMBEM_ERR_INVALID, "null vector");
   HIP_TRY(hipSetDevice(plan->opts.device));
-  const size_t bytes = sizeof(double) * (size_t)plan->hp.n;
+  const size_t bytes = sizeof(double) * (size_t)plan->hp.n * (plan->opts.kernel == FMMBEM_KERNEL_STOKES_BEM ? 3 : 1);
   hipStream_t s = plan->own_stream;
   HIP_TRY(hipMemcpyAsync(plan->stage_x, x, bytes, hipMemcpyHostToDevice, s));
   const int rc = plan->run(p, plan->stage_x, plan->stage_y, s, false);
@@ -628,36 +650,39 @@ int fmmbem_plan_get_pairs(const fmmbem_plan* plan, int which, int32_t* out, int6
 int fmmbem_plan_get_near_row(const fmmbem_plan* plan, int64_t row, uint32_t* cols, double* vals, int64_t* n) {
   if (!plan || !n) return fail(FMMBEM_ERR_INVALID, "null argument");
   const HostPlan& h = plan->hp;
-  if (row < h.row_begin || row >= h.row_end) return fail(FMMBEM_ERR_INVALID, "row not owned by this shard");
-  // owning leaf: last leaf whose first row <= row
+  const int dof = plan->opts.kernel == FMMBEM_KERNEL_STOKES_BEM ? 3 : 1;
+  const int64_t prow = row / dof;                      // panel row (tree order); row counts unknowns
+  const int comp = (int)(row % dof);
+  if (prow < h.row_begin || prow >= h.row_end) return fail(FMMBEM_ERR_INVALID, "row not owned by this shard");
+  // owning leaf: last leaf whose first row <= prow
   int lo = h.leaf_begin, hi = h.leaf_end - 1;
   while (lo < hi) {
     const int mid = (lo + hi + 1) / 2;
-    if (h.box_body_begin[h.leaf_box[mid]] <= row) lo = mid; else hi = mid - 1;
+    if (h.box_body_begin[h.leaf_box[mid]] <= prow) lo = mid; else hi = mid - 1;
   }
   const int leaf = lo, tb = h.leaf_box[leaf];
-  const int ncols = h.near_ncols[leaf];
+  const int ncols = dof * h.near_ncols[leaf];
   *n = ncols;
   if (cols) {
     int at = 0;
     for (int64_t s = h.near_ptr[leaf]; s < h.near_ptr[leaf + 1]; ++s) {
       const int sb = h.leaf_box[h.near_src[s]];
-      for (int j = h.box_body_begin[sb]; j < h.box_body_end[sb]; ++j) cols[at++] = (uint32_t)j;
+      for (int j = h.box_body_begin[sb]; j < h.box_body_end[sb]; ++j)
+        for (int b = 0; b < dof; ++b) cols[at++] = (uint32_t)(dof * j + b);
     }
   }
   if (vals) {
     if (!plan->on_device) return fail(FMMBEM_ERR_NO_DEVICE, "near values live on the device");
     if (!plan->opts.sparse_local) return fail(FMMBEM_ERR_INVALID, "matrix-free plan holds no near matrix");
     HIP_TRY(hipSetDevice(plan->opts.device));
-    // recompute this leaf's block offset
     int64_t off = 0;
     for (int l = h.leaf_begin; l < leaf; ++l) {
       const int b = h.leaf_box[l];
-      off += (int64_t)(h.box_body_end[b] - h.box_body_begin[b]) * ((h.near_ncols[l] + 1) & ~1);
+      off += (int64_t)dof * (h.box_body_end[b] - h.box_body_begin[b]) * ((dof * h.near_ncols[l] + 1) & ~1);
     }
     const int stride = (ncols + 1) & ~1;
-    const int r = (int)(row - h.box_body_begin[tb]);
-    HIP_TRY(hipMemcpy(vals, plan->d.near_val + off + (int64_t)r * stride, sizeof(double) * (size_t)ncols, hipMemcpyDeviceToHost));
+    const int64_t r = (prow - h.box_body_begin[tb]) * dof + comp;
+    HIP_TRY(hipMemcpy(vals, plan->d.near_val + off + r * stride, sizeof(double) * (size_t)ncols, hipMemcpyDeviceToHost));
   }
   return FMMBEM_OK;
 }
@@ -668,15 +693,16 @@ int fmmbem_plan_get_expansions(const fmmbem_plan* plan, int which, int p, double
   if (p < 1 || p > plan->hp.opt.p_max) return fail(FMMBEM_ERR_INVALID, "p outside [1, p_max]");
   HIP_TRY(hipSetDevice(plan->opts.device));
   const DevicePlan& d = plan->d;
-  std::vector<double2> tmp((size_t)d.nboxes * 2 * d.s_max);
+  const int ns = d.nslots;
+  std::vector<double2> tmp((size_t)d.nboxes * ns * d.s_max);
   HIP_TRY(hipMemcpy(tmp.data(), which == 0 ? d.M : d.L, tmp.size() * sizeof(double2), hipMemcpyDeviceToHost));
   const int S = p * (p + 1) / 2;
   for (int b = 0; b < d.nboxes; ++b)
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < ns; ++s)
       for (int i = 0; i < S; ++i) {
-        const double2 v = tmp[((size_t)b * 2 + s) * d.s_max + i];
-        out[(((size_t)b * 2 + s) * S + i) * 2] = v.x;
-        out[(((size_t)b * 2 + s) * S + i) * 2 + 1] = v.y;
+        const double2 v = tmp[((size_t)b * ns + s) * d.s_max + i];
+        out[(((size_t)b * ns + s) * S + i) * 2] = v.x;
+        out[(((size_t)b * ns + s) * S + i) * 2 + 1] = v.y;
       }
   return FMMBEM_OK;
 }

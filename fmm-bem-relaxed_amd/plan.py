@@ -53,6 +53,27 @@ class LaplaceSphericalBEM:
         self.P = int(p)
 
 
+class StokesSphericalBEM:
+    """Kernel descriptor of kernel/StokesSphericalBEM.hpp:131-141: order p, Gauss key k, viscosity mu and the
+    near-regime rule K_fine (ctor default 25; examples/StokesBEM.cpp:128-129,218 uses 19).  Only the VELOCITY
+    boundary condition (stokeslet single layer, the operator the solve uses) is built; charges and results are
+    Vec<3,double> per panel, i.e. arrays of shape (N, 3)."""
+    VELOCITY, TRACTION = 0, 1
+
+    def __init__(self, p=5, k=3, mu=1e-3):
+        if not 1 <= int(p) <= _capi.PMAX:
+            raise ValueError("p must be in 1..%d" % _capi.PMAX)
+        self.P, self.K, self.Mu, self.K_fine = int(p), int(k), float(mu), 25
+
+    def set_p(self, p):
+        if not 1 <= int(p) <= _capi.PMAX:
+            raise ValueError("p must be in 1..%d" % _capi.PMAX)
+        self.P = int(p)
+
+    def set_Kfine(self, k):
+        self.K_fine = int(k)
+
+
 def unit_sphere(recursions, center=(0.0, 0.0, 0.0)):
     """Triangulation::UnitSphere (examples/BEM/Triangulation.hpp:105-121) -> (N, 3, 3) vertex array."""
     n = C.c_size_t(0)
@@ -89,6 +110,12 @@ class FMM_plan:
         o.sparse_local = 1 if opts.sparse_local else 0
         o.host_only = 1 if host_only else 0
         o.device = int(device)
+        self.dof = 1
+        if isinstance(K, StokesSphericalBEM):
+            o.kernel = _capi.KERNEL_STOKES_BEM
+            o.mu = K.Mu
+            o.quad_k_fine = K.K_fine
+            self.dof = 3
         o.shard_rank, o.shard_world = int(shard[0]), int(shard[1])
         self.p_max = o.p_max
         bcp = None
@@ -111,9 +138,10 @@ class FMM_plan:
     def execute(self, charges):
         """results = plan.execute(charges) at the kernel's current p. numpy in, numpy out (host)."""
         x = np.ascontiguousarray(charges, dtype=np.float64)
-        if x.shape != (self.n,):
-            raise ValueError("charges must have one value per panel")
-        y = np.empty(self.n)
+        want = (self.n,) if self.dof == 1 else (self.n, self.dof)
+        if x.shape != want:
+            raise ValueError("charges must have shape %r" % (want,))
+        y = np.empty(want)
         _capi.check(_capi.lib().fmmbem_plan_execute(self._h, self._K.P, x.ctypes.data_as(C.c_void_p),
                                                     y.ctypes.data_as(C.c_void_p)))
         return y
@@ -133,8 +161,8 @@ class FMM_plan:
     def execute_torch(self, x, out=None, p=None):
         """x: float64 CUDA tensor (N,), ORIGINAL panel order. Runs on torch's current stream."""
         import torch
-        if x.dtype != torch.float64 or not x.is_cuda or not x.is_contiguous() or x.numel() != self.n:
-            raise ValueError("x must be a contiguous float64 CUDA tensor with one value per panel")
+        if x.dtype != torch.float64 or not x.is_cuda or not x.is_contiguous() or x.numel() != self.n * self.dof:
+            raise ValueError("x must be a contiguous float64 CUDA tensor with dof values per panel")
         if out is None:
             out = torch.empty_like(x)
         self.execute_device(x.data_ptr(), out.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream, p)
@@ -184,7 +212,7 @@ class FMM_plan:
     def expansions(self, which, p=None):
         p = self._K.P if p is None else p
         nb = self.stats()["n_boxes"]
-        out = np.empty((nb, 2, p * (p + 1) // 2), dtype=np.complex128)
+        out = np.empty((nb, 2 if self.dof == 1 else 8, p * (p + 1) // 2), dtype=np.complex128)
         _capi.check(_capi.lib().fmmbem_plan_get_expansions(self._h, 0 if which == "M" else 1, p,
                                                            out.ctypes.data_as(C.c_void_p)))
         return out

@@ -36,7 +36,9 @@ typedef enum {
 
 /* kernel ids: which reference Kernel class the plan stands in for */
 typedef enum {
-  FMMBEM_KERNEL_LAPLACE_BEM = 0 /* kernel/LaplaceSphericalBEM.hpp */
+  FMMBEM_KERNEL_LAPLACE_BEM = 0, /* kernel/LaplaceSphericalBEM.hpp: 1 unknown per panel                  */
+  FMMBEM_KERNEL_STOKES_BEM = 1   /* kernel/StokesSphericalBEM.hpp, VELOCITY boundary condition (stokeslet
+                                  * single layer): 3 unknowns per panel, x/y hold Vec<3,double> per panel  */
 } fmmbem_kernel;
 
 /* boundary-condition flag per panel: LaplaceSphericalBEM::Panel::BoundaryType
@@ -59,7 +61,11 @@ typedef struct {
   int32_t  device;            /* HIP device ordinal                                                */
   int32_t  shard_rank;        /* target-leaf shard owned by this plan: rank of world               */
   int32_t  shard_world;       /* 1 = whole operator                                                */
-  int32_t  reserved[6];
+  int32_t  quad_k_fine;       /* Stokes: near-regime Gauss rule K_fine (StokesSphericalBEM::set_Kfine,
+                               * kernel/StokesSphericalBEM.hpp:139-141; ctor default 25, driver 19)  */
+  int32_t  reserved0;
+  double   mu;                /* Stokes: viscosity (StokesSphericalBEM(p,k,mu), :131)               */
+  int32_t  reserved[2];
 } fmmbem_options;
 
 /* Statistics of a plan and of its last execute (times in milliseconds, device-side HIP events). */
@@ -95,8 +101,8 @@ void fmmbem_plan_destroy(fmmbem_plan *plan);
 
 /* ---- the hot path ----------------------------------------------------------------------- */
 /* results = plan.execute(charges) with kernel().set_p(p) applied first
- * (FMM_plan.hpp:75-90; GMRES.hpp:194-201).  x, y: n_panels doubles in ORIGINAL panel order,
- * HOST pointers; y is overwritten.  With shard_world > 1, y holds this shard's rows and zeros
+ * (FMM_plan.hpp:75-90; GMRES.hpp:194-201).  x, y: n_panels x dof doubles (dof = 1 Laplace, 3 Stokes,
+ * interleaved per panel as std::vector<Vec<3,double>>) in ORIGINAL panel order, HOST pointers; y is overwritten.  With shard_world > 1, y holds this shard's rows and zeros
  * elsewhere (sum over shards = full result). */
 int fmmbem_plan_execute(fmmbem_plan *plan, int p, const double *x, double *y);
 
@@ -124,12 +130,13 @@ int fmmbem_plan_get_boxes(const fmmbem_plan *plan, double *center, double *side,
 /* Pair lists; which: 0 = P2P (source leaf, target leaf), 1 = M2L (source box, target box),
  * 2 = M2M (child, parent), 3 = L2L (parent, child).  out may be NULL; returns the count via *n. */
 int fmmbem_plan_get_pairs(const fmmbem_plan *plan, int which, int32_t *out, int64_t *n);
-/* One assembled near-matrix row (tree-order row index, must be owned): column tree indices and
- * values, ascending columns.  cols/vals may be NULL; *n receives the row length. */
+/* One assembled near-matrix row (tree-order index of the unknown, i.e. dof*panel + component; must be
+ * owned): column indices (same numbering) and values, ascending columns.  cols/vals may be NULL; *n
+ * receives the row length. */
 int fmmbem_plan_get_near_row(const fmmbem_plan *plan, int64_t row, uint32_t *cols, double *vals,
                              int64_t *n);
 /* Multipole (which=0) or local (which=1) coefficients of the last execute for every box:
- * out[box][slot][p(p+1)/2][re,im], slot 0 = G expansion, slot 1 = dG/dn expansion. */
+ * out[box][slot][p(p+1)/2][re,im]; Laplace: 2 slots (G, dG/dn); Stokes: 8 slots (M[2][4]). */
 int fmmbem_plan_get_expansions(const fmmbem_plan *plan, int which, int p, double *out);
 
 /* ---- mesh generator of the reference's drivers ------------------------------------------- */

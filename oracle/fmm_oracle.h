@@ -88,6 +88,9 @@ typedef struct orc_ctx {
   /* expansions (allocated for pcap) */
   int pcap;
   cplx *M, *L;             /* [box][2][pcap*(pcap+1)/2]                        */
+  /* Stokes (stokes.c): viscosity, near-regime rule K_fine, 3x3 near blocks, 2x4 expansions */
+  double mu; int kfine, nqf; double qfp[ORC_MAXK][3], qfw[ORC_MAXK];
+  double *val9; int spcap; cplx *MS, *LS;
 } orc_ctx;
 
 /* precomputed tables of LaplaceSpherical (kernel/LaplaceSpherical.hpp:87-117) */
@@ -132,9 +135,18 @@ void orc_l2p_panel(const orc_tables *t, const cplx *L0, const cplx *L1, const do
 
 /* ---- matvec.c ---- */
 int  orc_build_near(orc_ctx *c);
+int  orc_build_near_pattern(orc_ctx *c);    /* row_ptr/col only */
 int  orc_matvec(orc_ctx *c, int P, const double *x, double *y, int flags, double stage_s[8]);
 void orc_direct(const orc_ctx *c, const double *x, double *y, int row_begin, int row_end);
 void orc_near_only(const orc_ctx *c, const double *x, double *y);
+
+/* ---- stokes.c ---- */
+int  orc_stokes_config(orc_ctx *c, double mu, int kfine);
+void orc_stokes_entry(const orc_ctx *c, const orc_panel *t, const orc_panel *s, double out[9]);
+int  orc_stokes_build_near(orc_ctx *c);
+int  orc_stokes_matvec(orc_ctx *c, int P, const double *x, double *y, int flags, double stage_s[8]);
+void orc_stokes_direct(const orc_ctx *c, const double *x, double *y, int row_begin, int row_end);
+void orc_red_blood_cell_map(long n, double *verts);
 
 #define ORC_FLAG_FAITHFUL 1   /* both expansions, serial SpMV/M2M/L2L like the reference */
 #define ORC_FLAG_TARGET_RANGE 2

@@ -13,8 +13,8 @@ static double omp_get_wtime(void) { return 0; }
 
 /* executor/EvalP2P.hpp:47-98 (P2P_Lazy::to_matrix): rows = target body, cols = source body, both in
  * tree order; columns sorted ascending per row; entry = K(target_i, source_j). */
-int orc_build_near(orc_ctx *c) {
-  if (c->val) return 0;
+int orc_build_near_pattern(orc_ctx *c) {
+  if (c->row_ptr) return 0;
   const int n = c->n;
   int64_t *cnt = calloc((size_t)n + 1, sizeof(int64_t));
   /* per target leaf: list of source leaves */
@@ -45,24 +45,33 @@ int orc_build_near(orc_ctx *c) {
   for (int i = 0; i < n; ++i) cnt[i+1] += cnt[i];
   c->row_ptr = cnt; c->nnz = cnt[n];
   c->col = malloc(sizeof(uint32_t)*(size_t)(c->nnz ? c->nnz : 1));
-  c->val = malloc(sizeof(double)*(size_t)(c->nnz ? c->nnz : 1));
-  if (!c->col || !c->val) return -1;
+  if (!c->col) return -1;
   #pragma omp parallel for schedule(dynamic, 1)
   for (int b = 0; b < c->nboxes; ++b) {
     if (!c->boxes[b].leaf) continue;
     for (uint32_t r = c->boxes[b].bb; r < c->boxes[b].be; ++r) {
-      const orc_panel *t = &c->panels[c->perm[r]];
       int64_t at = c->row_ptr[r];
       for (int i = tptr[b]; i < tptr[b+1]; ++i) {
         const orc_box *sb = &c->boxes[tsrc[i]];
-        for (uint32_t j = sb->bb; j < sb->be; ++j, ++at) {
-          c->col[at] = j;
-          c->val[at] = orc_kernel(c, t, &c->panels[c->perm[j]]);
-        }
+        for (uint32_t j = sb->bb; j < sb->be; ++j, ++at) c->col[at] = j;
       }
     }
   }
   free(tptr); free(tsrc);
+  return 0;
+}
+
+int orc_build_near(orc_ctx *c) {
+  if (c->val) return 0;
+  if (orc_build_near_pattern(c)) return -1;
+  c->val = malloc(sizeof(double)*(size_t)(c->nnz ? c->nnz : 1));
+  if (!c->val) return -1;
+  #pragma omp parallel for schedule(dynamic, 16)
+  for (int i = 0; i < c->n; ++i) {
+    const orc_panel *t = &c->panels[c->perm[i]];
+    for (int64_t k = c->row_ptr[i]; k < c->row_ptr[i+1]; ++k)
+      c->val[k] = orc_kernel(c, t, &c->panels[c->perm[c->col[k]]]);
+  }
   return 0;
 }
 

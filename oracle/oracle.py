@@ -69,6 +69,17 @@ def lib():
         L.orc_quadrature.argtypes = [i32, vp, vp]
         L.orc_quadrature.restype = i32
         L.orc_num_threads.restype = i32
+        L.orc_stokes_config.argtypes = [vp, dbl, i32]
+        L.orc_stokes_config.restype = i32
+        L.orc_stokes_build_near.argtypes = [vp]
+        L.orc_stokes_build_near.restype = i32
+        L.orc_stokes_matvec.argtypes = [vp, i32, vp, vp, i32, vp]
+        L.orc_stokes_matvec.restype = i32
+        L.orc_stokes_direct.argtypes = [vp, vp, vp, i32, i32]
+        L.orc_stokes_get_near.argtypes = [vp, vp]
+        L.orc_stokes_get_expansions.argtypes = [vp, i32, i32, vp]
+        L.orc_stokes_entries.argtypes = [vp, i32, vp, vp, vp]
+        L.orc_red_blood_cell_map.argtypes = [C.c_long, vp]
         _LIB = L
     return _LIB
 
@@ -277,3 +288,61 @@ def cart2sph(d):
     r, t, p = C.c_double(), C.c_double(), C.c_double()
     lib().orc_cart2sph(C.byref(r), C.byref(t), C.byref(p), _p(d))
     return r.value, t.value, p.value
+
+
+def red_blood_cell(recursions):
+    """Triangulation::RedBloodCell (examples/BEM/Triangulation.hpp:210-255), identity rotation, zero shift."""
+    v = unit_sphere(recursions)
+    lib().orc_red_blood_cell_map(len(v), _p(v))
+    return v
+
+
+class StokesOracle(Oracle):
+    """FMM_plan<StokesSphericalBEM>-equivalent on the CPU, velocity boundary condition only
+    (kernel/StokesSphericalBEM.hpp:260-375, 391-432, 512-528; StokesSpherical.hpp:318-401)."""
+
+    def __init__(self, vertices, K=4, K_fine=19, mu=1e-3, theta=0.5, ncrit=64):
+        super().__init__(vertices, K=K, theta=theta, ncrit=ncrit)
+        if lib().orc_stokes_config(self._h, mu, K_fine):
+            raise ValueError("invalid K_fine")
+        self.mu = mu
+
+    def matvec(self, x, p, faithful=False, return_times=False):
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(self.n, 3)
+        y = np.empty((self.n, 3))
+        st = np.zeros(8)
+        rc = lib().orc_stokes_matvec(self._h, p, _p(x), _p(y), FAITHFUL if faithful else 0, _p(st))
+        if rc:
+            raise RuntimeError("orc_stokes_matvec rc=%d" % rc)
+        return (y, dict(zip(STAGES, st.tolist()))) if return_times else y
+
+    def direct(self, x, rows=None):
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(self.n, 3)
+        y = np.zeros((self.n, 3))
+        b, e = (0, self.n) if rows is None else rows
+        lib().orc_stokes_direct(self._h, _p(x), _p(y), b, e)
+        return y if rows is None else y[b:e]
+
+    def near_csr(self):
+        if lib().orc_stokes_build_near(self._h):
+            raise MemoryError("near matrix")
+        nnz = lib().orc_near_nnz(self._h)
+        rp = np.empty(self.n + 1, dtype=np.int64)
+        col = np.empty(nnz, dtype=np.uint32)
+        lib().orc_get_near(self._h, _p(rp), _p(col), None)
+        val = np.empty((nnz, 3, 3))
+        lib().orc_stokes_get_near(self._h, _p(val))
+        return rp, col, val
+
+    def expansions(self, p, which):
+        nb = self.stats()["boxes"]
+        out = np.empty((nb, 8, p * (p + 1) // 2), dtype=np.complex128)
+        lib().orc_stokes_get_expansions(self._h, p, 0 if which == "M" else 1, _p(out))
+        return out
+
+    def kernel_entries(self, ti, sj):
+        ti = np.ascontiguousarray(ti, dtype=np.int32)
+        sj = np.ascontiguousarray(sj, dtype=np.int32)
+        out = np.empty((len(ti), 3, 3))
+        lib().orc_stokes_entries(self._h, len(ti), _p(ti), _p(sj), _p(out))
+        return out

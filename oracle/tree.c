@@ -241,7 +241,7 @@ void orc_destroy(orc_ctx *c) {
   free(c->panels); free(c->quad); free(c->boxes); free(c->perm); free(c->code); free(c->level_offset);
   free(c->p2p); free(c->lr); free(c->p2m); free(c->m2m); free(c->l2l); free(c->l2p);
   free(c->lr_ptr); free(c->lr_src); free(c->row_ptr); free(c->col); free(c->val);
-  free(c->M); free(c->L); free(c);
+  free(c->M); free(c->L); free(c->val9); free(c->MS); free(c->LS); free(c);
 }
 
 void orc_stats(const orc_ctx *c, int64_t out[16]) {
