@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-accuracy", action="store_true")
     ap.add_argument("--cpu-recursions", type=int, default=8)
+    ap.add_argument("--workload", choices=["laplace", "stokes_rbc"], default="laplace",
+                    help="laplace: the BASELINE metric workload (default); stokes_rbc: SURVEY 8(d) config 4 "
+                         "(StokesSphericalBEM velocity BC on RedBloodCell(r), p=8, k=4, K_fine=19, mu=1e-3)")
     return ap.parse_args()
 
 
@@ -93,11 +96,26 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    # ---- workload: `spheres` disjoint unit spheres, centres 3 apart on the x axis ----
-    parts = [fb.unit_sphere(args.recursions, center=(3.0 * i, 0.0, 0.0)) for i in range(args.spheres)]
-    v = np.concatenate(parts) if len(parts) > 1 else parts[0]
+    stokes = args.workload == "stokes_rbc"
+    if stokes:
+        # ---- config 4: one red blood cell (examples/BEM/Triangulation.hpp:184-255), identity rotation, no shift ----
+        v = fb.unit_sphere(args.recursions)
+        r, C0, C2, C4 = 3.91, 0.81, 7.83, -4.39
+        xx, yy = v[..., 0] * r, v[..., 1] * r
+        ratio = np.sqrt(xx * xx + yy * yy) / r
+        zz = np.sqrt(1 - ratio ** 2 + 1e-12) * (C0 + C2 * ratio ** 2 + C4 * ratio ** 4) * 0.5 * np.sign(v[..., 2])
+        v = np.stack([xx, yy, zz], axis=-1)
+        if args.p == 10:
+            args.p = 8
+        K = fb.StokesSphericalBEM(args.p, 4, 1e-3)
+        K.set_Kfine(19)
+    else:
+        # ---- workload: `spheres` disjoint unit spheres, centres 3 apart on the x axis ----
+        parts = [fb.unit_sphere(args.recursions, center=(3.0 * i, 0.0, 0.0)) for i in range(args.spheres)]
+        v = np.concatenate(parts) if len(parts) > 1 else parts[0]
+        K = fb.LaplaceSphericalBEM(args.p, 3)
     n = len(v)
-    K = fb.LaplaceSphericalBEM(args.p, 3)
+    dof = 3 if stokes else 1
     opts = fb.FMMOptions()
     opts.set_mac_theta(args.theta)
     opts.set_max_per_box(args.ncrit)
@@ -107,7 +125,7 @@ def main():
     plan = op.plan
 
     g = torch.Generator(device="cpu").manual_seed(1234)
-    x = torch.rand(n, dtype=torch.float64, generator=g).to(dev)
+    x = torch.rand(n * dof, dtype=torch.float64, generator=g).to(dev)
     y = torch.empty_like(x)
 
     def step():
@@ -146,7 +164,7 @@ def main():
 
     # ---- roofline of the P2P kernel on this rank's shard (SURVEY.md section 8d "Algorithmic bytes, P2P") ----
     rows = st["owned_row_end"] - st["owned_row_begin"]
-    p2p_bytes = st["near_nnz"] * 8 + n * 8 + rows * 8
+    p2p_bytes = st["near_nnz"] * 8 * dof * dof + n * 8 * dof + rows * 8 * dof
     near_ms = st["ms_near"]
     p2p_gbs = p2p_bytes / (near_ms * 1e-3) / 1e9 if near_ms > 0 else 0.0
     traffic = None
@@ -157,17 +175,22 @@ def main():
     except Exception:
         pass
     P = args.p
-    m2l_flops = st["m2l_pairs_owned"] * 8.0 * (P * (P + 1) // 2) * P * P       # 4 FMAs = 8 flop per complex MAC
+    n_exp = 4 if stokes else 1                                                  # live expansions per box
+    m2l_flops = n_exp * st["m2l_pairs_owned"] * 8.0 * (P * (P + 1) // 2) * P * P   # 4 FMAs = 8 flop per complex MAC
     m2l_tflops = m2l_flops / (st["ms_m2l"] * 1e-3) / 1e12 if st["ms_m2l"] > 0 else 0.0
 
     out = {
-        "metric": "FMM matvecs/s (LaplaceBEM sphere N=1e6 p=10) + achieved HBM GB/s on P2P",
+        "metric": ("FMM matvecs/s (StokesBEM red blood cell, velocity BC) + achieved HBM GB/s on P2P" if stokes else
+                   "FMM matvecs/s (LaplaceBEM sphere N=1e6 p=10) + achieved HBM GB/s on P2P"),
         "value": args.steps / elapsed, "unit": "matvecs/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "LaplaceSphericalBEM, %d disjoint UnitSphere(r=%d), N=%d panels, p=%d, k=3, theta=%g, "
-                               "ncrit=%d, all POTENTIAL; target leaves sharded over %d GPU(s), 1 all-reduce of y per matvec"
-                               % (args.spheres, args.recursions, n, P, args.theta, args.ncrit, world),
+        "config": {"workload": ("StokesSphericalBEM velocity BC, RedBloodCell(r=%d), N=%d panels (%d unknowns), p=%d, k=4, "
+                                "K_fine=19, mu=1e-3, theta=%g, ncrit=%d; %d GPU(s)"
+                                % (args.recursions, n, 3 * n, P, args.theta, args.ncrit, world)) if stokes else
+                               ("LaplaceSphericalBEM, %d disjoint UnitSphere(r=%d), N=%d panels, p=%d, k=3, theta=%g, "
+                                "ncrit=%d, all POTENTIAL; target leaves sharded over %d GPU(s), 1 all-reduce of y per matvec"
+                                % (args.spheres, args.recursions, n, P, args.theta, args.ncrit, world)),
                    "n_panels": n, "p": P, "near_nnz": st["near_nnz_total"], "m2l_pairs": st["m2l_pairs"],
                    "boxes": st["n_boxes"], "leaves": st["n_leaves"]},
         "roofline": {"kernel": "near_spmv (P2P)", "bound": "hbm", "achieved": p2p_gbs, "peak": HBM_PEAK_GBS,
@@ -183,7 +206,16 @@ def main():
         "host_lists_s": st["build_host_ms"] * 1e-3,
     }
 
-    if world == 1 and not args.no_accuracy:
+    if world == 1 and not args.no_accuracy and stokes:
+        from oracle import oracle as O
+        o = O.StokesOracle(v, K=4, K_fine=19, mu=1e-3, theta=args.theta, ncrit=args.ncrit)
+        xs = x.cpu().numpy().reshape(n, 3)
+        lo = n // 3
+        dd = o.direct(xs, rows=(lo, lo + 128))
+        ys = y.cpu().numpy().reshape(n, 3)[lo:lo + 128]
+        out["rel_l2_vs_direct_sample"] = float(np.linalg.norm(ys - dd) / np.linalg.norm(dd))
+        o.close()
+    if world == 1 and not args.no_accuracy and not stokes:
         # north_star gate at full size: relative L2 vs the O(N^2) Direct sum on a 256-target sample (oracle as checker)
         from oracle import oracle as O
         o = O.Oracle(v, K=3, theta=args.theta, ncrit=args.ncrit)
@@ -193,7 +225,7 @@ def main():
         ys = y.cpu().numpy()[lo:lo + 256]
         out["rel_l2_vs_direct_sample"] = float(np.linalg.norm(ys - d) / np.linalg.norm(d))
         o.close()
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and not stokes:
         out["cpu_baseline"] = cpu_baseline(args)
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
     print(json.dumps(out), flush=True)
