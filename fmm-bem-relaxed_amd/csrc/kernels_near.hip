@@ -418,10 +418,10 @@ __global__ void scatter_y_kernel(const uint32_t* __restrict__ perm, const double
 //   3. per-row wave shuffle reduction, lane 0 stores y_tree[row].
 // Algorithmic bytes: 8 B per near entry (+ 8 B x read + 8 B y write per panel); no column indices.
 // ---------------------------------------------------------------------------------------------
-constexpr int kSpmvWaves = 4, kVecs = 4;
+constexpr int kSpmvWaves = 4;
 constexpr int kSpmvChunk = 2048;                     // columns of x staged in LDS at a time (16 KiB)
 
-template <int kRows, bool NT>
+template <int kRows, int kVecs, bool NT>
 __global__ __launch_bounds__(kSpmvWaves * kWave) void near_spmv_kernel(DevicePlan d) {
   extern __shared__ double xs[];                      // [kSpmvChunk] doubles, then the run descriptors
   int* run_row0 = reinterpret_cast<int*>(xs + kSpmvChunk);
@@ -531,8 +531,10 @@ hipError_t launch_near_spmv(const DevicePlan& d, hipStream_t s) {
   const size_t lds = (size_t)kSpmvChunk * sizeof(double) + 2 * (size_t)d.max_runs * sizeof(int);
   // 6 persistent workgroups per CU; 4 rows x 4 vectors in flight per wavefront with nontemporal loads measured
   // best at N = 1M (rows 1/2/4/8: 2.54/1.91/1.37/1.83 ms before chunked staging; plain loads +25 %)
+  // 6 persistent workgroups per CU; rows x vectors in flight per wavefront measured at N = 1M (ms):
+  // 4x4 1.05, 2x4 0.99, 4x2 1.14, 8x2 1.21, 2x2 1.09, 4x1 1.09; plain (non-nontemporal) loads +25 %
   const dim3 g(nb < 256 * 6 ? nb : 256 * 6), b(kSpmvWaves * kWave);
-  hipLaunchKernelGGL((near_spmv_kernel<4, true>), g, b, lds, s, d);
+  hipLaunchKernelGGL((near_spmv_kernel<2, 4, true>), g, b, lds, s, d);
   return hipGetLastError();
 }
 

@@ -475,6 +475,8 @@ void fmmbem_options_default(fmmbem_options* o) {
   o->ncrit = 64;
   o->sparse_local = 1;
   o->shard_world = 1;
+  o->quad_k_fine = 25;          // StokesSphericalBEM ctor default (kernel/StokesSphericalBEM.hpp:131)
+  o->mu = 1e-3;
 }
 
 int fmmbem_plan_create(const fmmbem_options* opts, size_t n_panels, const double* vertices, const uint8_t* bc,

@@ -69,6 +69,34 @@ class LaplaceSphericalBEM {
   int P;
 };
 
+// kernel/StokesSphericalBEM.hpp:9-141 -- panel type, Vec<3,double> charges/results, p, K, K_fine, mu.
+// Only VELOCITY panels are accepted by the library (the reference's traction far field is not reproducible).
+class StokesSphericalBEM {
+ public:
+  typedef std::array<double, 3> point_type;
+  typedef std::array<double, 3> charge_type;
+  typedef std::array<double, 3> result_type;
+  struct Panel {
+    typedef enum { VELOCITY, TRACTION } BoundaryType;
+    std::array<point_type, 3> vertices;
+    BoundaryType BC = VELOCITY;
+    Panel() = default;
+    Panel(point_type p0, point_type p1, point_type p2) : vertices{{p0, p1, p2}} {}
+    void switch_BC() { BC = BC == VELOCITY ? TRACTION : VELOCITY; }
+  };
+  typedef Panel source_type;
+  typedef Panel target_type;
+  unsigned K, K_fine = 25;
+  double Mu;
+  explicit StokesSphericalBEM(int p = 5, unsigned k = 3, double mu = 1e-3) : K(k), Mu(mu), P(p) {}
+  void set_p(int p) { P = p; }
+  void set_Kfine(unsigned k) { K_fine = k; }
+  int p() const { return P; }
+
+ private:
+  int P;
+};
+
 template <class Kernel>
 class FMM_plan;
 
@@ -123,6 +151,58 @@ class FMM_plan<LaplaceSphericalBEM> {
   void operator()(const std::vector<charge_type>& x, std::vector<result_type>& y) { y = execute(x); }
 
   fmmbem_plan* handle() { return plan_; }
+
+ private:
+  kernel_type K;
+  FMMOptions opts_;
+  size_t n_;
+  fmmbem_plan* plan_ = nullptr;
+};
+
+template <>
+class FMM_plan<StokesSphericalBEM> {
+ public:
+  typedef StokesSphericalBEM kernel_type;
+  typedef kernel_type::source_type source_type;
+  typedef kernel_type::charge_type charge_type;
+  typedef kernel_type::result_type result_type;
+
+  FMM_plan(const kernel_type& k, const std::vector<source_type>& source, FMMOptions& opts, int p_max = 0, int device = 0)
+      : K(k), opts_(opts), n_(source.size()) {
+    std::vector<double> v(9 * n_);
+    std::vector<uint8_t> bc(n_);
+    for (size_t i = 0; i < n_; ++i) {
+      for (int a = 0; a < 3; ++a)
+        for (int c = 0; c < 3; ++c) v[9 * i + 3 * a + c] = source[i].vertices[a][c];
+      bc[i] = source[i].BC == source_type::TRACTION;
+    }
+    fmmbem_options o;
+    fmmbem_options_default(&o);
+    o.kernel = FMMBEM_KERNEL_STOKES_BEM;
+    o.p_max = p_max > 0 ? p_max : K.p();
+    o.quad_k = (int)K.K;
+    o.quad_k_fine = (int)K.K_fine;
+    o.mu = K.Mu;
+    o.theta = opts.theta;
+    o.ncrit = opts.NCRIT_;
+    o.sparse_local = 1;
+    o.device = device;
+    fmmbem::check(fmmbem_plan_create(&o, n_, v.data(), bc.data(), &plan_));
+  }
+  ~FMM_plan() { fmmbem_plan_destroy(plan_); }
+  FMM_plan(const FMM_plan&) = delete;
+  FMM_plan& operator=(const FMM_plan&) = delete;
+
+  kernel_type& kernel() { return K; }
+  FMMOptions& options() { return opts_; }
+
+  std::vector<result_type> execute(const std::vector<charge_type>& charges) {
+    if (charges.size() != n_) throw fmmbem::Error(FMMBEM_ERR_INVALID, "charges.size() != number of panels");
+    std::vector<result_type> results(charges.size());
+    // std::array<double,3> is three contiguous doubles: the vectors are the N x 3 arrays the C ABI expects
+    fmmbem::check(fmmbem_plan_execute(plan_, K.p(), charges.data()->data(), results.data()->data()));
+    return results;
+  }
 
  private:
   kernel_type K;

@@ -32,6 +32,29 @@ int main(int argc, char** argv) {
       for (double x : res) sum += x;
       std::printf("%zu %d %.17g %.17g %.17g\n", n, p, sum, res[0], res[n - 1]);
     }
+    // examples/StokesBEM.cpp:113-141 -- same mesh as Stokes velocity panels, charges (1,0,0)
+    typedef StokesSphericalBEM::Panel SPanel;
+    std::vector<SPanel> spanels;
+    for (size_t i = 0; i < n; ++i)
+      spanels.emplace_back(StokesSphericalBEM::point_type{v[9 * i], v[9 * i + 1], v[9 * i + 2]}, StokesSphericalBEM::point_type{v[9 * i + 3], v[9 * i + 4], v[9 * i + 5]},
+                           StokesSphericalBEM::point_type{v[9 * i + 6], v[9 * i + 7], v[9 * i + 8]});
+    StokesSphericalBEM KS(8, 3, 1e-3);
+    KS.set_Kfine(19);
+    FMM_plan<StokesSphericalBEM> splan(KS, spanels, opts, 8);
+    std::vector<StokesSphericalBEM::charge_type> f(n, StokesSphericalBEM::charge_type{1., 0., 0.});
+    std::vector<StokesSphericalBEM::result_type> u = splan.execute(f);
+    double s3[3] = {0, 0, 0};
+    for (const auto& r : u)
+      for (int c = 0; c < 3; ++c) s3[c] += r[c];
+    std::printf("stokes %zu %d %.17g %.17g %.17g\n", n, KS.p(), s3[0], s3[1], s3[2]);
+    // a traction panel is refused, not silently mis-evaluated
+    spanels[0].switch_BC();
+    try {
+      FMM_plan<StokesSphericalBEM> bad(KS, spanels, opts, 8);
+      std::printf("traction accepted\n");
+    } catch (const fmmbem::Error& e) {
+      std::printf("traction refused %d\n", e.status);
+    }
   } catch (const fmmbem::Error& e) {
     std::printf("error %d %s\n", e.status, e.what());
     return 2;

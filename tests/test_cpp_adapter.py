@@ -33,7 +33,8 @@ def test_adapter_matches_oracle(tmp_path, oracle_mod):
     v = oracle_mod.unit_sphere(5)
     o = oracle_mod.Oracle(v)
     one = np.ones(o.n)
-    lines = [ln.split() for ln in r.stdout.strip().splitlines()]
+    out = [ln.split() for ln in r.stdout.strip().splitlines()]
+    lines = [ln for ln in out if ln[0].isdigit()]
     assert [int(ln[1]) for ln in lines] == [12, 10, 5]
     for ln in lines:
         n, p = int(ln[0]), int(ln[1])
@@ -41,3 +42,10 @@ def test_adapter_matches_oracle(tmp_path, oracle_mod):
         assert n == o.n
         assert abs(float(ln[2]) - y.sum()) / abs(y.sum()) < 1e-12
         assert abs(float(ln[3]) - y[0]) / abs(y[0]) < 1e-11 and abs(float(ln[4]) - y[-1]) / abs(y[-1]) < 1e-11
+    st = [ln for ln in out if ln[0] == "stokes"][0]
+    so = oracle_mod.StokesOracle(v, K=3, K_fine=19, mu=1e-3)
+    f = np.zeros((so.n, 3)); f[:, 0] = 1.0
+    u = so.matvec(f, 8)
+    for c in range(3):
+        assert abs(float(st[3 + c]) - u[:, c].sum()) <= 1e-11 * np.abs(u).sum()
+    assert ["traction", "refused", "6"] in out                  # FMMBEM_ERR_UNSUPPORTED
