@@ -51,6 +51,8 @@ struct DevicePlan {
   const int *near_ncols, *near_stride;
   const int64_t* near_off;
   double* near_val;
+  const int4* near_items;                            // SpMV work items {leaf, first row, rows, column-split?}, largest first
+  int near_nitems;
   // boxes / expansions
   const double* box_center;
   double2 *M, *L, *Mh;

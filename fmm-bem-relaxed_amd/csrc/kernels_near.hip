@@ -7,6 +7,9 @@
 //   scatter_y       y[perm[i]] = y_tree[i]        (EvalInteractionLazySparse.hpp:146-148)
 #include "device_plan.hpp"
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace fmmbem {
 
 namespace {
@@ -421,24 +424,32 @@ __global__ void scatter_y_kernel(const uint32_t* __restrict__ perm, const double
 constexpr int kSpmvWaves = 4;
 constexpr int kSpmvChunk = 2048;                     // columns of x staged in LDS at a time (16 KiB)
 
-template <int kRows, int kVecs, bool NT>
-__global__ __launch_bounds__(kSpmvWaves * kWave) void near_spmv_kernel(DevicePlan d) {
+constexpr int kSpmvOcc = 5;                           // wavefronts per SIMD = workgroups per CU (82 VGPRs)
+constexpr int kColRows = 8;                           // work items with fewer rows split the COLUMNS over the wavefronts
+
+template <int kRows, int kVecs>
+__global__ __launch_bounds__(kSpmvWaves * kWave, kSpmvOcc) void near_spmv_kernel(DevicePlan d) {
   extern __shared__ double xs[];                      // [kSpmvChunk] doubles, then the run descriptors
+  __shared__ double part[kSpmvWaves][kColRows];
   int* run_row0 = reinterpret_cast<int*>(xs + kSpmvChunk);
   int* run_off = run_row0 + d.max_runs;
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   const dvec2* xv = reinterpret_cast<const dvec2*>(xs);
+  const int dof = d.dof;
 
-  // Persistent workgroups (grid = a few per CU) striding over the owned target leaves: a leaf is only
-  // ~75 KB of matrix, and one short-lived workgroup per leaf leaves the CUs mostly empty (measured: 3.5
-  // resident wavefronts per CU, launch-rate bound).
-  for (int t = d.leaf_begin + blockIdx.x; t < d.leaf_end; t += gridDim.x) {
+  // Persistent workgroups (a few per CU) are dealt the work items -- row ranges of one target leaf, largest
+  // first -- round-robin.  One short-lived workgroup per leaf leaves the CUs mostly empty (3.5 resident
+  // wavefronts per CU, launch-rate bound); whole leaves as items strand the workgroup that owns a coarse leaf;
+  // a dynamic queue costs more than it balances (one atomic per item: 65 k same-address atomics, +0.2 ms).
+  for (int item = blockIdx.x; item < d.near_nitems; item += gridDim.x) {
+    const int4 it = d.near_items[item];
+    const int t = it.x, r0 = it.y, nrows = it.z;
+    const bool colsplit = it.w != 0;
     // rows / columns counted in unknowns: dof per panel (Stokes: the 3x3 blocks are simply 3 rows x 3 columns)
-    const int dof = d.dof;
-    const int ncols = dof * d.near_ncols[t], stride = d.near_stride[t], nrows = dof * d.leaf_nrows[t];
+    const int ncols = dof * d.near_ncols[t], stride = d.near_stride[t];
     const Runs runs = load_runs(d, t, run_row0, run_off);
-    const double* blk = d.near_val + d.near_off[t];
-    const int row0 = dof * d.leaf_row0[t];
+    const double* blk = d.near_val + d.near_off[t] + (int64_t)r0 * stride;
+    double* yt = d.yt + dof * d.leaf_row0[t] + r0;
     // the x slice is staged kSpmvChunk columns at a time: a few coarse leaves of an adaptive tree see
     // >10^4 columns, and sizing the LDS for them would leave one workgroup per CU
     for (int c0 = 0; c0 < stride; c0 += kSpmvChunk) {
@@ -450,28 +461,33 @@ __global__ __launch_bounds__(kSpmvWaves * kWave) void near_spmv_kernel(DevicePla
       }
       __syncthreads();
       const int nvec = cw >> 1;                       // 16-B vectors of this chunk per row
-      for (int r = wave; r < nrows; r += kRows * kSpmvWaves) {
+      // row mode: wavefront w takes rows w, w+4, ... over all columns; column mode: every wavefront takes
+      // a quarter of the columns (64-B aligned) of every row and the quarters are summed in fixed order
+      const int seg = colsplit ? ((((nvec + kSpmvWaves - 1) / kSpmvWaves) + 3) & ~3) : nvec;
+      const int v0 = colsplit ? wave * seg : 0, v1 = min(nvec, v0 + seg);
+      const int rstep = colsplit ? 1 : kSpmvWaves;
+      for (int r = colsplit ? 0 : wave; r < nrows; r += colsplit ? kRows : kRows * kSpmvWaves) {
         const dvec2* row[kRows];
         double acc[kRows];
 #pragma unroll
         for (int i = 0; i < kRows; ++i) {
-          const int ri = r + i * kSpmvWaves;
+          const int ri = r + i * rstep;
           row[i] = reinterpret_cast<const dvec2*>(blk + (int64_t)(ri < nrows ? ri : r) * stride + c0);
           acc[i] = 0;
         }
-        for (int c = lane; c < nvec; c += kVecs * kWave) {
+        for (int c = v0 + lane; c < v1; c += kVecs * kWave) {
           dvec2 v[kRows][kVecs];
 #pragma unroll
           for (int u = 0; u < kVecs; ++u) {
             const int cc = c + u * kWave;
-            const bool ok = cc < nvec;
+            const bool ok = cc < v1;
 #pragma unroll
-            for (int i = 0; i < kRows; ++i) v[i][u] = ok ? (NT ? __builtin_nontemporal_load(&row[i][cc]) : row[i][cc]) : dvec2{0, 0};
+            for (int i = 0; i < kRows; ++i) v[i][u] = ok ? __builtin_nontemporal_load(&row[i][cc]) : dvec2{0, 0};
           }
 #pragma unroll
           for (int u = 0; u < kVecs; ++u) {
             const int cc = c + u * kWave;
-            if (cc < nvec) {
+            if (cc < v1) {
               const dvec2 x2 = xv[cc];
 #pragma unroll
               for (int i = 0; i < kRows; ++i) acc[i] = fma(v[i][u].x, x2.x, fma(v[i][u].y, x2.y, acc[i]));
@@ -483,13 +499,24 @@ __global__ __launch_bounds__(kSpmvWaves * kWave) void near_spmv_kernel(DevicePla
         if (lane == 0) {
 #pragma unroll
           for (int i = 0; i < kRows; ++i) {
-            const int ri = r + i * kSpmvWaves;
-            if (ri < nrows) d.yt[row0 + ri] = c0 ? d.yt[row0 + ri] + acc[i] : acc[i];
+            const int ri = r + i * rstep;
+            if (ri < nrows) {
+              if (colsplit) part[wave][ri] = acc[i];
+              else yt[ri] = c0 ? yt[ri] + acc[i] : acc[i];
+            }
           }
         }
       }
+      if (colsplit) {
+        __syncthreads();
+        if ((int)threadIdx.x < nrows) {
+          const int ri = threadIdx.x;
+          const double sum = ((part[0][ri] + part[1][ri]) + part[2][ri]) + part[3][ri];
+          yt[ri] = c0 ? yt[ri] + sum : sum;
+        }
+      }
     }
-    __syncthreads();                                  // xs / run descriptors are rewritten for the next leaf
+    __syncthreads();                                  // xs / run descriptors / part are rewritten for the next item
   }
 }
 
@@ -526,15 +553,15 @@ hipError_t launch_gather_x(const DevicePlan& d, const double* x, hipStream_t s) 
 }
 
 hipError_t launch_near_spmv(const DevicePlan& d, hipStream_t s) {
-  const int nb = d.leaf_end - d.leaf_begin;
-  if (nb <= 0) return hipSuccess;
+  if (d.near_nitems <= 0) return hipSuccess;
   const size_t lds = (size_t)kSpmvChunk * sizeof(double) + 2 * (size_t)d.max_runs * sizeof(int);
-  // 6 persistent workgroups per CU; 4 rows x 4 vectors in flight per wavefront with nontemporal loads measured
-  // best at N = 1M (rows 1/2/4/8: 2.54/1.91/1.37/1.83 ms before chunked staging; plain loads +25 %)
-  // 6 persistent workgroups per CU; rows x vectors in flight per wavefront measured at N = 1M (ms):
-  // 4x4 1.05, 2x4 0.99, 4x2 1.14, 8x2 1.21, 2x2 1.09, 4x1 1.09; plain (non-nontemporal) loads +25 %
-  const dim3 g(nb < 256 * 6 ? nb : 256 * 6), b(kSpmvWaves * kWave);
-  hipLaunchKernelGGL((near_spmv_kernel<2, 4, true>), g, b, lds, s, d);
+  // rows x vectors in flight per wavefront measured at N = 1M (ms): 4x4 1.05,
+  // 2x4 0.99, 4x2 1.14, 8x2 1.21, 2x2 1.09, 4x1 1.09; plain (non-nontemporal) loads +25 %
+  // The grid is exactly what is resident at once (kSpmvOcc workgroups per CU): with one more per CU the stragglers
+  // start when the others finish (0.98 ms instead of 0.79 at N = 1M); occupancy 6 (80 VGPRs) and 2x2 loads at
+  // occupancy 8 measure within 3 % of this.
+  const dim3 g(std::min(d.near_nitems, 256 * kSpmvOcc)), b(kSpmvWaves * kWave);
+  hipLaunchKernelGGL((near_spmv_kernel<2, 4>), g, b, lds, s, d);
   return hipGetLastError();
 }
 

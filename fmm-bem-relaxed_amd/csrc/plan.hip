@@ -258,6 +258,31 @@ int fmmbem_plan::to_device() {
   TRY(upload(leaf_row0, &d.leaf_row0)); TRY(upload(leaf_nrows, &d.leaf_nrows)); TRY(upload(hp.leaf_box, &d.leaf_box));
   TRY(upload(run_ptr, &d.near_ptr)); TRY(upload(run_row0, &d.near_run_row0)); TRY(upload(run_off, &d.near_run_off));
   TRY(upload(hp.near_ncols, &d.near_ncols)); TRY(upload(near_stride, &d.near_stride)); TRY(upload(near_off, &d.near_off));
+  {
+    // SpMV work items: a leaf's row block, cut into row ranges of <= kItemBytes so that no workgroup is left
+    // streaming one coarse leaf alone (two-sphere N=1M: one leaf is 58 rows x 16 031 columns = 7.4 MB against
+    // a mean of 75 KB), dealt round-robin to the persistent workgroups largest first.  Ranges shorter than 8
+    // rows are processed with the columns split over the wavefronts instead of the rows.
+    constexpr int64_t kItemBytes = 128 << 10;
+    struct Item { int leaf, r0, nr; int64_t bytes; };
+    std::vector<Item> items;
+    for (int l = hp.leaf_begin; l < hp.leaf_end; ++l) {
+      const int nr = dof * leaf_nrows[l];
+      const int64_t row_bytes = (int64_t)near_stride[l] * 8;
+      if (nr == 0 || row_bytes == 0) continue;
+      int per = (int)std::max<int64_t>(1, kItemBytes / row_bytes);
+      if (per >= 8) per &= ~7; else per = std::min(4, nr);
+      const int cnt = (nr + per - 1) / per;
+      per = (nr + cnt - 1) / cnt;
+      if (per >= 8) per = (per + 7) & ~7;
+      for (int r0 = 0; r0 < nr; r0 += per) { const int k = std::min(per, nr - r0); items.push_back({l, r0, k, k * row_bytes}); }
+    }
+    std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.bytes > b.bytes; });
+    std::vector<int4> packed(items.size());
+    for (size_t i = 0; i < items.size(); ++i) packed[i] = make_int4(items[i].leaf, items[i].r0, items[i].nr, items[i].nr < 8);
+    d.near_nitems = (int)packed.size();
+    TRY(upload(packed, &d.near_items));
+  }
   if (opts.sparse_local) TRY(alloc((size_t)total, &d.near_val, false));   // matrix-free mode keeps no matrix
   else { d.near_val = nullptr; near_bytes = 0; }
 

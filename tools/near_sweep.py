@@ -1,0 +1,44 @@
+"""Times the assembled near-field SpMV alone (fmmbem_plan_near_device) for kernel variants selected through
+FMMBEM_SPMV_VARIANT -- a tuning aid, not part of the product or the bench."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import fmm_bem_relaxed_amd as fb  # noqa: E402
+
+
+def main():
+    variants = [a for a in sys.argv[1:]] or ["0"]
+    v = np.concatenate([fb.unit_sphere(9, center=(3.0 * i, 0, 0)) for i in range(2)])
+    plan = fb.FMM_plan(fb.LaplaceSphericalBEM(10, 3), v, fb.FMMOptions(), p_max=10)
+    st = plan.stats()
+    nbytes = 8 * st["near_nnz"] + 16 * plan.n
+    x = torch.rand(plan.n, dtype=torch.float64, device="cuda")
+    y = torch.empty_like(x)
+    ref = None
+    for var in variants:
+        var, dbg = (var.split(":") + ["0"])[:2]
+        os.environ["FMMBEM_SPMV_VARIANT"] = var
+        os.environ["FMMBEM_SPMV_DEBUG"] = dbg
+        var = int(var)
+        for _ in range(3):
+            plan.near_device(x.data_ptr(), y.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            plan.near_device(x.data_ptr(), y.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+        if ref is None:
+            ref = y.clone()
+        err = float((y - ref).abs().max() / ref.abs().max())
+        print("variant %d dbg %s: %.4f ms incl. gather/scatter  %.0f GB/s  maxdiff vs first %.2e" % (var, dbg, ms, nbytes / ms / 1e6, err), flush=True)
+
+
+if __name__ == "__main__":
+    main()
