@@ -13,7 +13,7 @@
 //               Stokes: slots 0-3 = the four harmonic potentials (f0,f1,f2,f.x) of the velocity group
 //   Mh          [nb][2][S_max] complex: M rescaled and phase-rotated (orders m >= 0), the M2L input
 //   m2l_*       CSR by target box: m2l_tgt [nt] (boxes to run), m2l_ptr [nb+1], m2l_src, m2l_cls
-//   class tabs  m2l_tab [classes][(2 p_max)^2] complex; up_tab/down_tab [classes][p_max^2] complex
+//   class tabs  m2l_g [classes][p_max(2 p_max+1)] real + m2l_z [classes][p_max] complex; up_tab/down_tab [classes][p_max^2] complex
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -73,9 +73,11 @@ struct DevicePlan {
   const int *mh_box;          int n_mh = 0;           // boxes whose Mh is needed (M2L sources)
   const int *m2l_tgt;         int n_m2l_tgt = 0;
   const int *m2l_ptr, *m2l_src, *m2l_cls;
-  const double2* m2l_tab;                             // [cls][y2_max]
+  const double* m2l_g;                                // [cls][g_max] real class tables G[r,a], entry r(r+1)/2+a, r < 2 p_max
+  const double2* m2l_z;                               // [cls][p_max] class phases Z^m, Z = i e^{i beta}
+  int g_max;                                          // p_max (2 p_max + 1)
   const int *m2l_lane;                                // [p-1][192] lane -> output map (m2l_layout.hpp)
-  const int *m2l_scat;                                // per p: table index -> LDS slot
+  const int *m2l_scat;                                // per p: table entry -> its 4 LDS places (m2l_layout.hpp)
   int m2l_scat_off[16];                               // offset of order p's scatter map in m2l_scat
   // scratch
   double *xt, *yt;                                    // tree-order x and near result

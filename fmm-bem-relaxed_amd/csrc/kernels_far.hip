@@ -280,7 +280,8 @@ __global__ __launch_bounds__(kShiftWaves * kWave) void m2m_kernel(DevicePlan d, 
 
 // ---------------------------------------------------------------------------------------------
 // mh_prep: Mh[n,m] = i^{-m} A[n,m] M[n,m] for the stored orders m >= 0 of every M2L source box
-// (negative orders follow from Mh[n,-m] = (-1)^m conj(Mh[n,m]) inside the M2L kernel).
+// (negative orders follow from Mh[n,-m] = (-1)^m conj(Mh[n,m]) inside the M2L kernel).  Stored ORDER-major,
+// Mh[m*P - m(m-1)/2 + (n-m)]: the M2L kernel sums over n for a fixed m and reads the run with wide scalar loads.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kWave) void mh_prep_kernel(DevicePlan d, const int P) {
   const int S = P * (P + 1) / 2;
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(kWave) void mh_prep_kernel(DevicePlan d, const int 
     const int n = kJK.j[idx], m = kJK.k[idx];
     const double2 v = M[idx];
     const double a = d.tabA[n * n + n + m];
-    Mh[idx] = mul_i_pow(double2{v.x * a, v.y * a}, -m);
+    Mh[m * P - m * (m - 1) / 2 + (n - m)] = mul_i_pow(double2{v.x * a, v.y * a}, -m);
   }
 }
 

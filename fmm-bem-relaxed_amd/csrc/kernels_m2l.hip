@@ -3,17 +3,23 @@
 // once per LR_list pair and expansion (executor/EvalInteractionLazySparse.hpp:269-283).
 //
 // Algebra (kernels_far.hip header): L[j,k] += i^{-k} (-1)^j A[j,k] * sum_{n<P,|m|<=n} Mh[n,m] * Yh[j+n, m-k]
-// with Mh the rescaled source multipole (mh_prep) and Yh the rescaled singular harmonics of the translation
-// vector, tabulated per translation class at plan build.
+// with Mh the rescaled source multipole (mh_prep) and Yh[r,c] = i^{|c|} EPS Y[r,c] / A[r,c] the rescaled singular
+// harmonics of the translation vector (rho, alpha, beta).  Yh factors into a phase and a REAL radial/polar part:
+//     Yh[r,c] = Z^c * gh[r,c],   Z = i e^{i beta},   gh[r,c] = G[r,|c|] * (c < 0 ? (-1)^c : 1),
+//     G[r,a] = EPS rho^{-r-1} P_r^a(cos alpha) pref[r,a] / A[r,a]
+// so that the double sum becomes
+//     Z^{-k} * sum_m Z^m * T_m,      T_m = sum_{n >= |m|} Mh[n,m] * gh[j+n, m-k]      (complex x real: 2 FMAs)
+// i.e. 2 FMAs per (n,m) term + 4 per m + 4 per source = 280 instead of 400 at p = 10, and -- what matters more,
+// the complex-table form of this kernel ran at the LDS bandwidth limit (one ds_read_b128 per 4 FMAs, 128 B/clk
+// per CU) -- 8 bytes of LDS per term instead of 16: one ds_read_b128 serves n and n+1 (m2l_layout.hpp).
 //
 // Mapping: one wavefront per target box (a TEAM of 2-3 wavefronts when P(P+1)/2 > 64), one output (j,k) per
 // lane, L accumulated in registers over the target's whole source list (CSR by target) and written once:
 // no atomics, fixed summation order.  Per source:
-//   * the class table ((2P)^2 complex, L2-resident) is PREFETCHED into registers while the previous source is
-//     being computed, then scattered into the wavefront's LDS image with a constant row stride chosen so the
-//     per-lane ds_read_b128 of the inner loop are bank-conflict free (m2l_layout.hpp);
-//   * Mh[n,m] is wave-uniform and comes through the scalar cache (s_load_dwordx16) straight into the SGPR
-//     operand of v_fma_f64, so the LDS pipe only carries the Yh gather: 1 ds_read_b128 per 4 FP64 FMAs.
+//   * the class table G (P(2P+1) doubles, L2-resident) is PREFETCHED into registers while the previous source is
+//     being computed, then scattered (both signs of c, both alignment copies) into the LDS image;
+//   * Mh[n,m] and Z^m are wave-uniform and come through the scalar cache straight into the SGPR operands of
+//     v_fma_f64; Z^k is one 16-byte vector load per lane, prefetched with the table.
 // One instantiation per p = 1..16: the solver's per-iteration relaxation of p only picks among them.
 #include "device_plan.hpp"
 #include "m2l_layout.hpp"
@@ -29,34 +35,44 @@ struct C2 { double x, y; };
 typedef __attribute__((address_space(4))) C2 ConstC2;      // complex value in the constant address space
 constexpr int kM2LTargets = 4;         // independent single-wavefront targets per workgroup when TEAM == 1
 
-constexpr int isqrt_cut(int P, int i, int NS) {          // round(P * sqrt(i / NS)) without <cmath>
-  int best = 0;
-  for (int c = 0; c <= P; ++c) {
-    const long a = (long)c * c * NS - (long)P * P * i, b = (long)best * best * NS - (long)P * P * i;
-    if ((a < 0 ? -a : a) < (b < 0 ? -b : b)) best = c;
-  }
-  return best;
-}
-
 template <int P, int NS_> struct Shape {
-  static constexpr int S = P * (P + 1) / 2, Y2 = 4 * P * P;
+  static constexpr int S = P * (P + 1) / 2, NE = m2l_entries(P);
   static constexpr int TEAM = m2l_team(P);               // wavefronts needed to give every output a lane
-  // The (n,m) terms of every output can additionally be split between NS wavefronts (contiguous n ranges
-  // of about P^2/NS terms each) that share one LDS image: NS times the wavefronts per CU for the same
-  // LDS, which is what hides the scalar-load latency of Mh.
+  // The m values of every output can additionally be split between NS wavefronts that share one LDS image:
+  // NS times the wavefronts per CU for the same LDS, which is what hides the scalar-load latency of Mh.
   static constexpr int NS = NS_;
-  static constexpr int cut(int i) { return i <= 0 ? 0 : (i >= NS ? P : isqrt_cut(P, i, NS)); }
   static constexpr int WAVES = TEAM * NS;
   static constexpr int TARGETS = WAVES == 1 ? kM2LTargets : 1;
   static constexpr int THREADS = WAVES * TARGETS * kWave;
-  static constexpr int R = m2l_stride(P), C0 = m2l_col0(P), SLOTS = m2l_lds_slots(P);
-  static constexpr int NLOAD = (Y2 + WAVES * kWave - 1) / (WAVES * kWave);   // table entries copied per lane
+  static constexpr int RR = m2l_rr(P), C0 = m2l_c0(P), O0 = m2l_odd_base(P), LDSD = m2l_lds_doubles(P);
+  static constexpr int NLOAD = (NE + WAVES * kWave - 1) / (WAVES * kWave);   // table entries copied per lane
+  // ds_read_b128 per m: pairs (n0, n0+1), n0 even, covering n = |m| .. P-1
+  static constexpr int reads(int m) { const int am = m < 0 ? -m : m; return (P - (am & ~1) + 1) / 2; }
+  // which wavefront sums the orders +-am (they share the Mh run): greedy over am = 1..P-1, 0 -> balanced reads
+  struct Parts { int v[P]; };
+  static constexpr Parts make_parts() {
+    Parts t{};
+    int load[4] = {0, 0, 0, 0};
+    for (int i = 0; i < P; ++i) {
+      const int am = i + 1 < P ? i + 1 : 0;
+      int best = 0;
+      for (int q = 1; q < NS; ++q) if (load[q] < load[best]) best = q;
+      load[best] += reads(am) * (am ? 2 : 1);
+      t.v[am] = best;
+    }
+    return t;
+  }
+  static constexpr Parts PT = make_parts();
 };
 
-__device__ inline void cfma(double2& acc, double2 a, double2 b) {     // acc += a*b
-  acc.x = fma(a.x, b.x, acc.x); acc.x = fma(-a.y, b.y, acc.x);
-  acc.y = fma(a.x, b.y, acc.y); acc.y = fma(a.y, b.x, acc.y);
+// A 16-byte LDS read whose two halves both count as used: where only one feeds an FMA hipcc narrows the read to
+// 8 bytes and pairs such reads into ds_read2_b64, which the conflict-free lane dealing does not cover.
+__device__ __forceinline__ double2 lds_pair(const double2* p) {
+  double2 v = *p;
+  asm("" : "+v"(v.x), "+v"(v.y));
+  return v;
 }
+
 __device__ inline double2 mul_i_pow(double2 a, int q) {              // a * i^q
   switch (q & 3) {
     case 0: return a;
@@ -69,60 +85,67 @@ __device__ inline double2 mul_i_pow(double2 a, int q) {              // a * i^q
 template <int P, int NS_>
 __global__ __launch_bounds__((Shape<P, NS_>::THREADS)) void m2l_kernel(DevicePlan d) {
   using Sh = Shape<P, NS_>;
-  constexpr int Y2 = Sh::Y2, TEAM = Sh::TEAM, TARGETS = Sh::TARGETS, R = Sh::R, NLOAD = Sh::NLOAD;
+  constexpr int NE = Sh::NE, TEAM = Sh::TEAM, TARGETS = Sh::TARGETS, RR = Sh::RR, NLOAD = Sh::NLOAD;
   constexpr int NS = Sh::NS, WAVES = Sh::WAVES;
-  __shared__ double2 Yall[TARGETS][Sh::SLOTS];
-  __shared__ double2 Comb[NS == 1 ? 1 : (NS - 1) * TEAM * kWave];   // partial sums of the other n-ranges
+  __shared__ double2 Gall[TARGETS][(Sh::LDSD + 1) / 2];
+  __shared__ double2 Comb[NS == 1 ? 1 : (NS - 1) * TEAM * kWave];   // partial sums of the other m sets
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int ti = blockIdx.x * TARGETS + (WAVES == 1 ? wave : 0);
   if (ti >= d.n_m2l_tgt) return;                       // WAVES==1: whole wavefront; else: whole workgroup
   const int tgt = d.m2l_tgt[ti];
   const int slot = d.act[blockIdx.y];
-  double2* Yt = Yall[WAVES == 1 ? wave : 0];
+  double* Gt = reinterpret_cast<double*>(Gall[WAVES == 1 ? wave : 0]);
   const int tid = WAVES == 1 ? lane : (int)threadIdx.x;  // index within the team (table copy)
-  const int npart = WAVES == 1 ? 0 : wave % NS;          // which n-range this wavefront sums
+  const int npart = WAVES == 1 ? 0 : wave % NS;          // which m set this wavefront sums
   const int otid = WAVES == 1 ? lane : (wave / NS) * kWave + lane;   // index in the lane -> output map
 
   // this lane's output (conflict-free dealing, m2l_layout.hpp)
   const int packed = d.m2l_lane[(P - 1) * kM2LMaxThreads + otid];
   const bool valid = packed >= 0;
   const int j = valid ? (packed & 0xff) : 0, k = valid ? ((packed >> 8) & 0xff) : 0, idx = valid ? (packed >> 16) : 0;
-  const double2* ybase = Yt + (j * R - k + Sh::C0);
+  // 16-byte slot of gh[j + 0, 0 - k] in this lane's alignment copy; (m + C0) * RR + n0 is added per term
+  const double2* gbase = reinterpret_cast<const double2*>(Gt) + (((j & 1) ? Sh::O0 + 1 : 0) + j - k * RR) / 2;
   double2 acc = {0, 0};
 
-  // This lane's share of the table copy: linear entries tid, tid + TEAM*64, ... -> LDS slots.  The staging
-  // registers are NAMED scalars (macro-expanded, at most 8 per lane), not an array: hipcc keeps a 7 x 16-B
-  // array that is live across the loop in scratch memory, which serialises the prefetch.
-  static_assert(NLOAD <= 8, "table copy needs more staging registers");
+  // This lane's share of the table copy: entries tid, tid + WAVES*64, ...; every entry has up to four LDS places.
+  // The staging registers are NAMED scalars (macro-expanded), not arrays: hipcc keeps an array that is live across
+  // the loop in scratch memory, which serialises the prefetch.
+  static_assert(NLOAD <= 4, "table copy needs more staging registers");
   const int* scat = d.m2l_scat + d.m2l_scat_off[P - 1];
-#define FMMBEM_REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#define FMMBEM_REP4(X) X(0) X(1) X(2) X(3)
 #define DECL(u)                                                                   \
-  const int i##u = tid + u * WAVES * kWave;                                       \
-  const int src##u = (u < NLOAD && i##u < Y2) ? i##u : 0;                         \
-  const int dst##u = (u < NLOAD && i##u < Y2) ? scat[i##u] : -1;                  \
-  double2 pre##u = {0, 0};
-  FMMBEM_REP8(DECL)
+  const int e##u = tid + u * WAVES * kWave;                                       \
+  const bool on##u = u < NLOAD && e##u < NE;                                      \
+  const int da##u = on##u ? scat[4 * e##u + 0] : -1, db##u = on##u ? scat[4 * e##u + 1] : -1; \
+  const int dc##u = on##u ? scat[4 * e##u + 2] : -1, dd##u = on##u ? scat[4 * e##u + 3] : -1; \
+  double pre##u = 0;
+  FMMBEM_REP4(DECL)
 #undef DECL
-#define LOAD(u) if (u < NLOAD) pre##u = tab[src##u];
-#define STORE(u) if (u < NLOAD && dst##u >= 0) Yt[dst##u] = pre##u;
+#define LOAD(u) if (u < NLOAD) pre##u = tab[on##u ? e##u : 0];
+#define PUT(dst, v) if (dst >= 0) Gt[dst >> 1] = (dst & 1) ? -(v) : (v);
+#define STORE(u) if (u < NLOAD) { PUT(da##u, pre##u) PUT(db##u, pre##u) PUT(dc##u, pre##u) PUT(dd##u, pre##u) }
 
   const int pb = d.m2l_ptr[tgt], pe = d.m2l_ptr[tgt + 1];
   if (pb == pe) {                                      // a box that only inherits from its parent: L = 0
     if (valid) d.L[((size_t)tgt * d.nslots + slot) * d.s_max + idx] = {0, 0};
     return;
   }
+  double2 zk;                                          // Z^k of the class in flight
   {
     const int cls = __builtin_amdgcn_readfirstlane(d.m2l_cls[pb]);
-    const double2* tab = d.m2l_tab + (size_t)cls * d.y2_max;
-    FMMBEM_REP8(LOAD)
+    const double* tab = d.m2l_g + (size_t)cls * d.g_max;
+    FMMBEM_REP4(LOAD)
+    zk = d.m2l_z[(size_t)cls * d.p_max + k];
   }
   for (int pi = pb; pi < pe; ++pi) {
     const int src = __builtin_amdgcn_readfirstlane(d.m2l_src[pi]);
+    const int cls = __builtin_amdgcn_readfirstlane(d.m2l_cls[pi]);
     const int pn = pi + 1 < pe ? pi + 1 : pi;          // last iteration re-reads its own table (harmless)
     const int cls_next = __builtin_amdgcn_readfirstlane(d.m2l_cls[pn]);
     if (WAVES == 1) __builtin_amdgcn_wave_barrier(); else __syncthreads();    // previous source's reads are done
-    FMMBEM_REP8(STORE)
+    FMMBEM_REP4(STORE)
+    const double2 zk_now = zk;
     if (WAVES == 1) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -131,14 +154,17 @@ __global__ __launch_bounds__((Shape<P, NS_>::THREADS)) void m2l_kernel(DevicePla
       __syncthreads();
     }
     {                                                  // next table in flight during this source's FMAs
-      const double2* tab = d.m2l_tab + (size_t)cls_next * d.y2_max;
-      FMMBEM_REP8(LOAD)
+      const double* tab = d.m2l_g + (size_t)cls_next * d.g_max;
+      FMMBEM_REP4(LOAD)
+      zk = d.m2l_z[(size_t)cls_next * d.p_max + k];
     }
     // Mh (orders m >= 0 only; Mh[n,-m] = (-1)^m conj(Mh[n,m]) costs only sign modifiers on the FMAs) was
-    // written by the preceding kernel and is immutable here: address it through the CONSTANT address space
-    // so that the wave-uniform loads are always selected as scalar (SMEM) loads feeding SGPR operands.
+    // written by the preceding kernel and is immutable here, like the class phases Z^m: address both through the
+    // CONSTANT address space so that the wave-uniform loads are always selected as scalar (SMEM) loads feeding
+    // SGPR operands.
     const ConstC2* mh = reinterpret_cast<const ConstC2*>(
         reinterpret_cast<uintptr_t>(d.Mh + ((size_t)src * d.nslots + slot) * d.s_max));
+    const ConstC2* zm = reinterpret_cast<const ConstC2*>(reinterpret_cast<uintptr_t>(d.m2l_z + (size_t)cls * d.p_max));
     // Warm the L2 for the NEXT source's Mh (a random 880-B record of a >100 MB array): one 16-B vector load
     // per lane now turns next iteration's dependent scalar loads from HBM/MALL misses into L2 hits.
     {
@@ -149,31 +175,48 @@ __global__ __launch_bounds__((Shape<P, NS_>::THREADS)) void m2l_kernel(DevicePla
         asm volatile("" ::"v"(touch.x), "v"(touch.y));
       }
     }
-    auto mac_range = [&](auto lo_c, auto hi_c) {
-      constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+    double2 as = {0, 0};                               // sum_m Z^m T_m of this source (this wavefront's m set)
+    auto mac_part = [&](auto part_c) {
+      constexpr int PART = decltype(part_c)::value;
 #pragma unroll
-      for (int n = LO; n < HI; ++n) {
+      for (int m = -(P - 1); m <= P - 1; ++m) {
+        const int am = m < 0 ? -m : m;
+        if (Sh::PT.v[am] != PART) continue;
+        const double sr = (m < 0 && (am & 1)) ? -1.0 : 1.0;            // (-1)^m for m < 0
+        const double si = (m < 0) ? -sr : 1.0;                         // conj
+        double tr = 0, tq = 0;
 #pragma unroll
-        for (int m = -n; m <= n; ++m) {
-          const int am = m < 0 ? -m : m;
-          const double sr = (m < 0 && (am & 1)) ? -1.0 : 1.0;          // (-1)^m for m < 0
-          const double si = (m < 0) ? -sr : 1.0;                       // conj
-          const double ar = sr * mh[n * (n + 1) / 2 + am].x, ai = si * mh[n * (n + 1) / 2 + am].y;
-          cfma(acc, double2{ar, ai}, ybase[n * R + m]);
+        for (int n0 = am & ~1; n0 < P; n0 += 2) {
+          const double2 g2 = lds_pair(gbase + ((m + Sh::C0) * RR + n0) / 2);
+          if (n0 >= am) {
+            tr = fma(sr * mh[am * P - am * (am - 1) / 2 + n0 - am].x, g2.x, tr);
+            tq = fma(si * mh[am * P - am * (am - 1) / 2 + n0 - am].y, g2.x, tq);
+          }
+          if (n0 + 1 < P) {
+            tr = fma(sr * mh[am * P - am * (am - 1) / 2 + n0 + 1 - am].x, g2.y, tr);
+            tq = fma(si * mh[am * P - am * (am - 1) / 2 + n0 + 1 - am].y, g2.y, tq);
+          }
         }
+        const double er = zm[am].x, ei = (m < 0 ? -1.0 : 1.0) * zm[am].y;      // Z^m, Z^{-m} = conj
+        as.x = fma(er, tr, as.x); as.x = fma(-ei, tq, as.x);
+        as.y = fma(er, tq, as.y); as.y = fma(ei, tr, as.y);
       }
     };
     if (valid) {
-      if (npart == 0) mac_range(std::integral_constant<int, 0>{}, std::integral_constant<int, Sh::cut(1)>{});
-      if (NS > 1 && npart == 1) mac_range(std::integral_constant<int, Sh::cut(1)>{}, std::integral_constant<int, Sh::cut(2)>{});
-      if (NS > 2 && npart == 2) mac_range(std::integral_constant<int, Sh::cut(2)>{}, std::integral_constant<int, Sh::cut(3)>{});
-      if (NS > 3 && npart == 3) mac_range(std::integral_constant<int, Sh::cut(3)>{}, std::integral_constant<int, Sh::cut(4)>{});
+      if (npart == 0) mac_part(std::integral_constant<int, 0>{});
+      if (NS > 1 && npart == 1) mac_part(std::integral_constant<int, 1>{});
+      if (NS > 2 && npart == 2) mac_part(std::integral_constant<int, 2>{});
+      if (NS > 3 && npart == 3) mac_part(std::integral_constant<int, 3>{});
+      // acc += Z^{-k} * as = conj(Z^k) * as
+      acc.x = fma(zk_now.x, as.x, acc.x); acc.x = fma(zk_now.y, as.y, acc.x);
+      acc.y = fma(zk_now.x, as.y, acc.y); acc.y = fma(-zk_now.y, as.x, acc.y);
     }
   }
 #undef LOAD
+#undef PUT
 #undef STORE
-#undef FMMBEM_REP8
-  if (NS > 1) {                                        // fold the other n-ranges into the first, fixed order
+#undef FMMBEM_REP4
+  if (NS > 1) {                                        // fold the other m sets into the first, fixed order
     if (npart > 0) Comb[(npart - 1) * TEAM * kWave + otid] = acc;
     __syncthreads();
     if (npart == 0) {

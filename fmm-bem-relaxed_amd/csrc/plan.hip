@@ -369,7 +369,9 @@ int fmmbem_plan::to_device() {
     TRY(upload(hp.m2l_ptr, &d.m2l_ptr)); TRY(upload(hp.m2l_src, &d.m2l_src)); TRY(upload(hp.m2l_cls, &d.m2l_cls));
     n_classes = (int64_t)hp.m2l_class_rep.size() / 2;
     const int R = 2 * pm;
-    std::vector<cplx> tab((size_t)n_classes * d.y2_max), h;
+    d.g_max = m2l_entries(pm);
+    std::vector<double> gtab((size_t)n_classes * d.g_max);
+    std::vector<cplx> ztab((size_t)n_classes * pm), h;
     for (int64_t c = 0; c < n_classes; ++c) {
       // translation = c_target - c_source (executor/M2L.hpp:40), rebuilt from the exact integer class
       // vector (half-cell units) so that the table does not depend on which pair was seen first
@@ -377,18 +379,19 @@ int fmmbem_plan::to_device() {
       double tr[3];
       for (int k = 0; k < 3; ++k) tr[k] = 0.5 * hp.cell[k] * double(hp.m2l_class_vec[3 * c + k]);
       const SphHost sp = cart2sph_host(tr);
-      harmonics(T, false, sp.rho, sp.alpha, sp.beta, R, h);                                      // evalLocal to order 2P
-      cplx* out = tab.data() + (size_t)c * d.y2_max;
+      // Yh[r,c] = i^{|c|} EPS Y[r,c] / A[r,c] = Z^c gh[r,c]: tabulate the real part G (harmonics at beta = 0,
+      // evalLocal to order 2P) and the phases Z^m = i^m e^{i m beta} separately (kernels_m2l.hip header)
+      harmonics(T, false, sp.rho, sp.alpha, 0.0, R, h);
+      double* out = gtab.data() + (size_t)c * d.g_max;
       for (int r = 0; r < R; ++r)
-        for (int cc = 0; cc <= r; ++cc) {
-          const cplx yh = i_pow(cc) * (h[(size_t)r * (r + 1) / 2 + cc] * kEps / T.A[r * r + r + cc]);
-          out[r * r + r + cc] = yh;
-          if (cc) out[r * r + r - cc] = ((cc & 1) ? -1.0 : 1.0) * std::conj(yh);
-        }
+        for (int cc = 0; cc <= r; ++cc)
+          out[r * (r + 1) / 2 + cc] = h[(size_t)r * (r + 1) / 2 + cc].real() * kEps / T.A[r * r + r + cc];
+      for (int m = 0; m < pm; ++m) ztab[(size_t)c * pm + m] = i_pow(m) * std::exp(cplx(0, 1) * double(m * sp.beta));
     }
-    const cplx* pt = nullptr;
-    TRY(upload(tab, &pt));
-    d.m2l_tab = reinterpret_cast<const double2*>(pt);
+    const cplx* pz = nullptr;
+    TRY(upload(gtab, &d.m2l_g));
+    TRY(upload(ztab, &pz));
+    d.m2l_z = reinterpret_cast<const double2*>(pz);
     // lane -> output maps and table -> LDS scatter maps of the M2L kernel, every order up to p_max
     std::vector<int32_t> lanes, scat, one;
     for (int p = 1; p <= kPmax; ++p) {
