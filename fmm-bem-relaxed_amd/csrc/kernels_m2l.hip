@@ -65,14 +65,6 @@ template <int P, int NS_> struct Shape {
   static constexpr Parts PT = make_parts();
 };
 
-// A 16-byte LDS read whose two halves both count as used: where only one feeds an FMA hipcc narrows the read to
-// 8 bytes and pairs such reads into ds_read2_b64, which the conflict-free lane dealing does not cover.
-__device__ __forceinline__ double2 lds_pair(const double2* p) {
-  double2 v = *p;
-  asm("" : "+v"(v.x), "+v"(v.y));
-  return v;
-}
-
 __device__ inline double2 mul_i_pow(double2 a, int q) {              // a * i^q
   switch (q & 3) {
     case 0: return a;
@@ -107,6 +99,10 @@ __global__ __launch_bounds__((Shape<P, NS_>::THREADS)) void m2l_kernel(DevicePla
   // 16-byte slot of gh[j + 0, 0 - k] in this lane's alignment copy; (m + C0) * RR + n0 is added per term
   const double2* gbase = reinterpret_cast<const double2*>(Gt) + (((j & 1) ? Sh::O0 + 1 : 0) + j - k * RR) / 2;
   double2 acc = {0, 0};
+  // Where only one half of a 16-byte LDS read feeds an FMA (first pair of an odd order), hipcc narrows the read to
+  // 8 bytes and pairs such reads into ds_read2_b64, which the conflict-free lane dealing does not cover: the unused
+  // half is multiplied by a zero the compiler cannot see and starts the sum instead.
+  const double zero = (double)(d.n_m2l_tgt >> 31);
 
   // This lane's share of the table copy: entries tid, tid + WAVES*64, ...; every entry has up to four LDS places.
   // The staging registers are NAMED scalars (macro-expanded), not arrays: hipcc keeps an array that is live across
@@ -185,16 +181,20 @@ __global__ __launch_bounds__((Shape<P, NS_>::THREADS)) void m2l_kernel(DevicePla
         const double sr = (m < 0 && (am & 1)) ? -1.0 : 1.0;            // (-1)^m for m < 0
         const double si = (m < 0) ? -sr : 1.0;                         // conj
         double tr = 0, tq = 0;
+        bool started_r = false, started_q = false;     // the first product initialises the sums (no v_mov 0 + fma)
 #pragma unroll
         for (int n0 = am & ~1; n0 < P; n0 += 2) {
-          const double2 g2 = lds_pair(gbase + ((m + Sh::C0) * RR + n0) / 2);
+          const double2 g2 = gbase[((m + Sh::C0) * RR + n0) / 2];
+          if (n0 < am) { tr = zero * g2.x; started_r = true; }           // keeps the read 16 bytes wide (see `zero`)
           if (n0 >= am) {
-            tr = fma(sr * mh[am * P - am * (am - 1) / 2 + n0 - am].x, g2.x, tr);
-            tq = fma(si * mh[am * P - am * (am - 1) / 2 + n0 - am].y, g2.x, tq);
+            const double ar = sr * mh[am * P - am * (am - 1) / 2 + n0 - am].x, ai = si * mh[am * P - am * (am - 1) / 2 + n0 - am].y;
+            if (started_r) tr = fma(ar, g2.x, tr); else { tr = ar * g2.x; started_r = true; }
+            if (started_q) tq = fma(ai, g2.x, tq); else { tq = ai * g2.x; started_q = true; }
           }
           if (n0 + 1 < P) {
-            tr = fma(sr * mh[am * P - am * (am - 1) / 2 + n0 + 1 - am].x, g2.y, tr);
-            tq = fma(si * mh[am * P - am * (am - 1) / 2 + n0 + 1 - am].y, g2.y, tq);
+            const double ar = sr * mh[am * P - am * (am - 1) / 2 + n0 + 1 - am].x, ai = si * mh[am * P - am * (am - 1) / 2 + n0 + 1 - am].y;
+            if (started_r) tr = fma(ar, g2.y, tr); else { tr = ar * g2.y; started_r = true; }
+            if (started_q) tq = fma(ai, g2.y, tq); else { tq = ai * g2.y; started_q = true; }
           }
         }
         const double er = zm[am].x, ei = (m < 0 ? -1.0 : 1.0) * zm[am].y;      // Z^m, Z^{-m} = conj
