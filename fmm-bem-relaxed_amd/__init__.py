@@ -3,7 +3,7 @@
 Only the hot path lives here: csrc/ (hand-written HIP for gfx950 + the C ABI of include/fmmbem.h)
 and this thin host-side mirror of the reference's operator interface.
 """
-from ._capi import FmmBemError, LIB_PATH, PMAX, SYMBOLS  # noqa: F401
+from ._capi import FmmBemError, LIB_PATH, Options, PMAX, SYMBOLS, lib  # noqa: F401
 from .plan import FMM_plan, FMMOptions, LaplaceSphericalBEM, StokesSphericalBEM, unit_sphere  # noqa: F401
 
 
@@ -12,7 +12,7 @@ def __getattr__(name):
     if name == "ShardedFMM":
         from .distributed import ShardedFMM
         return ShardedFMM
-    if name in ("SolverOptions", "gmres", "laplace_bem_first_kind"):
+    if name in ("SolverOptions", "gmres", "fgmres", "LocalInnerSolver", "BlockDiagonal", "laplace_bem_first_kind"):
         from . import solver
         return getattr(solver, name)
     raise AttributeError(name)

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libfmmbem_hip.so")
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC, ERR_TREE, ERR_UNSUPPORTED = range(7)
 PMAX = 16
 KERNEL_LAPLACE_BEM, KERNEL_STOKES_BEM = 0, 1
+EVAL_FMM, EVAL_LOCAL, EVAL_BLOCK_DIAGONAL = 0, 1, 2
 BC_POTENTIAL, BC_NORMAL_DERIV = 0, 1
 
 
@@ -22,7 +23,7 @@ class Options(C.Structure):
     _fields_ = [("kernel", C.c_int32), ("p_max", C.c_int32), ("quad_k", C.c_int32), ("theta", C.c_double),
                 ("ncrit", C.c_uint32), ("sparse_local", C.c_int32), ("host_only", C.c_int32),
                 ("device", C.c_int32), ("shard_rank", C.c_int32), ("shard_world", C.c_int32),
-                ("quad_k_fine", C.c_int32), ("reserved0", C.c_int32), ("mu", C.c_double),
+                ("quad_k_fine", C.c_int32), ("evaluator", C.c_int32), ("mu", C.c_double),
                 ("reserved", C.c_int32 * 2)]
 
 

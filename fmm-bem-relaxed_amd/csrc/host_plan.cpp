@@ -256,7 +256,14 @@ std::string HostPlan::build(const HostOptions& o, int64_t n_panels, const double
   };
   {
     std::deque<std::pair<int, int>> fifo;
-    fifo.emplace_back(0, 0);
+    // evaluator: 0 = EvalInteractionLazySparse; 1 = EvalLocalSparse.hpp:34-86, the same traversal with accepted
+    // multipoles dropped (:120-127); 2 = EvalDiagonalSparse.hpp:33-49, every leaf with itself in box order
+    if (opt.evaluator == 2) {
+      for (int b = 0; b < nboxes; ++b)
+        if (box_leaf[b]) { p2p_src.push_back(b); p2p_tgt.push_back(b); }
+    } else {
+      fifo.emplace_back(0, 0);
+    }
     while (!fifo.empty()) {
       const auto [s, t] = fifo.front();
       fifo.pop_front();
@@ -272,7 +279,7 @@ std::string HostPlan::build(const HostOptions& o, int64_t n_panels, const double
       const int open = split_source ? s : t;
       for (int c = box_child_begin[open]; c < box_child_end[open]; ++c) {
         const int ns = split_source ? c : s, nt = split_source ? t : c;
-        if (accept(ns, nt)) { lr_src.push_back(ns); lr_tgt.push_back(nt); }
+        if (accept(ns, nt)) { if (opt.evaluator == 0) { lr_src.push_back(ns); lr_tgt.push_back(nt); } }
         else fifo.emplace_back(ns, nt);
       }
     }

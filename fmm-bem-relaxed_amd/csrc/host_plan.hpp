@@ -33,6 +33,7 @@ struct HostOptions {
   double theta = 0.5;
   unsigned ncrit = 64;
   int shard_rank = 0, shard_world = 1;
+  int evaluator = 0;           // 0 FMM, 1 local only, 2 block diagonal (executor/make_executor.hpp:24-60)
 };
 
 // Panels in TREE order, structure-of-arrays (what the kernels stream).

@@ -521,12 +521,14 @@ int fmmbem_plan_create(const fmmbem_options* opts, size_t n_panels, const double
         if (bc[i]) return fail(FMMBEM_ERR_UNSUPPORTED, "Stokes: only VELOCITY panels (the traction far field of the reference is not reproducible)");
   }
   if (!vertices || n_panels == 0) return fail(FMMBEM_ERR_INVALID, "no panels");
+  if (opts->evaluator < FMMBEM_EVAL_FMM || opts->evaluator > FMMBEM_EVAL_BLOCK_DIAGONAL) return fail(FMMBEM_ERR_INVALID, "unknown evaluator");
   std::unique_ptr<fmmbem_plan> pl(new (std::nothrow) fmmbem_plan);
   if (!pl) return fail(FMMBEM_ERR_ALLOC, "plan");
   pl->opts = *opts;
   HostOptions ho;
   ho.p_max = opts->p_max; ho.quad_k = opts->quad_k; ho.theta = opts->theta; ho.ncrit = opts->ncrit;
   ho.shard_rank = opts->shard_rank; ho.shard_world = opts->shard_world < 1 ? 1 : opts->shard_world;
+  ho.evaluator = opts->evaluator;
   const double t0 = now_ms();
   std::string err;
   try {

@@ -95,8 +95,14 @@ class FMM_plan:
 
     def __init__(self, K, panels, opts=None, bc=None, p_max=None, device=0, shard=(0, 1), host_only=False):
         opts = opts if opts is not None else FMMOptions()
-        if opts.local_evaluation or opts.block_diagonal or not opts.lazy_evaluation:
-            raise _capi.FmmBemError(_capi.ERR_UNSUPPORTED, "only the lazy FMM evaluators (sparse or matrix-free near field) are built")
+        # executor/make_executor.hpp:24-60: lazy_evaluation wins, then local_evaluation, then block_diagonal; the
+        # non-lazy upward/interact/downward evaluators compute the same operator as the lazy ones
+        evaluator = _capi.EVAL_FMM
+        if not opts.lazy_evaluation:
+            if opts.local_evaluation:
+                evaluator = _capi.EVAL_LOCAL
+            elif opts.block_diagonal:
+                evaluator = _capi.EVAL_BLOCK_DIAGONAL
         self._K = K
         self._opts = opts
         v = np.ascontiguousarray(panels, dtype=np.float64).reshape(-1, 9)
@@ -109,6 +115,7 @@ class FMM_plan:
         o.ncrit = opts.ncrit
         o.sparse_local = 1 if opts.sparse_local else 0
         o.host_only = 1 if host_only else 0
+        o.evaluator = evaluator
         o.device = int(device)
         self.dof = 1
         if isinstance(K, StokesSphericalBEM):

@@ -117,6 +117,106 @@ def gmres(MV, x, b, opts, M=None, log=None):
     return x, it, abs(resid)
 
 
+def fgmres(MV, x, b, opts, M, log=None):
+    """FGMRES(MV, x, b, opts, M, context) of examples/BEM/GMRES.hpp:276-380: flexible GMRES, the preconditioned
+    vectors Z_j = M(V_j) are kept and the solution is updated from them (:318-320, :368-371)."""
+    execute = getattr(MV, "execute_torch", None) or MV.execute
+    K = MV.kernel()
+    R, n = opts.restart, x.numel()
+    V = torch.empty((R + 1, n), dtype=x.dtype, device=x.device)
+    Z = torch.empty((R, n), dtype=x.dtype, device=x.device)
+    H = [[0.0] * R for _ in range(R + 1)]
+    cs, sn, s = [0.0] * R, [0.0] * R, [0.0] * (R + 1)
+    normb = float(torch.linalg.vector_norm(b))
+    it, resid = 0, 0.0
+    while True:
+        w = execute(x) - b
+        beta = float(torch.linalg.vector_norm(w))
+        V[0] = w * (-1.0 / beta)
+        s[0] = beta
+        i = -1
+        resid = s[0] / normb
+        while True:
+            i += 1
+            it += 1
+            p = max(1, opts.predict_p(abs(resid)))        # :324 (the product has no order 0)
+            K.set_p(p)
+            Z[i] = M(V[i])
+            w = execute(Z[i]).clone()
+            hcol = torch.empty(i + 2, dtype=x.dtype, device=x.device)
+            for k in range(i + 1):
+                hk = torch.dot(w, V[k])
+                hcol[k] = hk
+                w -= hk * V[k]
+            hn = torch.linalg.vector_norm(w)
+            hcol[i + 1] = hn
+            V[i + 1] = w / hn
+            col = hcol.tolist()
+            for k in range(i + 2):
+                H[k][i] = col[k]
+            for k in range(i):
+                t = cs[k] * H[k][i] + sn[k] * H[k + 1][i]
+                H[k + 1][i] = -sn[k] * H[k][i] + cs[k] * H[k + 1][i]
+                H[k][i] = t
+            cs[i], sn[i] = _generate_plane_rotation(H[i][i], H[i + 1][i])
+            t = cs[i] * H[i][i] + sn[i] * H[i + 1][i]
+            H[i + 1][i] = -sn[i] * H[i][i] + cs[i] * H[i + 1][i]
+            H[i][i] = t
+            s[i + 1] = -sn[i] * s[i]
+            s[i] = cs[i] * s[i]
+            resid = s[i + 1] / normb
+            if log is not None:
+                log.append((it, p, abs(resid)))
+            if abs(resid) < opts.residual:
+                break
+            if not (i + 1 < R and i + 1 <= opts.max_iters and abs(resid) > opts.residual):
+                break
+        y = s[:i + 1]
+        for j in range(i, -1, -1):
+            y[j] /= H[j][j]
+            for k in range(j - 1, -1, -1):
+                y[k] -= H[k][j] * y[j]
+        for j in range(i + 1):
+            x += y[j] * Z[j]
+        if not (abs(resid) > opts.residual and it < opts.max_iters):
+            break
+    return x, it, abs(resid)
+
+
+class _InnerSolver:
+    """Preconditioner = a few GMRES steps on a near-field-only operator (examples/BEM/LocalPC.hpp:26-59,
+    BlockDiagonalPC.hpp:16-60): options.residual = 1e-1, variable_p = false, max_iters = 1, restart 50."""
+
+    def __init__(self, fb, K, panels, fmm_opts, bc=None, device=0):
+        self.plan = fb.FMM_plan(K, panels, fmm_opts, bc=bc, device=device)
+        self.options = SolverOptions(residual=1e-1, max_iters=1, max_p=K.P, restart=50, variable_p=False)
+
+    def __call__(self, v):
+        y = torch.zeros_like(v)
+        gmres(self.plan, y, v.contiguous(), self.options)
+        return y
+
+
+class LocalInnerSolver(_InnerSolver):
+    """Preconditioners::LocalInnerSolver -- FMMOptions of local_options(), LocalPC.hpp:7-16."""
+
+    def __init__(self, fb, K, panels, bc=None, device=0):
+        o = fb.FMMOptions()
+        o.local_evaluation, o.lazy_evaluation, o.sparse_local = True, False, True
+        o.set_mac_theta(0.5)
+        super().__init__(fb, K, panels, o, bc, device)
+
+
+class BlockDiagonal(_InnerSolver):
+    """Preconditioners::BlockDiagonal -- FMMOptions of BlockDiagonal::local_options(), BlockDiagonalPC.hpp:53-63."""
+
+    def __init__(self, fb, K, panels, bc=None, device=0):
+        o = fb.FMMOptions()
+        o.local_evaluation, o.lazy_evaluation, o.sparse_local, o.block_diagonal = False, False, True, True
+        o.set_mac_theta(0.5)
+        super().__init__(fb, K, panels, o, bc, device)
+
+
 def laplace_bem_first_kind(fb, panels, p=12, k=3, tol=1e-5, theta=0.5, ncrit=64, max_iters=500, device=0, log=None):
     """The solve of examples/LaplaceBEM.cpp:168-291 (first-kind equation, identity preconditioner):
     b = A_flipped-BC * 1 (:218-232), x0 = 0, GMRES with relaxed p (max_p = p). Returns (x, iterations, residual)."""

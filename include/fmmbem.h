@@ -48,6 +48,14 @@ enum { FMMBEM_BC_POTENTIAL = 0, FMMBEM_BC_NORMAL_DERIV = 1 };
 /* Mirrors FMMOptions (include/FMMOptions.hpp:9-60) + the kernel constructor arguments
  * LaplaceSphericalBEM(p, k) (kernel/LaplaceSphericalBEM.hpp:131) + device placement.
  * Initialise with fmmbem_options_default(). */
+/* executor/make_executor.hpp:24-60 (FMMOptions lazy_evaluation / local_evaluation / block_diagonal) */
+typedef enum {
+  FMMBEM_EVAL_FMM = 0,            /* EvalInteractionLazy(Sparse): near field + far field (the solver's operator)      */
+  FMMBEM_EVAL_LOCAL = 1,          /* EvalLocal(Sparse): the near-field blocks only (Preconditioners::LocalInnerSolver,
+                                   * examples/BEM/LocalPC.hpp:26-59)                                                  */
+  FMMBEM_EVAL_BLOCK_DIAGONAL = 2  /* EvalDiagonalSparse: every leaf with itself (examples/BEM/BlockDiagonalPC.hpp:16-60)  */
+} fmmbem_evaluator;
+
 typedef struct {
   int32_t  kernel;            /* fmmbem_kernel                                                     */
   int32_t  p_max;             /* largest expansion order any execute() will ask for (1..16)        */
@@ -63,7 +71,7 @@ typedef struct {
   int32_t  shard_world;       /* 1 = whole operator                                                */
   int32_t  quad_k_fine;       /* Stokes: near-regime Gauss rule K_fine (StokesSphericalBEM::set_Kfine,
                                * kernel/StokesSphericalBEM.hpp:139-141; ctor default 25, driver 19)  */
-  int32_t  reserved0;
+  int32_t  evaluator;         /* fmmbem_evaluator: which branch of make_evaluators the plan takes   */
   double   mu;                /* Stokes: viscosity (StokesSphericalBEM(p,k,mu), :131)               */
   int32_t  reserved[2];
 } fmmbem_options;

@@ -41,6 +41,13 @@ class FMMOptions {
   void set_mac_theta(double t) { theta = t; }
   void set_max_per_box(unsigned n) { NCRIT_ = n; }
   unsigned max_per_box() const { return NCRIT_; }
+  // executor/make_executor.hpp:24-60: lazy_evaluation wins, then local_evaluation, then block_diagonal; the
+  // non-lazy upward/interact/downward evaluators compute the same operator as the lazy ones
+  int c_evaluator() const {
+    if (evaluator != FMM) throw fmmbem::Error(FMMBEM_ERR_UNSUPPORTED, "the treecode evaluator is not built");
+    if (lazy_evaluation) return FMMBEM_EVAL_FMM;
+    return local_evaluation ? FMMBEM_EVAL_LOCAL : block_diagonal ? FMMBEM_EVAL_BLOCK_DIAGONAL : FMMBEM_EVAL_FMM;
+  }
 };
 
 // kernel/LaplaceSphericalBEM.hpp:14-140 -- the part of the kernel object the plan boundary uses:
@@ -129,8 +136,7 @@ class FMM_plan<LaplaceSphericalBEM> {
     o.ncrit = opts.NCRIT_;
     o.sparse_local = opts.sparse_local ? 1 : 0;   // examples/LaplaceBEM.cpp:81 sets it; FMMOptions defaults to false
     o.device = device;
-    if (!opts.lazy_evaluation || opts.local_evaluation || opts.block_diagonal || opts.evaluator != FMMOptions::FMM)
-      throw fmmbem::Error(FMMBEM_ERR_UNSUPPORTED, "only the lazy FMM evaluators are built");
+    o.evaluator = opts.c_evaluator();
     fmmbem::check(fmmbem_plan_create(&o, n_, v.data(), bc.data(), &plan_));
   }
   ~FMM_plan() { fmmbem_plan_destroy(plan_); }
@@ -186,6 +192,7 @@ class FMM_plan<StokesSphericalBEM> {
     o.theta = opts.theta;
     o.ncrit = opts.NCRIT_;
     o.sparse_local = 1;
+    o.evaluator = opts.c_evaluator();
     o.device = device;
     fmmbem::check(fmmbem_plan_create(&o, n_, v.data(), bc.data(), &plan_));
   }

@@ -112,6 +112,8 @@ void orc_semi_analytical(double *G, double *dGdn, const double y0[3], const doub
                          const double y2[3], const double x[3], int same);
 
 /* ---- tree.c ---- */
+enum { ORC_EVAL_FMM = 0, ORC_EVAL_LOCAL = 1, ORC_EVAL_BLOCK_DIAGONAL = 2 };
+orc_ctx *orc_create_eval(int n, const double *verts, const uint8_t *bc, int K, double theta, unsigned ncrit, int evaluator);
 orc_ctx *orc_create(int n, const double *verts, const uint8_t *bc, int K, double theta,
                     unsigned ncrit);
 void orc_destroy(orc_ctx *c);

@@ -35,6 +35,8 @@ def lib():
         L.orc_unit_sphere.argtypes = [i32, vp]
         L.orc_create.restype = vp
         L.orc_create.argtypes = [i32, vp, vp, i32, dbl, C.c_uint]
+        L.orc_create_eval.restype = vp
+        L.orc_create_eval.argtypes = [i32, vp, vp, i32, dbl, C.c_uint, i32]
         L.orc_destroy.argtypes = [vp]
         L.orc_stats.argtypes = [vp, vp]
         L.orc_build_near.argtypes = [vp]
@@ -121,13 +123,14 @@ FAITHFUL = 1
 class Oracle:
     """One FMM_plan<LaplaceSphericalBEM>-equivalent on the CPU (include/FMM_plan.hpp:34-90)."""
 
-    def __init__(self, vertices, bc=None, K=3, theta=0.5, ncrit=64):
+    def __init__(self, vertices, bc=None, K=3, theta=0.5, ncrit=64, evaluator=0):
+        """evaluator: 0 FMM, 1 local only (EvalLocalSparse), 2 block diagonal (EvalDiagonalSparse)."""
         v = np.ascontiguousarray(vertices, dtype=np.float64).reshape(-1, 9)
         self.n = v.shape[0]
         if bc is None:
             bc = np.zeros(self.n, dtype=np.uint8)
         bc = np.ascontiguousarray(bc, dtype=np.uint8)
-        self._h = lib().orc_create(self.n, _p(v), _p(bc), K, theta, ncrit)
+        self._h = lib().orc_create_eval(self.n, _p(v), _p(bc), K, theta, ncrit, evaluator)
         if not self._h:
             raise ValueError("orc_create failed (bad quadrature key or empty input)")
         self.bc = bc
@@ -301,8 +304,8 @@ class StokesOracle(Oracle):
     """FMM_plan<StokesSphericalBEM>-equivalent on the CPU, velocity boundary condition only
     (kernel/StokesSphericalBEM.hpp:260-375, 391-432, 512-528; StokesSpherical.hpp:318-401)."""
 
-    def __init__(self, vertices, K=4, K_fine=19, mu=1e-3, theta=0.5, ncrit=64):
-        super().__init__(vertices, K=K, theta=theta, ncrit=ncrit)
+    def __init__(self, vertices, K=4, K_fine=19, mu=1e-3, theta=0.5, ncrit=64, evaluator=0):
+        super().__init__(vertices, K=K, theta=theta, ncrit=ncrit, evaluator=evaluator)
         if lib().orc_stokes_config(self._h, mu, K_fine):
             raise ValueError("invalid K_fine")
         self.mu = mu

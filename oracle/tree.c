@@ -103,6 +103,14 @@ static void propagate_local(orc_ctx *c, int b, char *initL, char *l2pset, int_ve
 }
 
 orc_ctx *orc_create(int n, const double *verts, const uint8_t *bc, int K, double theta, unsigned ncrit) {
+  return orc_create_eval(n, verts, bc, K, theta, ncrit, ORC_EVAL_FMM);
+}
+
+/* evaluator: which of make_evaluators' branches (executor/make_executor.hpp:24-60) the plan takes:
+ *   ORC_EVAL_FMM             EvalInteractionLazySparse (near matrix + far field)
+ *   ORC_EVAL_LOCAL           EvalLocalSparse.hpp:34-86: same traversal, accepted multipoles ignored (:120-127)
+ *   ORC_EVAL_BLOCK_DIAGONAL  EvalDiagonalSparse.hpp:33-49: every leaf with itself, in box order */
+orc_ctx *orc_create_eval(int n, const double *verts, const uint8_t *bc, int K, double theta, unsigned ncrit, int evaluator) {
   double qp[ORC_MAXK][3];
   orc_ctx *c = calloc(1, sizeof(*c));
   c->n = n; c->K = K; c->theta = theta; c->ncrit = ncrit;
@@ -188,7 +196,11 @@ orc_ctx *orc_create(int n, const double *verts, const uint8_t *bc, int K, double
   /* ---- dual tree traversal: EvalInteractionLazySparse.hpp:68-110, interact :239-252 ---- */
   pair_vec q = {0}, p2p = {0}, lr = {0};
   size_t head = 0;
-  orc_pair rr = {0, 0}; PUSH(q, rr);
+  orc_pair rr = {0, 0};
+  if (evaluator == ORC_EVAL_BLOCK_DIAGONAL) {
+    for (int b = 0; b < c->nboxes; ++b)
+      if (c->boxes[b].leaf) { orc_pair pr = {b, b}; PUSH(p2p, pr); }
+  } else PUSH(q, rr);
   while (head < q.n) {
     orc_pair pr = q.d[head++];
     const orc_box *b1 = &c->boxes[pr.first], *b2 = &c->boxes[pr.second];
@@ -201,7 +213,7 @@ orc_ctx *orc_create(int n, const double *verts, const uint8_t *bc, int K, double
     const orc_box *sp = split_first ? b1 : b2;
     for (uint32_t ch = sp->cb; ch < sp->ce; ++ch) {
       orc_pair np = split_first ? (orc_pair){ (int)ch, pr.second } : (orc_pair){ pr.first, (int)ch };
-      if (mac(c, &c->boxes[np.first], &c->boxes[np.second])) PUSH(lr, np); else PUSH(q, np);
+      if (mac(c, &c->boxes[np.first], &c->boxes[np.second])) { if (evaluator == ORC_EVAL_FMM) PUSH(lr, np); } else PUSH(q, np);
     }
     if (head > (1u << 20) && head*2 > q.n) {       /* compact the FIFO */
       memmove(q.d, q.d + head, sizeof(orc_pair)*(q.n - head)); q.n -= head; head = 0;

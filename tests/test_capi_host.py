@@ -75,11 +75,11 @@ def test_error_codes(fb):
     assert e.value.status == 1
     with pytest.raises(ValueError):
         fb.LaplaceSphericalBEM(17, 3)
-    opts = fb.FMMOptions()
-    opts.local_evaluation = True          # preconditioner-only evaluators are not built
-    with pytest.raises(fb.FmmBemError) as e:
-        fb.FMM_plan(fb.LaplaceSphericalBEM(5, 3), v, opts, host_only=True)
-    assert e.value.status == 6
+    o = fb.Options()
+    fb.lib().fmmbem_options_default(ctypes.byref(o))
+    o.host_only, o.evaluator = 1, 3                                           # no such evaluator
+    h = ctypes.c_void_p()
+    assert fb.lib().fmmbem_plan_create(ctypes.byref(o), len(v), v.ctypes.data_as(ctypes.c_void_p), None, ctypes.byref(h)) == 1
     with pytest.raises(fb.FmmBemError):
         fb.FMM_plan(fb.LaplaceSphericalBEM(5, 3), v, host_only=True, shard=(2, 2))
 
