@@ -103,6 +103,9 @@ __global__ __launch_bounds__((Shape<P, NS_>::THREADS)) void m2l_kernel(DevicePla
   // 8 bytes and pairs such reads into ds_read2_b64, which the conflict-free lane dealing does not cover: the unused
   // half is multiplied by a zero the compiler cannot see and starts the sum instead.
   const double zero = (double)(d.n_m2l_tgt >> 31);
+  // ... and the half it multiplies may be a place the table scatter never writes (|c| > r): clear the image once,
+  // stale LDS contents can be NaN or Inf.
+  for (int i = tid; i < Sh::LDSD; i += WAVES * kWave) Gt[i] = 0.0;
 
   // This lane's share of the table copy: entries tid, tid + WAVES*64, ...; every entry has up to four LDS places.
   // The staging registers are NAMED scalars (macro-expanded), not arrays: hipcc keeps an array that is live across
