@@ -90,11 +90,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU execution path")
+    # one rank per GPU over RCCL.  FMMBEM_BENCH_BACKEND=gloo is a rehearsal aid for a one-GPU box: the ranks then share
+    # device 0 and the all-reduce goes through the host (numbers from such a run mean nothing).
+    backend = os.environ.get("FMMBEM_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     stokes = args.workload == "stokes_rbc"
     if stokes:
