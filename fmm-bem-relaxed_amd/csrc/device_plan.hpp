@@ -21,6 +21,15 @@
 
 namespace fmmbem {
 
+// M2M or L2L operator at one order p, terms dealt to virtual rows (shift_ops.hpp VOp); passed to the kernel by value.
+struct ShiftOpDev {
+  const uint16_t *src, *y;     // [i * V + v]
+  const double* real;
+  const uint16_t *npiece;      // [row]
+  const uint16_t *piece;       // [k * S + row] -> v
+  int T, V, maxp;
+};
+
 struct DevicePlan {
   int64_t n = 0;
   int nq = 0;
@@ -66,10 +75,6 @@ struct DevicePlan {
   const int *up_cls, *down_cls;                       // per box: class of (parent-child) / (child-parent)
   const double2 *up_tab, *down_tab;                   // [cls][p2_max]
   // M2M / L2L as sparse operators in ELL form (shift_ops.hpp), rows = stored coefficient index at p_max
-  const uint16_t *up_src, *up_y, *down_src, *down_y;
-  const double *up_real, *down_real;
-  const int *up_len, *down_cnt;
-  int up_maxlen = 0, down_maxlen = 0;
   const int *mh_box;          int n_mh = 0;           // boxes whose Mh is needed (M2L sources)
   const int *m2l_tgt;         int n_m2l_tgt = 0;
   const int *m2l_ptr, *m2l_src, *m2l_cls;
@@ -90,10 +95,10 @@ hipError_t launch_near_spmv(const DevicePlan& d, hipStream_t s);
 hipError_t launch_near_matfree(const DevicePlan& d, hipStream_t s);
 hipError_t launch_scatter_y(const DevicePlan& d, double* y, hipStream_t s);
 hipError_t launch_p2m(const DevicePlan& d, int p, hipStream_t s);
-hipError_t launch_m2m_level(const DevicePlan& d, int p, int first, int count, hipStream_t s);
+hipError_t launch_m2m_level(const DevicePlan& d, const ShiftOpDev& op, int p, int first, int count, hipStream_t s);
 hipError_t launch_mh_prep(const DevicePlan& d, int p, hipStream_t s);
 hipError_t launch_m2l(const DevicePlan& d, int p, hipStream_t s);
-hipError_t launch_l2l_level(const DevicePlan& d, int p, int first, int count, hipStream_t s);
+hipError_t launch_l2l_level(const DevicePlan& d, const ShiftOpDev& op, int p, int first, int count, hipStream_t s);
 hipError_t launch_l2p(const DevicePlan& d, int p, double* y, hipStream_t s);
 hipError_t launch_near_assemble_stokes(const DevicePlan& d, hipStream_t s);
 hipError_t launch_p2m_stokes(const DevicePlan& d, int p, hipStream_t s);

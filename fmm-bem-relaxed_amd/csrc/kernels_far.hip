@@ -224,13 +224,54 @@ __global__ __launch_bounds__(kP2MWaves * kWave) void p2m_kernel(DevicePlan d, co
 // ---------------------------------------------------------------------------------------------
 constexpr int kShiftWaves = 8;
 
-__global__ __launch_bounds__(kShiftWaves * kWave) void m2m_kernel(DevicePlan d, const int P, int first, int count) {
+// One wavefront applies a shift operator: in[] = source expansion (LDS), Y[] = the class's harmonics (LDS);
+// every lane sums whole pieces (<= T terms, ELL over pieces: coalesced) into pv[] (LDS), then lane = output row adds
+// its pieces in order.  The caller wraps it in wavefront barriers.
+__device__ __forceinline__ double2 shift_apply_row(const ShiftOpDev& op, const double2* pv, int S, int idx) {
+  double2 sum = {0, 0};
+  const int np = op.npiece[idx];
+  for (int k = 0; k < np; ++k) {
+    const double2 t = pv[op.piece[(size_t)k * S + idx]];
+    sum.x += t.x; sum.y += t.y;
+  }
+  return sum;
+}
+__device__ __forceinline__ void shift_pieces(const ShiftOpDev& op, const double2* in, const double2* Y, double2* pv, int lane) {
+  for (int v = lane; v < op.V; v += kWave) {            // V is a multiple of 64; padding pieces are zeros
+    double2 acc = {0, 0};
+    for (int i = 0; i < op.T; i += 4) {                 // four terms' operands in flight
+      unsigned sc[4], yi[4];
+      double r[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const size_t e = (size_t)(i + u) * op.V + v;
+        sc[u] = op.src[e]; yi[u] = op.y[e]; r[u] = op.real[e];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        double2 x = in[sc[u] & 0x7fff];
+        if (sc[u] & 0x8000) x.y = -x.y;
+        const double2 t = cmul(x, Y[yi[u]]);
+        acc.x = fma(t.x, r[u], acc.x); acc.y = fma(t.y, r[u], acc.y);
+      }
+    }
+    pv[v] = acc;
+  }
+}
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(kShiftWaves * kWave) void m2m_kernel(DevicePlan d, ShiftOpDev op, const int P, int first, int count) {
   extern __shared__ double2 lds2[];
-  const int S = P * (P + 1) / 2, P2 = P * P, SM = d.s_max;
+  const int S = P * (P + 1) / 2, P2 = P * P, SM = d.s_max, W = S + P2 + op.V;
   const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
-  double2* Ms = lds2 + (size_t)w * (S + P2);          // this wavefront's child multipole
-  double2* Y = Ms + S;                                // ... and its translation harmonics
-  double2* part = lds2 + (size_t)kShiftWaves * (S + P2) + (size_t)w * S;
+  double2* Ms = lds2 + (size_t)w * W;                 // this wavefront's child multipole
+  double2* Y = Ms + S;                                // ... its translation harmonics
+  double2* pv = Y + P2;                               // ... and its per-piece partial sums
+  double2* part = lds2 + (size_t)kShiftWaves * W + (size_t)w * S;
   const int slot = d.act[blockIdx.y];
   for (int it = blockIdx.x; it < count; it += gridDim.x) {
     const int parent = d.m2m_parent[first + it];
@@ -241,34 +282,14 @@ __global__ __launch_bounds__(kShiftWaves * kWave) void m2m_kernel(DevicePlan d, 
       const double2* tab = d.up_tab + (size_t)d.up_cls[c] * d.p2_max;
       for (int i = lane; i < S; i += kWave) Ms[i] = src[i];
       for (int i = lane; i < P2; i += kWave) Y[i] = tab[i];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      for (int idx = lane; idx < S; idx += kWave) {
-        const int len = d.up_len[idx];
-        double2 acc = {0, 0};
-        for (int i = 0; i < len; i += 4) {              // four terms' operands in flight (rows are zero-padded)
-          unsigned sc[4], yi[4];
-          double r[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const size_t e = (size_t)(i + u) * SM + idx;
-            sc[u] = d.up_src[e]; yi[u] = d.up_y[e]; r[u] = d.up_real[e];
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            double2 v = Ms[sc[u] & 0x7fff];
-            if (sc[u] & 0x8000) v.y = -v.y;
-            const double2 t = cmul(v, Y[yi[u]]);
-            acc.x = fma(t.x, r[u], acc.x); acc.y = fma(t.y, r[u], acc.y);
-          }
-        }
-        part[idx] = acc;
-      }
+      wave_lds_sync();
+      shift_pieces(op, Ms, Y, pv, lane);
+      wave_lds_sync();
+      for (int idx = lane; idx < S; idx += kWave) part[idx] = shift_apply_row(op, pv, S, idx);
     }
     __syncthreads();
     double2* dst = d.M + ((size_t)parent * d.nslots + slot) * SM;
-    const double2* parts = lds2 + (size_t)kShiftWaves * (S + P2);
+    const double2* parts = lds2 + (size_t)kShiftWaves * W;
     for (int idx = threadIdx.x; idx < S; idx += blockDim.x) {
       double2 sum = {0, 0};
       for (int c = 0; c < nchild; ++c) { sum.x += parts[(size_t)c * S + idx].x; sum.y += parts[(size_t)c * S + idx].y; }
@@ -302,14 +323,14 @@ __global__ __launch_bounds__(kWave) void mh_prep_kernel(DevicePlan d, const int 
 // independent children per workgroup), same sparse-operator scheme as M2M; the terms usable at order p are
 // a prefix of each row's list (down_cnt).  Workgroups stride over the level's children.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kShiftWaves * kWave) void l2l_kernel(DevicePlan d, const int P, int first, int count) {
+__global__ __launch_bounds__(kShiftWaves * kWave) void l2l_kernel(DevicePlan d, ShiftOpDev op, const int P, int first, int count) {
   extern __shared__ double2 lds2[];
-  const int S = P * (P + 1) / 2, P2 = P * P, SM = d.s_max;
+  const int S = P * (P + 1) / 2, P2 = P * P, SM = d.s_max, W = S + P2 + op.V;
   const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
-  double2* Ls = lds2 + (size_t)w * (S + P2);
+  double2* Ls = lds2 + (size_t)w * W;
   double2* Y = Ls + S;
+  double2* pv = Y + P2;
   const int slot = d.act[blockIdx.y];
-  const int* cnt = d.down_cnt + (size_t)(P - 1) * SM;
   for (int it = blockIdx.x * kShiftWaves + w; it < count; it += gridDim.x * kShiftWaves) {
     const int child = d.l2l_child[first + it];
     const int parent = d.box_parent[child];
@@ -318,30 +339,14 @@ __global__ __launch_bounds__(kShiftWaves * kWave) void l2l_kernel(DevicePlan d, 
     __builtin_amdgcn_wave_barrier();
     for (int i = lane; i < S; i += kWave) Ls[i] = src[i];
     for (int i = lane; i < P2; i += kWave) Y[i] = tab[i];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    wave_lds_sync();
+    shift_pieces(op, Ls, Y, pv, lane);
+    wave_lds_sync();
     double2* dst = d.L + ((size_t)child * d.nslots + slot) * SM;
     for (int idx = lane; idx < S; idx += kWave) {
-      const int len = cnt[idx];
+      const double2 add = shift_apply_row(op, pv, S, idx);
       double2 acc = dst[idx];
-      for (int i = 0; i < len; i += 4) {                // four terms' operands in flight
-        unsigned sc[4], yi[4];
-        double r[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const size_t e = (size_t)(i + u) * SM + idx;
-          const bool on = i + u < len;                    // a row's usable terms at order p are a prefix
-          sc[u] = on ? d.down_src[e] : 0; yi[u] = on ? d.down_y[e] : 0; r[u] = on ? d.down_real[e] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          double2 v = Ls[sc[u] & 0x7fff];
-          if (sc[u] & 0x8000) v.y = -v.y;
-          const double2 t = cmul(v, Y[yi[u]]);
-          acc.x = fma(t.x, r[u], acc.x); acc.y = fma(t.y, r[u], acc.y);
-        }
-      }
+      acc.x += add.x; acc.y += add.y;
       dst[idx] = acc;
     }
   }
@@ -501,8 +506,8 @@ hipError_t upload_constants_once() {
     for (int k = 1; k < 40; ++k) recip[k] = 1.0 / k;
     if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(kRecip), recip, sizeof(recip));
     // M2M at p = 16 needs a little over 64 KiB of dynamic LDS
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(m2m_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(l2l_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(m2m_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(l2l_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     return e;
   }();
   return st;
@@ -523,14 +528,14 @@ hipError_t launch_p2m(const DevicePlan& d, int p, hipStream_t s) {
   return hipGetLastError();
 }
 
-hipError_t launch_m2m_level(const DevicePlan& d, int p, int first, int count, hipStream_t s) {
+hipError_t launch_m2m_level(const DevicePlan& d, const ShiftOpDev& op, int p, int first, int count, hipStream_t s) {
   if (hipError_t e = upload_constants_once(); e != hipSuccess) return e;
   if (count <= 0) return hipSuccess;
   if (p < 1 || p > kPmaxDev) return hipErrorInvalidValue;
   {
     const size_t S = (size_t)p * (p + 1) / 2, P2 = (size_t)p * p;
-    const size_t lds = (kShiftWaves * (S + P2) + kShiftWaves * S) * sizeof(double2);
-    hipLaunchKernelGGL(m2m_kernel, dim3(count < 1024 ? count : 1024, d.n_act), dim3(kShiftWaves * kWave), lds, s, d, p, first, count);
+    const size_t lds = (kShiftWaves * (S + P2 + op.V) + kShiftWaves * S) * sizeof(double2);
+    hipLaunchKernelGGL(m2m_kernel, dim3(count < 1024 ? count : 1024, d.n_act), dim3(kShiftWaves * kWave), lds, s, d, op, p, first, count);
   }
   return hipGetLastError();
 }
@@ -543,15 +548,15 @@ hipError_t launch_mh_prep(const DevicePlan& d, int p, hipStream_t s) {
   return hipGetLastError();
 }
 
-hipError_t launch_l2l_level(const DevicePlan& d, int p, int first, int count, hipStream_t s) {
+hipError_t launch_l2l_level(const DevicePlan& d, const ShiftOpDev& op, int p, int first, int count, hipStream_t s) {
   if (hipError_t e = upload_constants_once(); e != hipSuccess) return e;
   if (count <= 0) return hipSuccess;
   if (p < 1 || p > kPmaxDev) return hipErrorInvalidValue;
   {
     const size_t S = (size_t)p * (p + 1) / 2, P2 = (size_t)p * p;
-    const size_t lds = kShiftWaves * (S + P2) * sizeof(double2);
+    const size_t lds = kShiftWaves * (S + P2 + op.V) * sizeof(double2);
     const int blocks = (count + kShiftWaves - 1) / kShiftWaves;
-    hipLaunchKernelGGL(l2l_kernel, dim3(blocks < 1024 ? blocks : 1024, d.n_act), dim3(kShiftWaves * kWave), lds, s, d, p, first, count);
+    hipLaunchKernelGGL(l2l_kernel, dim3(blocks < 1024 ? blocks : 1024, d.n_act), dim3(kShiftWaves * kWave), lds, s, d, op, p, first, count);
   }
   return hipGetLastError();
 }

@@ -122,6 +122,7 @@ struct fmmbem_plan {
   bool on_device = false;
   std::vector<void*> allocs;
   std::vector<std::pair<int, int>> m2m_launch, l2l_launch;     // (first, count) per level
+  std::vector<ShiftOpDev> up_ops, down_ops;                    // M2M / L2L operators, index p - 1
   int64_t near_bytes = 0;
   int64_t n_classes = 0;
   double build_host_ms = 0, build_assemble_ms = 0;
@@ -349,11 +350,14 @@ int fmmbem_plan::to_device() {
     d.up_tab = reinterpret_cast<const double2*>(pu);
     d.down_tab = reinterpret_cast<const double2*>(pd);
     const ShiftOps ops = build_shift_ops(pm, T.A, kEps);
-    d.up_maxlen = ops.up_maxlen; d.down_maxlen = ops.down_maxlen;
-    TRY(upload(ops.up_src, &d.up_src)); TRY(upload(ops.up_y, &d.up_y)); TRY(upload(ops.up_real, &d.up_real));
-    TRY(upload(ops.up_len, &d.up_len));
-    TRY(upload(ops.down_src, &d.down_src)); TRY(upload(ops.down_y, &d.down_y)); TRY(upload(ops.down_real, &d.down_real));
-    TRY(upload(ops.down_cnt, &d.down_cnt));
+    auto up_op = [&](const VOp& v, ShiftOpDev& o) -> int {
+      TRY(upload(v.src, &o.src)); TRY(upload(v.y, &o.y)); TRY(upload(v.real, &o.real));
+      TRY(upload(v.npiece, &o.npiece)); TRY(upload(v.piece, &o.piece));
+      o.T = v.T; o.V = v.V; o.maxp = v.maxp;
+      return FMMBEM_OK;
+    };
+    up_ops.resize(pm); down_ops.resize(pm);
+    for (int p = 1; p <= pm; ++p) { TRY(up_op(ops.up_v[p - 1], up_ops[p - 1])); TRY(up_op(ops.down_v[p - 1], down_ops[p - 1])); }
   }
 
   // M2L: targets to run, sources whose Mh is needed, class tables Yh[r,c] = i^{|c|} EPS Y[r,c] / A[r,c]
@@ -463,7 +467,7 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
     if (d.kernel == FMMBEM_KERNEL_STOKES_BEM) HIP_TRY(launch_p2m_stokes(d, p, s)); else HIP_TRY(launch_p2m(d, p, s));
     HIP_TRY(end(3, s));
     HIP_TRY(begin(4, s));
-    for (auto [first, count] : m2m_launch) HIP_TRY(launch_m2m_level(d, p, first, count, s));
+    for (auto [first, count] : m2m_launch) HIP_TRY(launch_m2m_level(d, up_ops[p - 1], p, first, count, s));
     HIP_TRY(end(4, s));
     HIP_TRY(begin(5, s));
     HIP_TRY(launch_mh_prep(d, p, s));
@@ -478,7 +482,7 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
     HIP_TRY(launch_m2l(d, p, s));
     HIP_TRY(end(6, s));
     HIP_TRY(begin(7, s));
-    for (auto [first, count] : l2l_launch) HIP_TRY(launch_l2l_level(d, p, first, count, s));
+    for (auto [first, count] : l2l_launch) HIP_TRY(launch_l2l_level(d, down_ops[p - 1], p, first, count, s));
     HIP_TRY(end(7, s));
     if (overlap) HIP_TRY(hipStreamWaitEvent(s, ev_join, 0));
     HIP_TRY(begin(8, s));

@@ -5,25 +5,31 @@
 // term (kernel/LaplaceSpherical.hpp:255-282, 385-410).  None of that depends on the boxes: the set of
 // terms of output row (j,k), the source coefficient each term reads (conjugated or not), the harmonic
 // Y[n,m] it multiplies and its real factor are fixed by p alone.  They are generated ONCE on the host, in
-// the reference's loop order, and stored in ELL form (term i of every row contiguous across rows) so that
-// lanes = rows read them coalesced.  Only the harmonics Y depend on the translation (one small table per
+// the reference's loop order, and stored in ELL form over equal-sized pieces of rows (VOp below) so that
+// lanes read them coalesced.  Only the harmonics Y depend on the translation (one small table per
 // parent/child offset class).
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <vector>
 
 namespace fmmbem {
 
+// One operator (up or down) at one order p with its terms dealt to "virtual rows" of at most T terms: output row
+// (j,k) of L2L has (p-j)^2 terms and of M2M (j+1)^2 -- 100 down to 1 at p = 10 -- so with lanes = rows a wavefront
+// runs 100 steps at 19 % lane use.  Rows are cut into pieces of T terms (reference order kept inside a piece and
+// between pieces), pieces are the lanes' work (ELL over pieces, coalesced), and a row sums its pieces in order.
+struct VOp {
+  int T = 8, V = 0, maxp = 0, S = 0;     // V: virtual rows, padded to a multiple of 64; S = p(p+1)/2
+  std::vector<uint16_t> src, y;          // [i * V + v], i < T
+  std::vector<double> real;
+  std::vector<uint16_t> npiece;          // [row] pieces of the row
+  std::vector<uint16_t> piece;           // [k * S + row] -> v, k < maxp
+};
+
 struct ShiftOps {
   int P = 0, S = 0;
-  // ELL arrays, entry [i * S + row]
-  int up_maxlen = 0, down_maxlen = 0;
-  std::vector<uint16_t> up_src, up_y;      // src: stored index | 0x8000 if conjugated; y: n^2+n+m of the harmonic
-  std::vector<double> up_real;             // real factor, EPS included
-  std::vector<int> up_len;                 // [S] terms per row (independent of the order p <= P in use)
-  std::vector<uint16_t> down_src, down_y;
-  std::vector<double> down_real;
-  std::vector<int> down_cnt;               // [(p-1) * S + row] terms usable at order p (terms sorted by n)
+  std::vector<VOp> up_v, down_v;           // index p - 1
 };
 
 // A: the Anm table (index n^2+n+m, n < 2*kPmax), EPS-scaled as in LaplaceSpherical::precompute
@@ -67,32 +73,34 @@ inline ShiftOps build_shift_ops(int P, const std::vector<double>& A, double eps)
         }
       }
     }
-  auto pack = [&](const std::vector<std::vector<Term>>& rows, int& maxlen, std::vector<uint16_t>& src,
-                  std::vector<uint16_t>& y, std::vector<double>& real) {
-    maxlen = 0;
-    for (auto& r : rows) maxlen = (int)r.size() > maxlen ? (int)r.size() : maxlen;
-    maxlen = (maxlen + 3) & ~3;                          // kernels consume terms four at a time; padding terms are zeros
-    src.assign((size_t)maxlen * o.S, 0);
-    y.assign((size_t)maxlen * o.S, 0);
-    real.assign((size_t)maxlen * o.S, 0.0);
-    for (int row = 0; row < o.S; ++row)
-      for (size_t i = 0; i < rows[row].size(); ++i) {
-        src[i * o.S + row] = rows[row][i].src;
-        y[i * o.S + row] = rows[row][i].y;
-        real[i * o.S + row] = rows[row][i].real;
-      }
-  };
-  pack(up, o.up_maxlen, o.up_src, o.up_y, o.up_real);
-  pack(down, o.down_maxlen, o.down_src, o.down_y, o.down_real);
-  o.up_len.resize(o.S);
-  for (int row = 0; row < o.S; ++row) o.up_len[row] = (int)up[row].size();
-  o.down_cnt.assign((size_t)P * o.S, 0);
-  for (int p = 1; p <= P; ++p)
-    for (int row = 0; row < o.S; ++row) {
-      int c = 0;
-      for (auto& t : down[row]) c += t.n < p;          // terms are generated with n ascending
-      o.down_cnt[(size_t)(p - 1) * o.S + row] = c;
+  auto deal = [&](const std::vector<std::vector<Term>>& rows, int p, bool prefix) {
+    VOp v;
+    v.S = p * (p + 1) / 2;
+    v.T = p <= 12 ? 8 : 16;                            // keeps the per-wavefront partial-sum array small at high order
+    struct Piece { int row, begin, cnt, k; };
+    std::vector<Piece> pieces;
+    v.npiece.assign(v.S, 0);
+    for (int row = 0; row < v.S; ++row) {
+      int len = 0;
+      if (prefix) { for (auto& t : rows[row]) len += t.n < p; } else len = (int)rows[row].size();
+      for (int b = 0, k = 0; b < len; b += v.T, ++k) { pieces.push_back({row, b, len - b < v.T ? len - b : v.T, k}); v.npiece[row] = (uint16_t)(k + 1); }
+      v.maxp = v.npiece[row] > v.maxp ? v.npiece[row] : v.maxp;
     }
+    std::stable_sort(pieces.begin(), pieces.end(), [](const Piece& a, const Piece& b) { return a.cnt > b.cnt; });
+    v.V = ((int)pieces.size() + 63) & ~63;
+    v.src.assign((size_t)v.T * v.V, 0); v.y.assign((size_t)v.T * v.V, 0); v.real.assign((size_t)v.T * v.V, 0.0);
+    v.piece.assign((size_t)(v.maxp ? v.maxp : 1) * v.S, 0);
+    for (size_t q = 0; q < pieces.size(); ++q) {
+      const Piece& pc = pieces[q];
+      v.piece[(size_t)pc.k * v.S + pc.row] = (uint16_t)q;
+      for (int i = 0; i < pc.cnt; ++i) {
+        const Term& t = rows[pc.row][pc.begin + i];
+        v.src[(size_t)i * v.V + q] = t.src; v.y[(size_t)i * v.V + q] = t.y; v.real[(size_t)i * v.V + q] = t.real;
+      }
+    }
+    return v;
+  };
+  for (int p = 1; p <= P; ++p) { o.up_v.push_back(deal(up, p, false)); o.down_v.push_back(deal(down, p, true)); }
   return o;
 }
 
