@@ -107,12 +107,7 @@ def main():
     stokes = args.workload == "stokes_rbc"
     if stokes:
         # ---- config 4: one red blood cell (examples/BEM/Triangulation.hpp:184-255), identity rotation, no shift ----
-        v = fb.unit_sphere(args.recursions)
-        r, C0, C2, C4 = 3.91, 0.81, 7.83, -4.39
-        xx, yy = v[..., 0] * r, v[..., 1] * r
-        ratio = np.sqrt(xx * xx + yy * yy) / r
-        zz = np.sqrt(1 - ratio ** 2 + 1e-12) * (C0 + C2 * ratio ** 2 + C4 * ratio ** 4) * 0.5 * np.sign(v[..., 2])
-        v = np.stack([xx, yy, zz], axis=-1)
+        v = fb.red_blood_cell(args.recursions)
         if args.p == 10:
             args.p = 8
         K = fb.StokesSphericalBEM(args.p, 4, 1e-3)

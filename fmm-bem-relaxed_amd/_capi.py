@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfmmbem_hip.so")
 
-OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC, ERR_TREE, ERR_UNSUPPORTED = range(7)
+OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC, ERR_TREE, ERR_UNSUPPORTED, ERR_IO = range(8)
 PMAX = 16
 KERNEL_LAPLACE_BEM, KERNEL_STOKES_BEM = 0, 1
 EVAL_FMM, EVAL_LOCAL, EVAL_BLOCK_DIAGONAL = 0, 1, 2
@@ -55,7 +55,8 @@ SYMBOLS = (
     "fmmbem_options_default", "fmmbem_plan_create", "fmmbem_plan_destroy", "fmmbem_plan_execute",
     "fmmbem_plan_execute_device", "fmmbem_plan_near_device", "fmmbem_plan_set_timing", "fmmbem_plan_stats",
     "fmmbem_plan_get_perm", "fmmbem_plan_get_boxes", "fmmbem_plan_get_pairs", "fmmbem_plan_get_near_row",
-    "fmmbem_plan_get_expansions", "fmmbem_mesh_unit_sphere", "fmmbem_status_string", "fmmbem_last_error",
+    "fmmbem_plan_get_expansions", "fmmbem_mesh_unit_sphere", "fmmbem_mesh_red_blood_cell", "fmmbem_mesh_read_msh",
+    "fmmbem_mesh_read_vert_face", "fmmbem_mesh_write_vert_face", "fmmbem_status_string", "fmmbem_last_error",
     "fmmbem_version",
 )
 
@@ -93,6 +94,10 @@ def lib():
     L.fmmbem_plan_get_near_row.argtypes = [vp, C.c_int64, vp, vp, i64p]
     L.fmmbem_plan_get_expansions.argtypes = [vp, i32, i32, vp]
     L.fmmbem_mesh_unit_sphere.argtypes = [i32, vp, C.POINTER(C.c_size_t)]
+    L.fmmbem_mesh_red_blood_cell.argtypes = [i32, vp, C.POINTER(C.c_size_t)]
+    L.fmmbem_mesh_read_msh.argtypes = [C.c_char_p, vp, C.POINTER(C.c_size_t)]
+    L.fmmbem_mesh_read_vert_face.argtypes = [C.c_char_p, C.c_char_p, vp, C.POINTER(C.c_size_t)]
+    L.fmmbem_mesh_write_vert_face.argtypes = [C.c_char_p, C.c_char_p, vp, C.c_size_t]
     L.fmmbem_status_string.argtypes = [i32]
     L.fmmbem_status_string.restype = C.c_char_p
     L.fmmbem_last_error.restype = C.c_char_p

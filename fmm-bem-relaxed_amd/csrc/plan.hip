@@ -23,13 +23,16 @@
 using namespace fmmbem;
 
 namespace {
-
 thread_local std::string g_last_error;
-
-int fail(int code, const std::string& msg) {
+}
+namespace fmmbem {
+int fail(int code, const std::string& msg) {          // also used by mesh_io.cpp
   g_last_error = msg;
   return code;
 }
+}  // namespace fmmbem
+
+namespace {
 
 #define HIP_TRY(expr)                                                                              \
   do {                                                                                             \
@@ -758,6 +761,7 @@ const char* fmmbem_status_string(int status) {
     case FMMBEM_ERR_ALLOC: return "allocation failed";
     case FMMBEM_ERR_TREE: return "octree too deep";
     case FMMBEM_ERR_UNSUPPORTED: return "unsupported option";
+    case FMMBEM_ERR_IO: return "file input/output error";
     default: return "unknown status";
   }
 }

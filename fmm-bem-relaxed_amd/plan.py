@@ -10,6 +10,7 @@ Same names, same argument meaning; errors are exceptions (FmmBemError) instead o
 All arithmetic happens in libfmmbem_hip.so on the GPU; this file only marshals arrays.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -83,6 +84,41 @@ def unit_sphere(recursions, center=(0.0, 0.0, 0.0)):
     if any(center):
         v += np.asarray(center, dtype=np.float64)
     return v
+
+
+def red_blood_cell(recursions):
+    """Triangulation::RedBloodCell, identity rotation, zero shift (examples/BEM/Triangulation.hpp:184-255)."""
+    n = C.c_size_t(0)
+    _capi.check(_capi.lib().fmmbem_mesh_red_blood_cell(recursions, None, C.byref(n)))
+    v = np.empty((n.value, 3, 3), dtype=np.float64)
+    _capi.check(_capi.lib().fmmbem_mesh_red_blood_cell(recursions, v.ctypes.data_as(C.c_void_p), C.byref(n)))
+    return v
+
+
+def _read(fn, *paths):
+    n = C.c_size_t(0)
+    args = [os.fsencode(p) for p in paths]
+    _capi.check(fn(*args, None, C.byref(n)))
+    v = np.empty((n.value, 3, 3), dtype=np.float64)
+    _capi.check(fn(*args, v.ctypes.data_as(C.c_void_p), C.byref(n)))
+    return v
+
+
+def read_msh(path):
+    """MeshIO::readMsh (examples/BEM/MshReader.hpp:18-94): gmsh v2 ASCII triangles -> (N, 3, 3)."""
+    return _read(_capi.lib().fmmbem_mesh_read_msh, path)
+
+
+def read_vert_face(vert_path, face_path):
+    """MeshIO::ReadVertFace (examples/BEM/VertFaceReader.hpp:17-76) -> (N, 3, 3)."""
+    return _read(_capi.lib().fmmbem_mesh_read_vert_face, vert_path, face_path)
+
+
+def write_vert_face(vert_path, face_path, panels):
+    """The .vert/.face dump of the generators (examples/BEM/Triangulation.hpp:124-134), readable by read_vert_face."""
+    v = np.ascontiguousarray(panels, dtype=np.float64).reshape(-1, 9)
+    _capi.check(_capi.lib().fmmbem_mesh_write_vert_face(os.fsencode(vert_path), os.fsencode(face_path),
+                                                        v.ctypes.data_as(C.c_void_p), len(v)))
 
 
 class FMM_plan:

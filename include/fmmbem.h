@@ -31,7 +31,8 @@ typedef enum {
   FMMBEM_ERR_HIP = 3,           /* a HIP runtime call or kernel launch failed                         */
   FMMBEM_ERR_ALLOC = 4,         /* host or device allocation failed                                   */
   FMMBEM_ERR_TREE = 5,          /* octree deeper than the 10 levels of the reference's 32-bit keys    */
-  FMMBEM_ERR_UNSUPPORTED = 6    /* option combination not implemented                                 */
+  FMMBEM_ERR_UNSUPPORTED = 6,   /* option combination not implemented                                 */
+  FMMBEM_ERR_IO = 7             /* a mesh file could not be opened or parsed                          */
 } fmmbem_status;
 
 /* kernel ids: which reference Kernel class the plan stands in for */
@@ -151,6 +152,22 @@ int fmmbem_plan_get_expansions(const fmmbem_plan *plan, int which, int p, double
 /* Triangulation::UnitSphere(panels, recursions) (examples/BEM/Triangulation.hpp:105-121):
  * N = 2*4^recursions panels.  vertices == NULL: only returns N through *n_panels. */
 int fmmbem_mesh_unit_sphere(int recursions, double *vertices, size_t *n_panels);
+/* Triangulation::RedBloodCell(panels, recursions) with identity rotation and zero shift
+ * (examples/BEM/Triangulation.hpp:184-255; examples/StokesBEM.cpp:111-113): same N, same calling convention. */
+int fmmbem_mesh_red_blood_cell(int recursions, double *vertices, size_t *n_panels);
+
+/* ---- mesh files of the reference's drivers ------------------------------------------------ */
+/* All readers: vertices == NULL only counts (*n_panels out); otherwise *n_panels holds the capacity of
+ * vertices (panels) on entry and the number read on return; vertices[panel][vertex][xyz].
+ * MeshIO::readMsh (examples/BEM/MshReader.hpp:18-94): gmsh format 2 ASCII; elements of type 2 (triangles) only,
+ * stored in element-number order with the winding swapped (v1, v3, v2) as the reference does. */
+int fmmbem_mesh_read_msh(const char *path, double *vertices, size_t *n_panels);
+/* MeshIO::ReadVertFace (examples/BEM/VertFaceReader.hpp:17-76): count line then "x y z" lines; count line then
+ * 1-indexed "v1 v2 v3" lines; winding kept. */
+int fmmbem_mesh_read_vert_face(const char *vert_path, const char *face_path, double *vertices, size_t *n_panels);
+/* The .vert/.face pair the generators dump (examples/BEM/Triangulation.hpp:124-134), three vertices per
+ * triangle, written WITH the count lines ReadVertFace expects and 17 significant digits. */
+int fmmbem_mesh_write_vert_face(const char *vert_path, const char *face_path, const double *vertices, size_t n_panels);
 
 /* ---- errors ------------------------------------------------------------------------------ */
 const char *fmmbem_status_string(int status);
