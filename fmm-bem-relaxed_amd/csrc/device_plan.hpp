@@ -67,6 +67,7 @@ struct DevicePlan {
   double2 *M, *L, *Mh;
   // tables
   const double *tabA, *tabInvA, *tabPref;             // [n^2+n+m], n < 2*kPmax
+  const double *tabStep;                              // [p-1][step][4] = {pref, c1, c2, 0} of the harmonic recurrences at order p, m-major steps
   // far-field lists
   const int *p2m_leaf;        int n_p2m = 0;          // box ids
   const int *l2p_leaf;        int n_l2p = 0;

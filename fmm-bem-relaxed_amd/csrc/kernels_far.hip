@@ -95,23 +95,26 @@ __device__ inline void fill_step_tables(const DevicePlan& d, int P, int lane, do
 // ---------------------------------------------------------------------------------------------
 constexpr int kP2MBand = 8;                           // rows per LDS tile (8.3 KiB): 8 lanes reduce one row
 
-constexpr int kP2MWaves = 4;                          // independent leaves per workgroup (tables shared)
+constexpr int kP2MWaves = 4;                          // independent leaves per workgroup
+struct D4 { double x, y, z, w; };
+typedef __attribute__((address_space(4))) D4 ConstD4;  // wave-uniform constants through the scalar cache
 
 template <int slot>
 __global__ __launch_bounds__(kP2MWaves * kWave) void p2m_kernel(DevicePlan d, const int P, const int wmode, const int out_slot) {
   __shared__ double2 tile_all[kP2MWaves][kP2MBand][kWave + 1];
   __shared__ double2 acc_all[kP2MWaves][kSmax];
   __shared__ int rowidx_all[kP2MWaves][kP2MBand];
-  __shared__ double sPref[kSmax], sC1[kSmax], sC2[kSmax];
   const int S = P * (P + 1) / 2;
+  // per-step recurrence constants: wave-uniform, fetched ONE STEP AHEAD with scalar loads (fetched at the point of
+  // use they cost an SMEM round trip per step; kept in LDS they cost three LDS reads per step of a kernel that
+  // SQ counters show at 83 % LDS issue)
+  const ConstD4* steptab = reinterpret_cast<const ConstD4*>(reinterpret_cast<uintptr_t>(d.tabStep + (size_t)(P - 1) * (kSmax + 1) * 4));
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   double2 (*tile)[kWave + 1] = tile_all[wave];
   double2* acc = acc_all[wave];
   int* rowidx = rowidx_all[wave];
   const int64_t N = d.n;
   const int nq = d.nq;
-  if (wave == 0) fill_step_tables(d, P, lane, sPref, sC1, sC2);
-  __syncthreads();
   for (int li = blockIdx.x * kP2MWaves + wave; li < d.n_p2m; li += gridDim.x * kP2MWaves) {
     const int leaf = d.p2m_leaf[li];
     const int box = d.leaf_box[leaf];
@@ -163,17 +166,20 @@ __global__ __launch_bounds__(kP2MWaves * kWave) void p2m_kernel(DevicePlan d, co
                              live ? d.quad[(q * 3 + 2) * N + i] - c2 : 0.5);
       double pn = 1, rhom = 1, er = 1, ei = 0, fact = 1;
       int step = 0;
+      D4 cnext = {steptab[0].x, steptab[0].y, steptab[0].z, 0};
 #pragma nounroll
       for (int m = 0; m < P; ++m) {
         double p = pn, p1 = p, rhon = rhom;
 #pragma nounroll
         for (int n = m; n < P; ++n, ++step) {
-          const double pref = sPref[step];
+          const D4 cst = cnext;
+          cnext = {steptab[step + 1].x, steptab[step + 1].y, steptab[step + 1].z, 0};     // row S is zeros
+          const double pref = cst.x;
           // Ynm[n,m] at (rho, alpha, -beta): rho^n P_n^m(cos a) pref e^{-i m beta}
           const double mag = rhon * p * pref;
           const double yr = mag * er, yi = -mag * ei;
           const double pcur = p;
-          const double pnext = sC1[step] * s.ca * pcur - sC2[step] * p1;   // Legendre recurrence, P_{n+1}^m
+          const double pnext = cst.y * s.ca * pcur - cst.z * p1;   // Legendre recurrence, P_{n+1}^m
           double vr, vi;
           if (slot == 0) {                            // source BC POTENTIAL: G moments (LaplaceSphericalBEM.hpp:326)
             vr = wq * yr; vi = wq * yi;

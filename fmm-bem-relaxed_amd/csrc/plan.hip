@@ -296,6 +296,22 @@ int fmmbem_plan::to_device() {
   TRY(alloc((size_t)nb * d.nslots * d.s_max, &d.L, true));
   TRY(alloc((size_t)nb * d.nslots * d.s_max, &d.Mh, true));
   TRY(upload(T.A, &d.tabA)); TRY(upload(T.invA, &d.tabInvA)); TRY(upload(T.pref, &d.tabPref));
+  {
+    // per-step constants of the harmonic recurrences in the m-major order P2M visits (n,m) at order p:
+    // pref = sqrt((n-m)!/(n+m)!) and the Legendre step P_{n+1}^m = c1 x P_n^m - c2 P_{n-1}^m (c1 = 2m+1, c2 = 0 at n = m)
+    const int smax = kPmax * (kPmax + 1) / 2;
+    std::vector<double> st((size_t)kPmax * (smax + 1) * 4, 0.0);
+    for (int p = 1; p <= kPmax; ++p) {
+      double* o = st.data() + (size_t)(p - 1) * (smax + 1) * 4;
+      for (int m = 0; m < p; ++m)
+        for (int n = m; n < p; ++n, o += 4) {
+          o[0] = T.pref[n * n + n + m];
+          o[1] = n == m ? (double)(2 * m + 1) : (double)(2 * n + 1) * (1.0 / (n - m + 1));
+          o[2] = n == m ? 0.0 : (double)(n + m) * (1.0 / (n - m + 1));
+        }
+    }
+    TRY(upload(st, &d.tabStep));
+  }
 
   // far-field lists
   std::vector<int> p2m_leaf, l2p_leaf;
