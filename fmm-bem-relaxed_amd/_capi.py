@@ -24,7 +24,7 @@ class Options(C.Structure):
                 ("ncrit", C.c_uint32), ("sparse_local", C.c_int32), ("host_only", C.c_int32),
                 ("device", C.c_int32), ("shard_rank", C.c_int32), ("shard_world", C.c_int32),
                 ("quad_k_fine", C.c_int32), ("evaluator", C.c_int32), ("mu", C.c_double),
-                ("reserved", C.c_int32 * 2)]
+                ("shard_upward", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -53,7 +53,8 @@ _lib = None
 # every symbol include/fmmbem.h declares (tests check that the library exports all of them)
 SYMBOLS = (
     "fmmbem_options_default", "fmmbem_plan_create", "fmmbem_plan_destroy", "fmmbem_plan_execute",
-    "fmmbem_plan_execute_device", "fmmbem_plan_near_device", "fmmbem_plan_set_timing", "fmmbem_plan_stats",
+    "fmmbem_plan_execute_device", "fmmbem_plan_exchange_doubles", "fmmbem_plan_upward_device",
+    "fmmbem_plan_downward_device", "fmmbem_plan_near_device", "fmmbem_plan_set_timing", "fmmbem_plan_stats",
     "fmmbem_plan_get_perm", "fmmbem_plan_get_boxes", "fmmbem_plan_get_pairs", "fmmbem_plan_get_near_row",
     "fmmbem_plan_get_expansions", "fmmbem_mesh_unit_sphere", "fmmbem_mesh_red_blood_cell", "fmmbem_mesh_read_msh",
     "fmmbem_mesh_read_vert_face", "fmmbem_mesh_write_vert_face", "fmmbem_status_string", "fmmbem_last_error",
@@ -86,6 +87,9 @@ def lib():
     L.fmmbem_plan_execute.argtypes = [vp, i32, vp, vp]
     L.fmmbem_plan_execute_device.argtypes = [vp, i32, vp, vp, vp]
     L.fmmbem_plan_near_device.argtypes = [vp, vp, vp, vp]
+    L.fmmbem_plan_exchange_doubles.argtypes = [vp, i32, C.POINTER(C.c_size_t)]
+    L.fmmbem_plan_upward_device.argtypes = [vp, i32, vp, vp, vp]
+    L.fmmbem_plan_downward_device.argtypes = [vp, i32, vp, vp, vp]
     L.fmmbem_plan_set_timing.argtypes = [vp, i32]
     L.fmmbem_plan_stats.argtypes = [vp, C.POINTER(Stats)]
     L.fmmbem_plan_get_perm.argtypes = [vp, vp]

@@ -60,6 +60,9 @@ struct DevicePlan {
   const int *near_ncols, *near_stride;
   const int64_t* near_off;
   double* near_val;
+  const int* xch_box;                                // sharded upward pass: private need_M boxes of every shard, by shard
+  int xch_ptr[9];                                    // ... xch_box[xch_ptr[r] .. xch_ptr[r+1]) belongs to shard r (<= 8 shards)
+  int xch_rank, xch_world, xch_max;                  // this shard, number of shards, largest per-shard count
   const int4* near_items;                            // SpMV work items {leaf, first row, rows, column-split?}, largest first
   int near_nitems;
   // boxes / expansions
@@ -97,6 +100,9 @@ hipError_t launch_near_matfree(const DevicePlan& d, hipStream_t s);
 hipError_t launch_scatter_y(const DevicePlan& d, double* y, hipStream_t s);
 hipError_t launch_p2m(const DevicePlan& d, int p, hipStream_t s);
 hipError_t launch_m2m_level(const DevicePlan& d, const ShiftOpDev& op, int p, int first, int count, hipStream_t s);
+// multipoles of the boxes a shard owns -> send buffer [idx][active slot][S(p)]; all shards' buffers -> M (own slice skipped)
+hipError_t launch_xch_pack(const DevicePlan& d, int p, double2* send, hipStream_t s);
+hipError_t launch_xch_unpack(const DevicePlan& d, int p, const double2* recv, hipStream_t s);
 hipError_t launch_mh_prep(const DevicePlan& d, int p, hipStream_t s);
 hipError_t launch_m2l(const DevicePlan& d, int p, hipStream_t s);
 hipError_t launch_l2l_level(const DevicePlan& d, const ShiftOpDev& op, int p, int first, int count, hipStream_t s);

@@ -328,9 +328,18 @@ std::string HostPlan::build(const HostOptions& o, int64_t n_panels, const double
   }
 
   // ---- shard: contiguous range of target leaves ----
+  std::vector<int> box_owner(nboxes, 0);                 // shard whose rows hold all of the box's bodies, -1 = spans shards
   {
     std::vector<int> cut;
     partition_leaves(*this, o.shard_world, cut);
+    if (o.shard_world > 1) {
+      std::vector<int64_t> rb(o.shard_world + 1, n);
+      for (int r = 0; r < o.shard_world; ++r) rb[r] = cut[r] < nl ? box_body_begin[leaf_box[cut[r]]] : n;
+      for (int b = 0; b < nboxes; ++b) {
+        const int r = int(std::upper_bound(rb.begin(), rb.end(), (int64_t)box_body_begin[b]) - rb.begin()) - 1;
+        box_owner[b] = (box_body_end[b] <= rb[r + 1]) ? r : -1;
+      }
+    }
     leaf_begin = cut[o.shard_rank];
     leaf_end = cut[o.shard_rank + 1];
     row_begin = leaf_begin < nl ? box_body_begin[leaf_box[leaf_begin]] : n;
@@ -350,16 +359,34 @@ std::string HostPlan::build(const HostOptions& o, int64_t n_panels, const double
   }
 
   // ---- operator lists ----
+  const bool su = o.shard_upward && o.shard_world > 1;
   for (int b = 0; b < nboxes; ++b) {
-    if (box_leaf[b] && need_M[b]) p2m_leaves.push_back(b);
+    if (box_leaf[b] && need_M[b] && (!su || box_owner[b] == o.shard_rank)) p2m_leaves.push_back(b);
     if (box_leaf[b] && has_L[b] && owned_L[b]) l2p_leaves.push_back(b);
   }
   m2m_level_ptr.assign(1, 0);
   m2m_ops = 0;
   for (int lev = nlevels - 1; lev >= 0; --lev) {       // deepest parents first
     for (int b = level_off[lev]; b < level_off[lev + 1]; ++b)
-      if (!box_leaf[b] && need_M[b]) { m2m_parents.push_back(b); m2m_ops += box_child_end[b] - box_child_begin[b]; }
+      if (!box_leaf[b] && need_M[b] && (!su || box_owner[b] == o.shard_rank)) {
+        m2m_parents.push_back(b);
+        m2m_ops += box_child_end[b] - box_child_begin[b];
+      }
     m2m_level_ptr.push_back((int)m2m_parents.size());
+  }
+  m2m_shared_ptr.assign(1, (int)m2m_parents.size());
+  xch_ptr.assign(1, 0);
+  if (su) {
+    for (int lev = nlevels - 1; lev >= 0; --lev) {     // parents spanning shards: every shard computes them
+      for (int b = level_off[lev]; b < level_off[lev + 1]; ++b)
+        if (!box_leaf[b] && need_M[b] && box_owner[b] < 0) { m2m_parents.push_back(b); m2m_ops += box_child_end[b] - box_child_begin[b]; }
+      m2m_shared_ptr.push_back((int)m2m_parents.size());
+    }
+    for (int r = 0; r < o.shard_world; ++r) {
+      for (int b = 0; b < nboxes; ++b)
+        if (need_M[b] && box_owner[b] == r) xch_box.push_back(b);
+      xch_ptr.push_back((int)xch_box.size());
+    }
   }
   l2l_level_ptr.assign(1, 0);
   l2l_ops = 0;

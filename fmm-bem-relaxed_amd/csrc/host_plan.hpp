@@ -34,6 +34,7 @@ struct HostOptions {
   unsigned ncrit = 64;
   int shard_rank = 0, shard_world = 1;
   int evaluator = 0;           // 0 FMM, 1 local only, 2 block diagonal (executor/make_executor.hpp:24-60)
+  bool shard_upward = false;   // shard_world > 1: P2M/M2M only for boxes this shard owns (+ the few spanning shards)
 };
 
 // Panels in TREE order, structure-of-arrays (what the kernels stream).
@@ -96,6 +97,11 @@ struct HostPlan {
   int leaf_begin = 0, leaf_end = 0;       // owned leaves
   int64_t row_begin = 0, row_end = 0;     // owned tree-order rows
   std::vector<uint8_t> owned_L;           // box is an owned leaf or an ancestor of one
+  // upward pass sharded by owner (opt.shard_upward): a box is private to the shard whose rows contain all its bodies,
+  // else shared.  p2m_leaves / m2m_parents[0 .. m2m_level_ptr.back()) then hold THIS shard's private boxes,
+  // m2m_parents[m2m_shared_ptr[l] .. m2m_shared_ptr[l+1]) the shared parents of one level (deepest first), and
+  // xch_box[xch_ptr[r] .. xch_ptr[r+1]) the private need_M boxes of shard r (what it sends in the all-gather).
+  std::vector<int> m2m_shared_ptr, xch_ptr, xch_box;
   int64_t near_nnz_owned = 0, m2l_pairs_owned = 0;
 
   PanelSoA panels;                        // tree order

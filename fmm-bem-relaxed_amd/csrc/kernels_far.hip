@@ -546,6 +546,48 @@ hipError_t launch_m2m_level(const DevicePlan& d, const ShiftOpDev& op, int p, in
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Sharded upward pass (multi-GPU): every shard computes P2M/M2M only for the boxes whose bodies are all its own,
+// the multipoles travel in ONE all-gather (the caller's collective, equal chunks of xch_max boxes), and the
+// few boxes spanning shards are then translated by everybody.  pack: M of my boxes -> send; unpack: every other
+// shard's chunk -> M.  Layout of a chunk: [box index within the shard][active slot][S(p)] complex.
+// ---------------------------------------------------------------------------------------------
+__global__ void xch_pack_kernel(DevicePlan d, const int P, double2* __restrict__ send) {
+  const int S = P * (P + 1) / 2, per = d.n_act * S;
+  const int first = d.xch_ptr[d.xch_rank], count = d.xch_ptr[d.xch_rank + 1] - first;
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t >= (int64_t)count * per) return;
+  const int idx = (int)(t / per), rem = (int)(t - (int64_t)idx * per), a = rem / S, i = rem - a * S;
+  send[t] = d.M[((size_t)d.xch_box[first + idx] * d.nslots + d.act[a]) * d.s_max + i];
+}
+
+__global__ void xch_unpack_kernel(DevicePlan d, const int P, const double2* __restrict__ recv) {
+  const int S = P * (P + 1) / 2, per = d.n_act * S;
+  const int total = d.xch_ptr[d.xch_world];
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t >= (int64_t)total * per) return;
+  const int g = (int)(t / per), rem = (int)(t - (int64_t)g * per), a = rem / S, i = rem - a * S;
+  int r = 0;
+  while (g >= d.xch_ptr[r + 1]) ++r;
+  if (r == d.xch_rank) return;                          // my own boxes are already in M
+  const int idx = g - d.xch_ptr[r];
+  d.M[((size_t)d.xch_box[g] * d.nslots + d.act[a]) * d.s_max + i] = recv[((size_t)r * d.xch_max + idx) * per + rem];
+}
+
+hipError_t launch_xch_pack(const DevicePlan& d, int p, double2* send, hipStream_t s) {
+  const int64_t n = (int64_t)(d.xch_ptr[d.xch_rank + 1] - d.xch_ptr[d.xch_rank]) * d.n_act * (p * (p + 1) / 2);
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(xch_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d, p, send);
+  return hipGetLastError();
+}
+
+hipError_t launch_xch_unpack(const DevicePlan& d, int p, const double2* recv, hipStream_t s) {
+  const int64_t n = (int64_t)d.xch_ptr[d.xch_world] * d.n_act * (p * (p + 1) / 2);
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(xch_unpack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d, p, recv);
+  return hipGetLastError();
+}
+
 hipError_t launch_mh_prep(const DevicePlan& d, int p, hipStream_t s) {
   if (hipError_t e = upload_constants_once(); e != hipSuccess) return e;
   if (d.n_mh <= 0) return hipSuccess;

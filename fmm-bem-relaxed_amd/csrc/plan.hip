@@ -125,6 +125,9 @@ struct fmmbem_plan {
   bool on_device = false;
   std::vector<void*> allocs;
   std::vector<std::pair<int, int>> m2m_launch, l2l_launch;     // (first, count) per level
+  std::vector<std::pair<int, int>> m2m_shared_launch;          // sharded upward pass: parents spanning shards
+  bool split_upward = false;                                   // P2M/M2M sharded by owner, multipoles all-gathered by the caller
+  unsigned pending_mask = 0;                                   // stages recorded by the upward half of a split execute
   std::vector<ShiftOpDev> up_ops, down_ops;                    // M2M / L2L operators, index p - 1
   int64_t near_bytes = 0;
   int64_t n_classes = 0;
@@ -166,7 +169,8 @@ struct fmmbem_plan {
     return FMMBEM_OK;
   }
   int to_device();
-  int run(int p, const double* d_x, double* d_y, hipStream_t s, bool near_only);
+  // phase 0: whole matvec; 1: upward half (gather, P2M, M2M of owned boxes, pack -> xbuf); 2: the rest (xbuf = gathered)
+  int run(int p, const double* d_x, double* d_y, hipStream_t s, bool near_only, int phase = 0, double* xbuf = nullptr);
   ~fmmbem_plan() {
     if (on_device) {
       (void)hipSetDevice(opts.device);
@@ -328,6 +332,19 @@ int fmmbem_plan::to_device() {
   for (size_t l = 0; l + 1 < hp.l2l_level_ptr.size(); ++l)
     if (hp.l2l_level_ptr[l + 1] > hp.l2l_level_ptr[l])
       l2l_launch.emplace_back(hp.l2l_level_ptr[l], hp.l2l_level_ptr[l + 1] - hp.l2l_level_ptr[l]);
+  for (size_t l = 0; l + 1 < hp.m2m_shared_ptr.size(); ++l)
+    if (hp.m2m_shared_ptr[l + 1] > hp.m2m_shared_ptr[l])
+      m2m_shared_launch.emplace_back(hp.m2m_shared_ptr[l], hp.m2m_shared_ptr[l + 1] - hp.m2m_shared_ptr[l]);
+  // sharded upward pass: who sends which multipoles
+  split_upward = hp.opt.shard_upward && hp.opt.shard_world > 1;
+  d.xch_rank = hp.opt.shard_rank; d.xch_world = split_upward ? hp.opt.shard_world : 0; d.xch_max = 0;
+  for (int r = 0; r < 9; ++r) d.xch_ptr[r] = 0;
+  if (split_upward) {
+    if (hp.opt.shard_world > 8) return fail(FMMBEM_ERR_UNSUPPORTED, "sharded upward pass: at most 8 shards");
+    for (int r = 0; r <= hp.opt.shard_world; ++r) d.xch_ptr[r] = hp.xch_ptr[r];
+    for (int r = 0; r < hp.opt.shard_world; ++r) d.xch_max = std::max(d.xch_max, hp.xch_ptr[r + 1] - hp.xch_ptr[r]);
+  }
+  TRY(upload(hp.xch_box, &d.xch_box));
 
   // parent<->child translation classes and their regular-harmonic tables
   {
@@ -448,15 +465,18 @@ int fmmbem_plan::to_device() {
   return FMMBEM_OK;
 }
 
-int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool near_only) {
+int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool near_only, int phase, double* xbuf) {
   if (!on_device) return fail(FMMBEM_ERR_NO_DEVICE, "plan was built host-only; there is no CPU execution path");
   if (p < 1 || p > hp.opt.p_max) return fail(FMMBEM_ERR_INVALID, "p outside [1, p_max]");
-  if (!d_x || !d_y) return fail(FMMBEM_ERR_INVALID, "null vector");
+  if ((phase != 2 && !d_x) || (phase != 1 && !d_y)) return fail(FMMBEM_ERR_INVALID, "null vector");
+  if (split_upward && phase == 0 && !near_only)
+    return fail(FMMBEM_ERR_UNSUPPORTED, "plan shards the upward pass: use fmmbem_plan_upward_device / _downward_device");
+  if (phase != 0 && (!split_upward || !xbuf)) return fail(FMMBEM_ERR_INVALID, "split execute needs shard_upward and an exchange buffer");
   HIP_TRY(hipSetDevice(opts.device));
   const bool tm = timing;
   const int64_t ring = ev_count % kRing;
   hipEvent_t* set = tm ? &ev[(size_t)ring * 2 * kStages] : nullptr;
-  unsigned mask = 0;
+  unsigned mask = phase == 2 ? pending_mask : 0;
   // stage i runs on stream st: begin/end events bracket exactly that kernel (or level sequence)
   auto begin = [&](int i, hipStream_t st) -> hipError_t { return tm ? hipEventRecord(set[2 * i], st) : hipSuccess; };
   auto end = [&](int i, hipStream_t st) -> hipError_t {
@@ -466,10 +486,23 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
   // Stage order of the reference (EvalInteractionLazySparse.hpp:120-168): near-field SpMV, then P2M, M2M,
   // M2L, L2L, L2P.  The near field only meets the far field in y, so it is launched on a second stream next
   // to M2L (an HBM-bound kernel beside an FMA-bound one); the two are joined before L2P adds into y.
-  const bool overlap = overlap_near && !near_only;
-  HIP_TRY(begin(0, s));
-  HIP_TRY(launch_gather_x(d, d_x, s));
-  HIP_TRY(end(0, s));
+  const bool overlap = overlap_near && !near_only && phase == 0;
+  if (phase != 2) {
+    HIP_TRY(begin(0, s));
+    HIP_TRY(launch_gather_x(d, d_x, s));
+    HIP_TRY(end(0, s));
+  }
+  if (phase == 1) {                                    // upward half: my leaves, my boxes, pack what the others need
+    HIP_TRY(begin(3, s));
+    if (d.kernel == FMMBEM_KERNEL_STOKES_BEM) HIP_TRY(launch_p2m_stokes(d, p, s)); else HIP_TRY(launch_p2m(d, p, s));
+    HIP_TRY(end(3, s));
+    HIP_TRY(begin(4, s));
+    for (auto [first, count] : m2m_launch) HIP_TRY(launch_m2m_level(d, up_ops[p - 1], p, first, count, s));
+    HIP_TRY(launch_xch_pack(d, p, reinterpret_cast<double2*>(xbuf), s));
+    HIP_TRY(end(4, s));
+    pending_mask = mask;
+    return FMMBEM_OK;
+  }
   auto near_field = [&](hipStream_t ns) -> int {
     HIP_TRY(begin(1, ns));
     if (opts.sparse_local) HIP_TRY(launch_near_spmv(d, ns)); else HIP_TRY(launch_near_matfree(d, ns));
@@ -482,13 +515,19 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
   };
   if (!overlap) TRY(near_field(s));
   if (!near_only) {
-    HIP_TRY(begin(3, s));
-    if (d.kernel == FMMBEM_KERNEL_STOKES_BEM) HIP_TRY(launch_p2m_stokes(d, p, s)); else HIP_TRY(launch_p2m(d, p, s));
-    HIP_TRY(end(3, s));
-    HIP_TRY(begin(4, s));
-    for (auto [first, count] : m2m_launch) HIP_TRY(launch_m2m_level(d, up_ops[p - 1], p, first, count, s));
-    HIP_TRY(end(4, s));
+    if (phase == 0) {
+      HIP_TRY(begin(3, s));
+      if (d.kernel == FMMBEM_KERNEL_STOKES_BEM) HIP_TRY(launch_p2m_stokes(d, p, s)); else HIP_TRY(launch_p2m(d, p, s));
+      HIP_TRY(end(3, s));
+      HIP_TRY(begin(4, s));
+      for (auto [first, count] : m2m_launch) HIP_TRY(launch_m2m_level(d, up_ops[p - 1], p, first, count, s));
+      HIP_TRY(end(4, s));
+    }
     HIP_TRY(begin(5, s));
+    if (phase == 2) {                                  // the other shards' multipoles, then the boxes spanning shards
+      HIP_TRY(launch_xch_unpack(d, p, reinterpret_cast<const double2*>(xbuf), s));
+      for (auto [first, count] : m2m_shared_launch) HIP_TRY(launch_m2m_level(d, up_ops[p - 1], p, first, count, s));
+    }
     HIP_TRY(launch_mh_prep(d, p, s));
     HIP_TRY(end(5, s));
     if (overlap) {                                     // fork: the near field streams HBM while M2L saturates the FMA pipes
@@ -552,6 +591,7 @@ int fmmbem_plan_create(const fmmbem_options* opts, size_t n_panels, const double
   ho.p_max = opts->p_max; ho.quad_k = opts->quad_k; ho.theta = opts->theta; ho.ncrit = opts->ncrit;
   ho.shard_rank = opts->shard_rank; ho.shard_world = opts->shard_world < 1 ? 1 : opts->shard_world;
   ho.evaluator = opts->evaluator;
+  ho.shard_upward = opts->shard_upward != 0;
   const double t0 = now_ms();
   std::string err;
   try {
@@ -580,6 +620,23 @@ void fmmbem_plan_destroy(fmmbem_plan* plan) { delete plan; }
 int fmmbem_plan_execute_device(fmmbem_plan* plan, int p, const double* d_x, double* d_y, void* stream) {
   if (!plan) return fail(FMMBEM_ERR_INVALID, "null plan");
   return plan->run(p, d_x, d_y, static_cast<hipStream_t>(stream), false);
+}
+
+int fmmbem_plan_exchange_doubles(const fmmbem_plan* plan, int p, size_t* per_shard) {
+  if (!plan || !per_shard) return fail(FMMBEM_ERR_INVALID, "null argument");
+  if (p < 1 || p > plan->hp.opt.p_max) return fail(FMMBEM_ERR_INVALID, "p outside [1, p_max]");
+  *per_shard = plan->split_upward ? (size_t)plan->d.xch_max * plan->d.n_act * (p * (p + 1) / 2) * 2 : 0;
+  return FMMBEM_OK;
+}
+
+int fmmbem_plan_upward_device(fmmbem_plan* plan, int p, const double* d_x, double* d_send, void* stream) {
+  if (!plan) return fail(FMMBEM_ERR_INVALID, "null plan");
+  return plan->run(p, d_x, nullptr, static_cast<hipStream_t>(stream), false, 1, d_send);
+}
+
+int fmmbem_plan_downward_device(fmmbem_plan* plan, int p, const double* d_recv, double* d_y, void* stream) {
+  if (!plan) return fail(FMMBEM_ERR_INVALID, "null plan");
+  return plan->run(p, nullptr, d_y, static_cast<hipStream_t>(stream), false, 2, const_cast<double*>(d_recv));
 }
 
 int fmmbem_plan_near_device(fmmbem_plan* plan, const double* d_x, double* d_y, void* stream) {

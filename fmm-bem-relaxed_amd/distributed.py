@@ -1,11 +1,15 @@
 """Multi-GPU form of the matvec: the target-leaf list is cut into contiguous shards, one per rank
-(one process per GPU); every rank builds the same tree, replicates the cheap upward pass, owns a
-slice of the near blocks and of the M2L/L2L/L2P work, and produces a result vector that is zero
-outside its rows.  ONE collective per matvec -- an all-reduce(sum) of the N-vector over RCCL/xGMI --
-makes the full result available on every rank (what GMRES needs for its next Arnoldi step).
+(one process per GPU); every rank builds the same tree, owns a slice of the near blocks and of the
+M2L/L2L/L2P work, and produces a result vector that is zero outside its rows.  An all-reduce(sum) of the
+N-vector over RCCL/xGMI makes the full result available on every rank (what GMRES needs for its next
+Arnoldi step).  The upward pass is either repeated by every rank (SURVEY.md section 8e as written: one
+collective per matvec) or -- shard_upward, the default -- computed by the owners of the boxes and shared
+with ONE all-gather of the multipoles (60 MB at N = 1M, p = 10) in front of M2L.
 
 The reference has no distributed code at all; this is the design of section 8(e).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -20,16 +24,20 @@ class ShardedFMM:
     """
 
     def __init__(self, K, panels, opts=None, bc=None, p_max=None, group=None, device=None,
-                 host_only=False, local_execute=None):
+                 host_only=False, local_execute=None, shard_upward=None):
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         if device is None:
             device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+        if shard_upward is None:
+            shard_upward = os.environ.get("FMMBEM_SHARD_UPWARD", "1") != "0"
+        self.split = bool(shard_upward) and self.world > 1 and local_execute is None
         self.plan = FMM_plan(K, panels, opts, bc=bc, p_max=p_max, device=device,
-                             shard=(self.rank, self.world), host_only=host_only)
+                             shard=(self.rank, self.world), host_only=host_only, shard_upward=self.split)
         self.n = self.plan.n
         self._local = local_execute if local_execute is not None else self.plan.execute_torch
+        self._xbuf = {}                                   # p -> (send, recv) exchange buffers
 
     def kernel(self):
         return self.plan.kernel()
@@ -42,9 +50,22 @@ class ShardedFMM:
         s = self.plan.stats()
         return self.plan.perm()[s["owned_row_begin"]:s["owned_row_end"]]
 
-    def execute(self, x):
+    def execute(self, x, out=None):
         """x: full charge vector, replicated on every rank (torch tensor). Returns the full result."""
-        y = self._local(x)
+        if not self.split:
+            y = self._local(x) if out is None else self._local(x, out=out)
+        else:
+            p = self.plan.kernel().P
+            if p not in self._xbuf:
+                per = self.plan.exchange_doubles(p)
+                self._xbuf[p] = (torch.empty(per, dtype=torch.float64, device=x.device),
+                                 torch.empty(per * self.world, dtype=torch.float64, device=x.device))
+            send, recv = self._xbuf[p]
+            y = torch.empty_like(x) if out is None else out
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+            self.plan.upward_device(x.data_ptr(), send.data_ptr(), stream, p)
+            dist.all_gather_into_tensor(recv, send, group=self.group)
+            self.plan.downward_device(recv.data_ptr(), y.data_ptr(), stream, p)
         if self.world > 1:
             dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.group)
         return y

@@ -129,7 +129,8 @@ class FMM_plan:
     intends to relax p upward).
     """
 
-    def __init__(self, K, panels, opts=None, bc=None, p_max=None, device=0, shard=(0, 1), host_only=False):
+    def __init__(self, K, panels, opts=None, bc=None, p_max=None, device=0, shard=(0, 1), host_only=False,
+                 shard_upward=False):
         opts = opts if opts is not None else FMMOptions()
         # executor/make_executor.hpp:24-60: lazy_evaluation wins, then local_evaluation, then block_diagonal; the
         # non-lazy upward/interact/downward evaluators compute the same operator as the lazy ones
@@ -160,6 +161,8 @@ class FMM_plan:
             o.quad_k_fine = K.K_fine
             self.dof = 3
         o.shard_rank, o.shard_world = int(shard[0]), int(shard[1])
+        o.shard_upward = 1 if (shard_upward and int(shard[1]) > 1) else 0
+        self.shard_upward = bool(o.shard_upward)
         self.p_max = o.p_max
         bcp = None
         if bc is not None:
@@ -197,6 +200,20 @@ class FMM_plan:
     def execute_device(self, x_ptr, y_ptr, stream=0, p=None):
         _capi.check(_capi.lib().fmmbem_plan_execute_device(self._h, self._K.P if p is None else int(p),
                                                            C.c_void_p(x_ptr), C.c_void_p(y_ptr), C.c_void_p(stream)))
+
+    # ---- split execute of a plan that shards the upward pass (include/fmmbem.h) ----
+    def exchange_doubles(self, p=None):
+        n = C.c_size_t(0)
+        _capi.check(_capi.lib().fmmbem_plan_exchange_doubles(self._h, self._K.P if p is None else int(p), C.byref(n)))
+        return n.value
+
+    def upward_device(self, x_ptr, send_ptr, stream=0, p=None):
+        _capi.check(_capi.lib().fmmbem_plan_upward_device(self._h, self._K.P if p is None else int(p), C.c_void_p(x_ptr),
+                                                          C.c_void_p(send_ptr), C.c_void_p(stream)))
+
+    def downward_device(self, recv_ptr, y_ptr, stream=0, p=None):
+        _capi.check(_capi.lib().fmmbem_plan_downward_device(self._h, self._K.P if p is None else int(p), C.c_void_p(recv_ptr),
+                                                            C.c_void_p(y_ptr), C.c_void_p(stream)))
 
     def near_device(self, x_ptr, y_ptr, stream=0):
         _capi.check(_capi.lib().fmmbem_plan_near_device(self._h, C.c_void_p(x_ptr), C.c_void_p(y_ptr), C.c_void_p(stream)))

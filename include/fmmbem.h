@@ -74,7 +74,10 @@ typedef struct {
                                * kernel/StokesSphericalBEM.hpp:139-141; ctor default 25, driver 19)  */
   int32_t  evaluator;         /* fmmbem_evaluator: which branch of make_evaluators the plan takes   */
   double   mu;                /* Stokes: viscosity (StokesSphericalBEM(p,k,mu), :131)               */
-  int32_t  reserved[2];
+  int32_t  shard_upward;      /* shard_world > 1: also shard P2M/M2M by owner; the multipoles are exchanged by ONE
+                               * all-gather the caller performs between fmmbem_plan_upward_device and
+                               * fmmbem_plan_downward_device (0: every shard repeats the whole upward pass)   */
+  int32_t  reserved;
 } fmmbem_options;
 
 /* Statistics of a plan and of its last execute (times in milliseconds, device-side HIP events). */
@@ -144,6 +147,15 @@ int fmmbem_plan_get_pairs(const fmmbem_plan *plan, int which, int32_t *out, int6
  * receives the row length. */
 int fmmbem_plan_get_near_row(const fmmbem_plan *plan, int64_t row, uint32_t *cols, double *vals,
                              int64_t *n);
+/* ---- split execute of a plan created with shard_upward = 1 and shard_world > 1 (no reference counterpart:
+ * the reference is single-node) ----------------------------------------------------------
+ *   upward:   x -> P2M and M2M of the boxes this shard owns -> d_send (exchange_doubles(p) doubles)
+ *   caller:   all-gather of the shards' d_send into d_recv (shard_world x exchange_doubles(p), rank order)
+ *   downward: d_recv -> the remaining M2M, M2L, L2L, L2P and the near field -> y (zero outside the owned rows) */
+int fmmbem_plan_exchange_doubles(const fmmbem_plan *plan, int p, size_t *per_shard);
+int fmmbem_plan_upward_device(fmmbem_plan *plan, int p, const double *d_x, double *d_send, void *stream);
+int fmmbem_plan_downward_device(fmmbem_plan *plan, int p, const double *d_recv, double *d_y, void *stream);
+
 /* Multipole (which=0) or local (which=1) coefficients of the last execute for every box:
  * out[box][slot][p(p+1)/2][re,im]; Laplace: 2 slots (G, dG/dn); Stokes: 8 slots (M[2][4]). */
 int fmmbem_plan_get_expansions(const fmmbem_plan *plan, int which, int p, double *out);
