@@ -96,6 +96,7 @@ struct DevicePlan {
 hipError_t launch_near_assemble(const DevicePlan& d, hipStream_t s);
 hipError_t launch_gather_x(const DevicePlan& d, const double* x, hipStream_t s);
 hipError_t launch_near_spmv(const DevicePlan& d, hipStream_t s);
+hipError_t launch_near_diag(const DevicePlan& d, const int* selfcol, double* out, hipStream_t s);
 hipError_t launch_near_matfree(const DevicePlan& d, hipStream_t s);
 hipError_t launch_scatter_y(const DevicePlan& d, double* y, hipStream_t s);
 hipError_t launch_p2m(const DevicePlan& d, int p, hipStream_t s);

@@ -522,6 +522,25 @@ __global__ __launch_bounds__(kSpmvWaves * kWave, kSpmvOcc) void near_spmv_kernel
 
 }  // namespace
 
+// diag[original unknown] = A_near[u,u]: the self-interaction K(s,s) that Preconditioners::Diagonal divides by
+// (examples/BEM/Preconditioner.hpp:19-42).  selfcol[leaf] = first column of the leaf's own panels in its block.
+__global__ void near_diag_kernel(DevicePlan d, const int* __restrict__ selfcol, double* __restrict__ out) {
+  const int t = d.leaf_begin + blockIdx.x;
+  const int dof = d.dof, nrows = dof * d.leaf_nrows[t], stride = d.near_stride[t], row0 = d.leaf_row0[t];
+  const double* blk = d.near_val + d.near_off[t];
+  for (int r = threadIdx.x; r < nrows; r += blockDim.x) {
+    const int panel = row0 + r / dof;
+    out[(int64_t)d.perm[panel] * dof + r % dof] = blk[(int64_t)r * stride + selfcol[t] + r];
+  }
+}
+
+hipError_t launch_near_diag(const DevicePlan& d, const int* selfcol, double* out, hipStream_t s) {
+  const int nb = d.leaf_end - d.leaf_begin;
+  if (nb <= 0) return hipSuccess;
+  hipLaunchKernelGGL(near_diag_kernel, dim3(nb), dim3(64), 0, s, d, selfcol, out);
+  return hipGetLastError();
+}
+
 hipError_t launch_near_assemble(const DevicePlan& d, hipStream_t s) {
   const int nb = d.leaf_end - d.leaf_begin;
   if (nb <= 0) return hipSuccess;

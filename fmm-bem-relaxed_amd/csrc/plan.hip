@@ -799,6 +799,40 @@ int fmmbem_plan_get_near_row(const fmmbem_plan* plan, int64_t row, uint32_t* col
   return FMMBEM_OK;
 }
 
+int fmmbem_plan_get_diagonal(const fmmbem_plan* plan, double* out) {
+  if (!plan || !out) return fail(FMMBEM_ERR_INVALID, "null argument");
+  if (!plan->on_device) return fail(FMMBEM_ERR_NO_DEVICE, "near values live on the device");
+  if (!plan->opts.sparse_local) return fail(FMMBEM_ERR_INVALID, "matrix-free plan holds no near matrix");
+  const HostPlan& h = plan->hp;
+  const int dof = plan->d.dof;
+  HIP_TRY(hipSetDevice(plan->opts.device));
+  std::vector<int> selfcol(h.nleaves(), 0);
+  for (int l = h.leaf_begin; l < h.leaf_end; ++l) {
+    int col = 0;
+    bool found = false;
+    for (int64_t s = h.near_ptr[l]; s < h.near_ptr[l + 1]; ++s) {
+      if (h.near_src[s] == l) { found = true; break; }
+      const int sb = h.leaf_box[h.near_src[s]];
+      col += h.box_body_end[sb] - h.box_body_begin[sb];
+    }
+    if (!found) return fail(FMMBEM_ERR_INVALID, "internal: a leaf without its self block");
+    selfcol[l] = dof * col;
+  }
+  int* d_sc = nullptr;
+  double* d_out = nullptr;
+  const size_t nb = sizeof(double) * (size_t)h.n * dof;
+  HIP_TRY(hipMalloc(&d_sc, sizeof(int) * selfcol.size()));
+  if (hipMalloc(&d_out, nb) != hipSuccess) { (void)hipFree(d_sc); return fail(FMMBEM_ERR_ALLOC, "device allocation failed"); }
+  hipError_t e = hipMemcpy(d_sc, selfcol.data(), sizeof(int) * selfcol.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemset(d_out, 0, nb);                       // rows of other shards stay zero
+  if (e == hipSuccess) e = launch_near_diag(plan->d, d_sc, d_out, plan->own_stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(plan->own_stream);
+  if (e == hipSuccess) e = hipMemcpy(out, d_out, nb, hipMemcpyDeviceToHost);
+  (void)hipFree(d_sc); (void)hipFree(d_out);
+  if (e != hipSuccess) return fail(FMMBEM_ERR_HIP, hipGetErrorString(e));
+  return FMMBEM_OK;
+}
+
 int fmmbem_plan_get_expansions(const fmmbem_plan* plan, int which, int p, double* out) {
   if (!plan || !out) return fail(FMMBEM_ERR_INVALID, "null argument");
   if (!plan->on_device) return fail(FMMBEM_ERR_NO_DEVICE, "expansions live on the device");

@@ -269,6 +269,12 @@ class FMM_plan:
             vals.ctypes.data_as(C.c_void_p) if values else None, C.byref(n)))
         return cols, vals
 
+    def diagonal(self):
+        """K(s,s) of every unknown, original order (the entries Preconditioners::Diagonal inverts)."""
+        out = np.empty(self.n * self.dof)
+        _capi.check(_capi.lib().fmmbem_plan_get_diagonal(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def expansions(self, which, p=None):
         p = self._K.P if p is None else p
         nb = self.stats()["n_boxes"]

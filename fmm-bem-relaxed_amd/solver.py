@@ -183,6 +183,17 @@ def fgmres(MV, x, b, opts, M, log=None):
     return x, it, abs(resid)
 
 
+class Diagonal:
+    """Preconditioners::Diagonal (examples/BEM/Preconditioner.hpp:19-42): y = x / K(s,s), panel by panel."""
+
+    def __init__(self, plan, device=None):
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        self.recip = (1.0 / torch.from_numpy(plan.diagonal())).to(dev)
+
+    def __call__(self, v):
+        return v * self.recip
+
+
 class _InnerSolver:
     """Preconditioner = a few GMRES steps on a near-field-only operator (examples/BEM/LocalPC.hpp:26-59,
     BlockDiagonalPC.hpp:16-60): options.residual = 1e-1, variable_p = false, max_iters = 1, restart 50."""

@@ -147,6 +147,11 @@ int fmmbem_plan_get_pairs(const fmmbem_plan *plan, int which, int32_t *out, int6
  * receives the row length. */
 int fmmbem_plan_get_near_row(const fmmbem_plan *plan, int64_t row, uint32_t *cols, double *vals,
                              int64_t *n);
+/* Diagonal of the assembled near matrix = the self-interactions K(s,s) that Preconditioners::Diagonal inverts
+ * (examples/BEM/Preconditioner.hpp:19-42; examples/LaplaceBEM.cpp:241-244): out[n_panels * dof], original order;
+ * rows of other shards are returned as zero. */
+int fmmbem_plan_get_diagonal(const fmmbem_plan *plan, double *out);
+
 /* ---- split execute of a plan created with shard_upward = 1 and shard_world > 1 (no reference counterpart:
  * the reference is single-node) ----------------------------------------------------------
  *   upward:   x -> P2M and M2M of the boxes this shard owns -> d_send (exchange_doubles(p) doubles)

@@ -79,3 +79,32 @@ def test_stokes_local_matches_oracle(fb, oracle_mod):
     u = pl.execute(f)
     uo = oracle_mod.StokesOracle(v, K=4, K_fine=19, mu=1e-3, evaluator=1).matvec(f, 6)
     assert np.linalg.norm(u - uo) <= 1e-13 * np.linalg.norm(uo)
+
+
+@pytest.mark.gpu
+def test_diagonal_preconditioner(fb, oracle_mod):
+    """Preconditioners::Diagonal (examples/BEM/Preconditioner.hpp:19-42, LaplaceBEM.cpp:241-244, 287-296): GMRES with
+    z = M(v) = v / K(s,s).  The diagonal comes out of the assembled near matrix; K(s,s) from the oracle is the check."""
+    import torch
+    v = fb.unit_sphere(5)
+    n = len(v)
+    bc = (np.arange(n) % 3 == 0).astype(np.uint8)
+    plan = fb.FMM_plan(fb.LaplaceSphericalBEM(10, 3), v, bc=bc)
+    dg = plan.diagonal()
+    o = oracle_mod.Oracle(v, bc=bc)
+    ref = o.kernel_entries(np.arange(n), np.arange(n))
+    assert np.max(np.abs(dg - ref)) <= 1e-14 * np.max(np.abs(ref))
+    # the same from a shard: its own rows, zeros elsewhere
+    part = fb.FMM_plan(fb.LaplaceSphericalBEM(10, 3), v, bc=bc, shard=(1, 2))
+    dp = part.diagonal()
+    own = dp != 0
+    assert 0 < own.sum() < n and np.array_equal(dp[own], dg[own])
+    # GMRES with it: same solution as without (right preconditioning in the reference's GMRES, :196-241)
+    pot = fb.FMM_plan(fb.LaplaceSphericalBEM(10, 3), v)
+    rhs = fb.FMM_plan(fb.LaplaceSphericalBEM(10, 3), v, bc=np.ones(n, dtype=np.uint8))
+    b = rhs.execute_torch(torch.ones(n, dtype=torch.float64, device="cuda"))
+    so = fb.SolverOptions(residual=1e-6, max_iters=100, max_p=10)
+    x1, it1, r1 = fb.gmres(pot, torch.zeros_like(b), b, so, M=fb.Diagonal(pot))
+    x0, it0, r0 = fb.gmres(pot, torch.zeros_like(b), b, so)
+    assert r1 < 1e-6 and abs(it1 - it0) <= 3
+    assert float(torch.linalg.vector_norm(x1 - x0) / torch.linalg.vector_norm(x0)) < 1e-4
