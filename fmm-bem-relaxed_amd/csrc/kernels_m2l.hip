@@ -234,6 +234,85 @@ __global__ __launch_bounds__((Shape<P, NS_>::THREADS)) void m2l_kernel(DevicePla
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Low orders (p <= 4, where the relaxed solver spends most of its iterations): with 1-10 outputs per box the kernel
+// above is a chain of per-source latencies (scalar Mh loads, table scatter, two barriers: 0.32 ms at p = 1 for
+// 1.96 M pairs).  Here a wavefront takes one target and its LANES take the sources: each lane gathers its source's
+// Mh, class table and phases straight from L2, forms all S outputs in registers, and the lanes are summed by a
+// fixed butterfly.  Same algebra: sum_m Z^m sum_n Mh[n,m] gh[j+n, m-k], times Z^{-k}.
+// ---------------------------------------------------------------------------------------------
+template <int P>
+__global__ __launch_bounds__(kM2LTargets * kWave) void m2l_small_kernel(DevicePlan d) {
+  constexpr int S = P * (P + 1) / 2;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int ti = blockIdx.x * kM2LTargets + threadIdx.x / kWave;
+  if (ti >= d.n_m2l_tgt) return;                       // whole wavefront
+  const int tgt = d.m2l_tgt[ti];
+  const int slot = d.act[blockIdx.y];
+  const int pb = d.m2l_ptr[tgt], pe = d.m2l_ptr[tgt + 1];
+  double2 acc[S];
+#pragma unroll
+  for (int i = 0; i < S; ++i) acc[i] = {0, 0};
+  for (int pi = pb + lane; pi < pe; pi += kWave) {
+    const int src = d.m2l_src[pi], cls = d.m2l_cls[pi];
+    const double2* mh = d.Mh + ((size_t)src * d.nslots + slot) * d.s_max;     // order-major: [am*P - am(am-1)/2 + n - am]
+    const double* G = d.m2l_g + (size_t)cls * d.g_max;                         // [r(r+1)/2 + a]
+    const double2* Z = d.m2l_z + (size_t)cls * d.p_max;                        // Z^m
+    double2 mv[S], z[P];
+    double g[(2 * P - 1) * P];                         // r <= 2P-2
+#pragma unroll
+    for (int i = 0; i < S; ++i) mv[i] = mh[i];
+#pragma unroll
+    for (int i = 0; i < P; ++i) z[i] = Z[i];
+#pragma unroll
+    for (int i = 0; i < (2 * P - 1) * P; ++i) g[i] = G[i];
+#pragma unroll
+    for (int j = 0; j < P; ++j)
+#pragma unroll
+      for (int k = 0; k <= j; ++k) {
+        double2 as = {0, 0};
+#pragma unroll
+        for (int m = -(P - 1); m <= P - 1; ++m) {
+          const int am = m < 0 ? -m : m;
+          const double sr = (m < 0 && (am & 1)) ? -1.0 : 1.0, si = (m < 0) ? -sr : 1.0;   // Mh[n,-m] = (-1)^m conj
+          double tr = 0, tq = 0;
+#pragma unroll
+          for (int n = am; n < P; ++n) {
+            const int c = m - k, a = c < 0 ? -c : c, r = j + n;
+            const double gh = ((c < 0 && (a & 1)) ? -1.0 : 1.0) * g[r * (r + 1) / 2 + a];
+            const double2 v = mv[am * P - am * (am - 1) / 2 + n - am];
+            tr = fma(sr * v.x, gh, tr);
+            tq = fma(si * v.y, gh, tq);
+          }
+          const double er = z[am].x, ei = (m < 0 ? -1.0 : 1.0) * z[am].y;       // Z^m, Z^{-m} = conj
+          as.x = fma(er, tr, as.x); as.x = fma(-ei, tq, as.x);
+          as.y = fma(er, tq, as.y); as.y = fma(ei, tr, as.y);
+        }
+        double2& t = acc[j * (j + 1) / 2 + k];          // += Z^{-k} * as = conj(Z^k) * as
+        t.x = fma(z[k].x, as.x, t.x); t.x = fma(z[k].y, as.y, t.x);
+        t.y = fma(z[k].x, as.y, t.y); t.y = fma(-z[k].y, as.x, t.y);
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < S; ++i) {
+#pragma unroll
+    for (int off = 32; off; off >>= 1) {
+      acc[i].x += __shfl_xor(acc[i].x, off, kWave);
+      acc[i].y += __shfl_xor(acc[i].y, off, kWave);
+    }
+  }
+  double2* L = d.L + ((size_t)tgt * d.nslots + slot) * d.s_max;
+#pragma unroll
+  for (int j = 0; j < P; ++j)
+#pragma unroll
+    for (int k = 0; k <= j; ++k)
+      if (lane == j * (j + 1) / 2 + k) {
+        const double f = ((j & 1) ? -1.0 : 1.0) * d.tabA[j * j + j + k];
+        const double2 a = acc[j * (j + 1) / 2 + k];
+        L[j * (j + 1) / 2 + k] = mul_i_pow(double2{a.x * f, a.y * f}, -k);
+      }
+}
+
 #define FMMBEM_DISPATCH_P(p, ...)                                                                     \
   switch (p) {                                                                                         \
     case 1: { constexpr int PP = 1; __VA_ARGS__; } break;   case 2: { constexpr int PP = 2; __VA_ARGS__; } break;    \
@@ -255,8 +334,12 @@ hipError_t launch_m2l(const DevicePlan& d, int p, hipStream_t s) {
   hipLaunchKernelGGL((m2l_kernel<PP, NSV>),                                                                \
                      dim3((d.n_m2l_tgt + Shape<PP, NSV>::TARGETS - 1) / Shape<PP, NSV>::TARGETS, d.n_act),  \
                      dim3(Shape<PP, NSV>::THREADS), 0, s, d)
+#define LAUNCH_SMALL()                                                                                     \
+  hipLaunchKernelGGL((m2l_small_kernel<(PP <= 4 ? PP : 1)>), dim3((d.n_m2l_tgt + kM2LTargets - 1) / kM2LTargets, d.n_act), \
+                     dim3(kM2LTargets * kWave), 0, s, d)
   // NS = 2 measured best at p = 10 on MI355X (N = 1M: NS 1/2/3/4 -> 3.24 / 2.37 / 2.47 / 2.57 ms)
-  FMMBEM_DISPATCH_P(p, if (PP < 6) { LAUNCH(1); } else { LAUNCH(2); })
+  FMMBEM_DISPATCH_P(p, if (PP <= 4) { LAUNCH_SMALL(); } else if (PP < 6) { LAUNCH(1); } else { LAUNCH(2); })
+#undef LAUNCH_SMALL
 #undef LAUNCH
   return hipGetLastError();
 }

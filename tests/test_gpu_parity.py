@@ -58,7 +58,7 @@ def test_near_field_only(case6):
     assert rel_l2(yd.cpu().numpy(), o.near_only(x)) <= 1e-14
 
 
-@pytest.mark.parametrize("p", [1, 2, 5, 10, 11, 12, 16])
+@pytest.mark.parametrize("p", [1, 2, 3, 4, 5, 6, 10, 11, 12, 16])
 def test_expansions_and_matvec_vs_oracle(case6, p):
     _, K, pl, o, x = case6
     K.set_p(p)
