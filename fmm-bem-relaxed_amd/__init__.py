@@ -4,8 +4,8 @@ Only the hot path lives here: csrc/ (hand-written HIP for gfx950 + the C ABI of 
 and this thin host-side mirror of the reference's operator interface.
 """
 from ._capi import FmmBemError, LIB_PATH, Options, PMAX, SYMBOLS, lib  # noqa: F401
-from .plan import (FMM_plan, FMMOptions, LaplaceSphericalBEM, StokesSphericalBEM, read_msh, read_vert_face,  # noqa: F401
-                   red_blood_cell, unit_sphere, write_vert_face)
+from .plan import (FMM_plan, FMMOptions, LaplaceSphericalBEM, StokesSphericalBEM, quadrature, read_msh,  # noqa: F401
+                   read_vert_face, red_blood_cell, unit_sphere, write_vert_face)
 
 
 def __getattr__(name):

@@ -57,7 +57,7 @@ SYMBOLS = (
     "fmmbem_plan_downward_device", "fmmbem_plan_near_device", "fmmbem_plan_set_timing", "fmmbem_plan_stats",
     "fmmbem_plan_get_perm", "fmmbem_plan_get_boxes", "fmmbem_plan_get_pairs", "fmmbem_plan_get_near_row",
     "fmmbem_plan_get_expansions", "fmmbem_plan_get_diagonal", "fmmbem_mesh_unit_sphere", "fmmbem_mesh_red_blood_cell", "fmmbem_mesh_read_msh",
-    "fmmbem_mesh_read_vert_face", "fmmbem_mesh_write_vert_face", "fmmbem_status_string", "fmmbem_last_error",
+    "fmmbem_mesh_read_vert_face", "fmmbem_mesh_write_vert_face", "fmmbem_quadrature", "fmmbem_status_string", "fmmbem_last_error",
     "fmmbem_version",
 )
 
@@ -103,6 +103,7 @@ def lib():
     L.fmmbem_mesh_read_msh.argtypes = [C.c_char_p, vp, C.POINTER(C.c_size_t)]
     L.fmmbem_mesh_read_vert_face.argtypes = [C.c_char_p, C.c_char_p, vp, C.POINTER(C.c_size_t)]
     L.fmmbem_mesh_write_vert_face.argtypes = [C.c_char_p, C.c_char_p, vp, C.c_size_t]
+    L.fmmbem_quadrature.argtypes = [i32, vp, vp, C.POINTER(i32)]
     L.fmmbem_status_string.argtypes = [i32]
     L.fmmbem_status_string.restype = C.c_char_p
     L.fmmbem_last_error.restype = C.c_char_p

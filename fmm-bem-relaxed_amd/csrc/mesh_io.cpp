@@ -155,6 +155,18 @@ int fmmbem_mesh_write_vert_face(const char* vert_path, const char* face_path, co
   return (vert && face) ? FMMBEM_OK : fail(FMMBEM_ERR_IO, "write failed");
 }
 
+int fmmbem_quadrature(int key, double* points, double* weights, int* n) {
+  if (!n) return fail(FMMBEM_ERR_INVALID, "null argument");
+  fmmbem::QuadRule r;
+  if (!fmmbem::quad_rule(key, r)) return fail(FMMBEM_ERR_INVALID, "invalid Gauss rule key (valid: 1 3 4 7 13 17 19 25)");
+  for (int q = 0; q < r.n; ++q) {
+    if (points) for (int k = 0; k < 3; ++k) points[3 * q + k] = r.pts[q][k];
+    if (weights) weights[q] = r.w[q];
+  }
+  *n = r.n;
+  return FMMBEM_OK;
+}
+
 int fmmbem_mesh_red_blood_cell(int recursions, double* vertices, size_t* n_panels) {
   if (!n_panels) return fail(FMMBEM_ERR_INVALID, "null argument");
   if (recursions < 1 || recursions > 12) return fail(FMMBEM_ERR_INVALID, "recursions outside [1, 12]");

@@ -86,6 +86,13 @@ def unit_sphere(recursions, center=(0.0, 0.0, 0.0)):
     return v
 
 
+def quadrature(key):
+    """Triangle Gauss rule of examples/BEM/GaussQuadrature.hpp: (barycentric points (n, 3), weights (n,))."""
+    pts, w, n = np.empty((25, 3)), np.empty(25), C.c_int(0)
+    _capi.check(_capi.lib().fmmbem_quadrature(int(key), pts.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p), C.byref(n)))
+    return pts[:n.value].copy(), w[:n.value].copy()
+
+
 def red_blood_cell(recursions):
     """Triangulation::RedBloodCell, identity rotation, zero shift (examples/BEM/Triangulation.hpp:184-255)."""
     n = C.c_size_t(0)

@@ -173,6 +173,10 @@ int fmmbem_mesh_unit_sphere(int recursions, double *vertices, size_t *n_panels);
  * (examples/BEM/Triangulation.hpp:184-255; examples/StokesBEM.cpp:111-113): same N, same calling convention. */
 int fmmbem_mesh_red_blood_cell(int recursions, double *vertices, size_t *n_panels);
 
+/* Triangle Gauss rule `key` of examples/BEM/GaussQuadrature.hpp:15-274 (what BEMConfig hands the kernels): barycentric
+ * points[n][3] and weights[n] (at most 25); either array may be NULL. */
+int fmmbem_quadrature(int key, double *points, double *weights, int *n);
+
 /* ---- mesh files of the reference's drivers ------------------------------------------------ */
 /* All readers: vertices == NULL only counts (*n_panels out); otherwise *n_panels holds the capacity of
  * vertices (panels) on entry and the number read on return; vertices[panel][vertex][xyz].
