@@ -47,8 +47,9 @@ def _generate_plane_rotation(dx, dy):          # GMRES.hpp:88-105
     return cs, tmp * cs
 
 
-def gmres(MV, x, b, opts, M=None, log=None):
-    """GMRES(MV, x, b, opts[, M]) of examples/BEM/GMRES.hpp:143-252.
+def gmres(MV, x, b, opts, M=None, log=None, stokes=False):
+    """GMRES(MV, x, b, opts[, M]) of examples/BEM/GMRES.hpp:143-252; stokes=True: the order rule of
+    examples/BEM/GMRES_Stokes.hpp:229, p = max(p_min, predict_p - 1), vectors = N x 3 values flattened.
 
     MV: object with execute_torch(tensor)->tensor (or execute) and kernel().set_p(p);
     x, b: float64 CUDA tensors (x is updated in place and returned); M: optional callable z = M(v).
@@ -73,7 +74,7 @@ def gmres(MV, x, b, opts, M=None, log=None):
         while True:                                       # inner loop, :186
             i += 1
             it += 1
-            p = max(1, opts.predict_p(abs(resid)))        # :195
+            p = max(opts.p_min, opts.predict_p(abs(resid)) - 1) if stokes else max(1, opts.predict_p(abs(resid)))   # :195
             K.set_p(p)
             z = V[i] if M is None else M(V[i])
             w = execute(z).clone()

@@ -85,3 +85,30 @@ def test_gpu_stokes_rejects_traction(fb):
     with pytest.raises(fb.FmmBemError) as e:
         fb.FMM_plan(fb.StokesSphericalBEM(5, 3), v, bc=np.ones(len(v), dtype=np.uint8))
     assert e.value.status == 6
+
+
+@pytest.mark.gpu
+def test_gpu_stokes_sphere_drag_solve(fb):
+    """examples/StokesBEM.cpp:255-361: unit sphere moving with U = (1,0,0); the driver overwrites its right-hand side
+    with the analytic (4 pi, 0, 0) per panel (:273-276), solves the first-kind (stokeslet) system with the relaxed
+    GMRES of GMRES_Stokes.hpp (p = max(p_min, predict_p - 1)) and reports the drag against 6 pi mu."""
+    import torch
+    mu = 1e-3
+    v = fb.unit_sphere(4)
+    n = len(v)
+    K = fb.StokesSphericalBEM(10, 4, mu)
+    K.set_Kfine(19)
+    plan = fb.FMM_plan(K, v, p_max=10)
+    b = torch.zeros((n, 3), dtype=torch.float64, device="cuda")
+    b[:, 0] = 4 * np.pi
+    so = fb.SolverOptions(residual=1e-5, max_iters=100, max_p=10, p_min=5)
+    log = []
+    x, it, res = fb.gmres(plan, torch.ones(3 * n, dtype=torch.float64, device="cuda"), b.reshape(-1), so, log=log, stokes=True)
+    assert res < 1e-5 and min(p for _, p, _ in log) >= 5 and log[0][1] == 9          # max(p_min, 10 - 1)
+    t = x.reshape(n, 3).cpu().numpy()
+    e0, e1 = v[:, 2] - v[:, 0], v[:, 1] - v[:, 0]
+    area = 0.5 * np.linalg.norm(np.cross(e0, e1), axis=1)
+    fx, fy, fz = (t * area[:, None]).sum(axis=0)
+    drag_error = abs(6 * np.pi * mu - fx) / (6 * np.pi * mu)
+    assert drag_error < 2e-2 and abs(fy) < 1e-6 * abs(fx) + 1e-12 and abs(fz) < 1e-6 * abs(fx) + 1e-12
+    assert np.sqrt(((t[:, 0] - 1.5 * mu) ** 2).mean()) / (1.5 * mu) < 0.1               # traction 1.5 mu U / R pointwise
