@@ -337,8 +337,8 @@ hipError_t launch_m2l(const DevicePlan& d, int p, hipStream_t s) {
 #define LAUNCH_SMALL()                                                                                     \
   hipLaunchKernelGGL((m2l_small_kernel<(PP <= 4 ? PP : 1)>), dim3((d.n_m2l_tgt + kM2LTargets - 1) / kM2LTargets, d.n_act), \
                      dim3(kM2LTargets * kWave), 0, s, d)
-  // NS = 2 measured best at p = 10 on MI355X (N = 1M: NS 1/2/3/4 -> 3.24 / 2.37 / 2.47 / 2.57 ms)
-  FMMBEM_DISPATCH_P(p, if (PP <= 4) { LAUNCH_SMALL(); } else if (PP < 6) { LAUNCH(1); } else { LAUNCH(2); })
+  // wavefronts per target (N = 1M, ms): p = 6: 0.98 / 1.04 / 1.49 with 1 / 2 / 3; p = 8: 1.68 / 1.56 / 1.71; p = 10: 2.96 / 2.27 / 2.31
+  FMMBEM_DISPATCH_P(p, if (PP <= 4) { LAUNCH_SMALL(); } else if (PP <= 6) { LAUNCH(1); } else { LAUNCH(2); })
 #undef LAUNCH_SMALL
 #undef LAUNCH
   return hipGetLastError();
