@@ -74,19 +74,23 @@ __device__ inline double2 mul_i_pow(double2 a, int q) {              // a * i^q
   }
 }
 
-template <int P, int NS_>
+// NSLOT expansion slots (Stokes: the four harmonic potentials; Laplace with mixed BC: G and dG/dn) share one pass over
+// a target's sources: same class table, same LDS reads, same barriers -- only Mh and the accumulators differ.
+template <int P, int NS_, int NSLOT>
 __global__ __launch_bounds__((Shape<P, NS_>::THREADS)) void m2l_kernel(DevicePlan d) {
   using Sh = Shape<P, NS_>;
   constexpr int NE = Sh::NE, TEAM = Sh::TEAM, TARGETS = Sh::TARGETS, RR = Sh::RR, NLOAD = Sh::NLOAD;
   constexpr int NS = Sh::NS, WAVES = Sh::WAVES;
   __shared__ double2 Gall[TARGETS][(Sh::LDSD + 1) / 2];
-  __shared__ double2 Comb[NS == 1 ? 1 : (NS - 1) * TEAM * kWave];   // partial sums of the other m sets
+  __shared__ double2 Comb[NS == 1 ? 1 : NSLOT * (NS - 1) * TEAM * kWave];   // partial sums of the other m sets
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int ti = blockIdx.x * TARGETS + (WAVES == 1 ? wave : 0);
   if (ti >= d.n_m2l_tgt) return;                       // WAVES==1: whole wavefront; else: whole workgroup
   const int tgt = d.m2l_tgt[ti];
-  const int slot = d.act[blockIdx.y];
+  int slot[NSLOT];
+#pragma unroll
+  for (int q = 0; q < NSLOT; ++q) slot[q] = d.act[blockIdx.y * NSLOT + q];
   double* Gt = reinterpret_cast<double*>(Gall[WAVES == 1 ? wave : 0]);
   const int tid = WAVES == 1 ? lane : (int)threadIdx.x;  // index within the team (table copy)
   const int npart = WAVES == 1 ? 0 : wave % NS;          // which m set this wavefront sums
@@ -98,7 +102,9 @@ __global__ __launch_bounds__((Shape<P, NS_>::THREADS)) void m2l_kernel(DevicePla
   const int j = valid ? (packed & 0xff) : 0, k = valid ? ((packed >> 8) & 0xff) : 0, idx = valid ? (packed >> 16) : 0;
   // 16-byte slot of gh[j + 0, 0 - k] in this lane's alignment copy; (m + C0) * RR + n0 is added per term
   const double2* gbase = reinterpret_cast<const double2*>(Gt) + (((j & 1) ? Sh::O0 + 1 : 0) + j - k * RR) / 2;
-  double2 acc = {0, 0};
+  double2 acc[NSLOT];
+#pragma unroll
+  for (int q = 0; q < NSLOT; ++q) acc[q] = {0, 0};
   // Where only one half of a 16-byte LDS read feeds an FMA (first pair of an odd order), hipcc narrows the read to
   // 8 bytes and pairs such reads into ds_read2_b64, which the conflict-free lane dealing does not cover: the unused
   // half is multiplied by a zero the compiler cannot see and starts the sum instead.
@@ -127,7 +133,8 @@ __global__ __launch_bounds__((Shape<P, NS_>::THREADS)) void m2l_kernel(DevicePla
 
   const int pb = d.m2l_ptr[tgt], pe = d.m2l_ptr[tgt + 1];
   if (pb == pe) {                                      // a box that only inherits from its parent: L = 0
-    if (valid) d.L[((size_t)tgt * d.nslots + slot) * d.s_max + idx] = {0, 0};
+    if (valid)
+      for (int q = 0; q < NSLOT; ++q) d.L[((size_t)tgt * d.nslots + slot[q]) * d.s_max + idx] = {0, 0};
     return;
   }
   double2 zk;                                          // Z^k of the class in flight
@@ -161,20 +168,27 @@ __global__ __launch_bounds__((Shape<P, NS_>::THREADS)) void m2l_kernel(DevicePla
     // written by the preceding kernel and is immutable here, like the class phases Z^m: address both through the
     // CONSTANT address space so that the wave-uniform loads are always selected as scalar (SMEM) loads feeding
     // SGPR operands.
-    const ConstC2* mh = reinterpret_cast<const ConstC2*>(
-        reinterpret_cast<uintptr_t>(d.Mh + ((size_t)src * d.nslots + slot) * d.s_max));
+    const ConstC2* mh[NSLOT];
+#pragma unroll
+    for (int q = 0; q < NSLOT; ++q)
+      mh[q] = reinterpret_cast<const ConstC2*>(reinterpret_cast<uintptr_t>(d.Mh + ((size_t)src * d.nslots + slot[q]) * d.s_max));
     const ConstC2* zm = reinterpret_cast<const ConstC2*>(reinterpret_cast<uintptr_t>(d.m2l_z + (size_t)cls * d.p_max));
     // Warm the L2 for the NEXT source's Mh (a random 880-B record of a >100 MB array): one 16-B vector load
     // per lane now turns next iteration's dependent scalar loads from HBM/MALL misses into L2 hits.
     {
       const int src_next = __builtin_amdgcn_readfirstlane(d.m2l_src[pn]);
-      const double2* nxt = d.Mh + ((size_t)src_next * d.nslots + slot) * d.s_max;
-      if (tid < Sh::S) {
-        const double2 touch = nxt[tid];
-        asm volatile("" ::"v"(touch.x), "v"(touch.y));
+#pragma unroll
+      for (int q = 0; q < NSLOT; ++q) {
+        const double2* nxt = d.Mh + ((size_t)src_next * d.nslots + slot[q]) * d.s_max;
+        if (tid < Sh::S) {
+          const double2 touch = nxt[tid];
+          asm volatile("" ::"v"(touch.x), "v"(touch.y));
+        }
       }
     }
-    double2 as = {0, 0};                               // sum_m Z^m T_m of this source (this wavefront's m set)
+    double2 as[NSLOT];                                 // sum_m Z^m T_m of this source (this wavefront's m set)
+#pragma unroll
+    for (int q = 0; q < NSLOT; ++q) as[q] = {0, 0};
     auto mac_part = [&](auto part_c) {
       constexpr int PART = decltype(part_c)::value;
 #pragma unroll
@@ -183,26 +197,41 @@ __global__ __launch_bounds__((Shape<P, NS_>::THREADS)) void m2l_kernel(DevicePla
         if (Sh::PT.v[am] != PART) continue;
         const double sr = (m < 0 && (am & 1)) ? -1.0 : 1.0;            // (-1)^m for m < 0
         const double si = (m < 0) ? -sr : 1.0;                         // conj
-        double tr = 0, tq = 0;
+        double tr[NSLOT], tq[NSLOT];
         bool started_r = false, started_q = false;     // the first product initialises the sums (no v_mov 0 + fma)
 #pragma unroll
         for (int n0 = am & ~1; n0 < P; n0 += 2) {
           const double2 g2 = gbase[((m + Sh::C0) * RR + n0) / 2];
-          if (n0 < am) { tr = zero * g2.x; started_r = true; }           // keeps the read 16 bytes wide (see `zero`)
+          if (n0 < am) {                               // keeps the read 16 bytes wide (see `zero`)
+#pragma unroll
+            for (int q = 0; q < NSLOT; ++q) tr[q] = zero * g2.x;
+            started_r = true;
+          }
           if (n0 >= am) {
-            const double ar = sr * mh[am * P - am * (am - 1) / 2 + n0 - am].x, ai = si * mh[am * P - am * (am - 1) / 2 + n0 - am].y;
-            if (started_r) tr = fma(ar, g2.x, tr); else { tr = ar * g2.x; started_r = true; }
-            if (started_q) tq = fma(ai, g2.x, tq); else { tq = ai * g2.x; started_q = true; }
+#pragma unroll
+            for (int q = 0; q < NSLOT; ++q) {
+              const double ar = sr * mh[q][am * P - am * (am - 1) / 2 + n0 - am].x, ai = si * mh[q][am * P - am * (am - 1) / 2 + n0 - am].y;
+              tr[q] = started_r ? fma(ar, g2.x, tr[q]) : ar * g2.x;
+              tq[q] = started_q ? fma(ai, g2.x, tq[q]) : ai * g2.x;
+            }
+            started_r = started_q = true;
           }
           if (n0 + 1 < P) {
-            const double ar = sr * mh[am * P - am * (am - 1) / 2 + n0 + 1 - am].x, ai = si * mh[am * P - am * (am - 1) / 2 + n0 + 1 - am].y;
-            if (started_r) tr = fma(ar, g2.y, tr); else { tr = ar * g2.y; started_r = true; }
-            if (started_q) tq = fma(ai, g2.y, tq); else { tq = ai * g2.y; started_q = true; }
+#pragma unroll
+            for (int q = 0; q < NSLOT; ++q) {
+              const double ar = sr * mh[q][am * P - am * (am - 1) / 2 + n0 + 1 - am].x, ai = si * mh[q][am * P - am * (am - 1) / 2 + n0 + 1 - am].y;
+              tr[q] = started_r ? fma(ar, g2.y, tr[q]) : ar * g2.y;
+              tq[q] = started_q ? fma(ai, g2.y, tq[q]) : ai * g2.y;
+            }
+            started_r = started_q = true;
           }
         }
         const double er = zm[am].x, ei = (m < 0 ? -1.0 : 1.0) * zm[am].y;      // Z^m, Z^{-m} = conj
-        as.x = fma(er, tr, as.x); as.x = fma(-ei, tq, as.x);
-        as.y = fma(er, tq, as.y); as.y = fma(ei, tr, as.y);
+#pragma unroll
+        for (int q = 0; q < NSLOT; ++q) {
+          as[q].x = fma(er, tr[q], as[q].x); as[q].x = fma(-ei, tq[q], as[q].x);
+          as[q].y = fma(er, tq[q], as[q].y); as[q].y = fma(ei, tr[q], as[q].y);
+        }
       }
     };
     if (valid) {
@@ -211,8 +240,11 @@ __global__ __launch_bounds__((Shape<P, NS_>::THREADS)) void m2l_kernel(DevicePla
       if (NS > 2 && npart == 2) mac_part(std::integral_constant<int, 2>{});
       if (NS > 3 && npart == 3) mac_part(std::integral_constant<int, 3>{});
       // acc += Z^{-k} * as = conj(Z^k) * as
-      acc.x = fma(zk_now.x, as.x, acc.x); acc.x = fma(zk_now.y, as.y, acc.x);
-      acc.y = fma(zk_now.x, as.y, acc.y); acc.y = fma(-zk_now.y, as.x, acc.y);
+#pragma unroll
+      for (int q = 0; q < NSLOT; ++q) {
+        acc[q].x = fma(zk_now.x, as[q].x, acc[q].x); acc[q].x = fma(zk_now.y, as[q].y, acc[q].x);
+        acc[q].y = fma(zk_now.x, as[q].y, acc[q].y); acc[q].y = fma(-zk_now.y, as[q].x, acc[q].y);
+      }
     }
   }
 #undef LOAD
@@ -220,17 +252,27 @@ __global__ __launch_bounds__((Shape<P, NS_>::THREADS)) void m2l_kernel(DevicePla
 #undef STORE
 #undef FMMBEM_REP4
   if (NS > 1) {                                        // fold the other m sets into the first, fixed order
-    if (npart > 0) Comb[(npart - 1) * TEAM * kWave + otid] = acc;
+    if (npart > 0)
+#pragma unroll
+      for (int e = 0; e < NSLOT; ++e) Comb[(e * (NS - 1) + npart - 1) * TEAM * kWave + otid] = acc[e];
     __syncthreads();
     if (npart == 0) {
 #pragma unroll
-      for (int q = 0; q < NS - 1; ++q) { acc.x += Comb[q * TEAM * kWave + otid].x; acc.y += Comb[q * TEAM * kWave + otid].y; }
+      for (int e = 0; e < NSLOT; ++e)
+#pragma unroll
+        for (int q = 0; q < NS - 1; ++q) {
+          acc[e].x += Comb[(e * (NS - 1) + q) * TEAM * kWave + otid].x;
+          acc[e].y += Comb[(e * (NS - 1) + q) * TEAM * kWave + otid].y;
+        }
     }
   }
   if (valid && npart == 0) {
-    double2* L = d.L + ((size_t)tgt * d.nslots + slot) * d.s_max;
     const double f = ((j & 1) ? -1.0 : 1.0) * d.tabA[j * j + j + k];
-    L[idx] = mul_i_pow(double2{acc.x * f, acc.y * f}, -k);
+#pragma unroll
+    for (int e = 0; e < NSLOT; ++e) {
+      double2* L = d.L + ((size_t)tgt * d.nslots + slot[e]) * d.s_max;
+      L[idx] = mul_i_pow(double2{acc[e].x * f, acc[e].y * f}, -k);
+    }
   }
 }
 
@@ -330,10 +372,13 @@ __global__ __launch_bounds__(kM2LTargets * kWave) void m2l_small_kernel(DevicePl
 
 hipError_t launch_m2l(const DevicePlan& d, int p, hipStream_t s) {
   if (d.n_m2l_tgt <= 0) return hipSuccess;
-#define LAUNCH(NSV)                                                                                        \
-  hipLaunchKernelGGL((m2l_kernel<PP, NSV>),                                                                \
-                     dim3((d.n_m2l_tgt + Shape<PP, NSV>::TARGETS - 1) / Shape<PP, NSV>::TARGETS, d.n_act),  \
+#define LAUNCH_Q(NSV, NQ)                                                                                     \
+  hipLaunchKernelGGL((m2l_kernel<PP, NSV, NQ>),                                                               \
+                     dim3((d.n_m2l_tgt + Shape<PP, NSV>::TARGETS - 1) / Shape<PP, NSV>::TARGETS, d.n_act / NQ), \
                      dim3(Shape<PP, NSV>::THREADS), 0, s, d)
+  // two active expansion slots at a time when their number is even (Stokes 4, Laplace with mixed BC 2)
+  // (Stokes config 4, p = 8, ms: 2.64 with one slot per pass, 2.32 with two, 3.02 with four -- SGPR spills)
+#define LAUNCH(NSV) do { if (d.n_act % 2 == 0 && PP <= 12) { LAUNCH_Q(NSV, 2); } else { LAUNCH_Q(NSV, 1); } } while (0)
 #define LAUNCH_SMALL()                                                                                     \
   hipLaunchKernelGGL((m2l_small_kernel<(PP <= 4 ? PP : 1)>), dim3((d.n_m2l_tgt + kM2LTargets - 1) / kM2LTargets, d.n_act), \
                      dim3(kM2LTargets * kWave), 0, s, d)
@@ -341,6 +386,7 @@ hipError_t launch_m2l(const DevicePlan& d, int p, hipStream_t s) {
   FMMBEM_DISPATCH_P(p, if (PP <= 4) { LAUNCH_SMALL(); } else if (PP <= 6) { LAUNCH(1); } else { LAUNCH(2); })
 #undef LAUNCH_SMALL
 #undef LAUNCH
+#undef LAUNCH_Q
   return hipGetLastError();
 }
 
