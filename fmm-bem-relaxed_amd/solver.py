@@ -35,6 +35,15 @@ class SolverOptions:
         return min(int(math.ceil(-math.log2(eps))) & 0xFFFFFFFF, self.max_p)
 
 
+def _apply(execute, z, out):
+    """w = A z into a reusable buffer when the operator can write in place (FMM_plan.execute_torch, ShardedFMM.execute)."""
+    try:
+        return execute(z, out=out)
+    except TypeError:
+        out.copy_(execute(z))
+        return out
+
+
 def _generate_plane_rotation(dx, dy):          # GMRES.hpp:88-105
     if dy == 0.0:
         return 1.0, 0.0
@@ -59,6 +68,7 @@ def gmres(MV, x, b, opts, M=None, log=None, stokes=False):
     K = MV.kernel()
     R, n = opts.restart, x.numel()
     V = torch.empty((R + 1, n), dtype=x.dtype, device=x.device)
+    wbuf = torch.empty(n, dtype=x.dtype, device=x.device)
     H = [[0.0] * R for _ in range(R + 1)]
     cs, sn, s = [0.0] * R, [0.0] * R, [0.0] * (R + 1)
     normb = float(torch.linalg.vector_norm(b))
@@ -77,16 +87,16 @@ def gmres(MV, x, b, opts, M=None, log=None, stokes=False):
             p = max(opts.p_min, opts.predict_p(abs(resid)) - 1) if stokes else max(1, opts.predict_p(abs(resid)))   # :195
             K.set_p(p)
             z = V[i] if M is None else M(V[i])
-            w = execute(z).clone()
-            hcol = torch.empty(i + 2, dtype=x.dtype, device=x.device)
-            for k in range(i + 1):                        # modified Gram-Schmidt, :203-208
+            w = _apply(execute, z, wbuf)
+            hs = []
+            for k in range(i + 1):                        # modified Gram-Schmidt, :203-208 (two launches per k)
                 hk = torch.dot(w, V[k])
-                hcol[k] = hk
-                w -= hk * V[k]
+                hs.append(hk)
+                w.addcmul_(V[k], hk, value=-1.0)          # w -= hk * V[k]
             hn = torch.linalg.vector_norm(w)
-            hcol[i + 1] = hn
-            V[i + 1] = w / hn
-            col = hcol.tolist()                           # the one sync of the iteration
+            hs.append(hn)
+            torch.div(w, hn, out=V[i + 1])
+            col = torch.stack(hs).tolist()                # the one sync of the iteration
             for k in range(i + 2):
                 H[k][i] = col[k]
             for k in range(i):                            # PlaneRotation, :108-117
@@ -125,6 +135,7 @@ def fgmres(MV, x, b, opts, M, log=None):
     K = MV.kernel()
     R, n = opts.restart, x.numel()
     V = torch.empty((R + 1, n), dtype=x.dtype, device=x.device)
+    wbuf = torch.empty(n, dtype=x.dtype, device=x.device)
     Z = torch.empty((R, n), dtype=x.dtype, device=x.device)
     H = [[0.0] * R for _ in range(R + 1)]
     cs, sn, s = [0.0] * R, [0.0] * R, [0.0] * (R + 1)
@@ -143,16 +154,16 @@ def fgmres(MV, x, b, opts, M, log=None):
             p = max(1, opts.predict_p(abs(resid)))        # :324 (the product has no order 0)
             K.set_p(p)
             Z[i] = M(V[i])
-            w = execute(Z[i]).clone()
-            hcol = torch.empty(i + 2, dtype=x.dtype, device=x.device)
+            w = _apply(execute, Z[i], wbuf)
+            hs = []
             for k in range(i + 1):
                 hk = torch.dot(w, V[k])
-                hcol[k] = hk
-                w -= hk * V[k]
+                hs.append(hk)
+                w.addcmul_(V[k], hk, value=-1.0)
             hn = torch.linalg.vector_norm(w)
-            hcol[i + 1] = hn
-            V[i + 1] = w / hn
-            col = hcol.tolist()
+            hs.append(hn)
+            torch.div(w, hn, out=V[i + 1])
+            col = torch.stack(hs).tolist()
             for k in range(i + 2):
                 H[k][i] = col[k]
             for k in range(i):
