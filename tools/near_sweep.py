@@ -1,5 +1,7 @@
-"""Times the assembled near-field SpMV alone (fmmbem_plan_near_device) for kernel variants selected through
-FMMBEM_SPMV_VARIANT -- a tuning aid, not part of the product or the bench."""
+#!/usr/bin/env python3
+"""Times the assembled near-field operator alone (fmmbem_plan_near_device: gather + near_spmv + scatter) on the bench
+input -- a tuning aid, not part of the product or the bench.  Environment variables named on the command line as
+NAME=VALUE are set before each timing, e.g.  python tools/near_sweep.py FMMBEM_OVERLAP_NEAR=0"""
 import os
 import sys
 
@@ -11,7 +13,7 @@ import fmm_bem_relaxed_amd as fb  # noqa: E402
 
 
 def main():
-    variants = [a for a in sys.argv[1:]] or ["0"]
+    settings = [a for a in sys.argv[1:] if "=" in a] or [""]
     v = np.concatenate([fb.unit_sphere(9, center=(3.0 * i, 0, 0)) for i in range(2)])
     plan = fb.FMM_plan(fb.LaplaceSphericalBEM(10, 3), v, fb.FMMOptions(), p_max=10)
     st = plan.stats()
@@ -19,25 +21,26 @@ def main():
     x = torch.rand(plan.n, dtype=torch.float64, device="cuda")
     y = torch.empty_like(x)
     ref = None
-    for var in variants:
-        var, dbg = (var.split(":") + ["0"])[:2]
-        os.environ["FMMBEM_SPMV_VARIANT"] = var
-        os.environ["FMMBEM_SPMV_DEBUG"] = dbg
-        var = int(var)
+    stream = torch.cuda.current_stream().cuda_stream
+    for setting in settings:
+        if setting:
+            k, val = setting.split("=", 1)
+            os.environ[k] = val
         for _ in range(3):
-            plan.near_device(x.data_ptr(), y.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            plan.near_device(x.data_ptr(), y.data_ptr(), stream)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(20):
-            plan.near_device(x.data_ptr(), y.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            plan.near_device(x.data_ptr(), y.data_ptr(), stream)
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 20
         if ref is None:
             ref = y.clone()
         err = float((y - ref).abs().max() / ref.abs().max())
-        print("variant %d dbg %s: %.4f ms incl. gather/scatter  %.0f GB/s  maxdiff vs first %.2e" % (var, dbg, ms, nbytes / ms / 1e6, err), flush=True)
+        print("%s: %.4f ms incl. gather/scatter  %.0f GB/s  maxdiff vs first %.2e" % (setting or "default", ms, nbytes / ms / 1e6, err),
+              flush=True)
 
 
 if __name__ == "__main__":
