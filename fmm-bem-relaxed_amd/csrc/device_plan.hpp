@@ -105,7 +105,9 @@ hipError_t launch_m2m_level(const DevicePlan& d, const ShiftOpDev& op, int p, in
 hipError_t launch_xch_pack(const DevicePlan& d, int p, double2* send, hipStream_t s);
 hipError_t launch_xch_unpack(const DevicePlan& d, int p, const double2* recv, hipStream_t s);
 hipError_t launch_mh_prep(const DevicePlan& d, int p, hipStream_t s);
-hipError_t launch_m2l(const DevicePlan& d, int p, hipStream_t s);
+// d_dev: a copy of d in device memory (the M2L kernel re-reads the plan fields it needs with scalar loads every source
+// instead of keeping them alive in SGPRs across its FMA region)
+hipError_t launch_m2l(const DevicePlan& d, const DevicePlan* d_dev, int p, hipStream_t s);
 hipError_t launch_l2l_level(const DevicePlan& d, const ShiftOpDev& op, int p, int first, int count, hipStream_t s);
 hipError_t launch_l2p(const DevicePlan& d, int p, double* y, hipStream_t s);
 hipError_t launch_near_assemble_stokes(const DevicePlan& d, hipStream_t s);

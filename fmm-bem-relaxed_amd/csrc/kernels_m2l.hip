@@ -33,6 +33,7 @@ namespace {
 constexpr int kWave = 64;
 struct C2 { double x, y; };
 typedef __attribute__((address_space(4))) C2 ConstC2;      // complex value in the constant address space
+typedef __attribute__((address_space(4))) DevicePlan ConstPlan;
 constexpr int kM2LTargets = 4;         // independent single-wavefront targets per workgroup when TEAM == 1
 
 template <int P, int NS_> struct Shape {
@@ -44,6 +45,7 @@ template <int P, int NS_> struct Shape {
   static constexpr int WAVES = TEAM * NS;
   static constexpr int TARGETS = WAVES == 1 ? kM2LTargets : 1;
   static constexpr int THREADS = WAVES * TARGETS * kWave;
+  static constexpr int COPYT = WAVES * kWave;             // threads sharing one target's table copy
   static constexpr int RR = m2l_rr(P), C0 = m2l_c0(P), O0 = m2l_odd_base(P), LDSD = m2l_lds_doubles(P);
   static constexpr int NLOAD = (NE + WAVES * kWave - 1) / (WAVES * kWave);   // table entries copied per lane
   // ds_read_b128 per m: pairs (n0, n0+1), n0 even, covering n = |m| .. P-1
@@ -77,11 +79,18 @@ __device__ inline double2 mul_i_pow(double2 a, int q) {              // a * i^q
 // NSLOT expansion slots (Stokes: the four harmonic potentials; Laplace with mixed BC: G and dG/dn) share one pass over
 // a target's sources: same class table, same LDS reads, same barriers -- only Mh and the accumulators differ.
 template <int P, int NS_, int NSLOT>
-__global__ __launch_bounds__((Shape<P, NS_>::THREADS)) void m2l_kernel(DevicePlan d) {
+__global__ __launch_bounds__((Shape<P, NS_>::THREADS)) void m2l_kernel(const DevicePlan* __restrict__ d_in) {
+  // The plan is read through a pointer: inside the source loop the pointer is made opaque once per iteration, so the
+  // few fields the loop needs are re-read by scalar loads (scalar cache hits) instead of being kept alive in SGPRs --
+  // the FMA region wants nearly all of them for Mh, and what else is live across it gets spilled to VGPR lanes and
+  // restored with VALU instructions every source.
+  const DevicePlan& d = *d_in;
   using Sh = Shape<P, NS_>;
   constexpr int NE = Sh::NE, TEAM = Sh::TEAM, TARGETS = Sh::TARGETS, RR = Sh::RR, NLOAD = Sh::NLOAD;
   constexpr int NS = Sh::NS, WAVES = Sh::WAVES;
-  __shared__ double2 Gall[TARGETS][(Sh::LDSD + 1) / 2];
+  // + one spare double per copying thread: table entries without a place are stored there, so that the scatter
+  // needs no per-destination branch (whose loop-invariant exec masks would sit in SGPRs across the FMA region)
+  __shared__ double2 Gall[TARGETS][(Sh::LDSD + Sh::COPYT + 1) / 2];
   __shared__ double2 Comb[NS == 1 ? 1 : NSLOT * (NS - 1) * TEAM * kWave];   // partial sums of the other m sets
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
@@ -117,18 +126,26 @@ __global__ __launch_bounds__((Shape<P, NS_>::THREADS)) void m2l_kernel(DevicePla
   // The staging registers are NAMED scalars (macro-expanded), not arrays: hipcc keeps an array that is live across
   // the loop in scratch memory, which serialises the prefetch.
   static_assert(NLOAD <= 4, "table copy needs more staging registers");
+  const int spare = (Sh::LDSD + tid) << 1;             // this thread's spare place, same encoding as the scatter map
+  auto fix_dst = [](int dst, int sp) { return dst >= 0 ? dst : sp; };
+  auto flip_sign = [](double v, int dst) {             // -v where bit 0 of the encoded place is set (integer xor, no mask)
+    return __hiloint2double(__double2hiint(v) ^ (dst << 31), __double2loint(v));
+  };
   const int* scat = d.m2l_scat + d.m2l_scat_off[P - 1];
 #define FMMBEM_REP4(X) X(0) X(1) X(2) X(3)
+  // Everything loop-invariant that the scatter needs lives in VGPRs (place, sign bit, clamped table index): as
+  // conditions they would be exec masks parked in SGPR pairs across the FMA region, i.e. spilled and restored.
 #define DECL(u)                                                                   \
-  const int e##u = tid + u * WAVES * kWave;                                       \
+  const int e##u = tid + u * Sh::COPYT;                                           \
   const bool on##u = u < NLOAD && e##u < NE;                                      \
-  const int da##u = on##u ? scat[4 * e##u + 0] : -1, db##u = on##u ? scat[4 * e##u + 1] : -1; \
-  const int dc##u = on##u ? scat[4 * e##u + 2] : -1, dd##u = on##u ? scat[4 * e##u + 3] : -1; \
+  const int le##u = on##u ? e##u : 0;                                             \
+  const int da##u = fix_dst(on##u ? scat[4 * e##u + 0] : -1, spare), db##u = fix_dst(on##u ? scat[4 * e##u + 1] : -1, spare); \
+  const int dc##u = fix_dst(on##u ? scat[4 * e##u + 2] : -1, spare), dd##u = fix_dst(on##u ? scat[4 * e##u + 3] : -1, spare); \
   double pre##u = 0;
   FMMBEM_REP4(DECL)
 #undef DECL
-#define LOAD(u) if (u < NLOAD) pre##u = tab[on##u ? e##u : 0];
-#define PUT(dst, v) if (dst >= 0) Gt[dst >> 1] = (dst & 1) ? -(v) : (v);
+#define LOAD(u) if (u < NLOAD) pre##u = tab[le##u];
+#define PUT(dst, v) Gt[dst >> 1] = flip_sign(v, dst);
 #define STORE(u) if (u < NLOAD) { PUT(da##u, pre##u) PUT(db##u, pre##u) PUT(dc##u, pre##u) PUT(dd##u, pre##u) }
 
   const int pb = d.m2l_ptr[tgt], pe = d.m2l_ptr[tgt + 1];
@@ -145,6 +162,9 @@ __global__ __launch_bounds__((Shape<P, NS_>::THREADS)) void m2l_kernel(DevicePla
     zk = d.m2l_z[(size_t)cls * d.p_max + k];
   }
   for (int pi = pb; pi < pe; ++pi) {
+    uintptr_t dl = reinterpret_cast<uintptr_t>(d_in);
+    asm volatile("" : "+s"(dl));                       // forget what was loaded through it
+    const ConstPlan& d = *reinterpret_cast<const ConstPlan*>(dl);   // constant address space: scalar loads
     const int src = __builtin_amdgcn_readfirstlane(d.m2l_src[pi]);
     const int cls = __builtin_amdgcn_readfirstlane(d.m2l_cls[pi]);
     const int pn = pi + 1 < pe ? pi + 1 : pi;          // last iteration re-reads its own table (harmless)
@@ -234,7 +254,7 @@ __global__ __launch_bounds__((Shape<P, NS_>::THREADS)) void m2l_kernel(DevicePla
         }
       }
     };
-    if (valid) {
+    {                                                  // lanes without an output run along (valid LDS addresses, results dropped)
       if (npart == 0) mac_part(std::integral_constant<int, 0>{});
       if (NS > 1 && npart == 1) mac_part(std::integral_constant<int, 1>{});
       if (NS > 2 && npart == 2) mac_part(std::integral_constant<int, 2>{});
@@ -370,12 +390,12 @@ __global__ __launch_bounds__(kM2LTargets * kWave) void m2l_small_kernel(DevicePl
 
 }  // namespace
 
-hipError_t launch_m2l(const DevicePlan& d, int p, hipStream_t s) {
+hipError_t launch_m2l(const DevicePlan& d, const DevicePlan* d_dev, int p, hipStream_t s) {
   if (d.n_m2l_tgt <= 0) return hipSuccess;
 #define LAUNCH_Q(NSV, NQ)                                                                                     \
   hipLaunchKernelGGL((m2l_kernel<PP, NSV, NQ>),                                                               \
                      dim3((d.n_m2l_tgt + Shape<PP, NSV>::TARGETS - 1) / Shape<PP, NSV>::TARGETS, d.n_act / NQ), \
-                     dim3(Shape<PP, NSV>::THREADS), 0, s, d)
+                     dim3(Shape<PP, NSV>::THREADS), 0, s, d_dev)
   // two active expansion slots at a time when their number is even (Stokes 4, Laplace with mixed BC 2)
   // (Stokes config 4, p = 8, ms: 2.64 with one slot per pass, 2.32 with two, 3.02 with four -- SGPR spills)
 #define LAUNCH(NSV) do { if (d.n_act % 2 == 0 && PP <= 12) { LAUNCH_Q(NSV, 2); } else { LAUNCH_Q(NSV, 1); } } while (0)

@@ -126,6 +126,7 @@ struct fmmbem_plan {
   std::vector<void*> allocs;
   std::vector<std::pair<int, int>> m2m_launch, l2l_launch;     // (first, count) per level
   std::vector<std::pair<int, int>> m2m_shared_launch;          // sharded upward pass: parents spanning shards
+  const DevicePlan* d_dev = nullptr;                            // copy of d in device memory
   bool split_upward = false;                                   // P2M/M2M sharded by owner, multipoles all-gathered by the caller
   unsigned pending_mask = 0;                                   // stages recorded by the upward half of a split execute
   std::vector<ShiftOpDev> up_ops, down_ops;                    // M2M / L2L operators, index p - 1
@@ -462,6 +463,13 @@ int fmmbem_plan::to_device() {
     HIP_TRY(hipStreamSynchronize(own_stream));
   }
   build_assemble_ms = now_ms() - t0;
+  {                                                    // the plan itself, readable from the device
+    void* pd = nullptr;
+    HIP_TRY(hipMalloc(&pd, sizeof(DevicePlan)));
+    allocs.push_back(pd);
+    HIP_TRY(hipMemcpy(pd, &d, sizeof(DevicePlan), hipMemcpyHostToDevice));
+    d_dev = static_cast<const DevicePlan*>(pd);
+  }
   return FMMBEM_OK;
 }
 
@@ -537,7 +545,7 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
       HIP_TRY(hipEventRecord(ev_join, near_stream));
     }
     HIP_TRY(begin(6, s));
-    HIP_TRY(launch_m2l(d, p, s));
+    HIP_TRY(launch_m2l(d, d_dev, p, s));
     HIP_TRY(end(6, s));
     HIP_TRY(begin(7, s));
     for (auto [first, count] : l2l_launch) HIP_TRY(launch_l2l_level(d, down_ops[p - 1], p, first, count, s));
