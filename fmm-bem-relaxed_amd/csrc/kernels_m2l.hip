@@ -211,46 +211,50 @@ __global__ __launch_bounds__((Shape<P, NS_>::THREADS)) void m2l_kernel(const Dev
     for (int q = 0; q < NSLOT; ++q) as[q] = {0, 0};
     auto mac_part = [&](auto part_c) {
       constexpr int PART = decltype(part_c)::value;
+      // orders +am and -am together: they share the Mh run (Mh[n,-m] = (-1)^m conj(Mh[n,m]): sign modifiers) and
+      // give four independent FMA chains per pass instead of two
 #pragma unroll
-      for (int m = -(P - 1); m <= P - 1; ++m) {
-        const int am = m < 0 ? -m : m;
+      for (int am = 0; am < P; ++am) {
         if (Sh::PT.v[am] != PART) continue;
-        const double sr = (m < 0 && (am & 1)) ? -1.0 : 1.0;            // (-1)^m for m < 0
-        const double si = (m < 0) ? -sr : 1.0;                         // conj
-        double tr[NSLOT], tq[NSLOT];
-        bool started_r = false, started_q = false;     // the first product initialises the sums (no v_mov 0 + fma)
+        const double sr = (am & 1) ? -1.0 : 1.0;                       // (-1)^m for the negative order; conj: -sr on im
+        double trp[NSLOT], tqp[NSLOT], trn[NSLOT], tqn[NSLOT];
+        bool started = false, started_r = false;   // the first product initialises the sums (no v_mov 0 + fma)
 #pragma unroll
         for (int n0 = am & ~1; n0 < P; n0 += 2) {
-          const double2 g2 = gbase[((m + Sh::C0) * RR + n0) / 2];
-          if (n0 < am) {                               // keeps the read 16 bytes wide (see `zero`)
+          const double2 gp = gbase[((am + Sh::C0) * RR + n0) / 2];
+          const double2 gn = am ? gbase[((-am + Sh::C0) * RR + n0) / 2] : gp;
+          if (n0 < am) {                               // keeps the reads 16 bytes wide (see `zero`)
 #pragma unroll
-            for (int q = 0; q < NSLOT; ++q) tr[q] = zero * g2.x;
+            for (int q = 0; q < NSLOT; ++q) { trp[q] = zero * gp.x; if (am) trn[q] = zero * gn.x; }
             started_r = true;
           }
-          if (n0 >= am) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int n = n0 + h;
+            if (n < am || n >= P) continue;
+            const double gpv = h ? gp.y : gp.x, gnv = h ? gn.y : gn.x;
 #pragma unroll
             for (int q = 0; q < NSLOT; ++q) {
-              const double ar = sr * mh[q][am * P - am * (am - 1) / 2 + n0 - am].x, ai = si * mh[q][am * P - am * (am - 1) / 2 + n0 - am].y;
-              tr[q] = started_r ? fma(ar, g2.x, tr[q]) : ar * g2.x;
-              tq[q] = started_q ? fma(ai, g2.x, tq[q]) : ai * g2.x;
+              const double ar = mh[q][am * P - am * (am - 1) / 2 + n - am].x, ai = mh[q][am * P - am * (am - 1) / 2 + n - am].y;
+              trp[q] = started_r ? fma(ar, gpv, trp[q]) : ar * gpv;
+              tqp[q] = started ? fma(ai, gpv, tqp[q]) : ai * gpv;
+              if (am) {
+                trn[q] = started_r ? fma(sr * ar, gnv, trn[q]) : (sr * ar) * gnv;
+                tqn[q] = started ? fma(-sr * ai, gnv, tqn[q]) : (-sr * ai) * gnv;
+              }
             }
-            started_r = started_q = true;
-          }
-          if (n0 + 1 < P) {
-#pragma unroll
-            for (int q = 0; q < NSLOT; ++q) {
-              const double ar = sr * mh[q][am * P - am * (am - 1) / 2 + n0 + 1 - am].x, ai = si * mh[q][am * P - am * (am - 1) / 2 + n0 + 1 - am].y;
-              tr[q] = started_r ? fma(ar, g2.y, tr[q]) : ar * g2.y;
-              tq[q] = started_q ? fma(ai, g2.y, tq[q]) : ai * g2.y;
-            }
-            started_r = started_q = true;
+            started = started_r = true;
           }
         }
-        const double er = zm[am].x, ei = (m < 0 ? -1.0 : 1.0) * zm[am].y;      // Z^m, Z^{-m} = conj
+        const double er = zm[am].x, ei = zm[am].y;                     // Z^m; Z^{-m} = conj
 #pragma unroll
         for (int q = 0; q < NSLOT; ++q) {
-          as[q].x = fma(er, tr[q], as[q].x); as[q].x = fma(-ei, tq[q], as[q].x);
-          as[q].y = fma(er, tq[q], as[q].y); as[q].y = fma(ei, tr[q], as[q].y);
+          as[q].x = fma(er, trp[q], as[q].x); as[q].x = fma(-ei, tqp[q], as[q].x);
+          as[q].y = fma(er, tqp[q], as[q].y); as[q].y = fma(ei, trp[q], as[q].y);
+          if (am) {
+            as[q].x = fma(er, trn[q], as[q].x); as[q].x = fma(ei, tqn[q], as[q].x);
+            as[q].y = fma(er, tqn[q], as[q].y); as[q].y = fma(-ei, trn[q], as[q].y);
+          }
         }
       }
     };
