@@ -400,9 +400,9 @@ hipError_t launch_m2l(const DevicePlan& d, const DevicePlan* d_dev, int p, hipSt
   hipLaunchKernelGGL((m2l_kernel<PP, NSV, NQ>),                                                               \
                      dim3((d.n_m2l_tgt + Shape<PP, NSV>::TARGETS - 1) / Shape<PP, NSV>::TARGETS, d.n_act / NQ), \
                      dim3(Shape<PP, NSV>::THREADS), 0, s, d_dev)
-  // two active expansion slots at a time when their number is even (Stokes 4, Laplace with mixed BC 2)
-  // (Stokes config 4, p = 8, ms: 2.64 with one slot per pass, 2.32 with two, 3.02 with four -- SGPR spills)
-#define LAUNCH(NSV) do { if (d.n_act % 2 == 0 && PP <= 12) { LAUNCH_Q(NSV, 2); } else { LAUNCH_Q(NSV, 1); } } while (0)
+  // several active expansion slots per pass (Stokes: 4; Laplace with mixed BC: 2)
+  // (Stokes config 4, p = 8, ms: 2.64 with one slot per pass, 2.32 with two; with the +-m pairing 1.96 with two, 1.84 with four)
+#define LAUNCH(NSV) do { if (d.n_act % 4 == 0 && PP <= 10) { LAUNCH_Q(NSV, 4); } else if (d.n_act % 2 == 0 && PP <= 12) { LAUNCH_Q(NSV, 2); } else { LAUNCH_Q(NSV, 1); } } while (0)
 #define LAUNCH_SMALL()                                                                                     \
   hipLaunchKernelGGL((m2l_small_kernel<(PP <= 4 ? PP : 1)>), dim3((d.n_m2l_tgt + kM2LTargets - 1) / kM2LTargets, d.n_act), \
                      dim3(kM2LTargets * kWave), 0, s, d)
