@@ -406,8 +406,9 @@ hipError_t launch_m2l(const DevicePlan& d, const DevicePlan* d_dev, int p, hipSt
 #define LAUNCH_SMALL()                                                                                     \
   hipLaunchKernelGGL((m2l_small_kernel<(PP <= 4 ? PP : 1)>), dim3((d.n_m2l_tgt + kM2LTargets - 1) / kM2LTargets, d.n_act), \
                      dim3(kM2LTargets * kWave), 0, s, d)
-  // wavefronts per target (N = 1M, ms): p = 6: 0.98 / 1.04 / 1.49 with 1 / 2 / 3; p = 8: 1.68 / 1.56 / 1.71; p = 10: 2.96 / 2.27 / 2.31
-  FMMBEM_DISPATCH_P(p, if (PP <= 4) { LAUNCH_SMALL(); } else if (PP <= 6) { LAUNCH(1); } else { LAUNCH(2); })
+  // wavefronts sharing a target's m sets, NS (N = 1M, ms with NS = 1 / 2 / 3 / 4): p = 6: 0.85 / 0.90 / 1.25 / 1.34;
+  // p = 8: 1.46 / 1.50 / 1.54 / 1.91; p = 10: 2.57 / 2.03 / 2.45 / 2.17; p = 12 (two wavefronts of outputs): 4.80 / 5.01 / 5.87 / 5.59
+  FMMBEM_DISPATCH_P(p, if (PP <= 4) { LAUNCH_SMALL(); } else if (PP == 9 || PP == 10) { LAUNCH(2); } else { LAUNCH(1); })
 #undef LAUNCH_SMALL
 #undef LAUNCH
 #undef LAUNCH_Q
