@@ -408,7 +408,9 @@ hipError_t launch_m2l(const DevicePlan& d, const DevicePlan* d_dev, int p, hipSt
                      dim3(kM2LTargets * kWave), 0, s, d)
   // wavefronts sharing a target's m sets, NS (N = 1M, ms with NS = 1 / 2 / 3 / 4): p = 6: 0.85 / 0.90 / 1.25 / 1.34;
   // p = 8: 1.46 / 1.50 / 1.54 / 1.91; p = 10: 2.57 / 2.03 / 2.45 / 2.17; p = 12 (two wavefronts of outputs): 4.80 / 5.01 / 5.87 / 5.59
-  FMMBEM_DISPATCH_P(p, if (PP <= 4) { LAUNCH_SMALL(); } else if (PP == 9 || PP == 10) { LAUNCH(2); } else { LAUNCH(1); })
+  // with several slots per pass the work per source grows and two wavefronts pay off from p = 7 (Stokes p = 8: 2.05 / 1.84)
+  const bool multi = d.n_act % 2 == 0;
+  FMMBEM_DISPATCH_P(p, if (PP <= 4) { LAUNCH_SMALL(); } else if (PP == 9 || PP == 10 || (multi && PP >= 7 && PP <= 10)) { LAUNCH(2); } else { LAUNCH(1); })
 #undef LAUNCH_SMALL
 #undef LAUNCH
 #undef LAUNCH_Q
