@@ -21,6 +21,20 @@
 
 namespace fmmbem {
 
+// One unit of near_spmv work with everything the pipelined kernel needs in one record (fetched two items ahead by
+// scalar loads): rows [yrow, yrow+nrows) (in unknowns) of one target leaf's dense block.
+struct NearItem {
+  int64_t val_off;     // first entry of the row range in near_val
+  int64_t run_begin;   // -> near_run_row0 / near_run_off
+  int nruns;
+  int yrow;            // first tree-order unknown of the range (index into yt)
+  int nrows;
+  int ncols, stride;   // columns in unknowns, row stride
+  int colsplit;        // nrows < 8: wavefronts split the columns instead of the rows
+  int pad[2];
+};
+static_assert(sizeof(NearItem) == 48, "NearItem is read as three 16-byte pieces");
+
 // M2M or L2L operator at one order p, terms dealt to virtual rows (shift_ops.hpp VOp); passed to the kernel by value.
 struct ShiftOpDev {
   const uint16_t *src, *y;     // [i * V + v]
@@ -64,6 +78,7 @@ struct DevicePlan {
   int xch_ptr[9];                                    // ... xch_box[xch_ptr[r] .. xch_ptr[r+1]) belongs to shard r (<= 8 shards)
   int xch_rank, xch_world, xch_max;                  // this shard, number of shards, largest per-shard count
   const int4* near_items;                            // SpMV work items {leaf, first row, rows, column-split?}, largest first
+  const NearItem* near_recs;                         // the same items as self-contained records (pipelined kernel)
   int near_nitems;
   // boxes / expansions
   const double* box_center;

@@ -411,15 +411,15 @@ __global__ void scatter_y_kernel(const uint32_t* __restrict__ perm, const double
 }
 
 // ---------------------------------------------------------------------------------------------
-// near_spmv: one 256-thread workgroup (4 wavefronts) per owned target leaf.
-//   1. the x values of the leaf's columns are staged once in LDS (<= max_ncols doubles), see load_runs;
-//   2. each wavefront takes kRows rows at a time (rows w, w+4, w+8, w+12 ...); a row is `stride`
-//      contiguous doubles read as 16-B vectors, lanes striding over the columns (fully coalesced 1-KiB
-//      wave loads); all kRows x kVecs loads of a batch are issued before the first FMA, so a wavefront
-//      keeps up to 16 KiB in flight and a typical leaf (~20-30 rows x ~500-600 columns) needs only one or
-//      two batches per wavefront;
+// near_spmv (P2P): y_t = A_near x_t over the owned rows -- include/Matvec.hpp:14-33 on the dense leaf blocks.
+//   1. the x values of a work item's columns are staged in LDS through the leaf's run descriptors;
+//   2. each wavefront takes kRows rows at a time (rows w, w+4, ...); a row is `stride` contiguous doubles read as
+//      16-B vectors, lanes striding over the columns (coalesced 1-KiB wave loads, nontemporal); all kRows x kVecs
+//      loads of a batch are issued before the first FMA;
 //   3. per-row wave shuffle reduction, lane 0 stores y_tree[row].
 // Algorithmic bytes: 8 B per near entry (+ 8 B x read + 8 B y write per panel); no column indices.
+// This plain form serves Stokes (3 unknowns per panel, 2048-column chunks); one unknown per panel takes the pipelined
+// form further down.
 // ---------------------------------------------------------------------------------------------
 constexpr int kSpmvWaves = 4;
 constexpr int kSpmvChunk = 2048;                     // columns of x staged in LDS at a time (16 KiB)
@@ -520,6 +520,149 @@ __global__ __launch_bounds__(kSpmvWaves * kWave, kSpmvOcc) void near_spmv_kernel
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// near_spmv, pipelined form (one unknown per panel): the same items, the same row/column-split arithmetic as
+// near_spmv_kernel above, but the set-up of item i+1 runs while item i streams.  A workgroup's time per item was
+// [x gather: one L2 round trip] [2-3 round trips of matrix rows] with two barriers, i.e. a streaming duty of ~80 %
+// (5.5 of the 7.0 TB/s a bare read of the same blocks reaches).  Here
+//   * item records are self-contained (NearItem) and fetched two items ahead by scalar loads;
+//   * the run descriptors of item i+2 and the x values of item i+1 (first kSpmvPipeChunk columns) are loaded into
+//     registers BEFORE item i's rows are streamed and written to the other halves of double-buffered LDS arrays after;
+//   * one barrier per item.
+// Wider leaves stage their further chunks in place as before.
+// ---------------------------------------------------------------------------------------------
+constexpr int kSpmvPipeChunk = 1024;                  // columns per x buffer (2 x 8 KiB)
+constexpr int kSpmvPre = kSpmvPipeChunk / (kSpmvWaves * kWave);       // x values a thread prefetches
+
+template <int kRows, int kVecs>
+__global__ __launch_bounds__(kSpmvWaves * kWave, kSpmvOcc) void near_spmv_pipe_kernel(DevicePlan d) {
+  extern __shared__ double xs_all[];                  // [2][kSpmvPipeChunk] doubles, then [2][2][max_runs] ints
+  __shared__ double part[kSpmvWaves][kColRows];
+  int* const runbuf = reinterpret_cast<int*>(xs_all + 2 * kSpmvPipeChunk);
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const int mr = d.max_runs, nitems = d.near_nitems, step = gridDim.x, tid = threadIdx.x;
+
+  int item = blockIdx.x;
+  if (item >= nitems) return;
+  NearItem it = d.near_recs[item];
+  NearItem nx = d.near_recs[item + step < nitems ? item + step : nitems - 1];
+  // prologue: runs of the first two items, x of the first
+  for (int i = tid; i < it.nruns; i += blockDim.x) { runbuf[i] = d.near_run_row0[it.run_begin + i]; runbuf[mr + i] = d.near_run_off[it.run_begin + i]; }
+  for (int i = tid; i < nx.nruns; i += blockDim.x) { runbuf[2 * mr + i] = d.near_run_row0[nx.run_begin + i]; runbuf[3 * mr + i] = d.near_run_off[nx.run_begin + i]; }
+  __syncthreads();
+  {
+    const Runs runs{runbuf, runbuf + mr, it.nruns};
+    const int cw = it.stride < kSpmvPipeChunk ? it.stride : kSpmvPipeChunk;
+    for (int c = tid; c < cw; c += blockDim.x) xs_all[c] = c < it.ncols ? d.xt[column_to_row(runs, c)] : 0.0;
+  }
+  __syncthreads();
+  int xb = 0, rb = 0;                                 // which halves hold the current item's x chunk 0 / runs
+  for (;; item += step) {
+    const bool more = item + step < nitems;
+    const int i2 = item + 2 * step;
+    const NearItem nn = d.near_recs[i2 < nitems ? i2 : nitems - 1];
+    // ---- set-up of the following items, in flight while this item's rows stream ----
+    // (issued behind the first matrix loads instead: the staging array lands in scratch, 0.91 ms)
+    double px[kSpmvPre];
+    int pr0 = 0, pr1 = 0;
+    const bool prun = i2 < nitems && tid < nn.nruns;     // max_runs <= blockDim.x is checked by the launcher
+    if (more) {
+      const Runs nruns{runbuf + (rb ^ 1) * 2 * mr, runbuf + (rb ^ 1) * 2 * mr + mr, nx.nruns};
+      const int ncw = nx.stride < kSpmvPipeChunk ? nx.stride : kSpmvPipeChunk;
+#pragma unroll
+      for (int u = 0; u < kSpmvPre; ++u) {
+        const int c = tid + u * (kSpmvWaves * kWave);
+        px[u] = (c < ncw && c < nx.ncols) ? d.xt[column_to_row(nruns, c)] : 0.0;
+      }
+      if (prun) { pr0 = d.near_run_row0[nn.run_begin + tid]; pr1 = d.near_run_off[nn.run_begin + tid]; }
+    }
+    // ---- this item ----
+    const int nrows = it.nrows, ncols = it.ncols, stride = it.stride;
+    const bool colsplit = it.colsplit != 0;
+    const double* blk = d.near_val + it.val_off;
+    double* yt = d.yt + it.yrow;
+    double* xs = xs_all + xb * kSpmvPipeChunk;
+    const dvec2* xv = reinterpret_cast<const dvec2*>(xs);
+    const Runs runs{runbuf + rb * 2 * mr, runbuf + rb * 2 * mr + mr, it.nruns};
+    for (int c0 = 0; c0 < stride; c0 += kSpmvPipeChunk) {
+      const int cw = stride - c0 < kSpmvPipeChunk ? stride - c0 : kSpmvPipeChunk;
+      if (c0) {                                       // further chunks of a wide leaf: staged in place
+        __syncthreads();
+        for (int c = tid; c < cw; c += blockDim.x) xs[c] = c0 + c < ncols ? d.xt[column_to_row(runs, c0 + c)] : 0.0;
+        __syncthreads();
+      }
+      const int nvec = cw >> 1;                       // 16-B vectors of this chunk per row
+      const int seg = colsplit ? ((((nvec + kSpmvWaves - 1) / kSpmvWaves) + 3) & ~3) : nvec;
+      const int v0 = colsplit ? wave * seg : 0, v1 = min(nvec, v0 + seg);
+      const int rstep = colsplit ? 1 : kSpmvWaves;
+      for (int r = colsplit ? 0 : wave; r < nrows; r += colsplit ? kRows : kRows * kSpmvWaves) {
+        const dvec2* row[kRows];
+        double acc[kRows];
+#pragma unroll
+        for (int i = 0; i < kRows; ++i) {
+          const int ri = r + i * rstep;
+          row[i] = reinterpret_cast<const dvec2*>(blk + (int64_t)(ri < nrows ? ri : r) * stride + c0);
+          acc[i] = 0;
+        }
+        for (int c = v0 + lane; c < v1; c += kVecs * kWave) {
+          dvec2 v[kRows][kVecs];
+#pragma unroll
+          for (int u = 0; u < kVecs; ++u) {
+            const int cc = c + u * kWave;
+            const bool ok = cc < v1;
+#pragma unroll
+            for (int i = 0; i < kRows; ++i) v[i][u] = ok ? __builtin_nontemporal_load(&row[i][cc]) : dvec2{0, 0};
+          }
+#pragma unroll
+          for (int u = 0; u < kVecs; ++u) {
+            const int cc = c + u * kWave;
+            if (cc < v1) {
+              const dvec2 x2 = xv[cc];
+#pragma unroll
+              for (int i = 0; i < kRows; ++i) acc[i] = fma(v[i][u].x, x2.x, fma(v[i][u].y, x2.y, acc[i]));
+            }
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < kRows; ++i) acc[i] = wave_sum(acc[i]);
+        if (lane == 0) {
+#pragma unroll
+          for (int i = 0; i < kRows; ++i) {
+            const int ri = r + i * rstep;
+            if (ri < nrows) {
+              if (colsplit) part[wave][ri] = acc[i];
+              else yt[ri] = c0 ? yt[ri] + acc[i] : acc[i];
+            }
+          }
+        }
+      }
+      if (colsplit) {
+        __syncthreads();
+        if (tid < nrows) {
+          const double sum = ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
+          yt[tid] = c0 ? yt[tid] + sum : sum;
+        }
+      }
+    }
+    if (!more) break;
+    // ---- hand over: next item's x and the item after's runs into the halves nobody reads now ----
+    {
+      double* xn = xs_all + (xb ^ 1) * kSpmvPipeChunk;
+      const int ncw = nx.stride < kSpmvPipeChunk ? nx.stride : kSpmvPipeChunk;
+#pragma unroll
+      for (int u = 0; u < kSpmvPre; ++u) {
+        const int c = tid + u * (kSpmvWaves * kWave);
+        if (c < ncw) xn[c] = px[u];
+      }
+    }
+    // runs[rb] belonged to this item; a wide leaf's later chunks were the last to read it, and every thread has passed
+    // them: the barriers inside the chunk loop order those reads before this write
+    if (prun) { runbuf[rb * 2 * mr + tid] = pr0; runbuf[rb * 2 * mr + mr + tid] = pr1; }
+    __syncthreads();
+    it = nx; nx = nn; xb ^= 1; rb ^= 1;
+  }
+}
+
 }  // namespace
 
 // diag[original unknown] = A_near[u,u]: the self-interaction K(s,s) that Preconditioners::Diagonal divides by
@@ -580,7 +723,13 @@ hipError_t launch_near_spmv(const DevicePlan& d, hipStream_t s) {
   // start when the others finish (0.98 ms instead of 0.79 at N = 1M); occupancy 6 (80 VGPRs) and 2x2 loads at
   // occupancy 8 measure within 3 % of this.
   const dim3 g(std::min(d.near_nitems, 256 * kSpmvOcc)), b(kSpmvWaves * kWave);
-  hipLaunchKernelGGL((near_spmv_kernel<2, 4>), g, b, lds, s, d);
+  static const bool pipe = !(getenv("FMMBEM_SPMV_PIPE") && atoi(getenv("FMMBEM_SPMV_PIPE")) == 0);
+  if (d.dof == 1 && d.max_runs <= kSpmvWaves * kWave && pipe) {
+    const size_t lds2 = 2 * (size_t)kSpmvPipeChunk * sizeof(double) + 4 * (size_t)d.max_runs * sizeof(int);
+    hipLaunchKernelGGL((near_spmv_pipe_kernel<2, 4>), g, b, lds2, s, d);
+  } else {
+    hipLaunchKernelGGL((near_spmv_kernel<2, 4>), g, b, lds, s, d);
+  }
   return hipGetLastError();
 }
 

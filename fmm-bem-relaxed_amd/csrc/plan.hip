@@ -291,6 +291,21 @@ int fmmbem_plan::to_device() {
     for (size_t i = 0; i < items.size(); ++i) packed[i] = make_int4(items[i].leaf, items[i].r0, items[i].nr, items[i].nr < 8);
     d.near_nitems = (int)packed.size();
     TRY(upload(packed, &d.near_items));
+    std::vector<NearItem> recs(items.size());
+    for (size_t i = 0; i < items.size(); ++i) {
+      const Item& it = items[i];
+      NearItem& q = recs[i];
+      q.val_off = near_off[it.leaf] + (int64_t)it.r0 * near_stride[it.leaf];
+      q.run_begin = run_ptr[it.leaf];
+      q.nruns = (int)(run_ptr[it.leaf + 1] - run_ptr[it.leaf]);
+      q.yrow = dof * leaf_row0[it.leaf] + it.r0;
+      q.nrows = it.nr;
+      q.ncols = dof * hp.near_ncols[it.leaf];
+      q.stride = near_stride[it.leaf];
+      q.colsplit = it.nr < 8;
+      q.pad[0] = q.pad[1] = 0;
+    }
+    TRY(upload(recs, &d.near_recs));
   }
   if (opts.sparse_local) TRY(alloc((size_t)total, &d.near_val, false));   // matrix-free mode keeps no matrix
   else { d.near_val = nullptr; near_bytes = 0; }
