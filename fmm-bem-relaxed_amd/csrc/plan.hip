@@ -648,7 +648,12 @@ int fmmbem_plan_execute_device(fmmbem_plan* plan, int p, const double* d_x, doub
 int fmmbem_plan_exchange_doubles(const fmmbem_plan* plan, int p, size_t* per_shard) {
   if (!plan || !per_shard) return fail(FMMBEM_ERR_INVALID, "null argument");
   if (p < 1 || p > plan->hp.opt.p_max) return fail(FMMBEM_ERR_INVALID, "p outside [1, p_max]");
-  *per_shard = plan->split_upward ? (size_t)plan->d.xch_max * plan->d.n_act * (p * (p + 1) / 2) * 2 : 0;
+  // from the host lists, so that a host-only plan (CPU tests of the N > 1 path) answers too
+  const HostPlan& h = plan->hp;
+  size_t most = 0;
+  for (size_t r = 0; r + 1 < h.xch_ptr.size(); ++r) most = std::max<size_t>(most, (size_t)(h.xch_ptr[r + 1] - h.xch_ptr[r]));
+  const size_t n_act = plan->opts.kernel == FMMBEM_KERNEL_STOKES_BEM ? 4 : (size_t)h.has_bc[0] + (size_t)h.has_bc[1];
+  *per_shard = (h.opt.shard_upward && h.opt.shard_world > 1) ? most * n_act * (size_t)(p * (p + 1) / 2) * 2 : 0;
   return FMMBEM_OK;
 }
 

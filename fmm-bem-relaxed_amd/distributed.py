@@ -21,10 +21,11 @@ class ShardedFMM:
 
     local_execute: callable(x) -> partial result (zeros outside the owned rows). Defaults to the HIP
     plan's execute_torch; tests inject a CPU stand-in to exercise the partition + collective under gloo.
+    local_split: (doubles_per_rank, upward(x, send), downward(recv, y)) stand-ins for the split execute, same purpose.
     """
 
     def __init__(self, K, panels, opts=None, bc=None, p_max=None, group=None, device=None,
-                 host_only=False, local_execute=None, shard_upward=None):
+                 host_only=False, local_execute=None, shard_upward=None, local_split=None):
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -32,9 +33,11 @@ class ShardedFMM:
             device = torch.cuda.current_device() if torch.cuda.is_available() else 0
         if shard_upward is None:
             shard_upward = os.environ.get("FMMBEM_SHARD_UPWARD", "1") != "0"
-        self.split = bool(shard_upward) and self.world > 1 and local_execute is None
+        self.split = (bool(shard_upward) and self.world > 1 and local_execute is None) or local_split is not None
+        self._split_fns = local_split
         self.plan = FMM_plan(K, panels, opts, bc=bc, p_max=p_max, device=device,
-                             shard=(self.rank, self.world), host_only=host_only, shard_upward=self.split)
+                             shard=(self.rank, self.world), host_only=host_only,
+                             shard_upward=self.split and self.world > 1)
         self.n = self.plan.n
         self._local = local_execute if local_execute is not None else self.plan.execute_torch
         self._xbuf = {}                                   # p -> (send, recv) exchange buffers
@@ -57,15 +60,20 @@ class ShardedFMM:
         else:
             p = self.plan.kernel().P
             if p not in self._xbuf:
-                per = self.plan.exchange_doubles(p)
+                per = self._split_fns[0] if self._split_fns else self.plan.exchange_doubles(p)
                 self._xbuf[p] = (torch.empty(per, dtype=torch.float64, device=x.device),
                                  torch.empty(per * self.world, dtype=torch.float64, device=x.device))
             send, recv = self._xbuf[p]
             y = torch.empty_like(x) if out is None else out
-            stream = torch.cuda.current_stream(x.device).cuda_stream
-            self.plan.upward_device(x.data_ptr(), send.data_ptr(), stream, p)
-            dist.all_gather_into_tensor(recv, send, group=self.group)
-            self.plan.downward_device(recv.data_ptr(), y.data_ptr(), stream, p)
+            if self._split_fns:
+                self._split_fns[1](x, send)
+                dist.all_gather_into_tensor(recv, send, group=self.group)
+                self._split_fns[2](recv, y)
+            else:
+                stream = torch.cuda.current_stream(x.device).cuda_stream
+                self.plan.upward_device(x.data_ptr(), send.data_ptr(), stream, p)
+                dist.all_gather_into_tensor(recv, send, group=self.group)
+                self.plan.downward_device(recv.data_ptr(), y.data_ptr(), stream, p)
         if self.world > 1:
             dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.group)
         return y

@@ -90,3 +90,62 @@ def test_shard_balance(fb):
         pairs.append(s["m2l_pairs_owned"])
     assert max(nnz) / (sum(nnz) / world) < 1.35
     assert max(pairs) / (sum(pairs) / world) < 1.6
+
+
+def _split_worker(rank, world, port, out):
+    """The split execute of fmm-bem-relaxed_amd/distributed.py (upward half -> all_gather_into_tensor -> downward half ->
+    all_reduce) with CPU stand-ins for the two halves: every rank contributes the x values of ITS rows, the gathered
+    buffer must hold every rank's piece at rank * per, and the result is again the oracle's rows of the shard."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import fmm_bem_relaxed_amd as fb
+        from oracle import oracle as O
+
+        v = fb.unit_sphere(5)
+        n = len(v)
+        K = fb.LaplaceSphericalBEM(6, 3)
+        orc = O.Oracle(v)
+        holder = {}
+        per = n + 1                                      # room for every row + a rank tag
+
+        def upward(x, send):
+            rows = holder["op"].owned_rows()
+            send.zero_()
+            send[torch.from_numpy(rows.astype(np.int64))] = x[torch.from_numpy(rows.astype(np.int64))]
+            send[n] = float(rank + 1)
+
+        def downward(recv, y):
+            pieces = recv.view(world, per)
+            assert [float(pieces[r, n]) for r in range(world)] == [float(r + 1) for r in range(world)]
+            xfull = pieces[:, :n].sum(dim=0)             # disjoint rows: the sum reassembles x
+            rows = holder["op"].owned_rows()
+            y.zero_()
+            y[torch.from_numpy(rows.astype(np.int64))] = torch.from_numpy(orc.matvec(xfull.numpy(), K.P)[rows])
+
+        op = fb.ShardedFMM(K, v, host_only=True, local_split=(per, upward, downward))
+        holder["op"] = op
+        # the plan itself was built with the owner lists of the sharded upward pass and reports the exchange size
+        assert op.split and op.plan.shard_upward and op.plan.exchange_doubles(6) > 0
+        sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(sizes, torch.tensor([op.plan.exchange_doubles(6)]))
+        x = torch.from_numpy(np.random.default_rng(8).random(n))
+        y = op.execute(x)
+        ok = np.array_equal(y.numpy(), orc.matvec(x.numpy(), K.P)) and sizes[0].item() == sizes[1].item()
+        if rank == 0:
+            out.put(bool(ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_split_execute_world2_gloo():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_split_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert out.get(timeout=5) is True
