@@ -61,16 +61,31 @@ inline bool m2l_lane_map(int P, std::vector<int32_t>& out) {
       cls[(lam % 16 + 16) % 16].push_back(j | (k << 8) | (idx << 16));
     }
   std::vector<int> fill(bins, 0);
-  int next_bin = 0;                          // rotate the starting bin so the bins fill evenly
-  for (int r = 0; r < 16; ++r) {
-    if ((int)cls[r].size() > bins) return false;
-    for (std::size_t i = 0; i < cls[r].size(); ++i) {
-      const int bin = (next_bin + (int)i) % bins;
-      const int wave = bin / 4, grp = bin % 4;
-      if (fill[bin] >= 16) return false;
-      out[wave * 64 + b128_lane_groups()[grp][fill[bin]++]] = cls[r][i];
+  if (team == 1) {
+    int next_bin = 0;                        // rotate the starting bin so the bins fill evenly
+    for (int r = 0; r < 16; ++r) {
+      if ((int)cls[r].size() > bins) return false;
+      for (std::size_t i = 0; i < cls[r].size(); ++i) {
+        const int bin = (next_bin + (int)i) % bins;
+        const int wave = bin / 4, grp = bin % 4;
+        if (fill[bin] >= 16) return false;
+        out[wave * 64 + b128_lane_groups()[grp][fill[bin]++]] = cls[r][i];
+      }
+      next_bin = (next_bin + (int)cls[r].size()) % bins;
     }
-    next_bin = (next_bin + (int)cls[r].size()) % bins;
+  } else {
+    // more outputs than lanes of one wavefront: fill the first wavefront's four groups completely (one output of
+    // every residue per group), the rest goes to the next -- a sparsely filled wavefront issues the same instructions
+    // but its ds_read_b128 touch one 16-lane group instead of four, and M2L runs at the LDS limit
+    for (int r = 0; r < 16; ++r) {
+      if ((int)cls[r].size() > bins) return false;
+      for (std::size_t i = 0; i < cls[r].size(); ++i) {
+        const int bin = (int)i;              // member i of every class -> bin i: residues in a bin stay distinct
+        const int wave = bin / 4, grp = bin % 4;
+        if (fill[bin] >= 16) return false;
+        out[wave * 64 + b128_lane_groups()[grp][fill[bin]++]] = cls[r][i];
+      }
+    }
   }
   return true;
 }
