@@ -258,8 +258,8 @@ __global__ __launch_bounds__((Shape<P, NS_>::THREADS)) void m2l_kernel(const Dev
         }
       }
     };
-    if (TEAM == 1 || valid) {                          // one wavefront of outputs: the few lanes without one run along
-      // (no exec mask to keep alive); several: a sparse wavefront masks its idle 16-lane groups off the LDS
+    if ((TEAM == 1 && Sh::S > 48) || valid) {          // a full wavefront of outputs: the few lanes without one run along
+      // (no exec mask to keep alive); otherwise idle 16-lane groups are masked off the LDS
       if (npart == 0) mac_part(std::integral_constant<int, 0>{});
       if (NS > 1 && npart == 1) mac_part(std::integral_constant<int, 1>{});
       if (NS > 2 && npart == 2) mac_part(std::integral_constant<int, 2>{});

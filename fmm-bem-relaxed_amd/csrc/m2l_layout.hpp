@@ -12,8 +12,8 @@
 // ds_read_b128 services a wavefront in four fixed 16-lane groups (MI355X_MICROARCH.md, LDS table); a group is
 // conflict-free iff its 16 slots are distinct mod 16.  The outputs are dealt to the groups so that the lane constant
 //     lambda(j,k) = j/2 - k*h (j even),  D + (j+1)/2 - k*h (j odd),   h = Rr/2, D = O0/2 mod 16
-// is distinct mod 16 inside every group -- possible for every p <= 16 with the (h, D) below (exhaustive search,
-// smallest h first): zero LDS bank conflicts in the hot loop.
+// is distinct mod 16 inside every group -- possible for every p <= 16 with the (h, D) below (exhaustive search for
+// the smallest h whose largest residue class fits the fewest groups): zero LDS bank conflicts in the hot loop.
 #pragma once
 #include <array>
 #include <cstddef>
@@ -22,8 +22,8 @@
 
 namespace fmmbem {
 
-constexpr int kM2LHalfStride[17] = {0, 2, 3, 4, 5, 6, 7, 8, 9, 10, 13, 12, 13, 14, 15, 17, 17};   // h, index = p
-constexpr int kM2LOddShift[17] = {0, 0, 0, 0, 0, 0, 0, 3, 0, 1, 4, 0, 0, 0, 3, 7, 4};             // D, index = p
+constexpr int kM2LHalfStride[17] = {0, 2, 3, 4, 5, 6, 7, 9, 9, 10, 13, 12, 13, 14, 15, 17, 17};   // h, index = p
+constexpr int kM2LOddShift[17] = {0, 0, 0, 0, 0, 0, 0, 3, 2, 1, 4, 0, 0, 0, 3, 7, 4};             // D, index = p
 
 constexpr int m2l_rr(int P) { return 2 * kM2LHalfStride[P]; }                 // column stride, doubles (>= 2P+2)
 constexpr int m2l_c0(int P) { return 2 * P - 2; }                             // column of c = 0 (c in [-(2P-2), P-1])
@@ -61,30 +61,16 @@ inline bool m2l_lane_map(int P, std::vector<int32_t>& out) {
       cls[(lam % 16 + 16) % 16].push_back(j | (k << 8) | (idx << 16));
     }
   std::vector<int> fill(bins, 0);
-  if (team == 1) {
-    int next_bin = 0;                        // rotate the starting bin so the bins fill evenly
-    for (int r = 0; r < 16; ++r) {
-      if ((int)cls[r].size() > bins) return false;
-      for (std::size_t i = 0; i < cls[r].size(); ++i) {
-        const int bin = (next_bin + (int)i) % bins;
-        const int wave = bin / 4, grp = bin % 4;
-        if (fill[bin] >= 16) return false;
-        out[wave * 64 + b128_lane_groups()[grp][fill[bin]++]] = cls[r][i];
-      }
-      next_bin = (next_bin + (int)cls[r].size()) % bins;
-    }
-  } else {
-    // more outputs than lanes of one wavefront: fill the first wavefront's four groups completely (one output of
-    // every residue per group), the rest goes to the next -- a sparsely filled wavefront issues the same instructions
-    // but its ds_read_b128 touch one 16-lane group instead of four, and M2L runs at the LDS limit
-    for (int r = 0; r < 16; ++r) {
-      if ((int)cls[r].size() > bins) return false;
-      for (std::size_t i = 0; i < cls[r].size(); ++i) {
-        const int bin = (int)i;              // member i of every class -> bin i: residues in a bin stay distinct
-        const int wave = bin / 4, grp = bin % 4;
-        if (fill[bin] >= 16) return false;
-        out[wave * 64 + b128_lane_groups()[grp][fill[bin]++]] = cls[r][i];
-      }
+  // member i of every residue class goes to 16-lane group i: residues inside a group stay distinct, and the outputs
+  // occupy the FEWEST groups -- a ds_read_b128 costs one LDS cycle per group that has a live lane, and M2L runs at the
+  // LDS limit.  (h, D) above are chosen so that the largest class fits: 2 groups at p = 6, 7; 3 at p = 8; 4 at p = 9,
+  // 10; from p = 11 the first wavefront is filled before the second.
+  for (int r = 0; r < 16; ++r) {
+    if ((int)cls[r].size() > bins) return false;
+    for (std::size_t i = 0; i < cls[r].size(); ++i) {
+      const int bin = (int)i, wave = bin / 4, grp = bin % 4;
+      if (fill[bin] >= 16) return false;
+      out[wave * 64 + b128_lane_groups()[grp][fill[bin]++]] = cls[r][i];
     }
   }
   return true;
