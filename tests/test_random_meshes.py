@@ -1,0 +1,67 @@
+"""Randomised parity (hypothesis): arbitrary triangle soups -- clustered, stretched, with panels of very different
+sizes -- through the host list builder (CPU, against the oracle's lists) and through the whole GPU matvec (against the
+oracle's matvec).  The reference's own tests only ever use its sphere generator; these are the inputs it would meet with
+a user's mesh."""
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings
+from hypothesis import strategies as st
+
+
+def _soup(seed, n, clusters, stretch, size_spread):
+    rng = np.random.default_rng(seed)
+    centres = rng.uniform(-1, 1, (clusters, 3)) * np.array([stretch, 1.0, 1.0 / stretch])
+    which = rng.integers(0, clusters, n)
+    c = centres[which] + rng.normal(0, 0.15, (n, 3))
+    h = 0.02 * np.exp(rng.uniform(-size_spread, size_spread, n))
+    e0, e1 = rng.normal(size=(n, 3)), rng.normal(size=(n, 3))
+    e0 /= np.linalg.norm(e0, axis=1, keepdims=True)
+    e1 -= (e1 * e0).sum(axis=1, keepdims=True) * e0
+    e1 /= np.linalg.norm(e1, axis=1, keepdims=True)
+    return np.stack([c, c + h[:, None] * e0, c + h[:, None] * (0.3 * e0 + e1)], axis=1)
+
+
+soup_args = dict(seed=st.integers(0, 2 ** 31 - 1), n=st.integers(2, 900), clusters=st.integers(1, 6),
+                 stretch=st.sampled_from([1.0, 3.0, 10.0]), size_spread=st.sampled_from([0.0, 1.0, 2.0]),
+                 ncrit=st.sampled_from([8, 32, 64, 126]), theta=st.sampled_from([0.4, 0.5, 0.7]))
+
+
+@settings(max_examples=25, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(**soup_args)
+def test_host_lists_equal_oracle_on_random_soups(fb, oracle_mod, seed, n, clusters, stretch, size_spread, ncrit, theta):
+    v = _soup(seed, n, clusters, stretch, size_spread)
+    opts = fb.FMMOptions()
+    opts.set_mac_theta(theta)
+    opts.set_max_per_box(ncrit)
+    try:
+        pl = fb.FMM_plan(fb.LaplaceSphericalBEM(5, 3), v, opts, host_only=True)
+    except fb.FmmBemError as e:                        # clumps the 10-level keys cannot separate
+        assert e.status == 5
+        return
+    o = oracle_mod.Oracle(v, theta=theta, ncrit=ncrit)
+    assert np.array_equal(pl.perm(), o.perm())
+    assert np.array_equal(pl.pairs("p2p"), o.pairs("p2p")) and np.array_equal(pl.pairs("m2l"), o.pairs("m2l"))
+    s, so = pl.stats(), o.stats()
+    assert (s["n_boxes"], s["n_leaves"], s["near_nnz_total"]) == (so["boxes"], so["leaves"], so["near_nnz"])
+
+
+@pytest.mark.gpu
+@settings(max_examples=30, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(p=st.integers(1, 16), k=st.sampled_from([1, 3, 4, 7]), mixed=st.booleans(), **soup_args)
+def test_gpu_matvec_equals_oracle_on_random_soups(fb, oracle_mod, seed, n, clusters, stretch, size_spread, ncrit, theta, p, k, mixed):
+    v = _soup(seed, n, clusters, stretch, size_spread)
+    rng = np.random.default_rng(seed + 1)
+    bc = (rng.random(n) < 0.5).astype(np.uint8) if mixed else None
+    x = rng.standard_normal(n)
+    opts = fb.FMMOptions()
+    opts.set_mac_theta(theta)
+    opts.set_max_per_box(ncrit)
+    try:
+        pl = fb.FMM_plan(fb.LaplaceSphericalBEM(p, k), v, opts, bc=bc)
+    except fb.FmmBemError as e:
+        assert e.status == 5
+        return
+    y = pl.execute(x)
+    yo = oracle_mod.Oracle(v, bc=bc, K=k, theta=theta, ncrit=ncrit).matvec(x, p)
+    assert np.all(np.isfinite(y))
+    assert np.linalg.norm(y - yo) <= 1e-11 * np.linalg.norm(yo)
