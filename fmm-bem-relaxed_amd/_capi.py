@@ -15,6 +15,7 @@ OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC, ERR_TREE, ERR_UNSUPPORTED, E
 PMAX = 16
 KERNEL_LAPLACE_BEM, KERNEL_STOKES_BEM = 0, 1
 EVAL_FMM, EVAL_LOCAL, EVAL_BLOCK_DIAGONAL = 0, 1, 2
+L2L_COMPLETE, L2L_REFERENCE = 0, 1
 BC_POTENTIAL, BC_NORMAL_DERIV = 0, 1
 
 
@@ -24,7 +25,7 @@ class Options(C.Structure):
                 ("ncrit", C.c_uint32), ("sparse_local", C.c_int32), ("host_only", C.c_int32),
                 ("device", C.c_int32), ("shard_rank", C.c_int32), ("shard_world", C.c_int32),
                 ("quad_k_fine", C.c_int32), ("evaluator", C.c_int32), ("mu", C.c_double),
-                ("shard_upward", C.c_int32), ("reserved", C.c_int32)]
+                ("shard_upward", C.c_int32), ("l2l_rule", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -36,7 +37,7 @@ class Stats(C.Structure):
         [("expansions_active", C.c_int32), ("last_p", C.c_int32)] +
         [(n, C.c_double) for n in ("build_host_ms", "build_assemble_ms", "ms_total", "ms_gather", "ms_near",
                                    "ms_scatter", "ms_p2m", "ms_m2m", "ms_mh", "ms_m2l", "ms_l2l", "ms_l2p")] +
-        [("timed_executes", C.c_int64)])
+        [("timed_executes", C.c_int64), ("l2l_reference_omitted", C.c_int64)])
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -327,6 +327,34 @@ std::string HostPlan::build(const HostOptions& o, int64_t n_panels, const double
     if (has_L[box_parent[b]]) has_L[b] = 1;
   }
 
+  // ---- the reference's lazy L2L rule (EvalInteractionLazySparse.hpp:199-237) ----
+  // resolve_LR_interactions walks the M2L list in traversal order; the FIRST time a box is a target it is marked and
+  // propagate_local queues parent->child for every descendant that is not marked yet.  A box that was an M2L target
+  // BEFORE one of its ancestors became one is therefore never given its ancestor's expansion: the far field the
+  // ancestor collected is lost for that subtree (an error that does not shrink with p).  Uniform trees (the reference's
+  // spheres) have no such edge; adaptive trees do.  The plan applies every edge unless opt.reference_l2l asks for the
+  // reference's set; l2l_ref_omitted counts the difference either way.
+  l2l_ref_edge.assign(nboxes, 0);
+  l2l_ref_omitted = 0;
+  {
+    std::vector<uint8_t> init(nboxes, 0);
+    std::vector<int> stack;
+    for (int t : lr_tgt) {
+      if (init[t]) continue;
+      init[t] = 1;
+      stack.assign(1, t);
+      while (!stack.empty()) {
+        const int b = stack.back();
+        stack.pop_back();
+        if (box_leaf[b]) continue;
+        for (int ch = box_child_begin[b]; ch < box_child_end[b]; ++ch)
+          if (!init[ch]) { init[ch] = 1; l2l_ref_edge[ch] = 1; stack.push_back(ch); }
+      }
+    }
+    for (int b = 1; b < nboxes; ++b)
+      if (has_L[box_parent[b]] && !l2l_ref_edge[b]) ++l2l_ref_omitted;
+  }
+
   // ---- shard: contiguous range of target leaves ----
   std::vector<int> box_owner(nboxes, 0);                 // shard whose rows hold all of the box's bodies, -1 = spans shards
   {
@@ -392,7 +420,7 @@ std::string HostPlan::build(const HostOptions& o, int64_t n_panels, const double
   l2l_ops = 0;
   for (int lev = 1; lev < nlevels; ++lev) {            // top-down
     for (int b = level_off[lev]; b < level_off[lev + 1]; ++b)
-      if (has_L[box_parent[b]] && owned_L[b]) { l2l_children.push_back(b); ++l2l_ops; }
+      if (has_L[box_parent[b]] && owned_L[b] && (!o.reference_l2l || l2l_ref_edge[b])) { l2l_children.push_back(b); ++l2l_ops; }
     l2l_level_ptr.push_back((int)l2l_children.size());
   }
 

@@ -34,6 +34,7 @@ struct HostOptions {
   unsigned ncrit = 64;
   int shard_rank = 0, shard_world = 1;
   int evaluator = 0;           // 0 FMM, 1 local only, 2 block diagonal (executor/make_executor.hpp:24-60)
+  bool reference_l2l = false;  // keep only the parent->child L2L edges the reference's lazy rule keeps (see host_plan.cpp)
   bool shard_upward = false;   // shard_world > 1: P2M/M2M only for boxes this shard owns (+ the few spanning shards)
 };
 
@@ -92,6 +93,8 @@ struct HostPlan {
   std::vector<int> l2l_children;          // children receiving L2L, top level first
   std::vector<int> l2l_level_ptr;
   int64_t m2m_ops = 0, l2l_ops = 0;
+  int64_t l2l_ref_omitted = 0;            // edges (parent holds L, child too) the reference's lazy rule never queues
+  std::vector<uint8_t> l2l_ref_edge;      // per box: the reference queues L2L parent(b) -> b
 
   // ---- shard (multi-GPU partition by target leaf) ----
   int leaf_begin = 0, leaf_end = 0;       // owned leaves

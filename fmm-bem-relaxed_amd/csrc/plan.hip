@@ -606,6 +606,7 @@ int fmmbem_plan_create(const fmmbem_options* opts, size_t n_panels, const double
         if (bc[i]) return fail(FMMBEM_ERR_UNSUPPORTED, "Stokes: only VELOCITY panels (the traction far field of the reference is not reproducible)");
   }
   if (!vertices || n_panels == 0) return fail(FMMBEM_ERR_INVALID, "no panels");
+  if (opts->l2l_rule != FMMBEM_L2L_COMPLETE && opts->l2l_rule != FMMBEM_L2L_REFERENCE) return fail(FMMBEM_ERR_INVALID, "unknown l2l_rule");
   if (opts->evaluator < FMMBEM_EVAL_FMM || opts->evaluator > FMMBEM_EVAL_BLOCK_DIAGONAL) return fail(FMMBEM_ERR_INVALID, "unknown evaluator");
   std::unique_ptr<fmmbem_plan> pl(new (std::nothrow) fmmbem_plan);
   if (!pl) return fail(FMMBEM_ERR_ALLOC, "plan");
@@ -615,6 +616,7 @@ int fmmbem_plan_create(const fmmbem_options* opts, size_t n_panels, const double
   ho.shard_rank = opts->shard_rank; ho.shard_world = opts->shard_world < 1 ? 1 : opts->shard_world;
   ho.evaluator = opts->evaluator;
   ho.shard_upward = opts->shard_upward != 0;
+  ho.reference_l2l = opts->l2l_rule == FMMBEM_L2L_REFERENCE;
   const double t0 = now_ms();
   std::string err;
   try {
@@ -702,6 +704,7 @@ int fmmbem_plan_stats(const fmmbem_plan* plan, fmmbem_stats* o) {
   o->near_nnz = h.near_nnz_owned; o->near_nnz_total = h.near_nnz_total;
   o->p2p_pairs = (int64_t)h.p2p_src.size(); o->m2l_pairs = (int64_t)h.lr_src.size(); o->m2l_pairs_owned = h.m2l_pairs_owned;
   o->m2m_ops = h.m2m_ops; o->l2l_ops = h.l2l_ops;
+  o->l2l_reference_omitted = h.l2l_ref_omitted;
   o->p2m_leaves = (int64_t)h.p2m_leaves.size(); o->l2p_leaves = (int64_t)h.l2p_leaves.size();
   o->m2l_classes = (int64_t)h.m2l_class_rep.size() / 2;
   o->owned_leaf_begin = h.leaf_begin; o->owned_leaf_end = h.leaf_end;

@@ -27,6 +27,9 @@ class FMMOptions:
         self.block_diagonal = False
         self.theta = 0.5                # DefaultMAC(0.5), FMMOptions.hpp:45
         self.ncrit = 64                 # NCRIT_, FMMOptions.hpp:46
+        # not in the reference: True applies exactly the L2L edges the reference's lazy evaluator queues, which on
+        # adaptive trees leaves some boxes without their ancestors' far field (include/fmmbem.h, fmmbem_l2l_rule)
+        self.reference_l2l = False
 
     def set_mac_theta(self, theta):     # FMMOptions.hpp:50-52
         self.theta = float(theta)
@@ -160,6 +163,7 @@ class FMM_plan:
         o.sparse_local = 1 if opts.sparse_local else 0
         o.host_only = 1 if host_only else 0
         o.evaluator = evaluator
+        o.l2l_rule = _capi.L2L_REFERENCE if getattr(opts, "reference_l2l", False) else _capi.L2L_COMPLETE
         o.device = int(device)
         self.dof = 1
         if isinstance(K, StokesSphericalBEM):

@@ -57,6 +57,16 @@ typedef enum {
   FMMBEM_EVAL_BLOCK_DIAGONAL = 2  /* EvalDiagonalSparse: every leaf with itself (examples/BEM/BlockDiagonalPC.hpp:16-60)  */
 } fmmbem_evaluator;
 
+/* Downward pass.  The reference's lazy evaluator queues L2L parent->child only for children that were not an M2L
+ * target EARLIER in the traversal than the parent (propagate_local / initialised_L,
+ * executor/EvalInteractionLazySparse.hpp:199-237): on adaptive trees such a child never receives the far field its
+ * ancestors collected and the result carries an error that does not decrease with p.  The reference's sphere meshes
+ * produce no such edge, there the two rules are the same list.  fmmbem_stats.l2l_reference_omitted counts them. */
+typedef enum {
+  FMMBEM_L2L_COMPLETE = 0,        /* every child of a box that holds a local expansion (default)                      */
+  FMMBEM_L2L_REFERENCE = 1        /* exactly the reference's list, omissions included (bit parity on adaptive trees)  */
+} fmmbem_l2l_rule;
+
 typedef struct {
   int32_t  kernel;            /* fmmbem_kernel                                                     */
   int32_t  p_max;             /* largest expansion order any execute() will ask for (1..16)        */
@@ -77,7 +87,7 @@ typedef struct {
   int32_t  shard_upward;      /* shard_world > 1: also shard P2M/M2M by owner; the multipoles are exchanged by ONE
                                * all-gather the caller performs between fmmbem_plan_upward_device and
                                * fmmbem_plan_downward_device (0: every shard repeats the whole upward pass)   */
-  int32_t  reserved;
+  int32_t  l2l_rule;          /* fmmbem_l2l_rule: which parent->child L2L edges the downward pass applies              */
 } fmmbem_options;
 
 /* Statistics of a plan and of its last execute (times in milliseconds, device-side HIP events). */
@@ -95,6 +105,7 @@ typedef struct {
   /* per-stage device times: MEAN over the executes recorded since timing was (re)enabled */
   double  ms_total, ms_gather, ms_near, ms_scatter, ms_p2m, ms_m2m, ms_mh, ms_m2l, ms_l2l, ms_l2p;
   int64_t timed_executes;       /* how many executes the means cover                                 */
+  int64_t l2l_reference_omitted;/* L2L edges FMMBEM_L2L_REFERENCE leaves out of this tree (0: the rules coincide) */
 } fmmbem_stats;
 
 typedef struct fmmbem_plan fmmbem_plan;

@@ -38,6 +38,7 @@ class FMMOptions {
   EvalType evaluator = FMM;
   double theta = 0.5;
   unsigned NCRIT_ = 64;
+  bool reference_l2l = false;   // not in the reference: apply only the L2L edges its lazy evaluator queues (fmmbem_l2l_rule)
   void set_mac_theta(double t) { theta = t; }
   void set_max_per_box(unsigned n) { NCRIT_ = n; }
   unsigned max_per_box() const { return NCRIT_; }
@@ -137,6 +138,7 @@ class FMM_plan<LaplaceSphericalBEM> {
     o.sparse_local = opts.sparse_local ? 1 : 0;   // examples/LaplaceBEM.cpp:81 sets it; FMMOptions defaults to false
     o.device = device;
     o.evaluator = opts.c_evaluator();
+    o.l2l_rule = opts.reference_l2l ? FMMBEM_L2L_REFERENCE : FMMBEM_L2L_COMPLETE;
     fmmbem::check(fmmbem_plan_create(&o, n_, v.data(), bc.data(), &plan_));
   }
   ~FMM_plan() { fmmbem_plan_destroy(plan_); }
@@ -193,6 +195,7 @@ class FMM_plan<StokesSphericalBEM> {
     o.ncrit = opts.NCRIT_;
     o.sparse_local = 1;
     o.evaluator = opts.c_evaluator();
+    o.l2l_rule = opts.reference_l2l ? FMMBEM_L2L_REFERENCE : FMMBEM_L2L_COMPLETE;
     o.device = device;
     fmmbem::check(fmmbem_plan_create(&o, n_, v.data(), bc.data(), &plan_));
   }

@@ -116,6 +116,7 @@ enum { ORC_EVAL_FMM = 0, ORC_EVAL_LOCAL = 1, ORC_EVAL_BLOCK_DIAGONAL = 2 };
 orc_ctx *orc_create_eval(int n, const double *verts, const uint8_t *bc, int K, double theta, unsigned ncrit, int evaluator);
 orc_ctx *orc_create(int n, const double *verts, const uint8_t *bc, int K, double theta,
                     unsigned ncrit);
+void orc_complete_l2l(orc_ctx *c);   /* not a reference rule: see tree.c */
 void orc_destroy(orc_ctx *c);
 void orc_stats(const orc_ctx *c, int64_t out[16]);
 

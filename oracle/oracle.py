@@ -37,6 +37,8 @@ def lib():
         L.orc_create.argtypes = [i32, vp, vp, i32, dbl, C.c_uint]
         L.orc_create_eval.restype = vp
         L.orc_create_eval.argtypes = [i32, vp, vp, i32, dbl, C.c_uint, i32]
+        L.orc_complete_l2l.restype = None
+        L.orc_complete_l2l.argtypes = [vp]
         L.orc_destroy.argtypes = [vp]
         L.orc_stats.argtypes = [vp, vp]
         L.orc_build_near.argtypes = [vp]
@@ -123,8 +125,10 @@ FAITHFUL = 1
 class Oracle:
     """One FMM_plan<LaplaceSphericalBEM>-equivalent on the CPU (include/FMM_plan.hpp:34-90)."""
 
-    def __init__(self, vertices, bc=None, K=3, theta=0.5, ncrit=64, evaluator=0):
-        """evaluator: 0 FMM, 1 local only (EvalLocalSparse), 2 block diagonal (EvalDiagonalSparse)."""
+    def __init__(self, vertices, bc=None, K=3, theta=0.5, ncrit=64, evaluator=0, complete_l2l=False):
+        """evaluator: 0 FMM, 1 local only (EvalLocalSparse), 2 block diagonal (EvalDiagonalSparse).
+        complete_l2l: replace the reference's L2L list (which omits stats()['l2l_skipped'] edges on adaptive trees)
+        by the complete one -- not a reference rule, see tree.c:orc_complete_l2l."""
         v = np.ascontiguousarray(vertices, dtype=np.float64).reshape(-1, 9)
         self.n = v.shape[0]
         if bc is None:
@@ -133,6 +137,8 @@ class Oracle:
         self._h = lib().orc_create_eval(self.n, _p(v), _p(bc), K, theta, ncrit, evaluator)
         if not self._h:
             raise ValueError("orc_create failed (bad quadrature key or empty input)")
+        if complete_l2l:
+            lib().orc_complete_l2l(self._h)
         self.bc = bc
 
     def close(self):
@@ -304,8 +310,8 @@ class StokesOracle(Oracle):
     """FMM_plan<StokesSphericalBEM>-equivalent on the CPU, velocity boundary condition only
     (kernel/StokesSphericalBEM.hpp:260-375, 391-432, 512-528; StokesSpherical.hpp:318-401)."""
 
-    def __init__(self, vertices, K=4, K_fine=19, mu=1e-3, theta=0.5, ncrit=64, evaluator=0):
-        super().__init__(vertices, K=K, theta=theta, ncrit=ncrit, evaluator=evaluator)
+    def __init__(self, vertices, K=4, K_fine=19, mu=1e-3, theta=0.5, ncrit=64, evaluator=0, complete_l2l=False):
+        super().__init__(vertices, K=K, theta=theta, ncrit=ncrit, evaluator=evaluator, complete_l2l=complete_l2l)
         if lib().orc_stokes_config(self._h, mu, K_fine):
             raise ValueError("invalid K_fine")
         self.mu = mu

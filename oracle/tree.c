@@ -248,6 +248,24 @@ orc_ctx *orc_create_eval(int n, const double *verts, const uint8_t *bc, int K, d
   return c;
 }
 
+/* NOT a reference rule.  Replaces the L2L list of resolve_LR_interactions (which omits n_l2l_skipped edges, see
+ * propagate_local above) by the complete one: every child of a box that holds a local expansion, parents first.  The
+ * product's default downward pass (FMMBEM_L2L_COMPLETE) is checked against the oracle in this mode; with
+ * n_l2l_skipped == 0 it is the same set of operations. */
+void orc_complete_l2l(orc_ctx *c) {
+  char *hasL = calloc((size_t)c->nboxes, 1);
+  for (int i = 0; i < c->n_lr; ++i) hasL[c->lr[i].second] = 1;
+  pair_vec l2l = {0};
+  for (int b = 1; b < c->nboxes; ++b)            /* BFS box order: a parent precedes its children */
+    if (hasL[c->boxes[b].parent]) {
+      hasL[b] = 1;
+      orc_pair pr = { (int)c->boxes[b].parent, b };
+      PUSH(l2l, pr);
+    }
+  free(hasL); free(c->l2l);
+  c->l2l = l2l.d; c->n_l2l = (int)l2l.n;
+}
+
 void orc_destroy(orc_ctx *c) {
   if (!c) return;
   free(c->panels); free(c->quad); free(c->boxes); free(c->perm); free(c->code); free(c->level_offset);

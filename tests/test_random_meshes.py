@@ -43,12 +43,19 @@ def test_host_lists_equal_oracle_on_random_soups(fb, oracle_mod, seed, n, cluste
     assert np.array_equal(pl.pairs("p2p"), o.pairs("p2p")) and np.array_equal(pl.pairs("m2l"), o.pairs("m2l"))
     s, so = pl.stats(), o.stats()
     assert (s["n_boxes"], s["n_leaves"], s["near_nnz_total"]) == (so["boxes"], so["leaves"], so["near_nnz"])
+    # downward pass: the default applies every parent->child edge, the reference's lazy rule leaves some out
+    # (EvalInteractionLazySparse.hpp:199-237); both lists against the oracle's
+    assert s["l2l_reference_omitted"] == so["l2l_skipped"]
+    assert s["l2l_ops"] == so["l2l_ops"] + so["l2l_skipped"]
+    opts.reference_l2l = True
+    assert fb.FMM_plan(fb.LaplaceSphericalBEM(5, 3), v, opts, host_only=True).stats()["l2l_ops"] == so["l2l_ops"]
 
 
 @pytest.mark.gpu
 @settings(max_examples=30, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
-@given(p=st.integers(1, 16), k=st.sampled_from([1, 3, 4, 7]), mixed=st.booleans(), **soup_args)
-def test_gpu_matvec_equals_oracle_on_random_soups(fb, oracle_mod, seed, n, clusters, stretch, size_spread, ncrit, theta, p, k, mixed):
+@given(p=st.integers(1, 16), k=st.sampled_from([1, 3, 4, 7]), mixed=st.booleans(), ref_rule=st.booleans(), **soup_args)
+def test_gpu_matvec_equals_oracle_on_random_soups(fb, oracle_mod, seed, n, clusters, stretch, size_spread, ncrit, theta, p, k, mixed,
+                                                  ref_rule):
     v = _soup(seed, n, clusters, stretch, size_spread)
     rng = np.random.default_rng(seed + 1)
     bc = (rng.random(n) < 0.5).astype(np.uint8) if mixed else None
@@ -56,12 +63,37 @@ def test_gpu_matvec_equals_oracle_on_random_soups(fb, oracle_mod, seed, n, clust
     opts = fb.FMMOptions()
     opts.set_mac_theta(theta)
     opts.set_max_per_box(ncrit)
+    opts.reference_l2l = ref_rule                      # the reference's L2L list, or the complete one (default)
     try:
         pl = fb.FMM_plan(fb.LaplaceSphericalBEM(p, k), v, opts, bc=bc)
     except fb.FmmBemError as e:
         assert e.status == 5
         return
     y = pl.execute(x)
-    yo = oracle_mod.Oracle(v, bc=bc, K=k, theta=theta, ncrit=ncrit).matvec(x, p)
+    yo = oracle_mod.Oracle(v, bc=bc, K=k, theta=theta, ncrit=ncrit, complete_l2l=not ref_rule).matvec(x, p)
     assert np.all(np.isfinite(y))
     assert np.linalg.norm(y - yo) <= 1e-11 * np.linalg.norm(yo)
+
+
+@pytest.mark.gpu
+@settings(max_examples=12, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(seed=st.integers(0, 2 ** 31 - 1), n=st.integers(2, 400), clusters=st.integers(1, 4), p=st.integers(1, 12),
+       kfine=st.sampled_from([7, 13, 19, 25]), ncrit=st.sampled_from([16, 64]), ref_rule=st.booleans())
+def test_gpu_stokes_matvec_equals_oracle_on_random_soups(fb, oracle_mod, seed, n, clusters, p, kfine, ncrit, ref_rule):
+    v = _soup(seed, n, clusters, 1.0, 1.0)
+    rng = np.random.default_rng(seed + 2)
+    f = rng.standard_normal((n, 3))
+    opts = fb.FMMOptions()
+    opts.set_max_per_box(ncrit)
+    opts.reference_l2l = ref_rule
+    K = fb.StokesSphericalBEM(p, 4, 1e-3)
+    K.set_Kfine(kfine)
+    try:
+        pl = fb.FMM_plan(K, v, opts)
+    except fb.FmmBemError as e:
+        assert e.status == 5
+        return
+    u = pl.execute(f)
+    uo = oracle_mod.StokesOracle(v, K=4, K_fine=kfine, mu=1e-3, ncrit=ncrit, complete_l2l=not ref_rule).matvec(f, p)
+    assert np.all(np.isfinite(u))
+    assert np.linalg.norm(u - uo) <= 1e-11 * np.linalg.norm(uo)
