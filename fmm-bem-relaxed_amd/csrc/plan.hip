@@ -142,6 +142,7 @@ struct fmmbem_plan {
   // Near field on its own stream beside M2L: measured +4% matvecs/s at N=1M (M2L fills the wavefront slots
   // first and the streaming kernel is starved: 1.0 -> 3.6 ms), so it is off unless FMMBEM_OVERLAP_NEAR=1.
   bool overlap_near = false;
+  bool overlap_early = false;                                  // FMMBEM_OVERLAP_NEAR=2: fork right after the gather (beside P2M/M2M) instead of beside M2L
   int64_t ev_count = 0;                                        // executes recorded since timing was enabled
   double *stage_x = nullptr, *stage_y = nullptr;               // device staging for host-pointer execute
   hipStream_t own_stream = nullptr;
@@ -261,7 +262,7 @@ int fmmbem_plan::to_device() {
     }
   }
   d.max_runs = max_runs;
-  if (const char* ov = getenv("FMMBEM_OVERLAP_NEAR")) overlap_near = atoi(ov) != 0;
+  if (const char* ov = getenv("FMMBEM_OVERLAP_NEAR")) { overlap_near = atoi(ov) != 0; overlap_early = atoi(ov) == 2; }
   d.max_ncols = max_cols;
   near_bytes = total * (int64_t)sizeof(double);
   TRY(upload(leaf_row0, &d.leaf_row0)); TRY(upload(leaf_nrows, &d.leaf_nrows)); TRY(upload(hp.leaf_box, &d.leaf_box));
@@ -537,6 +538,12 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
     return FMMBEM_OK;
   };
   if (!overlap) TRY(near_field(s));
+  if (overlap && overlap_early) {
+    HIP_TRY(hipEventRecord(ev_fork, s));
+    HIP_TRY(hipStreamWaitEvent(near_stream, ev_fork, 0));
+    TRY(near_field(near_stream));
+    HIP_TRY(hipEventRecord(ev_join, near_stream));
+  }
   if (!near_only) {
     if (phase == 0) {
       HIP_TRY(begin(3, s));
@@ -553,7 +560,7 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
     }
     HIP_TRY(launch_mh_prep(d, p, s));
     HIP_TRY(end(5, s));
-    if (overlap) {                                     // fork: the near field streams HBM while M2L saturates the FMA pipes
+    if (overlap && !overlap_early) {                   // fork: the near field streams HBM while M2L saturates the FMA pipes
       HIP_TRY(hipEventRecord(ev_fork, s));
       HIP_TRY(hipStreamWaitEvent(near_stream, ev_fork, 0));
       TRY(near_field(near_stream));
