@@ -128,9 +128,10 @@ def gmres(MV, x, b, opts, M=None, log=None, stokes=False):
     return x, it, abs(resid)
 
 
-def fgmres(MV, x, b, opts, M, log=None):
+def fgmres(MV, x, b, opts, M, log=None, stokes=False):
     """FGMRES(MV, x, b, opts, M, context) of examples/BEM/GMRES.hpp:276-380: flexible GMRES, the preconditioned
-    vectors Z_j = M(V_j) are kept and the solution is updated from them (:318-320, :368-371)."""
+    vectors Z_j = M(V_j) are kept and the solution is updated from them (:318-320, :368-371).
+    stokes=True: the order rule of examples/BEM/GMRES_Stokes.hpp:373, p = max(5, predict_p)."""
     execute = getattr(MV, "execute_torch", None) or MV.execute
     K = MV.kernel()
     R, n = opts.restart, x.numel()
@@ -151,7 +152,7 @@ def fgmres(MV, x, b, opts, M, log=None):
         while True:
             i += 1
             it += 1
-            p = max(1, opts.predict_p(abs(resid)))        # :324 (the product has no order 0)
+            p = max(5 if stokes else 1, opts.predict_p(abs(resid)))        # :324 (the product has no order 0)
             K.set_p(p)
             Z[i] = M(V[i])
             w = _apply(execute, Z[i], wbuf)

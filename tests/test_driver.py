@@ -45,3 +45,19 @@ def test_mesh_and_preconditioner_flags(tmp_path):
                            capture_output=True, text=True, check=True)
         rel = float([ln for ln in r.stdout.splitlines() if ln.startswith("relative error")][0].split(":")[1])
         assert rel < 3e-2, (flags, r.stdout[-400:])
+
+
+@pytest.mark.gpu
+def test_stokes_driver_sphere_drag():
+    """examples/StokesBEM.py mirrors examples/StokesBEM.cpp: flow past the unit sphere, drag against 6 pi mu; orders follow
+    GMRES_Stokes.hpp:229 (max(p_min, predict_p - 1)): first iteration at p - 1, never below p_min."""
+    for flags, first_p in ((["-recursions", "4", "-p", "10"], 9), (["-recursions", "4", "-p", "10", "-local"], 10),
+                           (["-recursions", "4", "-p", "8", "-diagonal", "-fixed_p"], 8)):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "StokesBEM.py")] + flags,
+                           capture_output=True, text=True, check=True)
+        out = r.stdout
+        ps = [int(ln.rsplit(":", 1)[1]) for ln in out.splitlines() if ln.startswith("it: ")]
+        assert ps[0] == first_p and min(ps) >= 5, (flags, ps)
+        err = float([ln for ln in out.splitlines() if ln.startswith("error on a sphere")][0].split(":")[1])
+        assert err < 2e-2, (flags, out[-600:])
+        assert "Area error" in out and "POINTWISE ERRORS" in out
