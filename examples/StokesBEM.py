@@ -29,7 +29,7 @@ def print_help_and_exit():
           "-ncrit <int> : Maximum # of particles per Octree box\n"
           "-recursions <int> : number of recursive subdivisions to create a sphere - # panels = 2*4^recursions\n"
           "-rbc <int> : number of recursive subdivisions to create a red blood cell - # panels = 2*4^recursions\n"
-          "-cells <int> : number of red blood cells to generate (only 1 is built)\n"
+          "-cells <int> : number of red blood cells to generate\n"
           "-fixed_p : Disable relaxation\n"
           "-pmin <int>, -mu <double>, -kfine <int>, -solver_tol <double>, -mesh <file.msh>, -vert <f> -face <f>,\n"
           "-fgmres, -diagonal, -local\n-help : print this message")
@@ -108,9 +108,7 @@ def main(argv):
         print("reading mesh from %s" % mesh)
         v = fb.read_msh(mesh)
     elif rbc:
-        if cells > 1:
-            raise SystemExit("-cells > 1: Triangulation::MultipleRedBloodCell is not built")
-        v = fb.red_blood_cell(recursions)
+        v = fb.red_blood_cell(recursions) if cells <= 1 else fb.red_blood_cells(recursions, cells)
     else:
         v = fb.unit_sphere(recursions)
     n = len(v)

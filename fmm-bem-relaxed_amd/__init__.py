@@ -5,7 +5,7 @@ and this thin host-side mirror of the reference's operator interface.
 """
 from ._capi import FmmBemError, LIB_PATH, Options, PMAX, SYMBOLS, lib  # noqa: F401
 from .plan import (FMM_plan, FMMOptions, LaplaceSphericalBEM, StokesSphericalBEM, quadrature, read_msh,  # noqa: F401
-                   read_vert_face, red_blood_cell, unit_sphere, write_vert_face)
+                   read_vert_face, red_blood_cell, red_blood_cells, unit_sphere, write_vert_face)
 
 
 def __getattr__(name):

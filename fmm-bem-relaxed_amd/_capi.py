@@ -57,7 +57,7 @@ SYMBOLS = (
     "fmmbem_plan_execute_device", "fmmbem_plan_exchange_doubles", "fmmbem_plan_upward_device",
     "fmmbem_plan_downward_device", "fmmbem_plan_near_device", "fmmbem_plan_set_timing", "fmmbem_plan_stats",
     "fmmbem_plan_get_perm", "fmmbem_plan_get_boxes", "fmmbem_plan_get_pairs", "fmmbem_plan_get_near_row",
-    "fmmbem_plan_get_expansions", "fmmbem_plan_get_diagonal", "fmmbem_mesh_unit_sphere", "fmmbem_mesh_red_blood_cell", "fmmbem_mesh_read_msh",
+    "fmmbem_plan_get_expansions", "fmmbem_plan_get_diagonal", "fmmbem_mesh_unit_sphere", "fmmbem_mesh_red_blood_cell", "fmmbem_mesh_red_blood_cells", "fmmbem_mesh_read_msh",
     "fmmbem_mesh_read_vert_face", "fmmbem_mesh_write_vert_face", "fmmbem_quadrature", "fmmbem_status_string", "fmmbem_last_error",
     "fmmbem_version",
 )
@@ -101,6 +101,7 @@ def lib():
     L.fmmbem_plan_get_diagonal.argtypes = [vp, vp]
     L.fmmbem_mesh_unit_sphere.argtypes = [i32, vp, C.POINTER(C.c_size_t)]
     L.fmmbem_mesh_red_blood_cell.argtypes = [i32, vp, C.POINTER(C.c_size_t)]
+    L.fmmbem_mesh_red_blood_cells.argtypes = [i32, i32, vp, vp, C.POINTER(C.c_size_t)]
     L.fmmbem_mesh_read_msh.argtypes = [C.c_char_p, vp, C.POINTER(C.c_size_t)]
     L.fmmbem_mesh_read_vert_face.argtypes = [C.c_char_p, C.c_char_p, vp, C.POINTER(C.c_size_t)]
     L.fmmbem_mesh_write_vert_face.argtypes = [C.c_char_p, C.c_char_p, vp, C.c_size_t]

@@ -188,4 +188,51 @@ int fmmbem_mesh_red_blood_cell(int recursions, double* vertices, size_t* n_panel
   return FMMBEM_OK;
 }
 
+// Triangulation::MultipleRedBloodCell (examples/BEM/Triangulation.hpp:260-321): `cells` cells of 2*4^recursions panels,
+// cell i rotated by RotationMatrix(alpha, beta, gamma) (:142-163) and shifted by s.  placement = cells x {alpha, beta,
+// gamma, sx, sy, sz}, or NULL for the reference's own sequence: it draws from the UNSEEDED drand48 stream (reproduced here
+// with a private erand48 state at the libc default), three angles per cell -- as arguments of one call, which g++
+// evaluates right to left (gamma first); that order is the one assumption this generator cannot pin without running
+// the reference -- then for i > 0: sy += 2*3.91 + 3.91 u, sx = i u + 2.83 u, sz = +-10 u.
+int fmmbem_mesh_red_blood_cells(int recursions, int cells, const double* placement, double* vertices, size_t* n_panels) {
+  if (!n_panels) return fail(FMMBEM_ERR_INVALID, "null argument");
+  if (recursions < 1 || recursions > 12 || cells < 1) return fail(FMMBEM_ERR_INVALID, "recursions outside [1, 12] or cells < 1");
+  const size_t per = (size_t)2 << (2 * recursions), n = per * (size_t)cells;
+  if (vertices) {
+    if (*n_panels < n) return fail(FMMBEM_ERR_INVALID, "vertices buffer too small for the mesh");
+    unsigned short st[3] = {0x330E, 0xABCD, 0x1234};
+    double sx = 0, sy = 0, sz = 0;
+    for (int i = 0; i < cells; ++i) {
+      double ang[3], sh[3];
+      if (placement) {
+        for (int k = 0; k < 3; ++k) { ang[k] = placement[6 * i + k]; sh[k] = placement[6 * i + 3 + k]; }
+      } else {
+        ang[2] = erand48(st); ang[1] = erand48(st); ang[0] = erand48(st);
+        if (i > 0) {
+          sy += 2 * 3.91 + 3.91 * erand48(st);
+          sx = i * erand48(st) + 2.83 * erand48(st);
+          sz = ((i % 2 == 0) ? 1 : -1) * 10 * erand48(st);
+        }
+        sh[0] = sx; sh[1] = sy; sh[2] = sz;
+      }
+      double* v = vertices + 9 * per * (size_t)i;
+      size_t one = per;
+      if (int rc = fmmbem_mesh_red_blood_cell(recursions, v, &one)) return rc;
+      const double ca = std::cos(ang[0]), cb = std::cos(ang[1]), cg = std::cos(ang[2]);
+      const double sa = std::sin(ang[0]), sb = std::sin(ang[1]), sg = std::sin(ang[2]);
+      const double M[3][3] = {{cb * cg, -cb * sg, sb},
+                              {ca * sg + cg * sa * sb, ca * cg - sa * sb * sg, -cb * sa},
+                              {sa * sg - ca * cg * sb, cg * sa + ca * sb * sg, ca * cb}};
+      for (size_t q = 0; q < 3 * per; ++q) {
+        double* x = v + 3 * q;
+        const double r[3] = {M[0][0] * x[0] + M[0][1] * x[1] + M[0][2] * x[2], M[1][0] * x[0] + M[1][1] * x[1] + M[1][2] * x[2],
+                             M[2][0] * x[0] + M[2][1] * x[1] + M[2][2] * x[2]};
+        for (int k = 0; k < 3; ++k) x[k] = r[k] + sh[k];
+      }
+    }
+  }
+  *n_panels = n;
+  return FMMBEM_OK;
+}
+
 }  // extern "C"

@@ -105,6 +105,22 @@ def red_blood_cell(recursions):
     return v
 
 
+def red_blood_cells(recursions, cells, placement=None):
+    """Triangulation::MultipleRedBloodCell (examples/BEM/Triangulation.hpp:260-321).  placement: (cells, 6) rows of
+    alpha, beta, gamma, shift x, y, z; None: the reference's own drand48-driven orientations and offsets."""
+    pl = None
+    if placement is not None:
+        placement = np.ascontiguousarray(placement, dtype=np.float64)
+        if placement.shape != (cells, 6):
+            raise ValueError("placement must be (cells, 6)")
+        pl = placement.ctypes.data_as(C.c_void_p)
+    n = C.c_size_t(0)
+    _capi.check(_capi.lib().fmmbem_mesh_red_blood_cells(recursions, cells, pl, None, C.byref(n)))
+    v = np.empty((n.value, 3, 3), dtype=np.float64)
+    _capi.check(_capi.lib().fmmbem_mesh_red_blood_cells(recursions, cells, pl, v.ctypes.data_as(C.c_void_p), C.byref(n)))
+    return v
+
+
 def _read(fn, *paths):
     n = C.c_size_t(0)
     args = [os.fsencode(p) for p in paths]

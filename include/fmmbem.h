@@ -183,6 +183,10 @@ int fmmbem_mesh_unit_sphere(int recursions, double *vertices, size_t *n_panels);
 /* Triangulation::RedBloodCell(panels, recursions) with identity rotation and zero shift
  * (examples/BEM/Triangulation.hpp:184-255; examples/StokesBEM.cpp:111-113): same N, same calling convention. */
 int fmmbem_mesh_red_blood_cell(int recursions, double *vertices, size_t *n_panels);
+/* Triangulation::MultipleRedBloodCell(panels, recursions, cells) (examples/BEM/Triangulation.hpp:260-321): N =
+ * cells * 2*4^recursions.  placement: cells x {alpha, beta, gamma, shift x, y, z} (RotationMatrix, :142-163), or NULL for
+ * the reference's own drand48-driven orientations and offsets (see csrc/mesh_io.cpp for what that sequence assumes). */
+int fmmbem_mesh_red_blood_cells(int recursions, int cells, const double *placement, double *vertices, size_t *n_panels);
 
 /* Triangle Gauss rule `key` of examples/BEM/GaussQuadrature.hpp:15-274 (what BEMConfig hands the kernels): barycentric
  * points[n][3] and weights[n] (at most 25); either array may be NULL. */

@@ -52,3 +52,26 @@ def test_errors_are_codes(fb, tmp_path):
     (tmp_path / "f").write_text("1\n1 2 3\n")
     with pytest.raises(fb.FmmBemError):
         fb.read_vert_face(str(tmp_path / "v"), str(tmp_path / "f"))           # vertex number out of range
+
+
+def test_multiple_red_blood_cells(fb):
+    """Triangulation::MultipleRedBloodCell (examples/BEM/Triangulation.hpp:260-321): cells of 2*4^r panels, each a rigid
+    motion of the single cell; the first cell of the reference's own sequence is rotated but not shifted (:273-279)."""
+    one = fb.red_blood_cell(3)
+    place = np.array([[0, 0, 0, 0, 0, 0], [0.3, -0.2, 1.1, 5.0, 9.0, -2.0]])
+    v = fb.red_blood_cells(3, 2, place)
+    assert v.shape == (2 * len(one), 3, 3) and np.array_equal(v[:len(one)], one)
+    a, b, g = place[1, :3]
+    ca, cb, cg, sa, sb, sg = np.cos(a), np.cos(b), np.cos(g), np.sin(a), np.sin(b), np.sin(g)
+    M = np.array([[cb * cg, -cb * sg, sb], [ca * sg + cg * sa * sb, ca * cg - sa * sb * sg, -cb * sa],
+                  [sa * sg - ca * cg * sb, cg * sa + ca * sb * sg, ca * cb]])           # RotationMatrix, :142-163
+    assert np.allclose(M @ M.T, np.eye(3), atol=1e-15)
+    assert np.allclose(v[len(one):], one @ M.T + place[1, 3:], rtol=0, atol=1e-14)
+    w = fb.red_blood_cells(3, 3)                        # the reference's drand48-driven placement: deterministic
+    assert np.array_equal(w, fb.red_blood_cells(3, 3)) and w.shape == (3 * len(one), 3, 3)
+    d = lambda c: np.linalg.norm(c.reshape(-1, 3), axis=1)
+    assert np.allclose(np.sort(d(w[:len(one)])), np.sort(d(one)), atol=1e-13)          # cell 0: rotation only
+    cen = [w[i * len(one):(i + 1) * len(one)].reshape(-1, 3).mean(axis=0) for i in range(3)]
+    assert cen[1][1] - cen[0][1] >= 2 * 3.91 - 1e-9 and cen[2][1] - cen[1][1] >= 2 * 3.91 - 1e-9   # cells do not overlap
+    with pytest.raises(fb.FmmBemError):
+        fb.red_blood_cells(3, 0)
