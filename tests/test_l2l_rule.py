@@ -8,7 +8,7 @@ FMMOptions.reference_l2l reproduces the reference's list."""
 import numpy as np
 import pytest
 
-from test_random_meshes import _soup
+from test_random_meshes import _coverage, _soup
 
 
 def _case():
@@ -75,3 +75,16 @@ def test_gpu_stokes_follows_the_chosen_rule(fb, oracle_mod, ref):
     u = fb.FMM_plan(K, v, _opts(fb, ncrit, ref)).execute(f)
     uo = oracle_mod.StokesOracle(v, K=4, K_fine=25, mu=1e-3, ncrit=ncrit, complete_l2l=not ref).matvec(f, 8)
     assert np.linalg.norm(u - uo) <= 1e-11 * np.linalg.norm(uo)
+
+
+def test_every_source_reaches_every_target_exactly_once(fb):
+    v, ncrit = _case()
+    n = len(v)
+    full = _coverage(fb.FMM_plan(fb.LaplaceSphericalBEM(5, 3), v, _opts(fb, ncrit, False), host_only=True), n)
+    assert np.all(full == n)
+    ref = _coverage(fb.FMM_plan(fb.LaplaceSphericalBEM(5, 3), v, _opts(fb, ncrit, True), host_only=True), n)
+    assert np.all(ref <= n) and np.any(ref < n)        # the reference's list loses sources on this tree
+    for r in (3, 5):                                   # ... and none on its own spheres
+        s = fb.unit_sphere(r)
+        for rule in (False, True):
+            assert np.all(_coverage(fb.FMM_plan(fb.LaplaceSphericalBEM(5, 3), s, _opts(fb, 64, rule), host_only=True), len(s)) == len(s))

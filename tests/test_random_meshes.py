@@ -21,6 +21,25 @@ def _soup(seed, n, clusters, stretch, size_spread):
     return np.stack([c, c + h[:, None] * e0, c + h[:, None] * (0.3 * e0 + e1)], axis=1)
 
 
+def _coverage(pl, n):
+    """The counting-kernel check of the reference (tests/correctness.cpp:69-78 with kernel/UnitKernel.hpp: every result
+    must equal the number of sources) on the plan's LISTS: sources reaching each leaf through its near blocks, through
+    M2L into the leaf or an ancestor, and down the L2L edges the plan applies."""
+    bx = pl.boxes()
+    cnt = (bx["be"] - bx["bb"]).astype(np.int64)
+    far = np.zeros(len(cnt), dtype=np.int64)
+    m2l = pl.pairs("m2l")
+    np.add.at(far, m2l[:, 1], cnt[m2l[:, 0]])
+    for parent, child in pl.pairs("l2l"):              # parents first (level order)
+        far[child] += far[parent]
+    near = np.zeros(len(cnt), dtype=np.int64)
+    p2p = pl.pairs("p2p")
+    np.add.at(near, p2p[:, 1], cnt[p2p[:, 0]])
+    leaves = np.nonzero(bx["leaf"])[0]
+    return near[leaves] + far[leaves]
+
+
+
 soup_args = dict(seed=st.integers(0, 2 ** 31 - 1), n=st.integers(2, 900), clusters=st.integers(1, 6),
                  stretch=st.sampled_from([1.0, 3.0, 10.0]), size_spread=st.sampled_from([0.0, 1.0, 2.0]),
                  ncrit=st.sampled_from([8, 32, 64, 126]), theta=st.sampled_from([0.4, 0.5, 0.7]))
@@ -47,8 +66,11 @@ def test_host_lists_equal_oracle_on_random_soups(fb, oracle_mod, seed, n, cluste
     # (EvalInteractionLazySparse.hpp:199-237); both lists against the oracle's
     assert s["l2l_reference_omitted"] == so["l2l_skipped"]
     assert s["l2l_ops"] == so["l2l_ops"] + so["l2l_skipped"]
+    assert np.all(_coverage(pl, n) == n)              # counting kernel: every source reaches every target exactly once
     opts.reference_l2l = True
-    assert fb.FMM_plan(fb.LaplaceSphericalBEM(5, 3), v, opts, host_only=True).stats()["l2l_ops"] == so["l2l_ops"]
+    ref = fb.FMM_plan(fb.LaplaceSphericalBEM(5, 3), v, opts, host_only=True)
+    assert ref.stats()["l2l_ops"] == so["l2l_ops"]
+    assert np.all(_coverage(ref, n) == n) == (so["l2l_skipped"] == 0)
 
 
 @pytest.mark.gpu
