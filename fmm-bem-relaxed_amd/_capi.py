@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfmmbem_hip.so")
+LIB_PATH = os.environ.get("FMMBEM_LIB") or os.path.join(_HERE, "libfmmbem_hip.so")   # FMMBEM_LIB: A/B builds of the same ABI
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC, ERR_TREE, ERR_UNSUPPORTED, ERR_IO = range(8)
 PMAX = 16

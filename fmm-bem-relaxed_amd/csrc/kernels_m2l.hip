@@ -35,6 +35,14 @@ struct C2 { double x, y; };
 typedef __attribute__((address_space(4))) C2 ConstC2;      // complex value in the constant address space
 typedef __attribute__((address_space(4))) DevicePlan ConstPlan;
 constexpr int kM2LTargets = 4;         // independent single-wavefront targets per workgroup when TEAM == 1
+#ifndef FMMBEM_M2L_XCD
+#define FMMBEM_M2L_XCD 1
+#endif
+constexpr bool kM2LXcdRemap = FMMBEM_M2L_XCD != 0;
+#ifndef FMMBEM_M2L_XCD_CHUNK
+#define FMMBEM_M2L_XCD_CHUNK 16
+#endif
+constexpr int kM2LXcdChunk = FMMBEM_M2L_XCD_CHUNK;
 
 template <int P, int NS_> struct Shape {
   static constexpr int S = P * (P + 1) / 2, NE = m2l_entries(P);
@@ -94,7 +102,13 @@ __global__ __launch_bounds__((Shape<P, NS_>::THREADS)) void m2l_kernel(const Dev
   __shared__ double2 Comb[NS == 1 ? 1 : NSLOT * (NS - 1) * TEAM * kWave];   // partial sums of the other m sets
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-  const int ti = blockIdx.x * TARGETS + (WAVES == 1 ? wave : 0);
+  // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2: give XCD x the x-th CONTIGUOUS eighth of the
+  // target list (level order, Morton order within a level) instead of every eighth target, so that the Mh records and
+  // class tables neighbouring targets share are fetched into one L2 instead of eight.  gridDim.x is a multiple of 8.
+  constexpr int CH = kM2LXcdChunk;                     // consecutive workgroups-worth of targets that stay on one XCD
+  const int rnd = (int)(blockIdx.x >> 3), xcd = (int)(blockIdx.x & 7);
+  const int tb = kM2LXcdRemap ? (rnd / CH) * 8 * CH + xcd * CH + rnd % CH : (int)blockIdx.x;
+  const int ti = tb * TARGETS + (WAVES == 1 ? wave : 0);
   if (ti >= d.n_m2l_tgt) return;                       // WAVES==1: whole wavefront; else: whole workgroup
   const int tgt = d.m2l_tgt[ti];
   int slot[NSLOT];
@@ -399,7 +413,7 @@ hipError_t launch_m2l(const DevicePlan& d, const DevicePlan* d_dev, int p, hipSt
   if (d.n_m2l_tgt <= 0) return hipSuccess;
 #define LAUNCH_Q(NSV, NQ)                                                                                     \
   hipLaunchKernelGGL((m2l_kernel<PP, NSV, NQ>),                                                               \
-                     dim3((d.n_m2l_tgt + Shape<PP, NSV>::TARGETS - 1) / Shape<PP, NSV>::TARGETS, d.n_act / NQ), \
+                     dim3((((d.n_m2l_tgt + Shape<PP, NSV>::TARGETS - 1) / Shape<PP, NSV>::TARGETS) + 8 * kM2LXcdChunk - 1) / (8 * kM2LXcdChunk) * (8 * kM2LXcdChunk), d.n_act / NQ), \
                      dim3(Shape<PP, NSV>::THREADS), 0, s, d_dev)
   // several active expansion slots per pass (Stokes: 4; Laplace with mixed BC: 2)
   // (Stokes config 4, p = 8, ms: 2.64 with one slot per pass, 2.32 with two; with the +-m pairing 1.96 with two, 1.84 with four)
