@@ -89,6 +89,7 @@ struct DevicePlan {
   // far-field lists
   const int *p2m_leaf;        int n_p2m = 0;          // box ids
   const int *l2p_leaf;        int n_l2p = 0;
+  const int *l2p_grp;         int n_l2p_grp = 0;      // L2P work: consecutive l2p_leaf entries [grp[i], grp[i+1]) that fill one wavefront
   const int *m2m_parent;      const int* box_child_begin; const int* box_child_end;
   const int *l2l_child;       const int* box_parent;
   const int *up_cls, *down_cls;                       // per box: class of (parent-child) / (child-parent)

@@ -372,58 +372,73 @@ __global__ __launch_bounds__(kShiftWaves * kWave) void l2l_kernel(DevicePlan d, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// L2P: one wavefront per target leaf; lane = panel centroid; the leaf's L (active slots) in LDS.
+// L2P: lane = panel centroid.  A leaf of the bench tree holds ~19 panels, so a wavefront takes a GROUP of consecutive
+// leaves (<= 64 rows, <= 8 leaves, DevicePlan::l2p_grp; a leaf with more rows is a group of its own and is walked in
+// chunks); the L of the group's leaves (active slots) is staged in LDS and every lane reads its own leaf's.
 // y[perm[i]] += r0 (POTENTIAL target) or -= r1 (NORMAL_DERIV target).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kWave) void l2p_kernel(DevicePlan d, const int P, double* __restrict__ y) {
-  const int S = P * (P + 1) / 2;
-  __shared__ double2 Ls[2][kSmax];
-  __shared__ double sPref[kSmax], sC1[kSmax], sC2[kSmax];
-  const int lane = threadIdx.x;
-  fill_step_tables(d, P, lane, sPref, sC1, sC2);
-  for (int li = blockIdx.x; li < d.n_l2p; li += gridDim.x) {
-  const int leaf = d.l2p_leaf[li];
-  const int box = d.leaf_box[leaf];
-  const int row0 = d.leaf_row0[leaf], nrows = d.leaf_nrows[leaf];
+constexpr int kL2PLeaves = 8, kL2PWaves = 4;
+__global__ __launch_bounds__(kL2PWaves * kWave) void l2p_kernel(DevicePlan d, const int P, double* __restrict__ y) {
+  extern __shared__ double2 l2p_lds[];                  // step tables (3 S doubles), then [wave][leaf][active slot][S]
+  const int S = P * (P + 1) / 2, na = d.n_act;
+  double* sPref = reinterpret_cast<double*>(l2p_lds);
+  double* sC1 = sPref + S;
+  double* sC2 = sC1 + S;
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, nwaves = blockDim.x / kWave;
+  double2* Lw = l2p_lds + (3 * S + 1) / 2 + (size_t)wave * kL2PLeaves * na * S;
+  if (wave == 0) fill_step_tables(d, P, lane, sPref, sC1, sC2);
   __syncthreads();
-  for (int s = 0; s < 2; ++s) {
-    const double2* src = d.L + ((size_t)box * d.nslots + s) * d.s_max;
-    for (int i = lane; i < S; i += kWave) Ls[s][i] = src[i];
-  }
-  __syncthreads();
-  const double c0 = d.box_center[3 * box], c1 = d.box_center[3 * box + 1], c2 = d.box_center[3 * box + 2];
-  for (int chunk = 0; chunk < nrows; chunk += kWave) {
-    if (chunk + lane >= nrows) break;
-    const int64_t i = row0 + chunk + lane;
-    const int tb = d.bc[i] ? 1 : 0;
-    const double2* Lt = Ls[tb];
-    const Sph s = cart2sph(d.cx[i] - c0, d.cy[i] - c1, d.cz[i] - c2);
-    double r = 0;
-    double pn = 1, rhom = 1, er = 1, ei = 0, fact = 1;
-    int step = 0;
-#pragma nounroll
-    for (int m = 0; m < P; ++m) {
-      double p = pn, p1 = p, rhon = rhom;
-      const double w = m == 0 ? 1.0 : 2.0;
-#pragma nounroll
-      for (int n = m; n < P; ++n, ++step) {
-        const double mag = rhon * p * sPref[step];
-        const double2 Lc = Lt[n * (n + 1) / 2 + m];
-        r += w * (Lc.x * (mag * er) - Lc.y * (mag * ei));        // Re(L * Ynm), Ynm = mag e^{+i m beta}
-        const double pcur = p;
-        p = sC1[step] * s.ca * pcur - sC2[step] * p1;
-        p1 = pcur;
-        rhon *= s.rho;
+  for (int gi = blockIdx.x * nwaves + wave; gi < d.n_l2p_grp; gi += gridDim.x * nwaves) {
+    const int l0 = d.l2p_grp[gi], nl = d.l2p_grp[gi + 1] - l0;
+    wave_lds_sync();                                    // the previous group's reads are done
+    int g = -1, first = 0, total = 0;                   // this lane's leaf within the group, its first lane, rows of the group
+    for (int k = 0; k < nl; ++k) {
+      const int leaf = d.l2p_leaf[l0 + k], box = d.leaf_box[leaf], nr = d.leaf_nrows[leaf];
+      for (int a = 0; a < na; ++a) {
+        const double2* src = d.L + ((size_t)box * d.nslots + (a == 0 ? d.act[0] : d.act[1])) * d.s_max;
+        for (int i = lane; i < S; i += kWave) Lw[(size_t)(k * na + a) * S + i] = src[i];
       }
-      pn = -pn * fact * s.sa;
-      fact += 2;
-      rhom *= s.rho;
-      const double nr = er * s.cb - ei * s.sb, ni = er * s.sb + ei * s.cb;
-      er = nr; ei = ni;
+      if (lane >= total && lane < total + nr) { g = k; first = total; }
+      total += nr;
     }
-    const uint32_t o = d.perm[i];
-    y[o] += tb ? -r : r;
-  }
+    wave_lds_sync();
+    if (nl == 1) { g = 0; first = 0; }                  // single leaf: every lane, chunk by chunk
+    const int leaf = d.l2p_leaf[l0 + (g < 0 ? 0 : g)], box = d.leaf_box[leaf];
+    const int row0 = d.leaf_row0[leaf], nrows = d.leaf_nrows[leaf];
+    const double c0 = d.box_center[3 * box], c1 = d.box_center[3 * box + 1], c2 = d.box_center[3 * box + 2];
+    for (int chunk = 0; chunk < total; chunk += kWave) {
+      const int r_in_leaf = chunk + lane - first;
+      if (g < 0 || r_in_leaf >= nrows) continue;
+      const int64_t i = row0 + r_in_leaf;
+      const int tb = d.bc[i] ? 1 : 0;
+      const double2* Lt = Lw + (size_t)(g * na + (na == 2 ? tb : 0)) * S;
+      const Sph s = cart2sph(d.cx[i] - c0, d.cy[i] - c1, d.cz[i] - c2);
+      double r = 0;
+      double pn = 1, rhom = 1, er = 1, ei = 0, fact = 1;
+      int step = 0;
+#pragma nounroll
+      for (int m = 0; m < P; ++m) {
+        double p = pn, p1 = p, rhon = rhom;
+        const double w = m == 0 ? 1.0 : 2.0;
+#pragma nounroll
+        for (int n = m; n < P; ++n, ++step) {
+          const double mag = rhon * p * sPref[step];
+          const double2 Lc = Lt[n * (n + 1) / 2 + m];
+          r += w * (Lc.x * (mag * er) - Lc.y * (mag * ei));        // Re(L * Ynm), Ynm = mag e^{+i m beta}
+          const double pcur = p;
+          p = sC1[step] * s.ca * pcur - sC2[step] * p1;
+          p1 = pcur;
+          rhon *= s.rho;
+        }
+        pn = -pn * fact * s.sa;
+        fact += 2;
+        rhom *= s.rho;
+        const double nr = er * s.cb - ei * s.sb, ni = er * s.sb + ei * s.cb;
+        er = nr; ei = ni;
+      }
+      const uint32_t o = d.perm[i];
+      y[o] += tb ? -r : r;
+    }
   }
 }
 
@@ -434,26 +449,39 @@ __global__ __launch_bounds__(kWave) void l2p_kernel(DevicePlan d, const int P, d
 // accumulated along the same recurrence as the Laplace L2P (Ynm and its theta derivative), then
 //   u_k = phi_k - x_0 d_k phi_0 - x_1 d_k phi_1 - x_2 d_k phi_2 + d_k phi_3   (Tornberg-Greengard)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kWave) void l2p_stokes_kernel(DevicePlan d, const int P, double* __restrict__ y) {
+__global__ __launch_bounds__(kL2PWaves * kWave) void l2p_stokes_kernel(DevicePlan d, const int P, double* __restrict__ y) {
+  extern __shared__ double2 l2p_lds[];                  // as l2p_kernel: step tables, then [wave][leaf][4 potentials][S]
   const int S = P * (P + 1) / 2;
-  __shared__ double2 Ls[4][kSmax];
-  __shared__ double sPref[kSmax], sC1[kSmax], sC2[kSmax];
-  const int lane = threadIdx.x;
-  fill_step_tables(d, P, lane, sPref, sC1, sC2);
-  for (int li = blockIdx.x; li < d.n_l2p; li += gridDim.x) {
-    const int leaf = d.l2p_leaf[li];
-    const int box = d.leaf_box[leaf];
-    const int row0 = d.leaf_row0[leaf], nrows = d.leaf_nrows[leaf];
-    __syncthreads();
-    for (int e = 0; e < 4; ++e) {
-      const double2* src = d.L + ((size_t)box * d.nslots + e) * d.s_max;
-      for (int i = lane; i < S; i += kWave) Ls[e][i] = src[i];
+  double* sPref = reinterpret_cast<double*>(l2p_lds);
+  double* sC1 = sPref + S;
+  double* sC2 = sC1 + S;
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, nwaves = blockDim.x / kWave;
+  double2* Lw = l2p_lds + (3 * S + 1) / 2 + (size_t)wave * kL2PLeaves * 4 * S;
+  if (wave == 0) fill_step_tables(d, P, lane, sPref, sC1, sC2);
+  __syncthreads();
+  for (int gi = blockIdx.x * nwaves + wave; gi < d.n_l2p_grp; gi += gridDim.x * nwaves) {
+    const int l0 = d.l2p_grp[gi], nl = d.l2p_grp[gi + 1] - l0;
+    wave_lds_sync();
+    int g = -1, first = 0, total = 0;
+    for (int k = 0; k < nl; ++k) {
+      const int leaf = d.l2p_leaf[l0 + k], box = d.leaf_box[leaf], nr = d.leaf_nrows[leaf];
+      for (int e = 0; e < 4; ++e) {
+        const double2* src = d.L + ((size_t)box * d.nslots + e) * d.s_max;
+        for (int i = lane; i < S; i += kWave) Lw[(size_t)(k * 4 + e) * S + i] = src[i];
+      }
+      if (lane >= total && lane < total + nr) { g = k; first = total; }
+      total += nr;
     }
-    __syncthreads();
+    wave_lds_sync();
+    if (nl == 1) { g = 0; first = 0; }
+    const int leaf = d.l2p_leaf[l0 + (g < 0 ? 0 : g)], box = d.leaf_box[leaf];
+    const int row0 = d.leaf_row0[leaf], nrows = d.leaf_nrows[leaf];
+    const double2* Ls = Lw + (size_t)(g < 0 ? 0 : g) * 4 * S;
     const double c0 = d.box_center[3 * box], c1 = d.box_center[3 * box + 1], c2 = d.box_center[3 * box + 2];
-    for (int chunk = 0; chunk < nrows; chunk += kWave) {
-      if (chunk + lane >= nrows) break;
-      const int64_t i = row0 + chunk + lane;
+    for (int chunk = 0; chunk < total; chunk += kWave) {
+      const int r_in_leaf = chunk + lane - first;
+      if (g < 0 || r_in_leaf >= nrows) continue;
+      const int64_t i = row0 + r_in_leaf;
       const double tx = d.cx[i], ty = d.cy[i], tz = d.cz[i];
       const Sph s = cart2sph(tx - c0, ty - c1, tz - c2);
       double val[3] = {0, 0, 0};               // potentials phi_0..2 at the target
@@ -479,7 +507,7 @@ __global__ __launch_bounds__(kWave) void l2p_stokes_kernel(DevicePlan d, const i
           const int idx = n * (n + 1) / 2 + m;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const double2 L = Ls[e][idx];
+            const double2 L = Ls[e * S + idx];
             const double re = L.x * yr - L.y * yi;                   // Re(L Ynm)
             if (e < 3) val[e] += w * re;
             g[e][0] += w * re * factor;
@@ -626,7 +654,13 @@ hipError_t launch_l2p(const DevicePlan& d, int p, double* y, hipStream_t s) {
   if (hipError_t e = upload_constants_once(); e != hipSuccess) return e;
   if (d.n_l2p <= 0) return hipSuccess;
   if (p < 1 || p > kPmaxDev) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(l2p_kernel, dim3(d.n_l2p < 256 * 32 ? d.n_l2p : 256 * 32), dim3(kWave), 0, s, d, p, y);
+  const int S = p * (p + 1) / 2;
+  const size_t per_wave = sizeof(double2) * (size_t)kL2PLeaves * d.n_act * S;          // 7 KB at p = 10, 35 KB at p = 16 with both slots
+  int nw = (int)((48 * 1024) / per_wave);
+  nw = nw < 1 ? 1 : nw > kL2PWaves ? kL2PWaves : nw;
+  const int nblk = (d.n_l2p_grp + nw - 1) / nw;
+  const size_t lds = sizeof(double2) * (size_t)((3 * S + 1) / 2) + nw * per_wave;
+  hipLaunchKernelGGL(l2p_kernel, dim3(nblk < 256 * 8 ? nblk : 256 * 8), dim3(nw * kWave), lds, s, d, p, y);
   return hipGetLastError();
 }
 
@@ -647,7 +681,13 @@ hipError_t launch_l2p_stokes(const DevicePlan& d, int p, double* y, hipStream_t 
   if (hipError_t e = upload_constants_once(); e != hipSuccess) return e;
   if (d.n_l2p <= 0) return hipSuccess;
   if (p < 1 || p > kPmaxDev) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(l2p_stokes_kernel, dim3(d.n_l2p < 256 * 32 ? d.n_l2p : 256 * 32), dim3(kWave), 0, s, d, p, y);
+  const int S = p * (p + 1) / 2;
+  const size_t per_wave = sizeof(double2) * (size_t)kL2PLeaves * 4 * S;
+  int nw = (int)((48 * 1024) / per_wave);
+  nw = nw < 1 ? 1 : nw > kL2PWaves ? kL2PWaves : nw;
+  const int nblk = (d.n_l2p_grp + nw - 1) / nw;
+  const size_t lds = sizeof(double2) * (size_t)((3 * S + 1) / 2) + nw * per_wave;
+  hipLaunchKernelGGL(l2p_stokes_kernel, dim3(nblk < 256 * 8 ? nblk : 256 * 8), dim3(nw * kWave), lds, s, d, p, y);
   return hipGetLastError();
 }
 }  // namespace fmmbem

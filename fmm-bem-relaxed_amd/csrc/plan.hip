@@ -340,6 +340,21 @@ int fmmbem_plan::to_device() {
   for (int b : hp.l2p_leaves) l2p_leaf.push_back(hp.box_leaf_index[b]);
   d.n_p2m = (int)p2m_leaf.size(); d.n_l2p = (int)l2p_leaf.size();
   TRY(upload(p2m_leaf, &d.p2m_leaf)); TRY(upload(l2p_leaf, &d.l2p_leaf));
+  {
+    // L2P work groups: a leaf of this tree holds ~19 panels, a third of a wavefront; consecutive leaves are packed until
+    // 64 rows or 8 leaves (a leaf with more than 64 panels is a group of its own)
+    std::vector<int> grp(1, 0);
+    int rows = 0;
+    for (size_t i = 0; i < l2p_leaf.size(); ++i) {
+      const int nr = hp.box_body_end[hp.leaf_box[l2p_leaf[i]]] - hp.box_body_begin[hp.leaf_box[l2p_leaf[i]]];
+      const int in_group = (int)i - grp.back();
+      if (in_group > 0 && (rows + nr > 64 || in_group == 8)) { grp.push_back((int)i); rows = 0; }
+      rows += nr;
+    }
+    grp.push_back((int)l2p_leaf.size());
+    d.n_l2p_grp = l2p_leaf.empty() ? 0 : (int)grp.size() - 1;
+    TRY(upload(grp, &d.l2p_grp));
+  }
   TRY(upload(hp.m2m_parents, &d.m2m_parent)); TRY(upload(hp.l2l_children, &d.l2l_child));
   TRY(upload(hp.box_child_begin, &d.box_child_begin)); TRY(upload(hp.box_child_end, &d.box_child_end));
   TRY(upload(hp.box_parent, &d.box_parent));
