@@ -242,6 +242,9 @@ __global__ __launch_bounds__(kP2MWaves * kWave) void p2m_kernel(DevicePlan d, co
 // Workgroups stride over the level's parents.
 // ---------------------------------------------------------------------------------------------
 constexpr int kShiftWaves = 8;
+#ifndef FMMBEM_L2L_WAVES
+#define FMMBEM_L2L_WAVES 4
+#endif
 
 // One wavefront applies a shift operator: in[] = source expansion (LDS), Y[] = the class's harmonics (LDS);
 // every lane sums whole pieces (<= T terms, ELL over pieces: coalesced) into pv[] (LDS), then lane = output row adds
@@ -342,7 +345,8 @@ __global__ __launch_bounds__(kWave) void mh_prep_kernel(DevicePlan d, const int 
 // independent children per workgroup), same sparse-operator scheme as M2M; the terms usable at order p are
 // a prefix of each row's list (down_cnt).  Workgroups stride over the level's children.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kShiftWaves * kWave) void l2l_kernel(DevicePlan d, ShiftOpDev op, const int P, int first, int count) {
+constexpr int kL2LWaves = FMMBEM_L2L_WAVES;            // independent children per workgroup (LDS: 10.7 KB each at p = 10)
+__global__ __launch_bounds__(kL2LWaves * kWave) void l2l_kernel(DevicePlan d, ShiftOpDev op, const int P, int first, int count) {
   extern __shared__ double2 lds2[];
   const int S = P * (P + 1) / 2, P2 = P * P, SM = d.s_max, W = S + P2 + op.V;
   const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
@@ -350,7 +354,7 @@ __global__ __launch_bounds__(kShiftWaves * kWave) void l2l_kernel(DevicePlan d, 
   double2* Y = Ls + S;
   double2* pv = Y + P2;
   const int slot = d.act[blockIdx.y];
-  for (int it = blockIdx.x * kShiftWaves + w; it < count; it += gridDim.x * kShiftWaves) {
+  for (int it = blockIdx.x * kL2LWaves + w; it < count; it += gridDim.x * kL2LWaves) {
     const int child = d.l2l_child[first + it];
     const int parent = d.box_parent[child];
     const double2* src = d.L + ((size_t)parent * d.nslots + slot) * SM;
@@ -643,9 +647,9 @@ hipError_t launch_l2l_level(const DevicePlan& d, const ShiftOpDev& op, int p, in
   if (p < 1 || p > kPmaxDev) return hipErrorInvalidValue;
   {
     const size_t S = (size_t)p * (p + 1) / 2, P2 = (size_t)p * p;
-    const size_t lds = kShiftWaves * (S + P2 + op.V) * sizeof(double2);
-    const int blocks = (count + kShiftWaves - 1) / kShiftWaves;
-    hipLaunchKernelGGL(l2l_kernel, dim3(blocks < 1024 ? blocks : 1024, d.n_act), dim3(kShiftWaves * kWave), lds, s, d, op, p, first, count);
+    const size_t lds = kL2LWaves * (S + P2 + op.V) * sizeof(double2);
+    const int blocks = (count + kL2LWaves - 1) / kL2LWaves;
+    hipLaunchKernelGGL(l2l_kernel, dim3(blocks < 1024 ? blocks : 1024, d.n_act), dim3(kL2LWaves * kWave), lds, s, d, op, p, first, count);
   }
   return hipGetLastError();
 }
