@@ -55,7 +55,7 @@ _lib = None
 SYMBOLS = (
     "fmmbem_options_default", "fmmbem_plan_create", "fmmbem_plan_destroy", "fmmbem_plan_execute",
     "fmmbem_plan_execute_device", "fmmbem_plan_exchange_doubles", "fmmbem_plan_upward_device",
-    "fmmbem_plan_downward_device", "fmmbem_plan_near_device", "fmmbem_plan_set_timing", "fmmbem_plan_stats",
+    "fmmbem_plan_downward_device", "fmmbem_plan_near_split_device", "fmmbem_plan_near_device", "fmmbem_plan_set_timing", "fmmbem_plan_stats",
     "fmmbem_plan_get_perm", "fmmbem_plan_get_boxes", "fmmbem_plan_get_pairs", "fmmbem_plan_get_near_row",
     "fmmbem_plan_get_expansions", "fmmbem_plan_get_diagonal", "fmmbem_mesh_unit_sphere", "fmmbem_mesh_red_blood_cell", "fmmbem_mesh_red_blood_cells", "fmmbem_mesh_read_msh",
     "fmmbem_mesh_read_vert_face", "fmmbem_mesh_write_vert_face", "fmmbem_quadrature", "fmmbem_status_string", "fmmbem_last_error",
@@ -88,6 +88,7 @@ def lib():
     L.fmmbem_plan_execute.argtypes = [vp, i32, vp, vp]
     L.fmmbem_plan_execute_device.argtypes = [vp, i32, vp, vp, vp]
     L.fmmbem_plan_near_device.argtypes = [vp, vp, vp, vp]
+    L.fmmbem_plan_near_split_device.argtypes = [vp, vp, vp]
     L.fmmbem_plan_exchange_doubles.argtypes = [vp, i32, C.POINTER(C.c_size_t)]
     L.fmmbem_plan_upward_device.argtypes = [vp, i32, vp, vp, vp]
     L.fmmbem_plan_downward_device.argtypes = [vp, i32, vp, vp, vp]

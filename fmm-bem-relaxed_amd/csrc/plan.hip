@@ -129,6 +129,7 @@ struct fmmbem_plan {
   const DevicePlan* d_dev = nullptr;                            // copy of d in device memory
   bool split_upward = false;                                   // P2M/M2M sharded by owner, multipoles all-gathered by the caller
   unsigned pending_mask = 0;                                   // stages recorded by the upward half of a split execute
+  bool pending_near = false;                                   // split execute: the near field already ran (fmmbem_plan_near_split_device)
   std::vector<ShiftOpDev> up_ops, down_ops;                    // M2M / L2L operators, index p - 1
   int64_t near_bytes = 0;
   int64_t n_classes = 0;
@@ -507,15 +508,15 @@ int fmmbem_plan::to_device() {
 int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool near_only, int phase, double* xbuf) {
   if (!on_device) return fail(FMMBEM_ERR_NO_DEVICE, "plan was built host-only; there is no CPU execution path");
   if (p < 1 || p > hp.opt.p_max) return fail(FMMBEM_ERR_INVALID, "p outside [1, p_max]");
-  if ((phase != 2 && !d_x) || (phase != 1 && !d_y)) return fail(FMMBEM_ERR_INVALID, "null vector");
+  if ((phase < 2 && !d_x) || (phase != 1 && !d_y)) return fail(FMMBEM_ERR_INVALID, "null vector");
   if (split_upward && phase == 0 && !near_only)
     return fail(FMMBEM_ERR_UNSUPPORTED, "plan shards the upward pass: use fmmbem_plan_upward_device / _downward_device");
-  if (phase != 0 && (!split_upward || !xbuf)) return fail(FMMBEM_ERR_INVALID, "split execute needs shard_upward and an exchange buffer");
+  if (phase != 0 && (!split_upward || (!xbuf && phase != 3))) return fail(FMMBEM_ERR_INVALID, "split execute needs shard_upward and an exchange buffer");
   HIP_TRY(hipSetDevice(opts.device));
   const bool tm = timing;
   const int64_t ring = ev_count % kRing;
   hipEvent_t* set = tm ? &ev[(size_t)ring * 2 * kStages] : nullptr;
-  unsigned mask = phase == 2 ? pending_mask : 0;
+  unsigned mask = phase >= 2 ? pending_mask : 0;
   // stage i runs on stream st: begin/end events bracket exactly that kernel (or level sequence)
   auto begin = [&](int i, hipStream_t st) -> hipError_t { return tm ? hipEventRecord(set[2 * i], st) : hipSuccess; };
   auto end = [&](int i, hipStream_t st) -> hipError_t {
@@ -526,7 +527,7 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
   // M2L, L2L, L2P.  The near field only meets the far field in y, so it is launched on a second stream next
   // to M2L (an HBM-bound kernel beside an FMA-bound one); the two are joined before L2P adds into y.
   const bool overlap = overlap_near && !near_only && phase == 0;
-  if (phase != 2) {
+  if (phase < 2) {
     HIP_TRY(begin(0, s));
     HIP_TRY(launch_gather_x(d, d_x, s));
     HIP_TRY(end(0, s));
@@ -540,6 +541,7 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
     HIP_TRY(launch_xch_pack(d, p, reinterpret_cast<double2*>(xbuf), s));
     HIP_TRY(end(4, s));
     pending_mask = mask;
+    pending_near = false;
     return FMMBEM_OK;
   }
   auto near_field = [&](hipStream_t ns) -> int {
@@ -552,7 +554,14 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
     HIP_TRY(end(2, ns));
     return FMMBEM_OK;
   };
-  if (!overlap) TRY(near_field(s));
+  if (phase == 3) {                                    // the near field of a split execute, while the caller's all-gather is in flight
+    TRY(near_field(s));
+    pending_mask = mask;
+    pending_near = true;
+    return FMMBEM_OK;
+  }
+  if (!overlap && !(phase == 2 && pending_near)) TRY(near_field(s));
+  pending_near = false;
   if (overlap && overlap_early) {
     HIP_TRY(hipEventRecord(ev_fork, s));
     HIP_TRY(hipStreamWaitEvent(near_stream, ev_fork, 0));
@@ -689,6 +698,11 @@ int fmmbem_plan_upward_device(fmmbem_plan* plan, int p, const double* d_x, doubl
 int fmmbem_plan_downward_device(fmmbem_plan* plan, int p, const double* d_recv, double* d_y, void* stream) {
   if (!plan) return fail(FMMBEM_ERR_INVALID, "null plan");
   return plan->run(p, nullptr, d_y, static_cast<hipStream_t>(stream), false, 2, const_cast<double*>(d_recv));
+}
+
+int fmmbem_plan_near_split_device(fmmbem_plan* plan, double* d_y, void* stream) {
+  if (!plan) return fail(FMMBEM_ERR_INVALID, "null plan");
+  return plan->run(plan->last_p > 0 ? plan->last_p : 1, nullptr, d_y, static_cast<hipStream_t>(stream), false, 3, nullptr);
 }
 
 int fmmbem_plan_near_device(fmmbem_plan* plan, const double* d_x, double* d_y, void* stream) {

@@ -4,7 +4,7 @@ M2L/L2L/L2P work, and produces a result vector that is zero outside its rows.  A
 N-vector over RCCL/xGMI makes the full result available on every rank (what GMRES needs for its next
 Arnoldi step).  The upward pass is either repeated by every rank (SURVEY.md section 8e as written: one
 collective per matvec) or -- shard_upward, the default -- computed by the owners of the boxes and shared
-with ONE all-gather of the multipoles (60 MB at N = 1M, p = 10) in front of M2L.
+with ONE all-gather of the multipoles (60 MB at N = 1M, p = 10) in front of M2L, overlapped with the near field.
 
 The reference has no distributed code at all; this is the design of section 8(e).
 """
@@ -41,6 +41,10 @@ class ShardedFMM:
         self.n = self.plan.n
         self._local = local_execute if local_execute is not None else self.plan.execute_torch
         self._xbuf = {}                                   # p -> (send, recv) exchange buffers
+        # overlap of the all-gather with the near field: RCCL only (an asynchronous gloo collective on device tensors
+        # goes through the host and was measured 20x slower in a one-GPU rehearsal); FMMBEM_OVERLAP_GATHER=0 switches it off
+        self._overlap = (self.split and dist.is_initialized() and dist.get_backend(group) == "nccl"
+                         and os.environ.get("FMMBEM_OVERLAP_GATHER", "1") != "0")
 
     def kernel(self):
         return self.plan.kernel()
@@ -72,7 +76,13 @@ class ShardedFMM:
             else:
                 stream = torch.cuda.current_stream(x.device).cuda_stream
                 self.plan.upward_device(x.data_ptr(), send.data_ptr(), stream, p)
-                dist.all_gather_into_tensor(recv, send, group=self.group)
+                if self._overlap:
+                    # the near field (HBM-bound, needs no multipoles) streams while the multipoles travel over xGMI
+                    work = dist.all_gather_into_tensor(recv, send, group=self.group, async_op=True)
+                    self.plan.near_split_device(y.data_ptr(), stream)
+                    work.wait()                           # RCCL: the current stream waits for the collective, the host does not
+                else:
+                    dist.all_gather_into_tensor(recv, send, group=self.group)
                 self.plan.downward_device(recv.data_ptr(), y.data_ptr(), stream, p)
         if self.world > 1:
             dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.group)

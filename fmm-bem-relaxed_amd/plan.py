@@ -242,6 +242,9 @@ class FMM_plan:
         _capi.check(_capi.lib().fmmbem_plan_downward_device(self._h, self._K.P if p is None else int(p), C.c_void_p(recv_ptr),
                                                             C.c_void_p(y_ptr), C.c_void_p(stream)))
 
+    def near_split_device(self, y_ptr, stream=0):
+        _capi.check(_capi.lib().fmmbem_plan_near_split_device(self._h, C.c_void_p(y_ptr), C.c_void_p(stream)))
+
     def near_device(self, x_ptr, y_ptr, stream=0):
         _capi.check(_capi.lib().fmmbem_plan_near_device(self._h, C.c_void_p(x_ptr), C.c_void_p(y_ptr), C.c_void_p(stream)))
 

@@ -167,10 +167,14 @@ int fmmbem_plan_get_diagonal(const fmmbem_plan *plan, double *out);
  * the reference is single-node) ----------------------------------------------------------
  *   upward:   x -> P2M and M2M of the boxes this shard owns -> d_send (exchange_doubles(p) doubles)
  *   caller:   all-gather of the shards' d_send into d_recv (shard_world x exchange_doubles(p), rank order)
+ *             [meanwhile, optionally: near_split -> y]
  *   downward: d_recv -> the remaining M2M, M2L, L2L, L2P and the near field -> y (zero outside the owned rows) */
 int fmmbem_plan_exchange_doubles(const fmmbem_plan *plan, int p, size_t *per_shard);
 int fmmbem_plan_upward_device(fmmbem_plan *plan, int p, const double *d_x, double *d_send, void *stream);
 int fmmbem_plan_downward_device(fmmbem_plan *plan, int p, const double *d_recv, double *d_y, void *stream);
+/* Optional, between the two: the near field of this shard (y = A_near x of the x given to upward; zero outside the owned
+ * rows), so that it runs while the caller's all-gather is in flight.  downward then skips it and adds the far field. */
+int fmmbem_plan_near_split_device(fmmbem_plan *plan, double *d_y, void *stream);
 
 /* Multipole (which=0) or local (which=1) coefficients of the last execute for every box:
  * out[box][slot][p(p+1)/2][re,im]; Laplace: 2 slots (G, dG/dn); Stokes: 8 slots (M[2][4]). */

@@ -25,8 +25,10 @@ def test_split_execute_sums_bitwise(fb, world, p):
     for r, pl in enumerate(plans):
         pl.upward_device(xd.data_ptr(), buf[r].data_ptr(), s, p)
     total = torch.zeros_like(xd)
-    for pl in plans:
+    for r, pl in enumerate(plans):
         y = torch.empty_like(xd)
+        if r % 2 == 0:                                 # the near field while the all-gather would be in flight, then the rest
+            pl.near_split_device(y.data_ptr(), s)
         pl.downward_device(buf.data_ptr(), y.data_ptr(), s, p)
         total += y
     torch.cuda.synchronize()
