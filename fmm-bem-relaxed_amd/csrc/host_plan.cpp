@@ -4,6 +4,10 @@
 #include <algorithm>
 #include <array>
 #include <cmath>
+#include <thread>
+#include <cstdlib>
+#include <cstdio>
+#include <chrono>
 #include <cstring>
 #include <deque>
 #include <numeric>
@@ -135,6 +139,15 @@ struct Coded { uint32_t code, idx; };
 }  // namespace
 
 std::string HostPlan::build(const HostOptions& o, int64_t n_panels, const double* vertices, const uint8_t* bc) {
+  // FMMBEM_BUILD_TRACE=1: phase times of this function on stderr (tuning aid)
+  const bool trace = std::getenv("FMMBEM_BUILD_TRACE") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto mark = [&](const char* what) {
+    if (!trace) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "host_plan %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
   opt = o;
   n = n_panels;
   if (n <= 0 || !vertices) return "no panels";
@@ -165,6 +178,7 @@ std::string HostPlan::build(const HostOptions& o, int64_t n_panels, const double
     cell[k] = (hi[k] - lo[k]) / double(1u << kLevels);
   }
 
+  mark("setup+bounds");
   // ---- Morton codes (Octree.hpp:118-129) ----
   std::vector<Coded> codes(n), scratch(n);
   for (int64_t i = 0; i < n; ++i) {
@@ -178,6 +192,7 @@ std::string HostPlan::build(const HostOptions& o, int64_t n_panels, const double
     codes[i] = {spread3(s[0]) | (spread3(s[1]) << 1) | (spread3(s[2]) << 2), (uint32_t)i};
   }
 
+  mark("morton codes");
   // ---- BFS construction with stable 8-way bucketing per box (Octree.hpp:617-692) ----
   box_key.assign(1, 1u);
   box_parent.assign(1, 0);
@@ -227,6 +242,7 @@ std::string HostPlan::build(const HostOptions& o, int64_t n_panels, const double
   codes.clear(); codes.shrink_to_fit();
   scratch.clear(); scratch.shrink_to_fit();
 
+  mark("tree");
   // ---- box geometry (Octree.hpp:334-355 through :109-113, :243-248) ----
   box_center.resize(3 * (size_t)nboxes);
   box_side.resize(nboxes);
@@ -247,6 +263,7 @@ std::string HostPlan::build(const HostOptions& o, int64_t n_panels, const double
     box_side[b] = root_side / double(1 << lev);
   }
 
+  mark("box geometry");
   // ---- dual tree traversal (EvalInteractionLazySparse.hpp:68-110, :239-252) ----
   auto accept = [&](int s, int t) {     // DefaultMAC, radius = side/2
     const double dx = box_center[3 * s] - box_center[3 * t], dy = box_center[3 * s + 1] - box_center[3 * t + 1],
@@ -285,6 +302,7 @@ std::string HostPlan::build(const HostOptions& o, int64_t n_panels, const double
     }
   }
 
+  mark("traversal");
   // ---- leaves in tree order ----
   box_leaf_index.assign(nboxes, -1);
   for (int b = 0; b < nboxes; ++b)
@@ -293,6 +311,7 @@ std::string HostPlan::build(const HostOptions& o, int64_t n_panels, const double
   for (int i = 0; i < (int)leaf_box.size(); ++i) box_leaf_index[leaf_box[i]] = i;
   const int nl = nleaves();
 
+  mark("leaves");
   // ---- near field grouped by target leaf; sources ascending (EvalP2P.hpp:87 sorts the columns) ----
   near_ptr.assign(nl + 1, 0);
   for (size_t i = 0; i < p2p_tgt.size(); ++i) ++near_ptr[box_leaf_index[p2p_tgt[i]] + 1];
@@ -316,6 +335,7 @@ std::string HostPlan::build(const HostOptions& o, int64_t n_panels, const double
     near_nnz_total += int64_t(cols) * (box_body_end[tb] - box_body_begin[tb]);
   }
 
+  mark("near lists");
   // ---- which boxes need a multipole / hold a local expansion (EvalInteractionLazySparse.hpp:173-237) ----
   // need_M: every M2L source and its whole subtree; has_L: every M2L target and its whole subtree.
   need_M.assign(nboxes, 0);
@@ -355,6 +375,7 @@ std::string HostPlan::build(const HostOptions& o, int64_t n_panels, const double
       if (has_L[box_parent[b]] && !l2l_ref_edge[b]) ++l2l_ref_omitted;
   }
 
+  mark("need/has + l2l rule");
   // ---- shard: contiguous range of target leaves ----
   std::vector<int> box_owner(nboxes, 0);                 // shard whose rows hold all of the box's bodies, -1 = spans shards
   {
@@ -386,6 +407,7 @@ std::string HostPlan::build(const HostOptions& o, int64_t n_panels, const double
     }
   }
 
+  mark("shard");
   // ---- operator lists ----
   const bool su = o.shard_upward && o.shard_world > 1;
   for (int b = 0; b < nboxes; ++b) {
@@ -424,6 +446,7 @@ std::string HostPlan::build(const HostOptions& o, int64_t n_panels, const double
     l2l_level_ptr.push_back((int)l2l_children.size());
   }
 
+  mark("operator lists");
   // ---- M2L grouped by target, traversal order kept within a target; translation classes ----
   m2l_ptr.assign(nboxes + 1, 0);
   m2l_pairs_owned = 0;
@@ -453,6 +476,7 @@ std::string HostPlan::build(const HostOptions& o, int64_t n_panels, const double
     }
   }
 
+  mark("m2l csr + classes");
   // ---- panels in tree order, SoA (LaplaceSphericalBEM.hpp:64-97) ----
   PanelSoA& P = panels;
   const int nq = rule.n;
@@ -462,7 +486,11 @@ std::string HostPlan::build(const HostOptions& o, int64_t n_panels, const double
   P.quad.resize((size_t)nq * 3 * n);
   P.vert.resize((size_t)9 * n);
   has_bc[0] = has_bc[1] = false;
-  for (int64_t i = 0; i < n; ++i) {
+  // independent per panel: cut into ranges for a few host threads (half of this function's time at N = 1M when serial)
+  const int nthreads = n < (1 << 16) ? 1 : (int)std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
+  std::vector<std::array<uint8_t, 2>> seen_bc(nthreads, std::array<uint8_t, 2>{0, 0});
+  auto fill_range = [&](int t, int64_t i0, int64_t i1) {
+  for (int64_t i = i0; i < i1; ++i) {
     const double* v = vertices + 9 * (size_t)perm[i];
     const double *p0 = v, *p1 = v + 3, *p2 = v + 6;
     P.cx[i] = (p0[0] + p1[0] + p2[0]) / 3;
@@ -480,8 +508,17 @@ std::string HostPlan::build(const HostOptions& o, int64_t n_panels, const double
     for (int k = 0; k < 9; ++k) P.vert[(size_t)k * n + i] = v[k];
     const uint8_t flag = bc ? (bc[perm[i]] ? 1 : 0) : 0;
     P.bc[i] = flag;
-    has_bc[flag] = true;
+    seen_bc[t][flag] = 1;
   }
+  };
+  if (nthreads == 1) fill_range(0, 0, n);
+  else {
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nthreads; ++t) pool.emplace_back(fill_range, t, n * t / nthreads, n * (t + 1) / nthreads);
+    for (auto& th : pool) th.join();
+  }
+  for (int t = 0; t < nthreads; ++t) { has_bc[0] = has_bc[0] || seen_bc[t][0]; has_bc[1] = has_bc[1] || seen_bc[t][1]; }
+  mark("panels SoA");
   return {};
 }
 

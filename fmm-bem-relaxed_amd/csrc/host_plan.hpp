@@ -13,6 +13,8 @@
 #include <cstdint>
 #include <string>
 #include <vector>
+#include <utility>
+#include <memory>
 
 namespace fmmbem {
 
@@ -39,13 +41,23 @@ struct HostOptions {
 };
 
 // Panels in TREE order, structure-of-arrays (what the kernels stream).
+// std::vector whose resize() leaves the new elements uninitialised: the 240 MB of panel arrays at N = 1M are written
+// exactly once, by several threads, and a zero-fill in front of that costs as much as the fill itself
+template <class T>
+struct default_init_allocator : std::allocator<T> {
+  template <class U> struct rebind { using other = default_init_allocator<U>; };
+  template <class U> void construct(U* p) noexcept { ::new (static_cast<void*>(p)) U; }
+  template <class U, class... A> void construct(U* p, A&&... a) { ::new (static_cast<void*>(p)) U(std::forward<A>(a)...); }
+};
+template <class T> using raw_vector = std::vector<T, default_init_allocator<T>>;
+
 struct PanelSoA {
-  std::vector<double> cx, cy, cz;         // centroid
-  std::vector<double> nx, ny, nz;         // unit normal
-  std::vector<double> area;
-  std::vector<double> quad;               // [q][xyz][N]  stored quadrature points
-  std::vector<double> vert;               // [vertex*3+xyz][N]
-  std::vector<uint8_t> bc;
+  raw_vector<double> cx, cy, cz;          // centroid
+  raw_vector<double> nx, ny, nz;          // unit normal
+  raw_vector<double> area;
+  raw_vector<double> quad;                // [q][xyz][N]  stored quadrature points
+  raw_vector<double> vert;                // [vertex*3+xyz][N]
+  raw_vector<uint8_t> bc;
 };
 
 struct HostPlan {

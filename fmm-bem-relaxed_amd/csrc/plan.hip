@@ -150,8 +150,8 @@ struct fmmbem_plan {
   hipStream_t near_stream = nullptr;                          // the HBM-bound near field runs beside the far field
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
-  template <class T>
-  int upload(const std::vector<T>& v, const T** out) {
+  template <class T, class A>
+  int upload(const std::vector<T, A>& v, const T** out) {
     *out = nullptr;
     void* p = nullptr;
     const size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
