@@ -203,8 +203,18 @@ int fmmbem_plan::to_device() {
   ev.assign((size_t)kRing * 2 * kStages, nullptr);
   for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
 
+  const bool trace = std::getenv("FMMBEM_BUILD_TRACE") != nullptr;     // phase times on stderr (tuning aid)
+  double t_last = now_ms();
+  auto mark = [&](const char* what) {
+    if (!trace) return;
+    (void)hipDeviceSynchronize();
+    const double now = now_ms();
+    std::fprintf(stderr, "to_device %-28s %8.2f ms\n", what, now - t_last);
+    t_last = now;
+  };
   const HarmonicTables T;
   const int nl = hp.nleaves(), nb = hp.nboxes, pm = hp.opt.p_max;
+  mark("streams, events, tables");
   d = DevicePlan{};
   d.n = hp.n; d.nq = hp.rule.n; d.nboxes = nb; d.nleaves = nl;
   d.p_max = pm; d.s_max = pm * (pm + 1) / 2; d.p2_max = pm * pm; d.y2_max = 4 * pm * pm;
@@ -335,6 +345,7 @@ int fmmbem_plan::to_device() {
     TRY(upload(st, &d.tabStep));
   }
 
+  mark("panels + near lists upload");
   // far-field lists
   std::vector<int> p2m_leaf, l2p_leaf;
   for (int b : hp.p2m_leaves) p2m_leaf.push_back(hp.box_leaf_index[b]);
@@ -379,6 +390,7 @@ int fmmbem_plan::to_device() {
   }
   TRY(upload(hp.xch_box, &d.xch_box));
 
+  mark("far-field lists");
   // parent<->child translation classes and their regular-harmonic tables
   {
     std::vector<int> up_cls(nb, 0), down_cls(nb, 0);
@@ -429,6 +441,7 @@ int fmmbem_plan::to_device() {
     for (int p = 1; p <= pm; ++p) { TRY(up_op(ops.up_v[p - 1], up_ops[p - 1])); TRY(up_op(ops.down_v[p - 1], down_ops[p - 1])); }
   }
 
+  mark("shift classes + operators");
   // M2L: targets to run, sources whose Mh is needed, class tables Yh[r,c] = i^{|c|} EPS Y[r,c] / A[r,c]
   {
     std::vector<int> tgt, mh;
@@ -477,6 +490,7 @@ int fmmbem_plan::to_device() {
     TRY(upload(lanes, &d.m2l_lane)); TRY(upload(scat, &d.m2l_scat));
   }
 
+  mark("m2l class tables");
   TRY(alloc((size_t)hp.n * dof, &d.xt, true));
   TRY(alloc((size_t)hp.n * dof, &d.yt, true));
   TRY(alloc((size_t)hp.n * dof, &stage_x, true));
@@ -487,6 +501,7 @@ int fmmbem_plan::to_device() {
   // otherwise race with the first execute).
   HIP_TRY(hipDeviceSynchronize());
 
+  mark("vectors");
   // near-field assembly on the device
   const double t0 = now_ms();
   if (opts.sparse_local) {
@@ -495,6 +510,7 @@ int fmmbem_plan::to_device() {
     HIP_TRY(hipStreamSynchronize(own_stream));
   }
   build_assemble_ms = now_ms() - t0;
+  mark("near assembly");
   {                                                    // the plan itself, readable from the device
     void* pd = nullptr;
     HIP_TRY(hipMalloc(&pd, sizeof(DevicePlan)));
