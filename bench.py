@@ -165,7 +165,8 @@ def main():
 
     # ---- roofline of the P2P kernel on this rank's shard (SURVEY.md section 8d "Algorithmic bytes, P2P") ----
     rows = st["owned_row_end"] - st["owned_row_begin"]
-    p2p_bytes = st["near_nnz"] * 8 * dof * dof + n * 8 * dof + rows * 8 * dof
+    # Stokes: the 3x3 block of a panel pair is symmetric and is streamed as 6 values, not the 9 of SURVEY 8d
+    p2p_bytes = st["near_nnz"] * 8 * (6 if stokes else 1) + n * 8 * dof + rows * 8 * dof
     near_ms = st["ms_near"]
     p2p_gbs = p2p_bytes / (near_ms * 1e-3) / 1e9 if near_ms > 0 else 0.0
     traffic = None

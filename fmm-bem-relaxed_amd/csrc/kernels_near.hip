@@ -665,6 +665,122 @@ __global__ __launch_bounds__(kSpmvWaves * kWave, kSpmvOcc) void near_spmv_pipe_k
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------
+// Stokes near field with the block symmetry folded (DevicePlan::near_sym): 48 instead of 72 bytes per panel pair.
+// near_sym_pack copies the six distinct entries of every 3x3 block out of the assembled matrix (the (a,b) entry with
+// a <= b; the quadrature blocks are symmetric bit for bit, the analytic self blocks to rounding, 1e-16).
+// near_spmv_sym3: the scheme of near_spmv_kernel with a PANEL row per wavefront step -- per source panel three 16-byte
+// vectors and the three x components from LDS feed nine FMAs into (y_x, y_y, y_z).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void near_sym_pack_kernel(DevicePlan d) {
+  for (int t = d.leaf_begin + blockIdx.x; t < d.leaf_end; t += gridDim.x) {
+    const int nrp = d.leaf_nrows[t], ncp = d.near_ncols[t], stride = d.near_stride[t];
+    const double* blk = d.near_val + d.near_off[t];
+    dvec2* sym = reinterpret_cast<dvec2*>(d.near_sym + d.near_sym_off[t]);
+    for (int64_t e = threadIdx.x; e < (int64_t)nrp * ncp; e += blockDim.x) {
+      const int tr = (int)(e / ncp), c = (int)(e - (int64_t)tr * ncp);
+      const double* r0 = blk + (int64_t)(3 * tr) * stride + 3 * c;
+      const double* r1 = r0 + stride;
+      const double* r2 = r1 + stride;
+      dvec2* row = sym + (int64_t)tr * 3 * ncp;
+      row[c] = dvec2{r0[0], r0[1]};
+      row[ncp + c] = dvec2{r0[2], r1[1]};
+      row[2 * ncp + c] = dvec2{r1[2], r2[2]};
+    }
+  }
+}
+
+constexpr int kSymChunk = 1024;                       // source panels of x staged at a time (3 x 8 KiB)
+template <int kRows, int kVecs>
+__global__ __launch_bounds__(kSpmvWaves * kWave, kSpmvOcc) void near_spmv_sym3_kernel(DevicePlan d) {
+  extern __shared__ double xs[];                      // [3][kSymChunk] doubles, then the run descriptors
+  __shared__ double part[kSpmvWaves][kColRows][3];
+  int* run_row0 = reinterpret_cast<int*>(xs + 3 * kSymChunk);
+  int* run_off = run_row0 + d.max_runs;
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  for (int item = blockIdx.x; item < d.sym_nitems; item += gridDim.x) {
+    const int4 it = d.sym_items[item];
+    const int t = it.x, r0 = it.y, nrows = it.z;       // panel rows
+    const bool colsplit = it.w != 0;
+    const int ncp = d.near_ncols[t];
+    const Runs runs = load_runs(d, t, run_row0, run_off);
+    const dvec2* blk = reinterpret_cast<const dvec2*>(d.near_sym + d.near_sym_off[t]) + (int64_t)r0 * 3 * ncp;
+    double* yt = d.yt + 3 * (int64_t)(d.leaf_row0[t] + r0);
+    for (int c0 = 0; c0 < ncp; c0 += kSymChunk) {
+      const int cw = ncp - c0 < kSymChunk ? ncp - c0 : kSymChunk;
+      if (c0) __syncthreads();
+      for (int c = threadIdx.x; c < cw; c += blockDim.x) {
+        const double* xp = d.xt + 3 * (int64_t)column_to_row(runs, c0 + c);
+        xs[c] = xp[0]; xs[kSymChunk + c] = xp[1]; xs[2 * kSymChunk + c] = xp[2];
+      }
+      __syncthreads();
+      const int seg = colsplit ? ((((cw + kSpmvWaves - 1) / kSpmvWaves) + 3) & ~3) : cw;
+      const int v0 = colsplit ? wave * seg : 0, v1 = min(cw, v0 + seg);
+      const int rstep = colsplit ? 1 : kSpmvWaves;
+      for (int r = colsplit ? 0 : wave; r < nrows; r += colsplit ? kRows : kRows * kSpmvWaves) {
+        const dvec2* row[kRows];
+        double ax[kRows], ay[kRows], az[kRows];
+#pragma unroll
+        for (int i = 0; i < kRows; ++i) {
+          const int ri = r + i * rstep;
+          row[i] = blk + (int64_t)(ri < nrows ? ri : r) * 3 * ncp + c0;
+          ax[i] = ay[i] = az[i] = 0;
+        }
+        for (int c = v0 + lane; c < v1; c += kVecs * kWave) {
+          dvec2 v[kRows][kVecs][3];
+#pragma unroll
+          for (int u = 0; u < kVecs; ++u) {
+            const int cc = c + u * kWave;
+            const bool ok = cc < v1;
+#pragma unroll
+            for (int i = 0; i < kRows; ++i)
+#pragma unroll
+              for (int k = 0; k < 3; ++k) v[i][u][k] = ok ? __builtin_nontemporal_load(&row[i][k * ncp + cc]) : dvec2{0, 0};
+          }
+#pragma unroll
+          for (int u = 0; u < kVecs; ++u) {
+            const int cc = c + u * kWave;
+            if (cc < v1) {
+              const double x0 = xs[cc], x1 = xs[kSymChunk + cc], x2 = xs[2 * kSymChunk + cc];
+#pragma unroll
+              for (int i = 0; i < kRows; ++i) {
+                const dvec2 a = v[i][u][0], b = v[i][u][1], e = v[i][u][2];   // (xx,xy) (xz,yy) (yz,zz)
+                ax[i] = fma(a.x, x0, fma(a.y, x1, fma(b.x, x2, ax[i])));
+                ay[i] = fma(a.y, x0, fma(b.y, x1, fma(e.x, x2, ay[i])));
+                az[i] = fma(b.x, x0, fma(e.x, x1, fma(e.y, x2, az[i])));
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < kRows; ++i) { ax[i] = wave_sum(ax[i]); ay[i] = wave_sum(ay[i]); az[i] = wave_sum(az[i]); }
+        if (lane == 0) {
+#pragma unroll
+          for (int i = 0; i < kRows; ++i) {
+            const int ri = r + i * rstep;
+            if (ri < nrows) {
+              if (colsplit) { part[wave][ri][0] = ax[i]; part[wave][ri][1] = ay[i]; part[wave][ri][2] = az[i]; }
+              else {
+                double* y = yt + 3 * ri;
+                y[0] = c0 ? y[0] + ax[i] : ax[i]; y[1] = c0 ? y[1] + ay[i] : ay[i]; y[2] = c0 ? y[2] + az[i] : az[i];
+              }
+            }
+          }
+        }
+      }
+      if (colsplit) {
+        __syncthreads();
+        if ((int)threadIdx.x < 3 * nrows) {
+          const int ri = threadIdx.x / 3, a = threadIdx.x % 3;
+          const double sum = ((part[0][ri][a] + part[1][ri][a]) + part[2][ri][a]) + part[3][ri][a];
+          yt[3 * ri + a] = c0 ? yt[3 * ri + a] + sum : sum;
+        }
+      }
+    }
+    __syncthreads();                                  // xs / run descriptors / part are rewritten for the next item
+  }
+}
+
 // diag[original unknown] = A_near[u,u]: the self-interaction K(s,s) that Preconditioners::Diagonal divides by
 // (examples/BEM/Preconditioner.hpp:19-42).  selfcol[leaf] = first column of the leaf's own panels in its block.
 __global__ void near_diag_kernel(DevicePlan d, const int* __restrict__ selfcol, double* __restrict__ out) {
@@ -714,8 +830,22 @@ hipError_t launch_gather_x(const DevicePlan& d, const double* x, hipStream_t s) 
   return hipGetLastError();
 }
 
+hipError_t launch_near_sym_pack(const DevicePlan& d, hipStream_t s) {
+  const int nb = d.leaf_end - d.leaf_begin;
+  if (nb <= 0 || !d.near_sym) return hipSuccess;
+  hipLaunchKernelGGL(near_sym_pack_kernel, dim3(nb < 256 * 8 ? nb : 256 * 8), dim3(256), 0, s, d);
+  return hipGetLastError();
+}
+
 hipError_t launch_near_spmv(const DevicePlan& d, hipStream_t s) {
   if (d.near_nitems <= 0) return hipSuccess;
+  if (d.dof == 3 && d.near_sym) {
+    const size_t lds3 = 3 * (size_t)kSymChunk * sizeof(double) + 2 * (size_t)d.max_runs * sizeof(int);
+    // panel rows x source-panel vectors in flight per wavefront, red blood cell N = 524 288 (ms): 1x3 2.10, 1x2 2.11, 1x1 2.15,
+    // 1x4 2.3-2.6, 2x2 3.39, 1x5 3.36, 4x1 4.14; 2x4, 4x2, 1x6 spill (7-9); the 9-value rows: 3.32
+    hipLaunchKernelGGL((near_spmv_sym3_kernel<1, 3>), dim3(std::min(d.sym_nitems, 256 * kSpmvOcc)), dim3(kSpmvWaves * kWave), lds3, s, d);
+    return hipGetLastError();
+  }
   const size_t lds = (size_t)kSpmvChunk * sizeof(double) + 2 * (size_t)d.max_runs * sizeof(int);
   // rows x vectors in flight per wavefront measured at N = 1M (ms): 4x4 1.05,
   // 2x4 0.99, 4x2 1.14, 8x2 1.21, 2x2 1.09, 4x1 1.09; plain (non-nontemporal) loads +25 %

@@ -321,6 +321,39 @@ int fmmbem_plan::to_device() {
   }
   if (opts.sparse_local) TRY(alloc((size_t)total, &d.near_val, false));   // matrix-free mode keeps no matrix
   else { d.near_val = nullptr; near_bytes = 0; }
+  {
+    // Stokes: the symmetric 6-value form of the same blocks, which is what the SpMV streams (FMMBEM_STOKES_SYM=0: the
+    // 9-value rows).  The assembled matrix stays for the introspection calls and the diagonal.
+    const char* e = std::getenv("FMMBEM_STOKES_SYM");
+    if (dof == 3 && opts.sparse_local && !(e && std::atoi(e) == 0)) {
+      std::vector<int64_t> sym_off(nl, 0);
+      int64_t sym_total = 0;
+      constexpr int64_t kItemBytes = 128 << 10;
+      struct Item { int leaf, r0, nr; int64_t bytes; };
+      std::vector<Item> items;
+      for (int l = hp.leaf_begin; l < hp.leaf_end; ++l) {
+        const int nr = leaf_nrows[l], ncp = hp.near_ncols[l];
+        sym_off[l] = sym_total;
+        sym_total += (int64_t)6 * nr * ncp;
+        const int64_t row_bytes = (int64_t)48 * ncp;
+        if (nr == 0 || row_bytes == 0) continue;
+        int per = (int)std::max<int64_t>(1, kItemBytes / row_bytes);
+        if (per >= 8) per &= ~7; else per = std::min(4, nr);
+        const int cnt = (nr + per - 1) / per;
+        per = (nr + cnt - 1) / cnt;
+        if (per >= 8) per = (per + 7) & ~7;
+        for (int r0 = 0; r0 < nr; r0 += per) { const int k = std::min(per, nr - r0); items.push_back({l, r0, k, k * row_bytes}); }
+      }
+      std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.bytes > b.bytes; });
+      std::vector<int4> packed(items.size());
+      for (size_t i = 0; i < items.size(); ++i) packed[i] = make_int4(items[i].leaf, items[i].r0, items[i].nr, items[i].nr < 8);
+      d.sym_nitems = (int)packed.size();
+      TRY(upload(packed, &d.sym_items));
+      TRY(upload(sym_off, &d.near_sym_off));
+      TRY(alloc((size_t)sym_total, &d.near_sym, false));
+      near_bytes = sym_total * (int64_t)sizeof(double);
+    }
+  }
 
   // boxes, expansions, tables
   TRY(upload(hp.box_center, &d.box_center));
@@ -505,7 +538,7 @@ int fmmbem_plan::to_device() {
   // near-field assembly on the device
   const double t0 = now_ms();
   if (opts.sparse_local) {
-    if (opts.kernel == FMMBEM_KERNEL_STOKES_BEM) HIP_TRY(launch_near_assemble_stokes(d, own_stream));
+    if (opts.kernel == FMMBEM_KERNEL_STOKES_BEM) { HIP_TRY(launch_near_assemble_stokes(d, own_stream)); HIP_TRY(launch_near_sym_pack(d, own_stream)); }
     else HIP_TRY(launch_near_assemble(d, own_stream));
     HIP_TRY(hipStreamSynchronize(own_stream));
   }
