@@ -82,7 +82,7 @@ struct DevicePlan {
   int near_nitems;
   // Stokes: the 3x3 block of a panel pair is symmetric ((delta_ij/r + x_i x_j/r^3) summed over the quadrature, the
   // products commute bit for bit), so the SpMV streams 6 values per pair instead of 9: per target PANEL row three planes
-  // of ncols 16-byte pairs (xx,xy) (xz,yy) (yz,zz).  Built from near_val after the assembly (near_sym_pack).
+  // of ncols 16-byte pairs (xx,xy) (xz,yy) (yz,zz), written by the assembly; near_val is then not allocated.
   double* near_sym = nullptr;
   const int64_t* near_sym_off;                        // [nl] offset of a leaf's block in near_sym (doubles)
   const int4* sym_items;      int sym_nitems = 0;     // {leaf, first panel row, panel rows, column-split?}, largest first
@@ -118,7 +118,6 @@ struct DevicePlan {
 hipError_t launch_near_assemble(const DevicePlan& d, hipStream_t s);
 hipError_t launch_gather_x(const DevicePlan& d, const double* x, hipStream_t s);
 hipError_t launch_near_spmv(const DevicePlan& d, hipStream_t s);
-hipError_t launch_near_sym_pack(const DevicePlan& d, hipStream_t s);
 hipError_t launch_near_diag(const DevicePlan& d, const int* selfcol, double* out, hipStream_t s);
 hipError_t launch_near_matfree(const DevicePlan& d, hipStream_t s);
 hipError_t launch_scatter_y(const DevicePlan& d, double* y, hipStream_t s);

@@ -332,8 +332,9 @@ __global__ __launch_bounds__(256) void near_assemble_stokes_kernel(DevicePlan d)
     const int ncols = d.near_ncols[t], stride = d.near_stride[t], nrows = d.leaf_nrows[t];
     const int row0 = d.leaf_row0[t];
     const Runs runs = load_runs(d, t, run_row0, run_off);
-    double* blk = d.near_val + d.near_off[t];
-    if (stride > 3 * ncols)                           // padding column (odd number of unknowns per row)
+    double* blk = d.near_sym ? nullptr : d.near_val + d.near_off[t];
+    dvec2* sym = d.near_sym ? reinterpret_cast<dvec2*>(d.near_sym + d.near_sym_off[t]) : nullptr;
+    if (blk && stride > 3 * ncols)                    // padding column (odd number of unknowns per row)
       for (int r = threadIdx.x; r < 3 * nrows; r += blockDim.x) blk[(int64_t)r * stride + 3 * ncols] = 0.0;
     for (int c0 = 0; c0 < ncols; c0 += kAsmChunk) {
       const int cw = ncols - c0 < kAsmChunk ? ncols - c0 : kAsmChunk;
@@ -346,10 +347,17 @@ __global__ __launch_bounds__(256) void near_assemble_stokes_kernel(DevicePlan d)
         const int64_t i = row0 + r;
         double m[9];
         stokes_entry(d, V3{d.cx[i], d.cy[i], d.cz[i]}, colmap[c], m);
+        if (sym) {                                     // the six entries (a <= b) of the symmetric block, three planes per panel row
+          dvec2* row = sym + (int64_t)r * 3 * ncols + c0 + c;
+          row[0] = dvec2{m[0], m[1]};
+          row[ncols] = dvec2{m[2], m[4]};
+          row[2 * ncols] = dvec2{m[5], m[8]};
+        } else {
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
+          for (int a = 0; a < 3; ++a)
 #pragma unroll
-          for (int b = 0; b < 3; ++b) blk[(int64_t)(3 * r + a) * stride + 3 * (c0 + c) + b] = m[3 * a + b];
+            for (int b = 0; b < 3; ++b) blk[(int64_t)(3 * r + a) * stride + 3 * (c0 + c) + b] = m[3 * a + b];
+        }
       }
     }
     __syncthreads();
@@ -667,29 +675,11 @@ __global__ __launch_bounds__(kSpmvWaves * kWave, kSpmvOcc) void near_spmv_pipe_k
 
 // ---------------------------------------------------------------------------------------------
 // Stokes near field with the block symmetry folded (DevicePlan::near_sym): 48 instead of 72 bytes per panel pair.
-// near_sym_pack copies the six distinct entries of every 3x3 block out of the assembled matrix (the (a,b) entry with
-// a <= b; the quadrature blocks are symmetric bit for bit, the analytic self blocks to rounding, 1e-16).
+// The assembly writes the six entries (a,b), a <= b, of every 3x3 block (the quadrature blocks are symmetric bit for bit, the
+// analytic self blocks to rounding, 1e-16); the 9-value rows are not kept.
 // near_spmv_sym3: the scheme of near_spmv_kernel with a PANEL row per wavefront step -- per source panel three 16-byte
 // vectors and the three x components from LDS feed nine FMAs into (y_x, y_y, y_z).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void near_sym_pack_kernel(DevicePlan d) {
-  for (int t = d.leaf_begin + blockIdx.x; t < d.leaf_end; t += gridDim.x) {
-    const int nrp = d.leaf_nrows[t], ncp = d.near_ncols[t], stride = d.near_stride[t];
-    const double* blk = d.near_val + d.near_off[t];
-    dvec2* sym = reinterpret_cast<dvec2*>(d.near_sym + d.near_sym_off[t]);
-    for (int64_t e = threadIdx.x; e < (int64_t)nrp * ncp; e += blockDim.x) {
-      const int tr = (int)(e / ncp), c = (int)(e - (int64_t)tr * ncp);
-      const double* r0 = blk + (int64_t)(3 * tr) * stride + 3 * c;
-      const double* r1 = r0 + stride;
-      const double* r2 = r1 + stride;
-      dvec2* row = sym + (int64_t)tr * 3 * ncp;
-      row[c] = dvec2{r0[0], r0[1]};
-      row[ncp + c] = dvec2{r0[2], r1[1]};
-      row[2 * ncp + c] = dvec2{r1[2], r2[2]};
-    }
-  }
-}
-
 constexpr int kSymChunk = 1024;                       // source panels of x staged at a time (3 x 8 KiB)
 template <int kRows, int kVecs>
 __global__ __launch_bounds__(kSpmvWaves * kWave, kSpmvOcc) void near_spmv_sym3_kernel(DevicePlan d) {
@@ -786,6 +776,16 @@ __global__ __launch_bounds__(kSpmvWaves * kWave, kSpmvOcc) void near_spmv_sym3_k
 __global__ void near_diag_kernel(DevicePlan d, const int* __restrict__ selfcol, double* __restrict__ out) {
   const int t = d.leaf_begin + blockIdx.x;
   const int dof = d.dof, nrows = dof * d.leaf_nrows[t], stride = d.near_stride[t], row0 = d.leaf_row0[t];
+  if (d.near_sym) {                                   // Stokes, symmetric blocks: (a,a) of the self block of panel row tr
+    const int ncp = d.near_ncols[t];
+    const dvec2* sym = reinterpret_cast<const dvec2*>(d.near_sym + d.near_sym_off[t]);
+    for (int r = threadIdx.x; r < nrows; r += blockDim.x) {
+      const int tr = r / 3, a = r % 3, cp = selfcol[t] / 3 + tr;
+      const dvec2* row = sym + (int64_t)tr * 3 * ncp;
+      out[(int64_t)d.perm[row0 + tr] * 3 + a] = a == 0 ? row[cp].x : a == 1 ? row[ncp + cp].y : row[2 * ncp + cp].y;
+    }
+    return;
+  }
   const double* blk = d.near_val + d.near_off[t];
   for (int r = threadIdx.x; r < nrows; r += blockDim.x) {
     const int panel = row0 + r / dof;
@@ -827,13 +827,6 @@ hipError_t launch_near_matfree(const DevicePlan& d, hipStream_t s) {
 hipError_t launch_gather_x(const DevicePlan& d, const double* x, hipStream_t s) {
   const int bs = 256;
   hipLaunchKernelGGL(gather_x_kernel, dim3((unsigned)((d.n * d.dof + bs - 1) / bs)), dim3(bs), 0, s, d.perm, x, d.xt, d.n, d.dof);
-  return hipGetLastError();
-}
-
-hipError_t launch_near_sym_pack(const DevicePlan& d, hipStream_t s) {
-  const int nb = d.leaf_end - d.leaf_begin;
-  if (nb <= 0 || !d.near_sym) return hipSuccess;
-  hipLaunchKernelGGL(near_sym_pack_kernel, dim3(nb < 256 * 8 ? nb : 256 * 8), dim3(256), 0, s, d);
   return hipGetLastError();
 }
 

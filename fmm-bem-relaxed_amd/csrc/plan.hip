@@ -319,13 +319,12 @@ int fmmbem_plan::to_device() {
     }
     TRY(upload(recs, &d.near_recs));
   }
-  if (opts.sparse_local) TRY(alloc((size_t)total, &d.near_val, false));   // matrix-free mode keeps no matrix
+  const bool stokes_sym = dof == 3 && opts.sparse_local && !(std::getenv("FMMBEM_STOKES_SYM") && std::atoi(std::getenv("FMMBEM_STOKES_SYM")) == 0);
+  if (opts.sparse_local && !stokes_sym) TRY(alloc((size_t)total, &d.near_val, false));   // matrix-free mode keeps no matrix
   else { d.near_val = nullptr; near_bytes = 0; }
   {
-    // Stokes: the symmetric 6-value form of the same blocks, which is what the SpMV streams (FMMBEM_STOKES_SYM=0: the
-    // 9-value rows).  The assembled matrix stays for the introspection calls and the diagonal.
-    const char* e = std::getenv("FMMBEM_STOKES_SYM");
-    if (dof == 3 && opts.sparse_local && !(e && std::atoi(e) == 0)) {
+    // Stokes: the near blocks in their symmetric 6-value form, the only copy (FMMBEM_STOKES_SYM=0: the 9-value rows instead)
+    if (stokes_sym) {
       std::vector<int64_t> sym_off(nl, 0);
       int64_t sym_total = 0;
       constexpr int64_t kItemBytes = 128 << 10;
@@ -538,7 +537,7 @@ int fmmbem_plan::to_device() {
   // near-field assembly on the device
   const double t0 = now_ms();
   if (opts.sparse_local) {
-    if (opts.kernel == FMMBEM_KERNEL_STOKES_BEM) { HIP_TRY(launch_near_assemble_stokes(d, own_stream)); HIP_TRY(launch_near_sym_pack(d, own_stream)); }
+    if (opts.kernel == FMMBEM_KERNEL_STOKES_BEM) HIP_TRY(launch_near_assemble_stokes(d, own_stream));
     else HIP_TRY(launch_near_assemble(d, own_stream));
     HIP_TRY(hipStreamSynchronize(own_stream));
   }
@@ -907,6 +906,22 @@ int fmmbem_plan_get_near_row(const fmmbem_plan* plan, int64_t row, uint32_t* col
     for (int l = h.leaf_begin; l < leaf; ++l) {
       const int b = h.leaf_box[l];
       off += (int64_t)dof * (h.box_body_end[b] - h.box_body_begin[b]) * ((dof * h.near_ncols[l] + 1) & ~1);
+    }
+    if (plan->d.near_sym) {                            // Stokes, symmetric blocks: expand row `comp` of the panel row's 3x3 blocks
+      const int ncp = h.near_ncols[leaf];
+      int64_t soff = 0;
+      for (int l = h.leaf_begin; l < leaf; ++l) {
+        const int b = h.leaf_box[l];
+        soff += (int64_t)6 * (h.box_body_end[b] - h.box_body_begin[b]) * h.near_ncols[l];
+      }
+      std::vector<double> six((size_t)6 * ncp);
+      HIP_TRY(hipMemcpy(six.data(), plan->d.near_sym + soff + (prow - h.box_body_begin[tb]) * 6 * ncp, sizeof(double) * six.size(), hipMemcpyDeviceToHost));
+      const double *p0 = six.data(), *p1 = p0 + 2 * ncp, *p2 = p1 + 2 * ncp;      // (xx,xy) (xz,yy) (yz,zz) per source panel
+      for (int c = 0; c < ncp; ++c) {
+        const double m[3][3] = {{p0[2 * c], p0[2 * c + 1], p1[2 * c]}, {p0[2 * c + 1], p1[2 * c + 1], p2[2 * c]}, {p1[2 * c], p2[2 * c], p2[2 * c + 1]}};
+        for (int b = 0; b < 3; ++b) vals[3 * c + b] = m[comp][b];
+      }
+      return FMMBEM_OK;
     }
     const int stride = (ncols + 1) & ~1;
     const int64_t r = (prow - h.box_body_begin[tb]) * dof + comp;

@@ -112,3 +112,22 @@ def test_gpu_stokes_sphere_drag_solve(fb):
     drag_error = abs(6 * np.pi * mu - fx) / (6 * np.pi * mu)
     assert drag_error < 2e-2 and abs(fy) < 1e-6 * abs(fx) + 1e-12 and abs(fz) < 1e-6 * abs(fx) + 1e-12
     assert np.sqrt(((t[:, 0] - 1.5 * mu) ** 2).mean()) / (1.5 * mu) < 0.1               # traction 1.5 mu U / R pointwise
+
+
+@pytest.mark.gpu
+def test_gpu_stokes_diagonal_and_rows_from_symmetric_blocks(fb, stokes5):
+    """The Stokes near blocks are held in their symmetric 6-value form only: the introspection row and the diagonal
+    (Preconditioners::Diagonal, examples/BEM/Preconditioner.hpp:19-42) are expanded from it."""
+    v, o = stokes5
+    K = fb.StokesSphericalBEM(8, 4, 1e-3)
+    K.set_Kfine(19)
+    pl = fb.FMM_plan(K, v)
+    diag = pl.diagonal().reshape(o.n, 3)
+    perm = pl.perm()
+    rp, col, val = o.near_csr()
+    for row in (0, 17, o.n - 1):
+        k = rp[row] + int(np.nonzero(col[rp[row]:rp[row + 1]] == row)[0][0])        # the self block of tree row `row`
+        for a in range(3):
+            assert abs(diag[perm[row], a] - val[k, a, a]) <= 1e-13 * abs(val[k, a, a])
+            cols, vals = pl.near_row(3 * row + a)
+            assert np.max(np.abs(vals - val[rp[row]:rp[row + 1], a, :].reshape(-1))) <= 1e-13 * np.abs(val).max()
