@@ -171,7 +171,7 @@ def main():
     p2p_gbs = p2p_bytes / (near_ms * 1e-3) / 1e9 if near_ms > 0 else 0.0
     traffic = None
     try:                                                     # PMC traffic comes from a separate rocprofv3 --pmc pass
-        prof = json.load(open(os.path.join(ROOT, "profiles", "pmc_near_spmv.json")))
+        prof = json.load(open(os.path.join(ROOT, "profiles", "pmc_near_spmv_stokes.json" if stokes else "pmc_near_spmv.json")))
         if prof.get("n_panels") == n and prof.get("n_gpus") == world:
             traffic = prof.get("hbm_bytes_per_launch")
     except Exception:

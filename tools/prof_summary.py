@@ -16,7 +16,7 @@ import sys
 
 
 def short(name):
-    name = name.replace("fmmbem::(anonymous namespace)::", "").replace("void ", "")
+    name = name.replace("fmmbem::(anonymous namespace)::", "").replace("void ", "").replace("fmmbem::", "")
     return name.split("(")[0]
 
 
