@@ -110,6 +110,11 @@ struct DevicePlan {
   const int *m2l_lane;                                // [p-1][192] lane -> output map (m2l_layout.hpp)
   const int *m2l_scat;                                // per p: table entry -> its 4 LDS places (m2l_layout.hpp)
   int m2l_scat_off[16];                               // offset of order p's scatter map in m2l_scat
+  // P2M as a precomputed operator: the multipole of a leaf is linear in the charges, M = sum_panels x_i * T_i with the
+  // panel's own moments T_i = sum_q w_q A_i Ynm(q - c_leaf) (G or, for NORMAL_DERIV panels, gradient moments) independent
+  // of x.  [panel (tree order)][ntab][s_max] complex, ntab = 1 (Laplace) or 4 (Stokes: moments of 1, x_q, y_q, z_q);
+  // built once at p_max (kernels_far.hip p2m_table); the coefficients of order p are a prefix of every record.
+  const double2* p2m_tab = nullptr;
   // scratch
   double *xt, *yt;                                    // tree-order x and near result
 };
@@ -122,6 +127,7 @@ hipError_t launch_near_diag(const DevicePlan& d, const int* selfcol, double* out
 hipError_t launch_near_matfree(const DevicePlan& d, hipStream_t s);
 hipError_t launch_scatter_y(const DevicePlan& d, double* y, hipStream_t s);
 hipError_t launch_p2m(const DevicePlan& d, int p, hipStream_t s);
+hipError_t launch_p2m_table(const DevicePlan& d, double2* tab, hipStream_t s);     // one-off: fills DevicePlan::p2m_tab's storage
 hipError_t launch_m2m_level(const DevicePlan& d, const ShiftOpDev& op, int p, int first, int count, hipStream_t s);
 // multipoles of the boxes a shard owns -> send buffer [idx][active slot][S(p)]; all shards' buffers -> M (own slice skipped)
 hipError_t launch_xch_pack(const DevicePlan& d, int p, double2* send, hipStream_t s);

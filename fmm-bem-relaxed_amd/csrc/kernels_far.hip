@@ -234,6 +234,141 @@ __global__ __launch_bounds__(kP2MWaves * kWave) void p2m_kernel(DevicePlan d, co
 }
 
 // ---------------------------------------------------------------------------------------------
+// P2M as a stored operator (DevicePlan::p2m_tab).  p2m_table (once per plan): thread = panel of a source leaf; for each of
+// its quadrature points the recurrences of p2m_kernel above, the weighted harmonic added to the panel's own record.
+// p2m_apply (every matvec): wavefront = leaf, lane = coefficient, a loop over the leaf's panels -- coalesced reads of
+// 16 S(p) bytes per panel, two FMAs per coefficient; no recurrences, no LDS, no cross-lane reduction.
+// ---------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(kWave) void p2m_table_kernel(DevicePlan d, double2* __restrict__ tab) {
+  const int P = d.p_max, SM = d.s_max;
+  const ConstD4* steptab = reinterpret_cast<const ConstD4*>(reinterpret_cast<uintptr_t>(d.tabStep + (size_t)(P - 1) * (kSmax + 1) * 4));
+  const int64_t N = d.n;
+  const int nq = d.nq;
+  for (int li = blockIdx.x; li < d.n_p2m; li += gridDim.x) {
+    const int leaf = d.p2m_leaf[li], box = d.leaf_box[leaf];
+    const int row0 = d.leaf_row0[leaf], nrows = d.leaf_nrows[leaf];
+    const double c0 = d.box_center[3 * box], c1 = d.box_center[3 * box + 1], c2 = d.box_center[3 * box + 2];
+    for (int r = threadIdx.x; r < nrows; r += blockDim.x) {
+      const int64_t i = row0 + r;
+      double2* out = tab + (size_t)i * NT * SM;
+      const bool deriv = NT == 1 && d.bc[i] != 0;      // Laplace NORMAL_DERIV panel: (n . grad)(rho^n Ynm) moments (LaplaceSphericalBEM.hpp:331-343)
+      const double n0 = d.nx[i], n1 = d.ny[i], n2 = d.nz[i];
+      for (int q = 0; q < nq; ++q) {
+        const double qx = d.quad[(q * 3 + 0) * N + i], qy = d.quad[(q * 3 + 1) * N + i], qz = d.quad[(q * 3 + 2) * N + i];
+        const double aw = d.area[i] * d.qw[q];
+        const Sph s = cart2sph(qx - c0, qy - c1, qz - c2);
+        double pn = 1, rhom = 1, er = 1, ei = 0, fact = 1;
+        int step = 0;
+#pragma nounroll
+        for (int m = 0; m < P; ++m) {
+          double p = pn, p1 = p, rhon = rhom;
+#pragma nounroll
+          for (int n = m; n < P; ++n, ++step) {
+            const double pref = steptab[step].x;
+            const double mag = rhon * p * pref;
+            const double yr = mag * er, yi = -mag * ei;                  // Ynm at (rho, alpha, -beta)
+            const double pcur = p;
+            const double pnext = steptab[step].y * s.ca * pcur - steptab[step].z * p1;
+            double vr = yr, vi = yi;
+            if (deriv) {
+              double tmag;
+              if (n == m) tmag = rhon * (pnext - (m + 1) * s.ca * pcur) / s.sa * pref;
+              else tmag = rhon * ((n - m + 1) * pnext - (n + 1) * s.ca * pcur) / s.sa * pref;
+              const double tr = tmag * er, ti = -tmag * ei;
+              const double rho = s.rho, sa = s.sa, ca = s.ca, cb = s.cb, sb = s.sb;
+              const double brr = (double)n / rho * yr, bri = (double)n / rho * yi;
+              const double ber = (double)m * yi, bei = -(double)m * yr;
+              const double gxr = sa * cb * brr + ca * cb / rho * tr - sb / rho / sa * ber;
+              const double gxi = sa * cb * bri + ca * cb / rho * ti - sb / rho / sa * bei;
+              const double gyr = sa * sb * brr + ca * sb / rho * tr + cb / rho / sa * ber;
+              const double gyi = sa * sb * bri + ca * sb / rho * ti + cb / rho / sa * bei;
+              const double gzr = ca * brr - sa / rho * tr;
+              const double gzi = ca * bri - sa / rho * ti;
+              vr = n0 * gxr + n1 * gyr + n2 * gzr;
+              vi = n0 * gxi + n1 * gyi + n2 * gzi;
+            }
+            const int idx = n * (n + 1) / 2 + m;
+            const double wt[4] = {aw, aw * qx, aw * qy, aw * qz};      // Stokes: moments of 1 and of the ABSOLUTE point (StokesSphericalBEM.hpp:417-431)
+#pragma unroll
+            for (int e = 0; e < NT; ++e) {
+              double2 acc = q ? out[(size_t)e * SM + idx] : double2{0, 0};
+              acc.x += wt[e] * vr; acc.y += wt[e] * vi;
+              out[(size_t)e * SM + idx] = acc;
+            }
+            p1 = pcur; p = pnext;
+            rhon *= s.rho;
+          }
+          pn = -pn * fact * s.sa;
+          rhom *= s.rho;
+          const double nr = er * s.cb - ei * s.sb, ni = er * s.sb + ei * s.cb;
+          er = nr; ei = ni;
+          fact += 2;
+        }
+      }
+    }
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(4 * kWave) void p2m_apply_kernel(DevicePlan d, const int P) {
+  const int S = P * (P + 1) / 2, SM = d.s_max;
+  const int lane = threadIdx.x & (kWave - 1);
+  const double2* __restrict__ tab = d.p2m_tab;
+  for (int li = blockIdx.x * 4 + threadIdx.x / kWave; li < d.n_p2m; li += gridDim.x * 4) {
+    const int leaf = d.p2m_leaf[li], box = d.leaf_box[leaf];
+    const int row0 = d.leaf_row0[leaf], nrows = d.leaf_nrows[leaf];
+    for (int idx = lane; idx < S; idx += kWave) {
+      if (NT == 1) {
+        double2 m0 = {0, 0}, m1 = {0, 0};              // G moments (POTENTIAL panels) / dG/dn moments (NORMAL_DERIV panels)
+        int r = 0;
+        constexpr int U = 4;                           // panels' records in flight (8: 0.231 against 0.214 ms at p = 10), added in panel order
+        for (; r + U <= nrows; r += U) {
+          const int64_t i = row0 + r;
+          double2 t[U];
+          double x[U];
+          bool dn[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) { t[u] = tab[(size_t)(i + u) * SM + idx]; x[u] = d.xt[i + u]; dn[u] = d.bc[i + u] != 0; }
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            if (dn[u]) { m1.x = fma(x[u], t[u].x, m1.x); m1.y = fma(x[u], t[u].y, m1.y); }
+            else { m0.x = fma(x[u], t[u].x, m0.x); m0.y = fma(x[u], t[u].y, m0.y); }
+          }
+        }
+        for (; r < nrows; ++r) {
+          const int64_t i = row0 + r;
+          const double2 t = tab[(size_t)i * SM + idx];
+          const double x = d.xt[i];
+          if (d.bc[i]) { m1.x = fma(x, t.x, m1.x); m1.y = fma(x, t.y, m1.y); }
+          else { m0.x = fma(x, t.x, m0.x); m0.y = fma(x, t.y, m0.y); }
+        }
+        for (int a = 0; a < d.n_act; ++a) {
+          const int slot = a == 0 ? d.act[0] : d.act[1];
+          d.M[((size_t)box * d.nslots + slot) * SM + idx] = slot ? m1 : m0;
+        }
+      } else {
+        double2 m[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+#pragma unroll 2
+        for (int r = 0; r < nrows; ++r) {
+          const int64_t i = row0 + r;
+          const double2* t = tab + (size_t)i * 4 * SM + idx;
+          const double f0 = d.xt[3 * i], f1 = d.xt[3 * i + 1], f2 = d.xt[3 * i + 2];
+          const double2 t0 = t[0], t1 = t[SM], t2 = t[2 * SM], t3 = t[3 * SM];
+          m[0].x = fma(f0, t0.x, m[0].x); m[0].y = fma(f0, t0.y, m[0].y);
+          m[1].x = fma(f1, t0.x, m[1].x); m[1].y = fma(f1, t0.y, m[1].y);
+          m[2].x = fma(f2, t0.x, m[2].x); m[2].y = fma(f2, t0.y, m[2].y);
+          m[3].x = fma(f0, t1.x, fma(f1, t2.x, fma(f2, t3.x, m[3].x)));
+          m[3].y = fma(f0, t1.y, fma(f1, t2.y, fma(f2, t3.y, m[3].y)));
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d.M[((size_t)box * d.nslots + e) * SM + idx] = m[e];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // M2M, one tree level per launch.  A workgroup = kShiftWaves wavefronts takes one parent box; wavefront w
 // translates child w (children are the <= 8 occupied octants) with the precomputed sparse operator
 // (shift_ops.hpp): lanes = output rows, ELL term lists read coalesced, the child's M and the class's
@@ -566,10 +701,24 @@ hipError_t upload_constants_once() {
 
 }  // namespace
 
+hipError_t launch_p2m_table(const DevicePlan& d, double2* tab, hipStream_t s) {
+  if (hipError_t e = upload_constants_once(); e != hipSuccess) return e;
+  if (d.n_p2m <= 0) return hipSuccess;
+  const dim3 g(d.n_p2m < 256 * 32 ? d.n_p2m : 256 * 32), b(kWave);
+  if (d.kernel == 1) hipLaunchKernelGGL((p2m_table_kernel<4>), g, b, 0, s, d, tab);
+  else hipLaunchKernelGGL((p2m_table_kernel<1>), g, b, 0, s, d, tab);
+  return hipGetLastError();
+}
+
 hipError_t launch_p2m(const DevicePlan& d, int p, hipStream_t s) {
   if (hipError_t e = upload_constants_once(); e != hipSuccess) return e;
   if (d.n_p2m <= 0) return hipSuccess;
   if (p < 1 || p > kPmaxDev) return hipErrorInvalidValue;
+  if (d.p2m_tab) {
+    const int nb = (d.n_p2m + 3) / 4;
+    hipLaunchKernelGGL((p2m_apply_kernel<1>), dim3(nb < 256 * 16 ? nb : 256 * 16), dim3(4 * kWave), 0, s, d, p);
+    return hipGetLastError();
+  }
   const int nblk = (d.n_p2m + kP2MWaves - 1) / kP2MWaves;
   const dim3 g(nblk < 256 * 8 ? nblk : 256 * 8), b(kP2MWaves * kWave);
   for (int a = 0; a < d.n_act; ++a) {
@@ -675,6 +824,11 @@ hipError_t launch_p2m_stokes(const DevicePlan& d, int p, hipStream_t s) {
   if (hipError_t e = upload_constants_once(); e != hipSuccess) return e;
   if (d.n_p2m <= 0) return hipSuccess;
   if (p < 1 || p > kPmaxDev) return hipErrorInvalidValue;
+  if (d.p2m_tab) {
+    const int nb = (d.n_p2m + 3) / 4;
+    hipLaunchKernelGGL((p2m_apply_kernel<4>), dim3(nb < 256 * 16 ? nb : 256 * 16), dim3(4 * kWave), 0, s, d, p);
+    return hipGetLastError();
+  }
   const int nblk = (d.n_p2m + kP2MWaves - 1) / kP2MWaves;
   const dim3 g(nblk < 256 * 8 ? nblk : 256 * 8), b(kP2MWaves * kWave);
   for (int e = 0; e < 4; ++e) hipLaunchKernelGGL((p2m_kernel<0>), g, b, 0, s, d, p, e + 1, e);

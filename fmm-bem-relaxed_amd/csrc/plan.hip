@@ -534,6 +534,22 @@ int fmmbem_plan::to_device() {
   HIP_TRY(hipDeviceSynchronize());
 
   mark("vectors");
+  // P2M as a stored operator: every panel's moments about its leaf centre, at p_max (FMMBEM_P2M_TABLE=0, or more than
+  // 16 GB of them: the recurrences are run every matvec instead)
+  {
+    const char* e = std::getenv("FMMBEM_P2M_TABLE");
+    const size_t ntab = opts.kernel == FMMBEM_KERNEL_STOKES_BEM ? 4 : 1;
+    const size_t count = (size_t)hp.n * ntab * d.s_max;
+    if (!(e && std::atoi(e) == 0) && hp.opt.evaluator == 0 && d.n_p2m > 0 && count * sizeof(double2) <= ((size_t)16 << 30)) {
+      double2* tab = nullptr;
+      TRY(alloc(count, &tab, true));
+      HIP_TRY(hipDeviceSynchronize());                 // the zero-fill ran on the NULL stream
+      HIP_TRY(launch_p2m_table(d, tab, own_stream));
+      HIP_TRY(hipStreamSynchronize(own_stream));
+      d.p2m_tab = tab;
+    }
+  }
+  mark("p2m table");
   // near-field assembly on the device
   const double t0 = now_ms();
   if (opts.sparse_local) {
