@@ -239,6 +239,8 @@ __global__ __launch_bounds__(kP2MWaves * kWave) void p2m_kernel(DevicePlan d, co
 // p2m_apply (every matvec): wavefront = leaf, lane = coefficient, a loop over the leaf's panels -- coalesced reads of
 // 16 S(p) bytes per panel, two FMAs per coefficient; no recurrences, no LDS, no cross-lane reduction.
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wave_lds_sync();     // below
+
 template <int NT>
 __global__ __launch_bounds__(kWave) void p2m_table_kernel(DevicePlan d, double2* __restrict__ tab) {
   const int P = d.p_max, SM = d.s_max;
@@ -315,9 +317,40 @@ __global__ __launch_bounds__(4 * kWave) void p2m_apply_kernel(DevicePlan d, cons
   const int S = P * (P + 1) / 2, SM = d.s_max;
   const int lane = threadIdx.x & (kWave - 1);
   const double2* __restrict__ tab = d.p2m_tab;
+  __shared__ double2 low_part[4][2 * kWave];
   for (int li = blockIdx.x * 4 + threadIdx.x / kWave; li < d.n_p2m; li += gridDim.x * 4) {
     const int leaf = d.p2m_leaf[li], box = d.leaf_box[leaf];
     const int row0 = d.leaf_row0[leaf], nrows = d.leaf_nrows[leaf];
+    if (NT == 1 && S <= kWave / 2) {
+      // low order (where the relaxed solver spends most iterations): S <= 32 coefficients would leave most lanes idle, so
+      // G = 64 / S groups of lanes take every G-th panel and the groups are added in order through the LDS
+      const int G = kWave / S, g = lane / S, idx = lane - g * S;
+      double2 m0 = {0, 0}, m1 = {0, 0};
+      if (g < G)
+        for (int r = g; r < nrows; r += G) {
+          const int64_t i = row0 + r;
+          const double2 t = tab[(size_t)i * SM + idx];
+          const double x = d.xt[i];
+          if (d.bc[i]) { m1.x = fma(x, t.x, m1.x); m1.y = fma(x, t.y, m1.y); }
+          else { m0.x = fma(x, t.x, m0.x); m0.y = fma(x, t.y, m0.y); }
+        }
+      double2* part = low_part[threadIdx.x / kWave];
+      wave_lds_sync();
+      part[lane] = m0; part[kWave + lane] = m1;
+      wave_lds_sync();
+      if (lane < S) {
+        double2 s0 = {0, 0}, s1 = {0, 0};
+        for (int q = 0; q < G; ++q) {
+          const double2 a = part[q * S + lane], b = part[kWave + q * S + lane];
+          s0.x += a.x; s0.y += a.y; s1.x += b.x; s1.y += b.y;
+        }
+        for (int a = 0; a < d.n_act; ++a) {
+          const int slot = a == 0 ? d.act[0] : d.act[1];
+          d.M[((size_t)box * d.nslots + slot) * SM + lane] = slot ? s1 : s0;
+        }
+      }
+      continue;
+    }
     for (int idx = lane; idx < S; idx += kWave) {
       if (NT == 1) {
         double2 m0 = {0, 0}, m1 = {0, 0};              // G moments (POTENTIAL panels) / dG/dn moments (NORMAL_DERIV panels)
