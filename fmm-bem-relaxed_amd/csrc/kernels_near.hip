@@ -846,7 +846,8 @@ hipError_t launch_near_spmv(const DevicePlan& d, hipStream_t s) {
   // start when the others finish (0.98 ms instead of 0.79 at N = 1M); occupancy 6 (80 VGPRs) and 2x2 loads at
   // occupancy 8 measure within 3 % of this.
   const dim3 g(std::min(d.near_nitems, 256 * kSpmvOcc)), b(kSpmvWaves * kWave);
-  static const bool pipe = !(getenv("FMMBEM_SPMV_PIPE") && atoi(getenv("FMMBEM_SPMV_PIPE")) == 0);
+  const char* pe = getenv("FMMBEM_SPMV_PIPE");                       // read per launch: tests switch it per plan
+  const bool pipe = !(pe && atoi(pe) == 0);
   if (d.dof == 1 && d.max_runs <= kSpmvWaves * kWave && pipe) {
     const size_t lds2 = 2 * (size_t)kSpmvPipeChunk * sizeof(double) + 4 * (size_t)d.max_runs * sizeof(int);
     hipLaunchKernelGGL((near_spmv_pipe_kernel<2, 4>), g, b, lds2, s, d);

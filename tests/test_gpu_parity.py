@@ -224,3 +224,23 @@ def test_matrix_free_near_field(fb, oracle_mod, bc_val):
     assert rel_l2(y, oracle_mod.Oracle(v, bc=bc).matvec(x, 10)) <= TOL_MATVEC
     dense = fb.FMM_plan(K, v, bc=bc).execute(x)
     assert rel_l2(y, dense) <= 1e-14
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"FMMBEM_P2M_TABLE": "0"}, {"FMMBEM_SPMV_PIPE": "0"}, {"FMMBEM_OVERLAP_NEAR": "2"}])
+def test_alternative_paths_match_oracle(fb, oracle_mod, monkeypatch, env):
+    """The switches that select the older / optional kernels (recurrence P2M instead of the stored moments, the plain
+    near_spmv kernel, the near field forked beside P2M/M2M) give the same operator."""
+    for k, val in env.items():
+        monkeypatch.setenv(k, val)
+    v = oracle_mod.unit_sphere(5)
+    rng = np.random.default_rng(3)
+    bc = (rng.random(len(v)) < 0.5).astype(np.uint8)
+    x = rng.standard_normal(len(v))
+    o = oracle_mod.Oracle(v, bc=bc)
+    K = fb.LaplaceSphericalBEM(10, 3)
+    pl = fb.FMM_plan(K, v, bc=bc)
+    for p in (10, 3):
+        K.set_p(p)
+        y, yo = pl.execute(x), o.matvec(x, p)
+        assert np.linalg.norm(y - yo) <= 1e-12 * np.linalg.norm(yo)

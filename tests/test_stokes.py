@@ -131,3 +131,17 @@ def test_gpu_stokes_diagonal_and_rows_from_symmetric_blocks(fb, stokes5):
             assert abs(diag[perm[row], a] - val[k, a, a]) <= 1e-13 * abs(val[k, a, a])
             cols, vals = pl.near_row(3 * row + a)
             assert np.max(np.abs(vals - val[rp[row]:rp[row + 1], a, :].reshape(-1))) <= 1e-13 * np.abs(val).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"FMMBEM_P2M_TABLE": "0"}, {"FMMBEM_STOKES_SYM": "0"}])
+def test_gpu_stokes_alternative_paths(fb, stokes5, monkeypatch, env):
+    """Recurrence P2M instead of the stored moments; the 9-value near rows instead of the symmetric blocks."""
+    for k, val in env.items():
+        monkeypatch.setenv(k, val)
+    v, o = stokes5
+    K = fb.StokesSphericalBEM(8, 4, 1e-3)
+    K.set_Kfine(19)
+    pl = fb.FMM_plan(K, v)
+    x = drand48(3 * o.n, seed=5).reshape(o.n, 3)
+    assert rel_l2(pl.execute(x), o.matvec(x, 8)) <= 1e-12
