@@ -24,6 +24,8 @@
 // in registers over the whole source list and written once -- no atomics, fixed summation order.
 #include "device_plan.hpp"
 
+#include <mutex>
+
 namespace fmmbem {
 
 namespace {
@@ -716,8 +718,17 @@ __global__ __launch_bounds__(kL2PWaves * kWave) void l2p_stokes_kernel(DevicePla
   }
 }
 
+// __constant__ symbols and function attributes belong to a device: once per device the process uses (one process per GPU is
+// the deployment model, but the C ABI takes a device ordinal and a process may create plans on several)
 hipError_t upload_constants_once() {
-  static hipError_t st = [] {
+  static std::mutex mu;
+  static bool done[64] = {};
+  int dev = 0;
+  if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+  if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+  std::lock_guard<std::mutex> lock(mu);
+  if (done[dev]) return hipSuccess;
+  const hipError_t st = [] {
     const JK t = make_jk();
     hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(kJK), &t, sizeof(t));
     double recip[40];
@@ -729,6 +740,7 @@ hipError_t upload_constants_once() {
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(l2l_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     return e;
   }();
+  if (st == hipSuccess) done[dev] = true;
   return st;
 }
 
