@@ -280,11 +280,11 @@ int fmmbem_plan::to_device() {
   TRY(upload(run_ptr, &d.near_ptr)); TRY(upload(run_row0, &d.near_run_row0)); TRY(upload(run_off, &d.near_run_off));
   TRY(upload(hp.near_ncols, &d.near_ncols)); TRY(upload(near_stride, &d.near_stride)); TRY(upload(near_off, &d.near_off));
   {
-    // SpMV work items: a leaf's row block, cut into row ranges of <= kItemBytes so that no workgroup is left
+    // SpMV work items: a leaf's row block, cut into row ranges of <= kItemBytes (256 KB) so that no workgroup is left
     // streaming one coarse leaf alone (two-sphere N=1M: one leaf is 58 rows x 16 031 columns = 7.4 MB against
     // a mean of 75 KB), dealt round-robin to the persistent workgroups largest first.  Ranges shorter than 8
     // rows are processed with the columns split over the wavefronts instead of the rows.
-    constexpr int64_t kItemBytes = 128 << 10;
+    constexpr int64_t kItemBytes = 256 << 10;          // two-sphere N = 1M (near ms): 64 KB 0.81, 128 0.72, 192 0.74, 256 0.705, 320 0.735, 384 0.72, 512 0.72
     struct Item { int leaf, r0, nr; int64_t bytes; };
     std::vector<Item> items;
     for (int l = hp.leaf_begin; l < hp.leaf_end; ++l) {
@@ -327,7 +327,7 @@ int fmmbem_plan::to_device() {
     if (stokes_sym) {
       std::vector<int64_t> sym_off(nl, 0);
       int64_t sym_total = 0;
-      constexpr int64_t kItemBytes = 128 << 10;
+      constexpr int64_t kItemBytes = 512 << 10;        // red blood cell N = 524 288 (near ms): 128 KB 2.06-2.08, 256 KB 2.06-2.09, 512 KB 2.01-2.03
       struct Item { int leaf, r0, nr; int64_t bytes; };
       std::vector<Item> items;
       for (int l = hp.leaf_begin; l < hp.leaf_end; ++l) {
