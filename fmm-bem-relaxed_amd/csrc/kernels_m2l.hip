@@ -34,7 +34,12 @@ constexpr int kWave = 64;
 struct C2 { double x, y; };
 typedef __attribute__((address_space(4))) C2 ConstC2;      // complex value in the constant address space
 typedef __attribute__((address_space(4))) DevicePlan ConstPlan;
-constexpr int kM2LTargets = 4;         // independent single-wavefront targets per workgroup when TEAM == 1
+#ifndef FMMBEM_M2L_TARGETS
+#define FMMBEM_M2L_TARGETS 1
+#endif
+// independent single-wavefront targets per workgroup when TEAM == 1.  Same box, N = 1M, M2L ms at p = 8 / 6 / 3 (small kernel):
+// 1: 1.23 / 0.76 / 0.121   2: 1.27 / 0.76 / 0.126   4: 1.31 / 0.80 / 0.128   8: 1.67 / 0.88 / 0.135
+constexpr int kM2LTargets = FMMBEM_M2L_TARGETS;
 #ifndef FMMBEM_M2L_XCD
 #define FMMBEM_M2L_XCD 1
 #endif
