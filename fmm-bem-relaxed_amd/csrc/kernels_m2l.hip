@@ -45,7 +45,7 @@ constexpr int kM2LTargets = FMMBEM_M2L_TARGETS;
 #endif
 constexpr bool kM2LXcdRemap = FMMBEM_M2L_XCD != 0;
 #ifndef FMMBEM_M2L_XCD_CHUNK
-#define FMMBEM_M2L_XCD_CHUNK 16
+#define FMMBEM_M2L_XCD_CHUNK 64
 #endif
 constexpr int kM2LXcdChunk = FMMBEM_M2L_XCD_CHUNK;
 
