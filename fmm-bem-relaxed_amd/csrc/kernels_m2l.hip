@@ -429,8 +429,13 @@ hipError_t launch_m2l(const DevicePlan& d, const DevicePlan* d_dev, int p, hipSt
   // wavefronts sharing a target's m sets, NS (N = 1M, ms with NS = 1 / 2 / 3 / 4): p = 6: 0.85 / 0.90 / 1.25 / 1.34;
   // p = 8: 1.46 / 1.50 / 1.54 / 1.91; p = 10: 2.57 / 2.03 / 2.45 / 2.17; p = 12 (two wavefronts of outputs): 4.80 / 5.01 / 5.87 / 5.59
   // with several slots per pass the work per source grows and two wavefronts pay off from p = 7 (Stokes p = 8: 2.05 / 1.84)
-  const bool multi = d.n_act % 2 == 0;
-  FMMBEM_DISPATCH_P(p, if (PP <= 4) { LAUNCH_SMALL(); } else if (PP == 9 || PP == 10 || (multi && PP >= 7 && PP <= 10)) { LAUNCH(2); } else { LAUNCH(1); })
+  // re-measured on one box with one target per workgroup and the XCD rounds (ms, NS = 1 / 2): p = 5 0.58 / 0.77, 6 0.75 / 0.83,
+  // 7 0.94 / 1.02, 8 1.21 / 1.35, 9 1.64 / 1.80, 10 2.18 / 1.93, 11 4.00 / 4.01, 12 3.94 / 4.11; Stokes (four slots per pass):
+  // p = 6 1.12 / 1.15, 7 1.23 / 1.36, 8 1.71 / 1.70, 9 2.02 / 2.32, 10 1.69 / 1.68  =>  two wavefronts at p = 10 only
+#ifndef FMMBEM_M2L_NS
+#define FMMBEM_M2L_NS 0                                // tuning: 1 or 2 forces the wavefronts per target for p >= 5
+#endif
+  FMMBEM_DISPATCH_P(p, if (PP <= 4) { LAUNCH_SMALL(); } else if (FMMBEM_M2L_NS == 2 || (FMMBEM_M2L_NS == 0 && PP == 10)) { LAUNCH(2); } else { LAUNCH(1); })
 #undef LAUNCH_SMALL
 #undef LAUNCH
 #undef LAUNCH_Q
