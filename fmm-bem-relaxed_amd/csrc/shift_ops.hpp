@@ -76,7 +76,10 @@ inline ShiftOps build_shift_ops(int P, const std::vector<double>& A, double eps)
   auto deal = [&](const std::vector<std::vector<Term>>& rows, int p, bool prefix) {
     VOp v;
     v.S = p * (p + 1) / 2;
-    v.T = p <= 12 ? 8 : 16;                            // keeps the per-wavefront partial-sum array small at high order
+    // terms per piece, same box, N = 1M, M2M + L2L ms with T = 2 / 4 / 8 / 16: p = 1 0.157 / 0.154 / 0.191, p = 3 - / 0.167 / 0.195 / 0.244,
+    // p = 5 0.241 / 0.214 / 0.229, p = 6 - / 0.220 / 0.237 / 0.277, p = 7 0.373 / 0.286 / 0.249, p = 10 - / 0.468 / 0.427 / 0.440;
+    // 16 above p = 12 keeps the per-wavefront partial-sum array small
+    v.T = p <= 6 ? 4 : p <= 12 ? 8 : 16;
     struct Piece { int row, begin, cnt, k; };
     std::vector<Piece> pieces;
     v.npiece.assign(v.S, 0);
