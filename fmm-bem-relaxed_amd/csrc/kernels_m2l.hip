@@ -91,8 +91,13 @@ __device__ inline double2 mul_i_pow(double2 a, int q) {              // a * i^q
 
 // NSLOT expansion slots (Stokes: the four harmonic potentials; Laplace with mixed BC: G and dG/dn) share one pass over
 // a target's sources: same class table, same LDS reads, same barriers -- only Mh and the accumulators differ.
+#ifndef FMMBEM_M2L_OCC4
+#define FMMBEM_M2L_OCC4 4                              // four slots per pass (Stokes): 129 VGPRs without the hint, one over four wavefronts per
+                                                       // SIMD; with it 128 and 12 B of scratch: 1.69 -> 1.52 ms at p = 8.  The same hint (5, 6) on the
+                                                       // single-slot kernels changes nothing
+#endif
 template <int P, int NS_, int NSLOT>
-__global__ __launch_bounds__((Shape<P, NS_>::THREADS)) void m2l_kernel(const DevicePlan* __restrict__ d_in) {
+__global__ __launch_bounds__((Shape<P, NS_>::THREADS), (NSLOT == 4 && P <= 10 ? FMMBEM_M2L_OCC4 : 1)) void m2l_kernel(const DevicePlan* __restrict__ d_in) {
   // The plan is read through a pointer: inside the source loop the pointer is made opaque once per iteration, so the
   // few fields the loop needs are re-read by scalar loads (scalar cache hits) instead of being kept alive in SGPRs --
   // the FMA region wants nearly all of them for Mh, and what else is live across it gets spilled to VGPR lanes and
