@@ -680,9 +680,16 @@ __global__ __launch_bounds__(kSpmvWaves * kWave, kSpmvOcc) void near_spmv_pipe_k
 // near_spmv_sym3: the scheme of near_spmv_kernel with a PANEL row per wavefront step -- per source panel three 16-byte
 // vectors and the three x components from LDS feed nine FMAs into (y_x, y_y, y_z).
 // ---------------------------------------------------------------------------------------------
-constexpr int kSymChunk = 1024;                       // source panels of x staged at a time (3 x 8 KiB)
+#ifndef FMMBEM_SYM_OCC
+#define FMMBEM_SYM_OCC 5
+#endif
+#ifndef FMMBEM_SYM_CHUNK
+#define FMMBEM_SYM_CHUNK 1024
+#endif
+constexpr int kSymOcc = FMMBEM_SYM_OCC;               // workgroups per CU
+constexpr int kSymChunk = FMMBEM_SYM_CHUNK;           // source panels of x staged at a time (3 x 8 KiB)
 template <int kRows, int kVecs>
-__global__ __launch_bounds__(kSpmvWaves * kWave, kSpmvOcc) void near_spmv_sym3_kernel(DevicePlan d) {
+__global__ __launch_bounds__(kSpmvWaves * kWave, kSymOcc) void near_spmv_sym3_kernel(DevicePlan d) {
   extern __shared__ double xs[];                      // [3][kSymChunk] doubles, then the run descriptors
   __shared__ double part[kSpmvWaves][kColRows][3];
   int* run_row0 = reinterpret_cast<int*>(xs + 3 * kSymChunk);
@@ -836,7 +843,7 @@ hipError_t launch_near_spmv(const DevicePlan& d, hipStream_t s) {
     const size_t lds3 = 3 * (size_t)kSymChunk * sizeof(double) + 2 * (size_t)d.max_runs * sizeof(int);
     // panel rows x source-panel vectors in flight per wavefront, red blood cell N = 524 288 (ms): 1x3 2.10, 1x2 2.11, 1x1 2.15,
     // 1x4 2.3-2.6, 2x2 3.39, 1x5 3.36, 4x1 4.14; 2x4, 4x2, 1x6 spill (7-9); the 9-value rows: 3.32
-    hipLaunchKernelGGL((near_spmv_sym3_kernel<1, 3>), dim3(std::min(d.sym_nitems, 256 * kSpmvOcc)), dim3(kSpmvWaves * kWave), lds3, s, d);
+    hipLaunchKernelGGL((near_spmv_sym3_kernel<1, 3>), dim3(std::min(d.sym_nitems, 256 * kSymOcc)), dim3(kSpmvWaves * kWave), lds3, s, d);
     return hipGetLastError();
   }
   const size_t lds = (size_t)kSpmvChunk * sizeof(double) + 2 * (size_t)d.max_runs * sizeof(int);
