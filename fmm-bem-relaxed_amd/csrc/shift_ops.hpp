@@ -79,7 +79,9 @@ inline ShiftOps build_shift_ops(int P, const std::vector<double>& A, double eps)
     // terms per piece, same box, N = 1M, M2M + L2L ms with T = 2 / 4 / 8 / 16: p = 1 0.157 / 0.154 / 0.191, p = 3 - / 0.167 / 0.195 / 0.244,
     // p = 5 0.241 / 0.214 / 0.229, p = 6 - / 0.220 / 0.237 / 0.277, p = 7 0.373 / 0.286 / 0.249, p = 10 - / 0.468 / 0.427 / 0.440;
     // 16 above p = 12 keeps the per-wavefront partial-sum array small
-    v.T = p <= 6 ? 4 : p <= 12 ? 8 : 16;
+    // 12 terms at the middle orders: M2M better at p = 8, 10 (0.147 / 0.211 against 0.166 / 0.220) but worse at p = 7, 9 (0.146 / 0.200
+    // against 0.13 / 0.18); L2L worse at p = 8, 10, better at p = 12 (0.298 against 0.330, the one case taken; prefix = the L2L operator)
+    v.T = p <= 6 ? 4 : p > 12 ? 16 : (prefix && p == 12) ? 12 : 8;
     struct Piece { int row, begin, cnt, k; };
     std::vector<Piece> pieces;
     v.npiece.assign(v.S, 0);
