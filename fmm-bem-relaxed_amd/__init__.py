@@ -4,7 +4,7 @@ Only the hot path lives here: csrc/ (hand-written HIP for gfx950 + the C ABI of 
 and this thin host-side mirror of the reference's operator interface.
 """
 from ._capi import FmmBemError, LIB_PATH, Options, PMAX, SYMBOLS, lib  # noqa: F401
-from .plan import (FMM_plan, FMMOptions, LaplaceSphericalBEM, StokesSphericalBEM, quadrature, read_msh,  # noqa: F401
+from .plan import (FMM_plan, FMMOptions, LaplaceSphericalBEM, StokesSphericalBEM, kernel_entries, quadrature, read_msh,  # noqa: F401
                    read_vert_face, red_blood_cell, red_blood_cells, unit_sphere, write_vert_face)
 
 

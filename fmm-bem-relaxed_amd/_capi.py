@@ -57,7 +57,7 @@ SYMBOLS = (
     "fmmbem_plan_execute_device", "fmmbem_plan_exchange_doubles", "fmmbem_plan_upward_device",
     "fmmbem_plan_downward_device", "fmmbem_plan_near_split_device", "fmmbem_plan_near_device", "fmmbem_plan_set_timing", "fmmbem_plan_stats",
     "fmmbem_plan_get_perm", "fmmbem_plan_get_boxes", "fmmbem_plan_get_pairs", "fmmbem_plan_get_near_row",
-    "fmmbem_plan_get_expansions", "fmmbem_plan_get_diagonal", "fmmbem_mesh_unit_sphere", "fmmbem_mesh_red_blood_cell", "fmmbem_mesh_red_blood_cells", "fmmbem_mesh_read_msh",
+    "fmmbem_plan_get_expansions", "fmmbem_plan_get_diagonal", "fmmbem_kernel_entries", "fmmbem_mesh_unit_sphere", "fmmbem_mesh_red_blood_cell", "fmmbem_mesh_red_blood_cells", "fmmbem_mesh_read_msh",
     "fmmbem_mesh_read_vert_face", "fmmbem_mesh_write_vert_face", "fmmbem_quadrature", "fmmbem_status_string", "fmmbem_last_error",
     "fmmbem_version",
 )
@@ -100,6 +100,7 @@ def lib():
     L.fmmbem_plan_get_near_row.argtypes = [vp, C.c_int64, vp, vp, i64p]
     L.fmmbem_plan_get_expansions.argtypes = [vp, i32, i32, vp]
     L.fmmbem_plan_get_diagonal.argtypes = [vp, vp]
+    L.fmmbem_kernel_entries.argtypes = [C.POINTER(Options), C.c_size_t, vp, vp, vp, vp]
     L.fmmbem_mesh_unit_sphere.argtypes = [i32, vp, C.POINTER(C.c_size_t)]
     L.fmmbem_mesh_red_blood_cell.argtypes = [i32, vp, C.POINTER(C.c_size_t)]
     L.fmmbem_mesh_red_blood_cells.argtypes = [i32, i32, vp, vp, C.POINTER(C.c_size_t)]

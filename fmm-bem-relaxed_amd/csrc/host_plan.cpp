@@ -138,6 +138,33 @@ inline int level_of_key(uint32_t key) { return (31 - __builtin_clz(key)) / 3; }
 struct Coded { uint32_t code, idx; };
 }  // namespace
 
+void alloc_panels(PanelSoA& P, int64_t n, int nq) {
+  P.cx.resize(n); P.cy.resize(n); P.cz.resize(n);
+  P.nx.resize(n); P.ny.resize(n); P.nz.resize(n);
+  P.area.resize(n); P.bc.resize(n);
+  P.quad.resize((size_t)nq * 3 * n);
+  P.vert.resize((size_t)9 * n);
+}
+
+// Panel(p0, p1, p2) of kernel/LaplaceSphericalBEM.hpp:64-97: centroid, normal (p2-p0) x (p1-p0) / 2A, area, the rule's points
+void fill_panel(PanelSoA& P, int64_t n, int64_t i, const double* v, const QuadRule& rule, uint8_t flag) {
+  const double *p0 = v, *p1 = v + 3, *p2 = v + 6;
+  P.cx[i] = (p0[0] + p1[0] + p2[0]) / 3;
+  P.cy[i] = (p0[1] + p1[1] + p2[1]) / 3;
+  P.cz[i] = (p0[2] + p1[2] + p2[2]) / 3;
+  const double a0[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
+  const double a1[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
+  const double c[3] = {a0[1] * a1[2] - a0[2] * a1[1], -(a0[0] * a1[2] - a0[2] * a1[0]), a0[0] * a1[1] - a0[1] * a1[0]};
+  const double A = 0.5 * std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+  P.area[i] = A;
+  P.nx[i] = c[0] / 2 / A; P.ny[i] = c[1] / 2 / A; P.nz[i] = c[2] / 2 / A;
+  for (int q = 0; q < rule.n; ++q)
+    for (int k = 0; k < 3; ++k)
+      P.quad[((size_t)q * 3 + k) * n + i] = p0[k] * rule.pts[q][0] + p1[k] * rule.pts[q][1] + p2[k] * rule.pts[q][2];
+  for (int k = 0; k < 9; ++k) P.vert[(size_t)k * n + i] = v[k];
+  P.bc[i] = flag;
+}
+
 std::string HostPlan::build(const HostOptions& o, int64_t n_panels, const double* vertices, const uint8_t* bc) {
   // FMMBEM_BUILD_TRACE=1: phase times of this function on stderr (tuning aid)
   const bool trace = std::getenv("FMMBEM_BUILD_TRACE") != nullptr;
@@ -480,36 +507,17 @@ std::string HostPlan::build(const HostOptions& o, int64_t n_panels, const double
   // ---- panels in tree order, SoA (LaplaceSphericalBEM.hpp:64-97) ----
   PanelSoA& P = panels;
   const int nq = rule.n;
-  P.cx.resize(n); P.cy.resize(n); P.cz.resize(n);
-  P.nx.resize(n); P.ny.resize(n); P.nz.resize(n);
-  P.area.resize(n); P.bc.resize(n);
-  P.quad.resize((size_t)nq * 3 * n);
-  P.vert.resize((size_t)9 * n);
+  alloc_panels(P, n, nq);
   has_bc[0] = has_bc[1] = false;
   // independent per panel: cut into ranges for a few host threads (half of this function's time at N = 1M when serial)
   const int nthreads = n < (1 << 16) ? 1 : (int)std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
   std::vector<std::array<uint8_t, 2>> seen_bc(nthreads, std::array<uint8_t, 2>{0, 0});
   auto fill_range = [&](int t, int64_t i0, int64_t i1) {
-  for (int64_t i = i0; i < i1; ++i) {
-    const double* v = vertices + 9 * (size_t)perm[i];
-    const double *p0 = v, *p1 = v + 3, *p2 = v + 6;
-    P.cx[i] = (p0[0] + p1[0] + p2[0]) / 3;
-    P.cy[i] = (p0[1] + p1[1] + p2[1]) / 3;
-    P.cz[i] = (p0[2] + p1[2] + p2[2]) / 3;
-    const double a0[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
-    const double a1[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
-    const double c[3] = {a0[1] * a1[2] - a0[2] * a1[1], -(a0[0] * a1[2] - a0[2] * a1[0]), a0[0] * a1[1] - a0[1] * a1[0]};
-    const double A = 0.5 * std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
-    P.area[i] = A;
-    P.nx[i] = c[0] / 2 / A; P.ny[i] = c[1] / 2 / A; P.nz[i] = c[2] / 2 / A;
-    for (int q = 0; q < nq; ++q)
-      for (int k = 0; k < 3; ++k)
-        P.quad[((size_t)q * 3 + k) * n + i] = p0[k] * rule.pts[q][0] + p1[k] * rule.pts[q][1] + p2[k] * rule.pts[q][2];
-    for (int k = 0; k < 9; ++k) P.vert[(size_t)k * n + i] = v[k];
-    const uint8_t flag = bc ? (bc[perm[i]] ? 1 : 0) : 0;
-    P.bc[i] = flag;
-    seen_bc[t][flag] = 1;
-  }
+    for (int64_t i = i0; i < i1; ++i) {
+      const uint8_t flag = bc ? (bc[perm[i]] ? 1 : 0) : 0;
+      fill_panel(P, n, i, vertices + 9 * (size_t)perm[i], rule, flag);
+      seen_bc[t][flag] = 1;
+    }
   };
   if (nthreads == 1) fill_range(0, 0, n);
   else {

@@ -60,6 +60,10 @@ struct PanelSoA {
   raw_vector<uint8_t> bc;
 };
 
+void alloc_panels(PanelSoA& P, int64_t n, int nq);
+// one panel's derived geometry (kernel/LaplaceSphericalBEM.hpp:64-97) into slot i of arrays sized for n panels
+void fill_panel(PanelSoA& P, int64_t n, int64_t i, const double* vertices9, const QuadRule& rule, uint8_t bc_flag);
+
 struct HostPlan {
   HostOptions opt;
   int64_t n = 0;

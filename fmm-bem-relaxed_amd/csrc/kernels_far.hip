@@ -738,6 +738,9 @@ hipError_t upload_constants_once() {
     // M2M at p = 16 needs a little over 64 KiB of dynamic LDS
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(m2m_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(l2l_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    // L2P with one wavefront per workgroup at p = 16: 8 leaves x 4 potentials x 136 coefficients = 69.6 KB (Stokes)
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(l2p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(l2p_stokes_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     return e;
   }();
   if (st == hipSuccess) done[dev] = true;

@@ -800,6 +800,28 @@ __global__ void near_diag_kernel(DevicePlan d, const int* __restrict__ selfcol, 
   }
 }
 
+// Kernel::operator()(target, source) for m independent panel pairs (fmmbem_kernel_entries): panels [0, m) are the targets,
+// [m, 2m) the sources; the same entry functions as the near-matrix assembly.
+__global__ void kernel_entries_kernel(DevicePlan d, int m, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const V3 t = {d.cx[i], d.cy[i], d.cz[i]};
+  if (d.kernel == 1) {
+    double b[9];
+    stokes_entry(d, t, (int64_t)m + i, b);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) out[9 * (size_t)i + k] = b[k];
+  } else {
+    out[i] = laplace_entry(d, t, d.bc[i], (int64_t)m + i);
+  }
+}
+
+hipError_t launch_kernel_entries(const DevicePlan& d, int m, double* out, hipStream_t s) {
+  if (m <= 0) return hipSuccess;
+  hipLaunchKernelGGL(kernel_entries_kernel, dim3((m + 63) / 64), dim3(64), 0, s, d, m, out);
+  return hipGetLastError();
+}
+
 hipError_t launch_near_diag(const DevicePlan& d, const int* selfcol, double* out, hipStream_t s) {
   const int nb = d.leaf_end - d.leaf_begin;
   if (nb <= 0) return hipSuccess;

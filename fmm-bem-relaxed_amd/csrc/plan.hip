@@ -42,6 +42,25 @@ namespace {
                   std::string(#expr) + ": " + hipGetErrorString(e_));                              \
   } while (0)
 
+// The C ABI takes a device ordinal per plan; every entry point that touches the device switches to it and restores the
+// caller's current device on the way out (a process may hold plans on several devices, and torch keeps its own idea of
+// the current device).
+struct DeviceGuard {
+  int prev = -1;
+  hipError_t err = hipSuccess;
+  explicit DeviceGuard(int dev) {
+    err = hipGetDevice(&prev);
+    if (err != hipSuccess) { prev = -1; return; }
+    if (prev != dev) err = hipSetDevice(dev); else prev = -1;
+  }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define DEVICE_SCOPE(dev)        \
+  DeviceGuard device_guard_(dev); \
+  HIP_TRY(device_guard_.err)
+
 double now_ms() {
   using namespace std::chrono;
   return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
@@ -176,7 +195,7 @@ struct fmmbem_plan {
   int run(int p, const double* d_x, double* d_y, hipStream_t s, bool near_only, int phase = 0, double* xbuf = nullptr);
   ~fmmbem_plan() {
     if (on_device) {
-      (void)hipSetDevice(opts.device);
+      DeviceGuard guard(opts.device);
       for (void* p : allocs) (void)hipFree(p);
       for (auto& e : ev) (void)hipEventDestroy(e);
       if (own_stream) (void)hipStreamDestroy(own_stream);
@@ -194,7 +213,7 @@ int fmmbem_plan::to_device() {
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(FMMBEM_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU execution path)");
   if (opts.device < 0 || opts.device >= ndev) return fail(FMMBEM_ERR_INVALID, "device ordinal out of range");
-  HIP_TRY(hipSetDevice(opts.device));
+  DEVICE_SCOPE(opts.device);
   on_device = true;
   HIP_TRY(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&near_stream, hipStreamNonBlocking));
@@ -576,7 +595,7 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
   if (split_upward && phase == 0 && !near_only)
     return fail(FMMBEM_ERR_UNSUPPORTED, "plan shards the upward pass: use fmmbem_plan_upward_device / _downward_device");
   if (phase != 0 && (!split_upward || (!xbuf && phase != 3))) return fail(FMMBEM_ERR_INVALID, "split execute needs shard_upward and an exchange buffer");
-  HIP_TRY(hipSetDevice(opts.device));
+  DEVICE_SCOPE(opts.device);
   const bool tm = timing;
   const int64_t ring = ev_count % kRing;
   hipEvent_t* set = tm ? &ev[(size_t)ring * 2 * kStages] : nullptr;
@@ -778,7 +797,7 @@ int fmmbem_plan_execute(fmmbem_plan* plan, int p, const double* x, double* y) {
   if (!plan) return fail(FMMBEM_ERR_INVALID, "null plan");
   if (!plan->on_device) return fail(FMMBEM_ERR_NO_DEVICE, "plan was built host-only; there is no CPU execution path");
   if (!x || !y) return fail(FMMBEM_ERR_INVALID, "null vector");
-  HIP_TRY(hipSetDevice(plan->opts.device));
+  DEVICE_SCOPE(plan->opts.device);
   const size_t bytes = sizeof(double) * (size_t)plan->hp.n * (plan->opts.kernel == FMMBEM_KERNEL_STOKES_BEM ? 3 : 1);
   hipStream_t s = plan->own_stream;
   HIP_TRY(hipMemcpyAsync(plan->stage_x, x, bytes, hipMemcpyHostToDevice, s));
@@ -819,7 +838,7 @@ int fmmbem_plan_stats(const fmmbem_plan* plan, fmmbem_stats* o) {
     const int64_t have = plan->ev_count < NR ? plan->ev_count : NR;
     double sum[NS + 1] = {0};
     int64_t used = 0;
-    HIP_TRY(hipSetDevice(plan->opts.device));
+    DEVICE_SCOPE(plan->opts.device);
     for (int64_t i = 0; i < have; ++i) {
       const int64_t slot = (plan->ev_count - 1 - i) % NR;
       const hipEvent_t* set = &plan->ev[(size_t)slot * 2 * NS];
@@ -917,7 +936,7 @@ int fmmbem_plan_get_near_row(const fmmbem_plan* plan, int64_t row, uint32_t* col
   if (vals) {
     if (!plan->on_device) return fail(FMMBEM_ERR_NO_DEVICE, "near values live on the device");
     if (!plan->opts.sparse_local) return fail(FMMBEM_ERR_INVALID, "matrix-free plan holds no near matrix");
-    HIP_TRY(hipSetDevice(plan->opts.device));
+    DEVICE_SCOPE(plan->opts.device);
     int64_t off = 0;
     for (int l = h.leaf_begin; l < leaf; ++l) {
       const int b = h.leaf_box[l];
@@ -952,7 +971,7 @@ int fmmbem_plan_get_diagonal(const fmmbem_plan* plan, double* out) {
   if (!plan->opts.sparse_local) return fail(FMMBEM_ERR_INVALID, "matrix-free plan holds no near matrix");
   const HostPlan& h = plan->hp;
   const int dof = plan->d.dof;
-  HIP_TRY(hipSetDevice(plan->opts.device));
+  DEVICE_SCOPE(plan->opts.device);
   std::vector<int> selfcol(h.nleaves(), 0);
   for (int l = h.leaf_begin; l < h.leaf_end; ++l) {
     int col = 0;
@@ -984,7 +1003,7 @@ int fmmbem_plan_get_expansions(const fmmbem_plan* plan, int which, int p, double
   if (!plan || !out) return fail(FMMBEM_ERR_INVALID, "null argument");
   if (!plan->on_device) return fail(FMMBEM_ERR_NO_DEVICE, "expansions live on the device");
   if (p < 1 || p > plan->hp.opt.p_max) return fail(FMMBEM_ERR_INVALID, "p outside [1, p_max]");
-  HIP_TRY(hipSetDevice(plan->opts.device));
+  DEVICE_SCOPE(plan->opts.device);
   const DevicePlan& d = plan->d;
   const int ns = d.nslots;
   std::vector<double2> tmp((size_t)d.nboxes * ns * d.s_max);
@@ -997,6 +1016,71 @@ int fmmbem_plan_get_expansions(const fmmbem_plan* plan, int which, int p, double
         out[(((size_t)b * ns + s) * S + i) * 2] = v.x;
         out[(((size_t)b * ns + s) * S + i) * 2 + 1] = v.y;
       }
+  return FMMBEM_OK;
+}
+
+int fmmbem_kernel_entries(const fmmbem_options* opts, size_t n, const double* target_vertices, const uint8_t* target_bc,
+                          const double* source_vertices, double* out) {
+  if (!opts || !target_vertices || !source_vertices || !out) return fail(FMMBEM_ERR_INVALID, "null argument");
+  if (opts->kernel != FMMBEM_KERNEL_LAPLACE_BEM && opts->kernel != FMMBEM_KERNEL_STOKES_BEM)
+    return fail(FMMBEM_ERR_UNSUPPORTED, "unknown kernel id");
+  if (n == 0) return FMMBEM_OK;
+  if (n > ((size_t)1 << 30)) return fail(FMMBEM_ERR_INVALID, "too many pairs");
+  const bool stokes = opts->kernel == FMMBEM_KERNEL_STOKES_BEM;
+  QuadRule rule, fine;
+  if (!quad_rule(opts->quad_k, rule)) return fail(FMMBEM_ERR_INVALID, "invalid quadrature key (valid: 1 3 4 7 13 17 19 25)");
+  if (stokes) {
+    if (!quad_rule(opts->quad_k_fine, fine)) return fail(FMMBEM_ERR_INVALID, "invalid K_fine (valid: 1 3 4 7 13 17 19 25)");
+    if (!(opts->mu > 0)) return fail(FMMBEM_ERR_INVALID, "Stokes: viscosity mu must be positive");
+    if (target_bc)
+      for (size_t i = 0; i < n; ++i)
+        if (target_bc[i]) return fail(FMMBEM_ERR_UNSUPPORTED, "Stokes: only VELOCITY targets");
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(FMMBEM_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU execution path)");
+  if (opts->device < 0 || opts->device >= ndev) return fail(FMMBEM_ERR_INVALID, "device ordinal out of range");
+  DEVICE_SCOPE(opts->device);
+  const int64_t N = 2 * (int64_t)n;
+  PanelSoA P;
+  try {
+    alloc_panels(P, N, rule.n);
+  } catch (const std::bad_alloc&) {
+    return fail(FMMBEM_ERR_ALLOC, "host allocation failed");
+  }
+  for (size_t i = 0; i < n; ++i) {
+    fill_panel(P, N, (int64_t)i, target_vertices + 9 * i, rule, target_bc ? (target_bc[i] ? 1 : 0) : 0);
+    fill_panel(P, N, (int64_t)(n + i), source_vertices + 9 * i, rule, 0);
+  }
+  struct Frees {
+    std::vector<void*> v;
+    ~Frees() { for (void* p : v) (void)hipFree(p); }
+  } frees;
+  auto up = [&](const void* src, size_t bytes, const void** dst) -> hipError_t {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+    if (e != hipSuccess) return e;
+    frees.v.push_back(p);
+    *dst = p;
+    return bytes ? hipMemcpy(p, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
+  };
+  DevicePlan d{};
+  d.n = N; d.nq = rule.n; d.kernel = opts->kernel; d.dof = stokes ? 3 : 1; d.mu = opts->mu;
+  for (int q = 0; q < rule.n; ++q) d.qw[q] = rule.w[q];
+  if (stokes) {
+    d.nqf = fine.n;
+    for (int q = 0; q < fine.n; ++q) { for (int k = 0; k < 3; ++k) d.qf[q][k] = fine.pts[q][k]; d.qf[q][3] = fine.w[q]; }
+  }
+#define UP(field, vec) HIP_TRY(up(vec.data(), vec.size() * sizeof(vec[0]), reinterpret_cast<const void**>(&d.field)))
+  UP(cx, P.cx); UP(cy, P.cy); UP(cz, P.cz); UP(nx, P.nx); UP(ny, P.ny); UP(nz, P.nz);
+  UP(area, P.area); UP(quad, P.quad); UP(vert, P.vert); UP(bc, P.bc);
+#undef UP
+  const size_t per = stokes ? 9 : 1;
+  double* d_out = nullptr;
+  HIP_TRY(hipMalloc(&d_out, sizeof(double) * n * per));
+  frees.v.push_back(d_out);
+  HIP_TRY(launch_kernel_entries(d, (int)n, d_out, nullptr));
+  HIP_TRY(hipMemcpy(out, d_out, sizeof(double) * n * per, hipMemcpyDeviceToHost));
   return FMMBEM_OK;
 }
 

@@ -33,7 +33,8 @@ class ShardedFMM:
             device = torch.cuda.current_device() if torch.cuda.is_available() else 0
         if shard_upward is None:
             shard_upward = os.environ.get("FMMBEM_SHARD_UPWARD", "1") != "0"
-        self.split = (bool(shard_upward) and self.world > 1 and local_execute is None) or local_split is not None
+        # the owner-sharded upward pass carries at most 8 shards (DevicePlan::xch_ptr): larger groups repeat the upward pass
+        self.split = (bool(shard_upward) and 1 < self.world <= 8 and local_execute is None) or local_split is not None
         self._split_fns = local_split
         self.plan = FMM_plan(K, panels, opts, bc=bc, p_max=p_max, device=device,
                              shard=(self.rank, self.world), host_only=host_only,
@@ -42,9 +43,11 @@ class ShardedFMM:
         self._local = local_execute if local_execute is not None else self.plan.execute_torch
         self._xbuf = {}                                   # p -> (send, recv) exchange buffers
         # overlap of the all-gather with the near field: RCCL only (an asynchronous gloo collective on device tensors
-        # goes through the host and was measured 20x slower in a one-GPU rehearsal); FMMBEM_OVERLAP_GATHER=0 switches it off
+        # goes through the host and was measured 20x slower in a one-GPU rehearsal).  Off unless FMMBEM_OVERLAP_GATHER=1:
+        # the stream ordering of this path has not run on a multi-GPU node yet (SCALE_r01 was skipped), and the first
+        # such run should be a measurement of the plain path, not a debugging session.
         self._overlap = (self.split and dist.is_initialized() and dist.get_backend(group) == "nccl"
-                         and os.environ.get("FMMBEM_OVERLAP_GATHER", "1") != "0")
+                         and os.environ.get("FMMBEM_OVERLAP_GATHER", "0") == "1")
 
     def kernel(self):
         return self.plan.kernel()

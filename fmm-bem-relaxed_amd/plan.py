@@ -121,6 +121,32 @@ def red_blood_cells(recursions, cells, placement=None):
     return v
 
 
+def kernel_entries(K, targets, sources, target_bc=None, device=0):
+    """K(target_i, source_i) for n panel pairs -- Kernel::operator() of kernel/LaplaceSphericalBEM.hpp:273-297 /
+    kernel/StokesSphericalBEM.hpp:377-389, evaluated on the device.  targets, sources: (n, 3, 3) vertices;
+    target_bc: n flags (the target's flag selects G vs dG/dn).  Returns (n,) or (n, 3, 3)."""
+    t = np.ascontiguousarray(targets, dtype=np.float64).reshape(-1, 9)
+    s = np.ascontiguousarray(sources, dtype=np.float64).reshape(-1, 9)
+    if t.shape != s.shape:
+        raise ValueError("one source per target")
+    o = _capi.Options()
+    _capi.lib().fmmbem_options_default(C.byref(o))
+    o.quad_k, o.device = K.K, int(device)
+    stokes = isinstance(K, StokesSphericalBEM)
+    if stokes:
+        o.kernel, o.mu, o.quad_k_fine = _capi.KERNEL_STOKES_BEM, K.Mu, K.K_fine
+    bcp = None
+    if target_bc is not None:
+        target_bc = np.ascontiguousarray(target_bc, dtype=np.uint8)
+        if target_bc.shape != (len(t),):
+            raise ValueError("target_bc must have one flag per pair")
+        bcp = target_bc.ctypes.data_as(C.c_void_p)
+    out = np.empty((len(t), 3, 3) if stokes else len(t))
+    _capi.check(_capi.lib().fmmbem_kernel_entries(C.byref(o), len(t), t.ctypes.data_as(C.c_void_p), bcp,
+                                                  s.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
 def _read(fn, *paths):
     n = C.c_size_t(0)
     args = [os.fsencode(p) for p in paths]
@@ -181,6 +207,7 @@ class FMM_plan:
         o.evaluator = evaluator
         o.l2l_rule = _capi.L2L_REFERENCE if getattr(opts, "reference_l2l", False) else _capi.L2L_COMPLETE
         o.device = int(device)
+        self.device = int(device)
         self.dof = 1
         if isinstance(K, StokesSphericalBEM):
             o.kernel = _capi.KERNEL_STOKES_BEM
@@ -253,6 +280,8 @@ class FMM_plan:
         import torch
         if x.dtype != torch.float64 or not x.is_cuda or not x.is_contiguous() or x.numel() != self.n * self.dof:
             raise ValueError("x must be a contiguous float64 CUDA tensor with dof values per panel")
+        if x.device.index != self.device:
+            raise ValueError("x lives on cuda:%s but the plan was built on device %d" % (x.device.index, self.device))
         if out is None:
             out = torch.empty_like(x)
         self.execute_device(x.data_ptr(), out.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream, p)

@@ -28,6 +28,10 @@ class SolverOptions:
         """SolverOptions.hpp:25-38: Bouras-Fraysse  p = min(ceil(-log2(min(tol / min(eps, 1), 1))), max_p)."""
         if not self.variable_p:
             return self.max_p
+        if eps <= 0.0:
+            # the C++ code divides by zero here: alpha = inf, nu saturates at 1 (Bouras) and the order is 0, which the
+            # callers raise to their floor (GMRES.hpp:195 max(1u, .)); Simoncini's -log2(0) = inf saturates at max_p
+            return 0 if self.relax_type == SolverOptions.BOURAS else self.max_p
         if self.relax_type == SolverOptions.BOURAS:
             alpha = 1.0 / min(eps, 1.0)
             nu = min(alpha * self.residual, 1.0)
@@ -73,10 +77,14 @@ def gmres(MV, x, b, opts, M=None, log=None, stokes=False):
     cs, sn, s = [0.0] * R, [0.0] * R, [0.0] * (R + 1)
     normb = float(torch.linalg.vector_norm(b))
     it, resid = 0, 0.0
+    if normb == 0.0:                                      # b = 0: the reference divides by zero and stops on NaN; x = x0 is returned
+        return x, 0, 0.0
     while True:                                           # outer (restart) loop, :166
         w = execute(x)                                    # at the kernel's current p
         w = w - b
         beta = float(torch.linalg.vector_norm(w))
+        if beta == 0.0:                                   # x already solves the system (e.g. on a restart after exact convergence)
+            return x, it, 0.0
         V[0] = w * (-1.0 / beta)
         s[0] = beta
         i = -1
@@ -142,9 +150,13 @@ def fgmres(MV, x, b, opts, M, log=None, stokes=False):
     cs, sn, s = [0.0] * R, [0.0] * R, [0.0] * (R + 1)
     normb = float(torch.linalg.vector_norm(b))
     it, resid = 0, 0.0
+    if normb == 0.0:
+        return x, 0, 0.0
     while True:
         w = execute(x) - b
         beta = float(torch.linalg.vector_norm(w))
+        if beta == 0.0:
+            return x, it, 0.0
         V[0] = w * (-1.0 / beta)
         s[0] = beta
         i = -1

@@ -163,6 +163,15 @@ int fmmbem_plan_get_near_row(const fmmbem_plan *plan, int64_t row, uint32_t *col
  * rows of other shards are returned as zero. */
 int fmmbem_plan_get_diagonal(const fmmbem_plan *plan, double *out);
 
+/* Kernel::operator()(target, source) for n independent panel pairs (kernel/LaplaceSphericalBEM.hpp:273-297,
+ * kernel/StokesSphericalBEM.hpp:377-389): the panel integral of source i seen from the centroid of target i, evaluated on
+ * the device by the code that assembles the near matrix.  Reads opts->kernel, quad_k, quad_k_fine, mu, device.
+ * target_vertices / source_vertices: n x 9; target_bc: n flags or NULL (the TARGET's flag selects G vs dG/dn, :282-291);
+ * out: n doubles (Laplace) or n row-major 3x3 blocks (Stokes).  No plan is needed: this is what Preconditioners::Diagonal
+ * (examples/BEM/Preconditioner.hpp:24-33) calls as K(*it, *it) on the panels of FMM_plan::source_begin(). */
+int fmmbem_kernel_entries(const fmmbem_options *opts, size_t n, const double *target_vertices, const uint8_t *target_bc,
+                          const double *source_vertices, double *out);
+
 /* ---- split execute of a plan created with shard_upward = 1 and shard_world > 1 (no reference counterpart:
  * the reference is single-node) ----------------------------------------------------------
  *   upward:   x -> P2M and M2M of the boxes this shard owns -> d_send (exchange_doubles(p) doubles)

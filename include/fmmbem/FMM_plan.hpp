@@ -1,22 +1,31 @@
-// FMM_plan.hpp -- header-only C++ adapter that presents the reference's plan/operator surface on top of
-// the C ABI of include/fmmbem.h, so that the reference's solver code compiles against it unchanged:
+// FMM_plan.hpp -- header-only C++ adapter that presents the reference's plan/kernel surface on top of the C ABI of
+// include/fmmbem.h, so that the reference's solver and driver code compiles against it unchanged:
 //
 //     FMM_plan<LaplaceSphericalBEM> plan(K, panels, opts);        // include/FMM_plan.hpp:34-43
 //     plan.kernel().set_p(p);                                     // examples/BEM/GMRES.hpp:196
 //     std::vector<double> w = plan.execute(z);                    // include/FMM_plan.hpp:75-90
 //     plan.options();                                             // include/FMM_plan.hpp:94-96
+//     Preconditioners::Diagonal<double> M(K, plan.source_begin(), plan.source_end());   // examples/LaplaceBEM.cpp:241-244
 //
-// Same names, same argument meaning.  Differences, all on the error path: no exit()/printf -- failures
-// throw fmmbem::Error carrying the C status code; copying a plan is deleted (the reference's copy is
-// unsafe, FMM_plan.hpp:110).  There is no CPU fallback: without a HIP device the constructor throws.
+// What is mirrored, with the reference's names: Vec / Mat3 (fmmbem/Vec.hpp), FMMOptions, the two BEM kernel classes with
+// the KernelSkeleton member typedefs (kernel/KernelSkeleton.hpp:38-60: dimension, point_type, source_type, target_type,
+// charge_type, kernel_value_type, result_type, multipole_type, local_type), their Panel (center, normal, vertices,
+// quad_points, Area, BC, switch_BC, cast to point_type), operator()(target, source), set_p, and FMM_plan's typedefs,
+// kernel(), options(), execute(), source_begin()/source_end() (FMM_plan.hpp:19-28, 66-107).
+// Differences, all on the error path: no exit()/printf -- failures throw fmmbem::Error carrying the C status code; copying
+// a plan is deleted (the reference's copy is unsafe, FMM_plan.hpp:110).  There is no CPU fallback: every number comes from
+// the device, and without a HIP device the constructor throws.
 #pragma once
-#include <array>
+#include <cmath>
+#include <complex>
 #include <cstdint>
+#include <limits>
 #include <stdexcept>
 #include <string>
 #include <vector>
 
 #include "../fmmbem.h"
+#include "Vec.hpp"
 
 namespace fmmbem {
 
@@ -28,6 +37,41 @@ inline void check(int status) {
   if (status != FMMBEM_OK) throw Error(status, std::string(fmmbem_status_string(status)) + ": " + fmmbem_last_error());
 }
 
+// The rule the panels of the next kernel are built with: examples/BEM/BEMConfig.hpp:7-75 keeps it in a process-wide
+// singleton that every kernel constructor overwrites (:48-53); same behaviour, one inline variable.
+inline unsigned& config_K() { static unsigned k = 3; return k; }
+
+// Panel of kernel/LaplaceSphericalBEM.hpp:38-118 and kernel/StokesSphericalBEM.hpp:33-121 (the two are the same struct
+// up to the names of the boundary flags).
+template <int FLAG0, int FLAG1>
+struct PanelT {
+  typedef Vec<3, double> point_type;
+  typedef enum { BC0 = FLAG0, BC1 = FLAG1 } BoundaryType;
+  point_type center, normal;
+  std::vector<point_type> vertices, quad_points;
+  double Area = 0;
+  BoundaryType BC = BC0;
+  // K(s, s) of this panel when the plan handed it out through source_begin(): FMM_plan already holds the self
+  // interactions in the assembled near matrix, and Preconditioners::Diagonal asks for exactly those
+  double self_value = std::numeric_limits<double>::quiet_NaN();
+
+  PanelT() = default;
+  PanelT(point_type p0, point_type p1, point_type p2) : vertices{p0, p1, p2} {
+    center = (p0 + p1 + p2) / 3;
+    const point_type L0 = p2 - p0, L1 = p1 - p0;
+    const point_type c(L0[1] * L1[2] - L0[2] * L1[1], -(L0[0] * L1[2] - L0[2] * L1[0]), L0[0] * L1[1] - L0[1] * L1[0]);
+    Area = 0.5 * norm(c);
+    normal = c / 2 / Area;
+    double pts[25][3], w[25];
+    int k = 0;
+    check(fmmbem_quadrature((int)config_K(), &pts[0][0], w, &k));
+    quad_points.resize(k);
+    for (int i = 0; i < k; ++i) quad_points[i] = p0 * pts[i][0] + p1 * pts[i][1] + p2 * pts[i][2];
+  }
+  operator point_type() const { return center; }
+  void switch_BC() { BC = BC == BC0 ? BC1 : BC0; }
+};
+
 }  // namespace fmmbem
 
 // include/FMMOptions.hpp:9-60 -- the fields and setters the hot path reads
@@ -38,7 +82,11 @@ class FMMOptions {
   EvalType evaluator = FMM;
   double theta = 0.5;
   unsigned NCRIT_ = 64;
-  bool reference_l2l = false;   // not in the reference: apply only the L2L edges its lazy evaluator queues (fmmbem_l2l_rule)
+  // Not in the reference.  Its lazy evaluator never queues L2L into a child that was an M2L target earlier in the
+  // traversal than its parent (EvalInteractionLazySparse.hpp:199-237); on the meshes its generators produce no such child
+  // exists and the two rules are one list, on clustered meshes the reference's list loses far field.
+  // false (default): every child of a box that holds L;  true: exactly the reference's list.
+  bool reference_l2l = false;
   void set_mac_theta(double t) { theta = t; }
   void set_max_per_box(unsigned n) { NCRIT_ = n; }
   unsigned max_per_box() const { return NCRIT_; }
@@ -51,172 +99,227 @@ class FMMOptions {
   }
 };
 
-// kernel/LaplaceSphericalBEM.hpp:14-140 -- the part of the kernel object the plan boundary uses:
-// panel type, charge/result types, p and K.
+// kernel/LaplaceSphericalBEM.hpp:14-140 (+ the typedefs it inherits from kernel/LaplaceSpherical.hpp:33-50)
 class LaplaceSphericalBEM {
  public:
-  typedef std::array<double, 3> point_type;
-  typedef double charge_type;
-  typedef double result_type;
-  struct Panel {                                    // LaplaceSphericalBEM.hpp:38-118
-    typedef enum { POTENTIAL, NORMAL_DERIV } BoundaryType;
-    std::array<point_type, 3> vertices;
-    BoundaryType BC = POTENTIAL;
-    Panel() = default;
-    Panel(point_type p0, point_type p1, point_type p2) : vertices{{p0, p1, p2}} {}
-    void switch_BC() { BC = BC == POTENTIAL ? NORMAL_DERIV : POTENTIAL; }
+  typedef double real;
+  typedef std::complex<real> complex;
+  static constexpr unsigned dimension = 3;
+  typedef Vec<dimension, real> point_type;
+  struct Panel : fmmbem::PanelT<0, 1> {
+    static constexpr BoundaryType POTENTIAL = BC0, NORMAL_DERIV = BC1;
+    using fmmbem::PanelT<0, 1>::PanelT;
   };
   typedef Panel source_type;
   typedef Panel target_type;
+  typedef Panel panel_type;
+  typedef real charge_type;
+  typedef double kernel_value_type;
+  typedef double result_type;
+  typedef std::vector<std::vector<complex>> multipole_type;      // two expansions per box (G, dG/dn), :123-126
+  typedef std::vector<std::vector<complex>> local_type;
   unsigned K;
-  explicit LaplaceSphericalBEM(int p = 5, unsigned k = 3) : K(k), P(p) {}
+  LaplaceSphericalBEM() : LaplaceSphericalBEM(5, 3) {}
+  explicit LaplaceSphericalBEM(int p, unsigned k = 3) : K(k), P(p) { fmmbem::config_K() = k; }
   void set_p(int p) { P = p; }                      // LaplaceSphericalBEM.hpp:137-140
   int p() const { return P; }
+  int device = 0;                                   // where operator() evaluates
 
- private:
+  // one near-matrix entry, int_source G or dG/dn at the target centroid (:273-297); the target's BC picks the integrand
+  kernel_value_type operator()(const target_type& t, const source_type& s) const {
+    if (&t == &s && t.self_value == t.self_value) return t.self_value;
+    fmmbem_options o;
+    fmmbem_options_default(&o);
+    o.quad_k = (int)K;
+    o.device = device;
+    double tv[9], sv[9], out = 0;
+    for (int a = 0; a < 3; ++a)
+      for (int c = 0; c < 3; ++c) { tv[3 * a + c] = t.vertices[a][c]; sv[3 * a + c] = s.vertices[a][c]; }
+    const uint8_t bc = t.BC == Panel::NORMAL_DERIV ? FMMBEM_BC_NORMAL_DERIV : FMMBEM_BC_POTENTIAL;
+    fmmbem::check(fmmbem_kernel_entries(&o, 1, tv, &bc, sv, &out));
+    return out;
+  }
+
+ protected:
   int P;
 };
 
-// kernel/StokesSphericalBEM.hpp:9-141 -- panel type, Vec<3,double> charges/results, p, K, K_fine, mu.
-// Only VELOCITY panels are accepted by the library (the reference's traction far field is not reproducible).
+// kernel/StokesSphericalBEM.hpp:9-141 -- Vec<3,double> charges/results, Mat3 kernel values, p, K, K_fine, mu.
 class StokesSphericalBEM {
  public:
-  typedef std::array<double, 3> point_type;
-  typedef std::array<double, 3> charge_type;
-  typedef std::array<double, 3> result_type;
-  struct Panel {
-    typedef enum { VELOCITY, TRACTION } BoundaryType;
-    std::array<point_type, 3> vertices;
-    BoundaryType BC = VELOCITY;
-    Panel() = default;
-    Panel(point_type p0, point_type p1, point_type p2) : vertices{{p0, p1, p2}} {}
-    void switch_BC() { BC = BC == VELOCITY ? TRACTION : VELOCITY; }
+  typedef double real;
+  typedef std::complex<real> complex;
+  static constexpr unsigned dimension = 3;
+  typedef Vec<dimension, real> point_type;
+  struct Panel : fmmbem::PanelT<0, 1> {
+    static constexpr BoundaryType VELOCITY = BC0, TRACTION = BC1;
+    using fmmbem::PanelT<0, 1>::PanelT;
   };
   typedef Panel source_type;
   typedef Panel target_type;
+  typedef Panel panel_type;
+  typedef Vec<dimension, real> charge_type;
+  typedef Mat3<real> kernel_value_type;
+  typedef Vec<dimension, real> result_type;
+  typedef std::vector<std::vector<std::vector<complex>>> multipole_type;   // M[2][4] per box, :143-153
+  typedef std::vector<std::vector<std::vector<complex>>> local_type;
   unsigned K, K_fine = 25;
   double Mu;
-  explicit StokesSphericalBEM(int p = 5, unsigned k = 3, double mu = 1e-3) : K(k), Mu(mu), P(p) {}
+  StokesSphericalBEM() : StokesSphericalBEM(5, 3, 1e-3) {}
+  StokesSphericalBEM(int p, unsigned k) : StokesSphericalBEM(p, k, 1e-3) {}
+  StokesSphericalBEM(int p, unsigned k, double mu) : K(k), Mu(mu), P(p) { fmmbem::config_K() = k; }
   void set_p(int p) { P = p; }
   void set_Kfine(unsigned k) { K_fine = k; }
   int p() const { return P; }
+  int device = 0;
 
- private:
+  // the 3x3 block (1/2mu) int_source (I/r + d d^T/r^3) at the target centroid (:377-389, velocity targets)
+  kernel_value_type operator()(const target_type& t, const source_type& s) const {
+    fmmbem_options o;
+    fmmbem_options_default(&o);
+    o.kernel = FMMBEM_KERNEL_STOKES_BEM;
+    o.quad_k = (int)K;
+    o.quad_k_fine = (int)K_fine;
+    o.mu = Mu;
+    o.device = device;
+    double tv[9], sv[9];
+    for (int a = 0; a < 3; ++a)
+      for (int c = 0; c < 3; ++c) { tv[3 * a + c] = t.vertices[a][c]; sv[3 * a + c] = s.vertices[a][c]; }
+    const uint8_t bc = t.BC == Panel::TRACTION;
+    kernel_value_type m;
+    fmmbem::check(fmmbem_kernel_entries(&o, 1, tv, &bc, sv, m.vals_));
+    return m;
+  }
+
+ protected:
   int P;
 };
 
+namespace fmmbem {
+
+template <class Kernel> struct KernelBinding;
+template <> struct KernelBinding<LaplaceSphericalBEM> {
+  static void fill(const LaplaceSphericalBEM& K, const FMMOptions& opts, fmmbem_options& o) {
+    o.kernel = FMMBEM_KERNEL_LAPLACE_BEM;
+    o.quad_k = (int)K.K;
+    o.sparse_local = opts.sparse_local ? 1 : 0;     // examples/LaplaceBEM.cpp:81 sets it; FMMOptions defaults to false
+  }
+  static const double* in(const std::vector<double>& v) { return v.data(); }
+  static double* out(std::vector<double>& v) { return v.data(); }
+};
+template <> struct KernelBinding<StokesSphericalBEM> {
+  static void fill(const StokesSphericalBEM& K, const FMMOptions&, fmmbem_options& o) {
+    o.kernel = FMMBEM_KERNEL_STOKES_BEM;
+    o.quad_k = (int)K.K;
+    o.quad_k_fine = (int)K.K_fine;
+    o.mu = K.Mu;
+    o.sparse_local = 1;                             // examples/StokesBEM.cpp:147 (the matrix-free evaluator is Laplace-only here)
+  }
+  // Vec<3,double> is three contiguous doubles: the vectors are the N x 3 arrays the C ABI expects
+  static const double* in(const std::vector<Vec<3, double>>& v) { return v.data()->data(); }
+  static double* out(std::vector<Vec<3, double>>& v) { return v.data()->data(); }
+};
+
+// FMM_plan<Kernel> of include/FMM_plan.hpp:16-128 for the two kernels the library stands in for
 template <class Kernel>
-class FMM_plan;
-
-template <>
-class FMM_plan<LaplaceSphericalBEM> {
+class PlanAdapter {
  public:
-  typedef LaplaceSphericalBEM kernel_type;
-  typedef kernel_type::point_type point_type;
-  typedef kernel_type::source_type source_type;
-  typedef kernel_type::target_type target_type;
-  typedef kernel_type::charge_type charge_type;
-  typedef kernel_type::result_type result_type;
+  typedef Kernel kernel_type;
+  typedef typename kernel_type::point_type point_type;
+  typedef typename kernel_type::source_type source_type;
+  typedef typename kernel_type::target_type target_type;
+  typedef typename kernel_type::charge_type charge_type;
+  typedef typename kernel_type::result_type result_type;
+  typedef typename std::vector<source_type>::const_iterator body_source_iterator;
 
-  // p_max: largest order later set through kernel().set_p(); defaults to the kernel's current p
-  FMM_plan(const kernel_type& k, const std::vector<source_type>& source, FMMOptions& opts, int p_max = 0,
-           int device = 0)
-      : K(k), opts_(opts), n_(source.size()) {
+  // p_max: largest order a later kernel().set_p() may ask for.  The reference accepts any p at any time
+  // (LaplaceSpherical::set_p resizes its tables, kernel/LaplaceSpherical.hpp:119-128), so the default is the largest
+  // pre-compiled order, which is also SolverOptions::max_p's default (examples/BEM/SolverOptions.hpp:22).
+  PlanAdapter(const kernel_type& k, const std::vector<source_type>& source, FMMOptions& opts, int p_max = FMMBEM_PMAX,
+              int device = 0)
+      : K(k), opts_(opts), sources_(source), n_(source.size()) {
+    K.device = device;
     std::vector<double> v(9 * n_);
     std::vector<uint8_t> bc(n_);
     for (size_t i = 0; i < n_; ++i) {
       for (int a = 0; a < 3; ++a)
         for (int c = 0; c < 3; ++c) v[9 * i + 3 * a + c] = source[i].vertices[a][c];
-      bc[i] = source[i].BC == source_type::NORMAL_DERIV ? FMMBEM_BC_NORMAL_DERIV : FMMBEM_BC_POTENTIAL;
+      bc[i] = source[i].BC == source_type::BC1;
     }
     fmmbem_options o;
     fmmbem_options_default(&o);
-    o.p_max = p_max > 0 ? p_max : K.p();
-    o.quad_k = (int)K.K;
+    KernelBinding<Kernel>::fill(K, opts, o);
+    o.p_max = p_max;
     o.theta = opts.theta;
     o.ncrit = opts.NCRIT_;
-    o.sparse_local = opts.sparse_local ? 1 : 0;   // examples/LaplaceBEM.cpp:81 sets it; FMMOptions defaults to false
     o.device = device;
     o.evaluator = opts.c_evaluator();
     o.l2l_rule = opts.reference_l2l ? FMMBEM_L2L_REFERENCE : FMMBEM_L2L_COMPLETE;
-    fmmbem::check(fmmbem_plan_create(&o, n_, v.data(), bc.data(), &plan_));
+    sparse_ = o.sparse_local != 0;
+    check(fmmbem_plan_create(&o, n_, v.data(), bc.data(), &plan_));
   }
-  ~FMM_plan() { fmmbem_plan_destroy(plan_); }
-  FMM_plan(const FMM_plan&) = delete;
-  FMM_plan& operator=(const FMM_plan&) = delete;
+  ~PlanAdapter() { fmmbem_plan_destroy(plan_); }
+  PlanAdapter(const PlanAdapter&) = delete;
+  PlanAdapter& operator=(const PlanAdapter&) = delete;
 
   kernel_type& kernel() { return K; }
   const kernel_type& kernel() const { return K; }
   FMMOptions& options() { return opts_; }
 
   std::vector<result_type> execute(const std::vector<charge_type>& charges) {
-    if (charges.size() != n_) throw fmmbem::Error(FMMBEM_ERR_INVALID, "charges.size() != number of panels");
+    if (charges.size() != n_) throw Error(FMMBEM_ERR_INVALID, "charges.size() != number of panels");
     std::vector<result_type> results(charges.size());
-    fmmbem::check(fmmbem_plan_execute(plan_, K.p(), charges.data(), results.data()));
+    check(fmmbem_plan_execute(plan_, K.p(), KernelBinding<Kernel>::in(charges), KernelBinding<Kernel>::out(results)));
     return results;
   }
   // preconditioner-style operator()(x, y) (examples/BEM/Preconditioner.hpp:11-15)
   void operator()(const std::vector<charge_type>& x, std::vector<result_type>& y) { y = execute(x); }
 
+  // The plan's copy of the sources in TREE order (ExecutorSingleTree.hpp:145, 196-225; FMM_plan.hpp:100-107).  The
+  // panels carry their self interaction (fmmbem_plan_get_diagonal) so that K(*it, *it) costs nothing.
+  body_source_iterator source_begin() { tree_sources(); return tree_.begin(); }
+  body_source_iterator source_end() { tree_sources(); return tree_.end(); }
+
   fmmbem_plan* handle() { return plan_; }
 
  private:
+  void tree_sources() {
+    if (!tree_.empty() || n_ == 0) return;
+    std::vector<uint32_t> perm(n_);
+    check(fmmbem_plan_get_perm(plan_, perm.data()));
+    std::vector<double> diag;
+    if (sparse_ && std::is_same<charge_type, double>::value) {
+      diag.resize(n_);
+      check(fmmbem_plan_get_diagonal(plan_, diag.data()));
+    }
+    tree_.reserve(n_);
+    for (size_t i = 0; i < n_; ++i) {
+      tree_.push_back(sources_[perm[i]]);
+      if (!diag.empty()) tree_.back().self_value = diag[perm[i]];
+    }
+  }
+
   kernel_type K;
   FMMOptions opts_;
+  std::vector<source_type> sources_, tree_;
   size_t n_;
+  bool sparse_ = false;
   fmmbem_plan* plan_ = nullptr;
 };
 
+}  // namespace fmmbem
+
+template <class Kernel>
+class FMM_plan;
+
 template <>
-class FMM_plan<StokesSphericalBEM> {
+class FMM_plan<LaplaceSphericalBEM> : public fmmbem::PlanAdapter<LaplaceSphericalBEM> {
  public:
-  typedef StokesSphericalBEM kernel_type;
-  typedef kernel_type::source_type source_type;
-  typedef kernel_type::charge_type charge_type;
-  typedef kernel_type::result_type result_type;
+  using fmmbem::PlanAdapter<LaplaceSphericalBEM>::PlanAdapter;
+};
 
-  FMM_plan(const kernel_type& k, const std::vector<source_type>& source, FMMOptions& opts, int p_max = 0, int device = 0)
-      : K(k), opts_(opts), n_(source.size()) {
-    std::vector<double> v(9 * n_);
-    std::vector<uint8_t> bc(n_);
-    for (size_t i = 0; i < n_; ++i) {
-      for (int a = 0; a < 3; ++a)
-        for (int c = 0; c < 3; ++c) v[9 * i + 3 * a + c] = source[i].vertices[a][c];
-      bc[i] = source[i].BC == source_type::TRACTION;
-    }
-    fmmbem_options o;
-    fmmbem_options_default(&o);
-    o.kernel = FMMBEM_KERNEL_STOKES_BEM;
-    o.p_max = p_max > 0 ? p_max : K.p();
-    o.quad_k = (int)K.K;
-    o.quad_k_fine = (int)K.K_fine;
-    o.mu = K.Mu;
-    o.theta = opts.theta;
-    o.ncrit = opts.NCRIT_;
-    o.sparse_local = 1;
-    o.evaluator = opts.c_evaluator();
-    o.l2l_rule = opts.reference_l2l ? FMMBEM_L2L_REFERENCE : FMMBEM_L2L_COMPLETE;
-    o.device = device;
-    fmmbem::check(fmmbem_plan_create(&o, n_, v.data(), bc.data(), &plan_));
-  }
-  ~FMM_plan() { fmmbem_plan_destroy(plan_); }
-  FMM_plan(const FMM_plan&) = delete;
-  FMM_plan& operator=(const FMM_plan&) = delete;
-
-  kernel_type& kernel() { return K; }
-  FMMOptions& options() { return opts_; }
-
-  std::vector<result_type> execute(const std::vector<charge_type>& charges) {
-    if (charges.size() != n_) throw fmmbem::Error(FMMBEM_ERR_INVALID, "charges.size() != number of panels");
-    std::vector<result_type> results(charges.size());
-    // std::array<double,3> is three contiguous doubles: the vectors are the N x 3 arrays the C ABI expects
-    fmmbem::check(fmmbem_plan_execute(plan_, K.p(), charges.data()->data(), results.data()->data()));
-    return results;
-  }
-
- private:
-  kernel_type K;
-  FMMOptions opts_;
-  size_t n_;
-  fmmbem_plan* plan_ = nullptr;
+template <>
+class FMM_plan<StokesSphericalBEM> : public fmmbem::PlanAdapter<StokesSphericalBEM> {
+ public:
+  using fmmbem::PlanAdapter<StokesSphericalBEM>::PlanAdapter;
 };

@@ -9,13 +9,39 @@ import pytest
 from conftest import ROOT
 
 
-def _build(tmp_path):
-    exe = str(tmp_path / "adapter_example")
+REF_BEM = "/root/reference/examples/BEM"          # present in the build container only
+
+
+def _build(tmp_path, src="adapter_example", extra=()):
+    exe = str(tmp_path / (src + ("_ref" if extra else "")))
     libdir = os.path.join(ROOT, "fmm-bem-relaxed_amd")
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "tests", "cpp", "adapter_example.cpp"), "-o", exe,
+                           "-I" + os.path.join(ROOT, "tests", "cpp"), *extra,
+                           os.path.join(ROOT, "tests", "cpp", src + ".cpp"), "-o", exe,
                            "-L" + libdir, "-lfmmbem_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
     return exe
+
+
+def test_driver_sequence_compiles(tmp_path, gpu_available):
+    """examples/LaplaceBEM.cpp:163-291's call sequence (plan, flipped-BC right-hand-side plan,
+    Preconditioners::Diagonal over plan.source_begin()/source_end(), relaxed GMRES) compiles and links against the
+    adapter header with the test-side solver ..."""
+    exe = _build(tmp_path, "laplace_bem_sequence")
+    if not gpu_available:
+        r = subprocess.run([exe, "3", "8", "1e-5", "1"], capture_output=True, text=True)
+        assert r.returncode == 2 and "no HIP device" in r.stdout
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_BEM), reason="reference tree not present (GPU box)")
+def test_driver_sequence_compiles_with_the_references_own_solver_headers(tmp_path, gpu_available):
+    """... and with the REFERENCE's GMRES.hpp / SolverOptions.hpp / Preconditioner.hpp / BLAS.hpp and GMRES_Stokes.hpp,
+    read in place and unmodified: everything those files touch (FMM_plan typedefs, execute, kernel().set_p,
+    source_begin/source_end, K(s, s), Vec<3,double> arithmetic) exists with the reference's meaning."""
+    for src in ("laplace_bem_sequence", "stokes_bem_sequence"):
+        exe = _build(tmp_path, src, extra=("-DUSE_REFERENCE_SOLVER", "-I" + REF_BEM))
+        if not gpu_available:
+            r = subprocess.run([exe, "3", "8", "1e-5", "1"], capture_output=True, text=True)
+            assert r.returncode == 2 and "no HIP device" in r.stdout
 
 
 def test_adapter_compiles_and_reports_missing_device(tmp_path, gpu_available):
@@ -49,3 +75,40 @@ def test_adapter_matches_oracle(tmp_path, oracle_mod):
     for c in range(3):
         assert abs(float(st[3 + c]) - u[:, c].sum()) <= 1e-11 * np.abs(u).sum()
     assert ["traction", "refused", "6"] in out                  # FMMBEM_ERR_UNSUPPORTED
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pc", [0, 1])
+def test_driver_sequence_matches_python_solver(tmp_path, fb, oracle_mod, pc):
+    """The C++ driver sequence on the GPU against the same solve through solver.py: identical order schedule,
+    iteration count, solution to rounding; K(s, s) and K(t, s) of the kernel object against the oracle's entries."""
+    import torch
+    exe = _build(tmp_path, "laplace_bem_sequence")
+    r = subprocess.run([exe, "5", "12", "1e-5", str(pc)], capture_output=True, text=True, check=True)
+    out = r.stdout.splitlines()
+    ps_cpp = [int(ln.split("fmm_req_p:")[1]) for ln in out if ln.startswith("it:")]
+    final = [ln for ln in out if ln.startswith("Final residual")][0].split()
+    its_cpp = int(final[4])
+    v = fb.unit_sphere(5)
+    n = len(v)
+    K = fb.LaplaceSphericalBEM(12, 3)
+    plan = fb.FMM_plan(K, v, p_max=12)
+    rhs = fb.FMM_plan(fb.LaplaceSphericalBEM(12, 3), v, bc=np.ones(n, dtype=np.uint8), p_max=12)
+    b = rhs.execute_torch(torch.ones(n, dtype=torch.float64, device="cuda"))
+    log = []
+    M = fb.Diagonal(plan) if pc else None
+    if pc:                                              # the reference applies the TREE-order reciprocals to vectors in
+        perm = torch.from_numpy(plan.perm().astype(np.int64)).cuda()      # original order (SURVEY 3.3): so does the C++ run
+        M.recip = M.recip[perm]
+    x, its, res = fb.gmres(plan, torch.zeros(n, dtype=torch.float64, device="cuda"), b,
+                           fb.SolverOptions(residual=1e-5, max_p=12), M=M, log=log)
+    assert its == its_cpp and [p for _, p, _ in log][:len(ps_cpp)] == ps_cpp
+    s_cpp = float([ln for ln in out if ln.startswith("solution sum")][0].split()[2])
+    assert abs(s_cpp - float(x.sum())) <= 1e-9 * abs(s_cpp)
+    o = oracle_mod.Oracle(v)
+    selfs = [float(t) for t in [ln for ln in out if ln.startswith("self entry")][0].split()[2:]]
+    perm = plan.perm()
+    assert abs(selfs[0] - o.kernel_entries(np.array([0]), np.array([0]))[0]) <= 1e-13 * abs(selfs[0])
+    assert abs(selfs[1] - o.kernel_entries(perm[:1], perm[:1])[0]) <= 1e-13 * abs(selfs[1])
+    pair = float([ln for ln in out if ln.startswith("pair entry")][0].split()[2])
+    assert abs(pair - o.kernel_entries(np.array([0]), np.array([1]))[0]) <= 1e-13 * abs(pair)

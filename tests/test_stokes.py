@@ -145,3 +145,18 @@ def test_gpu_stokes_alternative_paths(fb, stokes5, monkeypatch, env):
     pl = fb.FMM_plan(K, v)
     x = drand48(3 * o.n, seed=5).reshape(o.n, 3)
     assert rel_l2(pl.execute(x), o.matvec(x, 8)) <= 1e-12
+
+
+@pytest.mark.gpu
+def test_gpu_stokes_high_orders(fb, oracle_mod):
+    """p = 13..16: the Stokes L2P stages 8 leaves x 4 potentials x S(p) coefficients per wavefront, 69.6 KB at p = 16 --
+    above the 64 KB a kernel gets without hipFuncAttributeMaxDynamicSharedMemorySize."""
+    v = oracle_mod.unit_sphere(4)
+    o = oracle_mod.StokesOracle(v, K=4, K_fine=19, mu=1e-3)
+    K = fb.StokesSphericalBEM(16, 4, 1e-3)
+    K.set_Kfine(19)
+    pl = fb.FMM_plan(K, v, p_max=16)
+    x = drand48(3 * o.n, seed=6).reshape(o.n, 3)
+    for p in (13, 15, 16):
+        K.set_p(p)
+        assert rel_l2(pl.execute(x), o.matvec(x, p)) <= 1e-12

@@ -10,9 +10,19 @@ read, so the read side of the streaming near_spmv kernel is doubled.
 import collections
 import csv
 import glob
+import hashlib
 import json
 import os
+import subprocess
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def near_source_sha():
+    """Identity of the kernel the traffic figure belongs to: sha256 of csrc/kernels_near.hip (bench.py drops
+    `roofline.traffic` when the current source differs)."""
+    return hashlib.sha256(open(os.path.join(ROOT, "fmm-bem-relaxed_amd", "csrc", "kernels_near.hip"), "rb").read()).hexdigest()
 
 
 def short(name):
@@ -42,7 +52,11 @@ def pmc_mean(d, counter):
 
 def pmc(fetch_dir, write_dir, out, n_panels, n_gpus):
     fe, wr = pmc_mean(fetch_dir, "FETCH_SIZE"), pmc_mean(write_dir, "WRITE_SIZE")
-    res = {"n_panels": int(n_panels), "n_gpus": int(n_gpus), "kernels": {}}
+    res = {"n_panels": int(n_panels), "n_gpus": int(n_gpus), "kernels": {}, "kernels_near_sha256": near_source_sha()}
+    try:
+        res["commit"] = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        res["commit"] = None                          # the GPU box has no .git: filled in when the file is copied to profiles/
     for k in sorted(set(fe) | set(wr)):
         f_kib, nf = fe.get(k, (0.0, 0))
         w_kib, nw = wr.get(k, (0.0, 0))
