@@ -5,12 +5,16 @@
  * follows.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
  * may load this library; the product (fmm-bem-relaxed_amd/) never does.
  *
- * PARITY STATUS: the reference cannot be built in this image (it needs Boost,
- * which is absent, and stand-in headers are not allowed), and its repository
- * holds no golden vectors.  Per-element parity is therefore UNPINNED.  What IS
- * pinned: the reference-run known answers recorded in SURVEY.md section 6
- * (exact list statistics for r=6,8,9; FMM-vs-Direct error levels at p=5,8,10,12),
- * checked by tests/test_oracle_known_answers.py, plus analytic identities.
+ * PARITY STATUS: the reference's FMM cannot be built in this image (it needs
+ * Boost, which is absent, and stand-in headers are not allowed), and its
+ * repository holds no golden vectors.  Per-element parity of the MATVEC is
+ * therefore UNPINNED.  What IS pinned: the reference-run known answers recorded
+ * in SURVEY.md section 6 (exact list statistics for r=6,8,9; FMM-vs-Direct error
+ * levels at p=5,8,10,12), checked by tests/test_oracle_known_answers.py;
+ * analytic identities per operator (tests/test_analytic_operators.py); and, for
+ * the CALLER of the path, the reference's own GMRES.hpp compiled unmodified
+ * around this oracle's matvec (ref_gmres_driver.cpp -> _ref/ref_gmres,
+ * fixtures tests/golden/gmres_ref_r*.json).
  */
 #ifndef FMM_ORACLE_H
 #define FMM_ORACLE_H
