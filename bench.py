@@ -12,9 +12,10 @@ torch.distributed.run (one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
   value     matvecs/s of the whole job (K matvecs / max-over-ranks wall time)
   roofline  the HBM-bound P2P kernel (near_spmv): algorithmic bytes per launch / mean launch duration
             measured with HIP events on the launch stream during the timed steps
-  cpu_baseline  the oracle ("port" of the reference's OpenMP path, faithful structure) timed on this box's
-            host cores on a bounded sample: one sphere r=8 (N=131 072 = 1/8 of the workload), p=10,
-            extrapolated by O(N) to the full workload
+  cpu_baseline  the oracle ("port" of the reference's OpenMP path, faithful structure, the reference's compiler flags)
+            timed on this box's host cores in a child process (tools/cpu_baseline.py): a quarter-size sample of the
+            same geometry first, then the workload itself when the sample says it fits --cpu-budget seconds
+            (`extrapolated` says which of the two `value` is)
 """
 import argparse
 import json
@@ -42,40 +43,28 @@ def parse():
     ap.add_argument("--ncrit", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-accuracy", action="store_true")
-    ap.add_argument("--cpu-recursions", type=int, default=8)
+    ap.add_argument("--cpu-budget", type=float, default=45.0,
+                    help="seconds of host time the cpu_baseline leg may spend on the full workload (else: quarter-size sample, extrapolated)")
     ap.add_argument("--workload", choices=["laplace", "stokes_rbc"], default="laplace",
                     help="laplace: the BASELINE metric workload (default); stokes_rbc: SURVEY 8(d) config 4 "
                          "(StokesSphericalBEM velocity BC on RedBloodCell(r), p=8, k=4, K_fine=19, mu=1e-3)")
     return ap.parse_args()
 
 
-def cpu_baseline(args):
-    """Oracle (faithful mode) on the host cores; bounded sample, see module docstring."""
-    import numpy as np
-    from oracle import oracle as O
-    r = args.cpu_recursions
-    v = O.unit_sphere(r)
-    o = O.Oracle(v, K=3, theta=args.theta, ncrit=args.ncrit)
-    t0 = time.time()
-    o.build_near()
-    build_s = time.time() - t0
-    x = np.random.default_rng(0).random(o.n)
-    o.matvec(x, args.p, faithful=True)                       # warm-up
-    times = []
-    for _ in range(3):                                       # tests/scaling.cpp:44-54 times 3 executes
-        t0 = time.time()
-        o.matvec(x, args.p, faithful=True)
-        times.append(time.time() - t0)
-    t = sum(times) / len(times)
-    n_full = args.spheres * 2 * 4 ** args.recursions
-    scale = n_full / o.n
-    return {
-        "value": 1.0 / (t * scale), "unit": "matvecs/s", "cores": O.num_threads(), "kind": "port",
-        "sample": "oracle faithful mode, UnitSphere(r=%d) N=%d p=%d: %.3f s/matvec (mean of 3 after 1 warm-up, "
-                  "near-matrix build %.1f s not counted), scaled x1/%.0f by O(N) to N=%d"
-                  % (r, o.n, args.p, t, build_s, scale, n_full),
-        "sample_s_per_matvec": t,
-    }
+def cpu_baseline(args, stokes):
+    """The oracle in faithful mode on this box's host cores, in a child process (tools/cpu_baseline.py): the reference's
+    flags, OMP_PROC_BIND=close, threads = the CPUs this process may run on; a quarter-size sample first, the full
+    workload as well when that fits --cpu-budget seconds."""
+    import subprocess
+    threads = len(os.sched_getaffinity(0))
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "cpu_baseline.py")]
+    if stokes:
+        cmd += ["stokes", str(args.recursions), str(args.p)]
+    else:
+        cmd += ["laplace", str(args.spheres), str(args.recursions), str(args.p)]
+    cmd += [str(args.theta), str(args.ncrit), str(threads), str(args.cpu_budget)]
+    out = subprocess.run(cmd, check=True, capture_output=True, text=True).stdout
+    return json.loads(out.strip().splitlines()[-1])
 
 
 def main():
@@ -236,8 +225,8 @@ def main():
         ys = y.cpu().numpy()[lo:lo + 256]
         out["rel_l2_vs_direct_sample"] = float(np.linalg.norm(ys - d) / np.linalg.norm(d))
         o.close()
-    if cpu_leg and not stokes:
-        out["cpu_baseline"] = cpu_baseline(args)
+    if cpu_leg:
+        out["cpu_baseline"] = cpu_baseline(args, stokes)
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
     print(json.dumps(out), flush=True)
     if world > 1:

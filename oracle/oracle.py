@@ -18,11 +18,14 @@ _LIB = None
 
 
 def build(force=False):
-    """Compile liboracle.so with gcc (make). Building the checker is not using it."""
-    so = os.path.join(_HERE, "liboracle.so")
+    """Compile liboracle.so with gcc (make). Building the checker is not using it.
+    FMM_ORACLE_FLAVOR=refflags selects liboracle_refflags.so: the same sources compiled with the reference's flags
+    (oracle/Makefile) -- what bench.py's cpu_baseline leg times, in a process of its own."""
+    refflags = os.environ.get("FMM_ORACLE_FLAVOR") == "refflags"
+    so = os.path.join(_HERE, "liboracle_refflags.so" if refflags else "liboracle.so")
     srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.check_call(["make", "-C", _HERE, "-s"])
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["refflags"] if refflags else []))
     return so
 
 
@@ -105,6 +108,15 @@ def unit_sphere(recursions, center=(0.0, 0.0, 0.0)):
     if any(center):
         v += np.asarray(center, dtype=np.float64)
     return v
+
+
+def semi_analytical(y0, y1, y2, x, same=False):
+    """AnalyticalIntegral::SemiAnalytical (examples/BEM/SemiAnalytical.hpp:148-203): (int 1/r, int d(1/r)/dn) over the
+    flat triangle y0 y1 y2 seen from x."""
+    a = [np.ascontiguousarray(t, dtype=np.float64) for t in (y0, y1, y2, x)]
+    G, dG = C.c_double(0.0), C.c_double(0.0)
+    lib().orc_semi_analytical(C.byref(G), C.byref(dG), _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), 1 if same else 0)
+    return G.value, dG.value
 
 
 def quadrature(key):
