@@ -57,6 +57,13 @@ def cpu_baseline(args, stokes):
     workload as well when that fits --cpu-budget seconds."""
     import subprocess
     threads = len(os.sched_getaffinity(0))
+    try:                                                     # one thread per PHYSICAL core this process may use
+        lines = subprocess.check_output(["lscpu", "-p=CPU,CORE,SOCKET"], text=True).splitlines()
+        cpus = os.sched_getaffinity(0)
+        cores = {tuple(ln.split(",")[1:]) for ln in lines if ln and not ln.startswith("#") and int(ln.split(",")[0]) in cpus}
+        threads = len(cores) or threads
+    except Exception:
+        pass
     cmd = [sys.executable, os.path.join(ROOT, "tools", "cpu_baseline.py")]
     if stokes:
         cmd += ["stokes", str(args.recursions), str(args.p)]

@@ -110,6 +110,14 @@ struct DevicePlan {
   const int *m2l_lane;                                // [p-1][192] lane -> output map (m2l_layout.hpp)
   const int *m2l_scat;                                // per p: table entry -> its 4 LDS places (m2l_layout.hpp)
   int m2l_scat_off[16];                               // offset of order p's scatter map in m2l_scat
+  // M2L by rotation / axial translation / rotation (kernels_m2l_rot.hip, m2l_rot.hpp): the owned pairs in CSR order by
+  // target, cut into items (whole targets with <= 64 pairs in all, or one target with more); per class
+  // {1/rho, cos alpha, sin alpha, cos beta, sin beta, 0, 0, 0}; per order p the constants in consumption order
+  const int *rot_src = nullptr, *rot_cls = nullptr, *rot_tgt = nullptr, *rot_item_ptr = nullptr;
+  int n_rot_items = 0;
+  const int* rot_empty = nullptr;   int n_rot_empty = 0;      // targets without a source of their own: L = 0
+  const double* rot_cls_rec = nullptr;
+  const double* rot_tab = nullptr;  int rot_tab_off[12] = {};
   // P2M as a precomputed operator: the multipole of a leaf is linear in the charges, M = sum_panels x_i * T_i with the
   // panel's own moments T_i = sum_q w_q A_i Ynm(q - c_leaf) (G or, for NORMAL_DERIV panels, gradient moments) independent
   // of x.  [panel (tree order)][ntab][s_max] complex, ntab = 1 (Laplace) or 4 (Stokes: moments of 1, x_q, y_q, z_q);
@@ -137,6 +145,8 @@ hipError_t launch_mh_prep(const DevicePlan& d, int p, hipStream_t s);
 // d_dev: a copy of d in device memory (the M2L kernel re-reads the plan fields it needs with scalar loads every source
 // instead of keeping them alive in SGPRs across its FMA region)
 hipError_t launch_m2l(const DevicePlan& d, const DevicePlan* d_dev, int p, hipStream_t s);
+bool m2l_rot_supported(int p);
+hipError_t launch_m2l_rot(const DevicePlan& d, int p, hipStream_t s);
 hipError_t launch_l2l_level(const DevicePlan& d, const ShiftOpDev& op, int p, int first, int count, hipStream_t s);
 hipError_t launch_l2p(const DevicePlan& d, int p, double* y, hipStream_t s);
 hipError_t launch_near_assemble_stokes(const DevicePlan& d, hipStream_t s);

@@ -1,0 +1,96 @@
+// m2l_rot.hpp -- M2L by rotation, axial translation, rotation back: the structure shared by the host (which tabulates
+// the constants once per plan) and the kernel (whose fully unrolled code consumes them in exactly this order).
+//
+// Reference operator: LaplaceSpherical::M2L (kernel/LaplaceSpherical.hpp:296-329), an O(p^4) double sum per pair.  Same
+// linear map, factored (the "point and shoot" form of White & Head-Gordon / Greengard & Rokhlin '97), O(p^3):
+//     L  =  E(-beta) X^T E(-alpha) conj(X)  .  Tz(rho)  .  X^T E(alpha) conj(X) E(beta)  M
+// for the translation vector (rho, alpha, beta) = cart2sph(c_target - c_source), acting on the coefficient vectors of
+// every degree n (orders m = -n..n, negative orders by conjugation, as the reference stores them):
+//   E(g)   = diag(e^{i m g})                     rotation about z
+//   X      = the fixed rotation that takes the y axis to the z axis (by pi/2 about x), in this basis
+//            X[m,m'] = i^{3|m| + |m'|} d^n_{m,m'}(pi/2)   (Wigner small-d; verified against sampled harmonics)
+//            so that  X^T E(alpha) conj(X)  is the rotation by alpha about y -- no per-translation matrix is needed
+//   Tz     = M2L along +z, which couples equal orders only:  L'[j,k] = sum_{n>=k} Tz[j,n,k] rho^{-(j+n+1)} M'[n,k],
+//            Tz[j,n,k] = (-1)^{k+j} A[n,k] A[j,k] EPS / A[j+n,0]  (the reference's Cnm entry for m = k, :106-116)
+// In real coordinates (a_0; a_m = Re, b_m = Im, m = 1..n) conj(X) and X^T are real and three quarters empty: an entry
+// (m, m' >= 1) carries ONE real coefficient  s = d[m,m'] + d[m,-m']  (n+m even, acts on a_m')  or  d[m,m'] - d[m,-m']
+// (n+m odd, acts on b_m'), routed by the phase i^{m+3m'} to Re or Im of the output with a sign; X^T has the same
+// entries times (-1)^{m+m'}.  n^2+n+1 multiply-adds per degree instead of (2n+1)^2 complex ones.
+// At p = 10: 4 x 340 (fixed rotations) + 4 x 180 (z rotations) + 670 (axial translation) + 200 (powers of rho) ~ 3 000
+// FMAs per pair against 15 400 for the double sum -- and every lane works on its own (target, source) pair out of
+// registers: no LDS image, no bank-conflict layout, no cliff where p(p+1)/2 passes 64.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+namespace fmmbem {
+
+constexpr int kRotPmax = 12;                       // orders the register-resident kernel is instantiated for
+
+// structural zero of the real rotation block of degree n at (output order m, input order mp)
+constexpr bool rot_live(int n, int m, int mp) {
+  if (mp == 0) return ((n + m) & 1) == 0;          // d[m,0] = 0 for n+m odd
+  return !(m == 0 && ((n + mp) & 1));              // d[0,mp] = 0 for n+mp odd
+}
+constexpr int rot_nnz(int n) {
+  int c = 0;
+  for (int m = 0; m <= n; ++m)
+    for (int mp = 0; mp <= n; ++mp) c += rot_live(n, m, mp) ? 1 : 0;
+  return c;
+}
+constexpr int rot_off(int n) {                     // first coefficient of degree n (degrees stored one after another)
+  int c = 0;
+  for (int i = 0; i < n; ++i) c += rot_nnz(i);
+  return c;
+}
+constexpr int tz_off(int P, int k) {               // axial block of order k at expansion order P: (P-k) x (P-k), [j-k][n-k]
+  int c = rot_off(P);
+  for (int i = 0; i < k; ++i) c += (P - i) * (P - i);
+  return c;
+}
+constexpr int rot_table_doubles(int P) { return (tz_off(P, P) + 7) & ~7; }
+
+// d^j_{mp,m}(pi/2): 2^-j sqrt((j+mp)!(j-mp)!/((j+m)!(j-m)!)) sum_s (-1)^{mp-m+s} C(j+m,s) C(j-m,mp-m+s); the sum is an
+// exact integer (|terms| sum to C(2j, j-mp) <= C(30,15))
+inline double wigner_d_half(int j, int mp, int m) {
+  auto binom = [](int n, int k) -> long long {
+    if (k < 0 || k > n) return 0;
+    long long r = 1;
+    for (int i = 1; i <= k; ++i) r = r * (n - k + i) / i;
+    return r;
+  };
+  long long tot = 0;
+  const int s0 = m - mp > 0 ? m - mp : 0, s1 = j + m < j - mp ? j + m : j - mp;
+  for (int s = s0; s <= s1; ++s) tot += (((mp - m + s) & 1) ? -1 : 1) * binom(j + m, s) * binom(j - m, mp - m + s);
+  long double f = 1.0L;                           // (j+mp)!(j-mp)! / ((j+m)!(j-m)!)
+  for (int i = 2; i <= j + mp; ++i) f *= i;
+  for (int i = 2; i <= j - mp; ++i) f *= i;
+  for (int i = 2; i <= j + m; ++i) f /= i;
+  for (int i = 2; i <= j - m; ++i) f /= i;
+  return (double)((long double)tot * std::sqrt(f) * std::ldexp(1.0L, -j));
+}
+
+// constants of order P in the order the kernel reads them
+inline void build_rot_table(int P, std::vector<double>& out) {
+  out.assign((size_t)rot_table_doubles(P), 0.0);
+  size_t at = 0;
+  for (int n = 0; n < P; ++n)
+    for (int m = 0; m <= n; ++m)
+      for (int mp = 0; mp <= n; ++mp) {
+        if (!rot_live(n, m, mp)) continue;
+        if (mp == 0) out[at++] = wigner_d_half(n, m, 0);
+        else if (((n + m) & 1) == 0) out[at++] = wigner_d_half(n, m, mp) + wigner_d_half(n, m, -mp);
+        else out[at++] = wigner_d_half(n, m, mp) - wigner_d_half(n, m, -mp);
+      }
+  auto fact = [](int k) { long double f = 1; for (int i = 2; i <= k; ++i) f *= i; return f; };
+  for (int k = 0; k < P; ++k)
+    for (int j = k; j < P; ++j)
+      for (int n = k; n < P; ++n) {
+        // (-1)^{k+j} A[n,k] A[j,k] EPS / A[j+n,0] with A[n,m] = (-1)^n / (EPS sqrt((n-m)!(n+m)!)): the EPS cancel
+        const int sgn = ((k + j + n + j + j + n) & 1) ? -1 : 1;
+        out[at++] = (double)(sgn * fact(j + n) / std::sqrt(fact(n - k) * fact(n + k) * fact(j - k) * fact(j + k)));
+      }
+}
+
+}  // namespace fmmbem

@@ -18,6 +18,7 @@
 #include "device_plan.hpp"
 #include "host_plan.hpp"
 #include "m2l_layout.hpp"
+#include "m2l_rot.hpp"
 #include "shift_ops.hpp"
 
 using namespace fmmbem;
@@ -190,6 +191,10 @@ struct fmmbem_plan {
     *out = static_cast<T*>(p);
     return FMMBEM_OK;
   }
+  // which M2L an execute at order p takes: the rotation kernel for the orders it is instantiated for unless
+  // FMMBEM_M2L_ROT=0 (A/B runs); FMMBEM_M2L_ROT_MIN / _MAX narrow the range
+  int rot_min = 1, rot_max = kRotPmax;
+  bool use_rot(int p) const { return p >= rot_min && p <= rot_max && m2l_rot_supported(p); }
   int to_device();
   // phase 0: whole matvec; 1: upward half (gather, P2M, M2M of owned boxes, pack -> xbuf); 2: the rest (xbuf = gathered)
   int run(int p, const double* d_x, double* d_y, hipStream_t s, bool near_only, int phase = 0, double* xbuf = nullptr);
@@ -292,6 +297,9 @@ int fmmbem_plan::to_device() {
     }
   }
   d.max_runs = max_runs;
+  if (const char* e = getenv("FMMBEM_M2L_ROT")) { if (atoi(e) == 0) rot_max = 0; }
+  if (const char* e = getenv("FMMBEM_M2L_ROT_MIN")) rot_min = atoi(e);
+  if (const char* e = getenv("FMMBEM_M2L_ROT_MAX")) rot_max = atoi(e);
   if (const char* ov = getenv("FMMBEM_OVERLAP_NEAR")) { overlap_near = atoi(ov) != 0; overlap_early = atoi(ov) == 2; }
   d.max_ncols = max_cols;
   near_bytes = total * (int64_t)sizeof(double);
@@ -541,6 +549,47 @@ int fmmbem_plan::to_device() {
     TRY(upload(lanes, &d.m2l_lane)); TRY(upload(scat, &d.m2l_scat));
   }
 
+  // M2L by rotation (kernels_m2l_rot.hip): the owned pairs in CSR order by target, cut into items; class records; constants
+  {
+    std::vector<int> rsrc, rcls, rtgt, item_ptr(1, 0), empty;
+    for (int b = 0; b < nb; ++b) {
+      if (!(hp.has_L[b] && hp.owned_L[b])) continue;
+      const int pb = hp.m2l_ptr[b], pe = hp.m2l_ptr[b + 1], cnt = pe - pb;
+      if (cnt == 0) { empty.push_back(b); continue; }
+      const int open = (int)rsrc.size() - item_ptr.back();          // pairs in the item being filled
+      if (open > 0 && open + cnt > 64) item_ptr.push_back((int)rsrc.size());
+      for (int i = pb; i < pe; ++i) { rsrc.push_back(hp.m2l_src[i]); rcls.push_back(hp.m2l_cls[i]); rtgt.push_back(b); }
+      if (cnt > 64) item_ptr.push_back((int)rsrc.size());           // a target with more than a wavefront of sources is an item of its own
+    }
+    if (item_ptr.back() != (int)rsrc.size()) item_ptr.push_back((int)rsrc.size());
+    d.n_rot_items = (int)item_ptr.size() - 1;
+    d.n_rot_empty = (int)empty.size();
+    TRY(upload(rsrc, &d.rot_src)); TRY(upload(rcls, &d.rot_cls)); TRY(upload(rtgt, &d.rot_tgt));
+    TRY(upload(item_ptr, &d.rot_item_ptr)); TRY(upload(empty, &d.rot_empty));
+    std::vector<double> rec((size_t)n_classes * 8, 0.0);
+    for (int64_t c = 0; c < n_classes; ++c) {
+      double tr[3];
+      for (int k = 0; k < 3; ++k) tr[k] = 0.5 * hp.cell[k] * double(hp.m2l_class_vec[3 * c + k]);
+      // cart2sph of the reference (kernel/LaplaceSpherical.hpp:528-541): rho = |d| + EPS, alpha = acos(z / rho), and the
+      // azimuth branches; kept as cosines and sines
+      double* o = rec.data() + (size_t)c * 8;
+      const double rho = std::sqrt(tr[0] * tr[0] + tr[1] * tr[1] + tr[2] * tr[2]) + kEps;
+      const double ca = tr[2] / rho;
+      o[0] = 1.0 / rho; o[1] = ca; o[2] = std::sqrt((1.0 - ca) * (1.0 + ca));
+      if (std::fabs(tr[0]) + std::fabs(tr[1]) < kEps) { o[3] = 1; o[4] = 0; }
+      else if (std::fabs(tr[0]) < kEps) { o[3] = 0; o[4] = tr[1] > 0 ? 1.0 : -1.0; }
+      else { const double h = 1.0 / std::sqrt(tr[0] * tr[0] + tr[1] * tr[1]); o[3] = tr[0] * h; o[4] = tr[1] * h; }
+    }
+    TRY(upload(rec, &d.rot_cls_rec));
+    std::vector<double> all, one;
+    for (int p = 1; p <= kRotPmax; ++p) {
+      d.rot_tab_off[p - 1] = (int)all.size();
+      build_rot_table(p, one);
+      all.insert(all.end(), one.begin(), one.end());
+    }
+    TRY(upload(all, &d.rot_tab));
+  }
+
   mark("m2l class tables");
   TRY(alloc((size_t)hp.n * dof, &d.xt, true));
   TRY(alloc((size_t)hp.n * dof, &d.yt, true));
@@ -665,7 +714,8 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
       HIP_TRY(launch_xch_unpack(d, p, reinterpret_cast<const double2*>(xbuf), s));
       for (auto [first, count] : m2m_shared_launch) HIP_TRY(launch_m2m_level(d, up_ops[p - 1], p, first, count, s));
     }
-    HIP_TRY(launch_mh_prep(d, p, s));
+    const bool rot = use_rot(p);
+    if (!rot) HIP_TRY(launch_mh_prep(d, p, s));      // the rotation kernel reads M itself
     HIP_TRY(end(5, s));
     if (overlap && !overlap_early) {                   // fork: the near field streams HBM while M2L saturates the FMA pipes
       HIP_TRY(hipEventRecord(ev_fork, s));
@@ -674,7 +724,7 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
       HIP_TRY(hipEventRecord(ev_join, near_stream));
     }
     HIP_TRY(begin(6, s));
-    HIP_TRY(launch_m2l(d, d_dev, p, s));
+    if (rot) HIP_TRY(launch_m2l_rot(d, p, s)); else HIP_TRY(launch_m2l(d, d_dev, p, s));
     HIP_TRY(end(6, s));
     HIP_TRY(begin(7, s));
     for (auto [first, count] : l2l_launch) HIP_TRY(launch_l2l_level(d, down_ops[p - 1], p, first, count, s));
