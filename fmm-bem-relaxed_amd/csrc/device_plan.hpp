@@ -146,7 +146,7 @@ hipError_t launch_mh_prep(const DevicePlan& d, int p, hipStream_t s);
 // instead of keeping them alive in SGPRs across its FMA region)
 hipError_t launch_m2l(const DevicePlan& d, const DevicePlan* d_dev, int p, hipStream_t s);
 bool m2l_rot_supported(int p);
-hipError_t launch_m2l_rot(const DevicePlan& d, int p, hipStream_t s);
+hipError_t launch_m2l_rot(const DevicePlan& d, const DevicePlan* d_dev, int p, hipStream_t s);
 hipError_t launch_l2l_level(const DevicePlan& d, const ShiftOpDev& op, int p, int first, int count, hipStream_t s);
 hipError_t launch_l2p(const DevicePlan& d, int p, double* y, hipStream_t s);
 hipError_t launch_near_assemble_stokes(const DevicePlan& d, hipStream_t s);

@@ -102,8 +102,17 @@ __device__ __forceinline__ void z_rotation(double (&a)[P * (P + 1) / 2], double 
   }
 }
 
+// Registers: a pair's data alone is 2 S doubles = 4 S VGPRs (112 at p = 7, 220 at p = 10), plus a degree block of
+// temporaries.  Wavefronts per SIMD asked of the compiler, measured at N = 1M (M2L ms, Laplace): p = 7: two 0.41, one 0.50;
+// p = 8: two 0.72, one 0.70; p = 9..12: two 1.00 / 1.51 / 3.28 / 5.59 (1-2 KB of scratch per lane), one 0.96 / 1.29 / 2.07 /
+// 2.73 (the overflow goes to AGPRs: no scratch up to p = 10).
+#ifndef FMMBEM_ROT_OCC
+#define FMMBEM_ROT_OCC(P) ((P) <= 4 ? 4 : (P) <= 6 ? 3 : (P) <= 7 ? 2 : 1)
+#endif
+constexpr int rot_waves(int P) { return FMMBEM_ROT_OCC(P); }
+
 template <int P>
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(P <= 4 ? 4 : P <= 8 ? 3 : 2))) void m2l_rot_kernel(const DevicePlan d, const double* __restrict__ tab_g) {
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(rot_waves(P), rot_waves(P)))) void m2l_rot_kernel(const DevicePlan d, const double* __restrict__ tab_g) {
   constexpr int S = P * (P + 1) / 2;
   constexpr int NT = (S + kTile - 1) / kTile;
   __shared__ double2 tile[kTile][kWave + 1];          // +1: the rows of one column sit in different banks
@@ -249,7 +258,8 @@ __global__ void m2l_rot_zero_kernel(const DevicePlan d, int S) {
 
 bool m2l_rot_supported(int p) { return p >= 1 && p <= kRotPmax; }
 
-hipError_t launch_m2l_rot(const DevicePlan& d, int p, hipStream_t s) {
+hipError_t launch_m2l_rot(const DevicePlan& d, const DevicePlan* d_dev, int p, hipStream_t s) {
+  (void)d_dev;
   if (d.n_rot_empty > 0) hipLaunchKernelGGL(m2l_rot_zero_kernel, dim3(d.n_rot_empty), dim3(kWave), 0, s, d, p * (p + 1) / 2);
   if (d.n_rot_items <= 0) return hipGetLastError();
   constexpr int CH = FMMBEM_ROT_XCD_CHUNK;

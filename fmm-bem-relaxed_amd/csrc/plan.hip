@@ -724,7 +724,7 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
       HIP_TRY(hipEventRecord(ev_join, near_stream));
     }
     HIP_TRY(begin(6, s));
-    if (rot) HIP_TRY(launch_m2l_rot(d, p, s)); else HIP_TRY(launch_m2l(d, d_dev, p, s));
+    if (rot) HIP_TRY(launch_m2l_rot(d, d_dev, p, s)); else HIP_TRY(launch_m2l(d, d_dev, p, s));
     HIP_TRY(end(6, s));
     HIP_TRY(begin(7, s));
     for (auto [first, count] : l2l_launch) HIP_TRY(launch_l2l_level(d, down_ops[p - 1], p, first, count, s));
