@@ -147,10 +147,26 @@ def main():
     elapsed = time.perf_counter() - t0
     st = plan.stats()
     plan.set_timing(False)
+    per_rank = None
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        # OUTSIDE the timed region: a few more steps with the collectives bracketed by device syncs, so that a SCALE line
+        # explains itself -- per rank: kernel stage times of its shard, seconds spent in collectives, bytes received
+        op.profile, op.collective_s, c0 = True, 0.0, op.calls
+        for _ in range(5):
+            step()
+        fence()
+        op.profile = False
+        up_b, y_b = op.exchange_bytes()
+        mine = [st["ms_total"], st["ms_near"], st["ms_p2m"] + st["ms_m2m"], st["ms_m2l"], st["ms_l2l"] + st["ms_l2p"],
+                op.collective_s / (op.calls - c0) * 1e3, float(up_b), float(y_b), float(st["near_nnz"]), float(st["m2l_pairs_owned"])]
+        allr = [torch.zeros(len(mine), dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(allr, torch.tensor(mine, dtype=torch.float64, device=dev))
+        keys = ("kernels_ms", "near_ms", "upward_ms", "m2l_ms", "downward_ms", "collectives_ms_synced", "multipole_bytes_in",
+                "result_bytes_in", "near_nnz", "m2l_pairs")
+        per_rank = [dict(zip(keys, t.tolist())) for t in allr]
     ms_per_step = elapsed / args.steps * 1e3
 
     if rank != 0:
@@ -177,7 +193,14 @@ def main():
         pass
     P = args.p
     n_exp = 4 if stokes else 1                                                  # live expansions per box
-    m2l_flops = n_exp * st["m2l_pairs_owned"] * 8.0 * (P * (P + 1) // 2) * P * P   # 4 FMAs = 8 flop per complex MAC
+    # reference operation count: the double sum of LaplaceSpherical::M2L, 4 FMAs = 8 flop per complex multiply-add ...
+    m2l_ref_flops = n_exp * st["m2l_pairs_owned"] * 8.0 * (P * (P + 1) // 2) * P * P
+    # ... and what the kernel executes: rotation / axial translation / rotation (csrc/m2l_rot.hpp), per pair and expansion
+    rot_fma = 4 * sum(n * n + n + 1 for n in range(1, P)) + sum((P - k) ** 2 * (2 if k else 1) for k in range(P))
+    rot_mul = 4 * 2 * sum(P - m for m in range(1, P)) + 2 * (P * P - 1)        # z rotations (2 mul + 2 FMA per coefficient), powers of rho
+    rot_fma += 4 * 2 * sum(P - m for m in range(1, P))
+    rot_on = os.environ.get("FMMBEM_M2L_ROT", "1") != "0" and P <= 12
+    m2l_flops = n_exp * st["m2l_pairs_owned"] * (2.0 * rot_fma + rot_mul) if rot_on else 0.70 * m2l_ref_flops
     m2l_tflops = m2l_flops / (st["ms_m2l"] * 1e-3) / 1e12 if st["ms_m2l"] > 0 else 0.0
 
     out = {
@@ -192,19 +215,25 @@ def main():
                                ("LaplaceSphericalBEM, %d disjoint UnitSphere(r=%d), N=%d panels, p=%d, k=3, theta=%g, "
                                 "ncrit=%d, all POTENTIAL; target leaves sharded over %d GPU(s), %s"
                                 % (args.spheres, args.recursions, n, P, args.theta, args.ncrit, world,
-                                   "1 all-gather of the multipoles + 1 all-reduce of y per matvec" if op.split else
-                                   "1 all-reduce of y per matvec")),
+                                   ("1 all-gather of the multipoles + " if op.split else "") +
+                                   ("1 all-gather of the result slices per matvec" if op.y_collective == "allgather" else
+                                    "1 all-reduce of y per matvec"))),
                    "n_panels": n, "p": P, "near_nnz": st["near_nnz_total"], "m2l_pairs": st["m2l_pairs"],
                    "boxes": st["n_boxes"], "leaves": st["n_leaves"]},
         "roofline": {"kernel": "near_spmv (P2P)", "bound": "hbm", "achieved": p2p_gbs, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": p2p_gbs / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": p2p_bytes, "launch_ms": near_ms,
                      "timed_launches": st["timed_executes"]},
-        "roofline_m2l": {"kernel": "m2l", "bound": "fp64 vector FMA", "achieved": m2l_tflops, "peak": FP64_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": m2l_tflops / FP64_PEAK_TFLOPS,
-                         "algorithmic_flops_per_launch": m2l_flops, "launch_ms": st["ms_m2l"]},
+        "roofline_m2l": {"kernel": "m2l_rot" if rot_on else "m2l", "bound": "fp64 vector FMA", "achieved": m2l_tflops,
+                         "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": m2l_tflops / FP64_PEAK_TFLOPS,
+                         "executed_flops_per_launch": m2l_flops, "launch_ms": st["ms_m2l"],
+                         "reference_flops_per_launch": m2l_ref_flops,
+                         "reference_equivalent_tflops": m2l_ref_flops / (st["ms_m2l"] * 1e-3) / 1e12 if st["ms_m2l"] > 0 else 0.0},
         "stage_ms": {k[3:]: st[k] for k in ("ms_total", "ms_gather", "ms_near", "ms_scatter", "ms_p2m", "ms_m2m",
                                             "ms_mh", "ms_m2l", "ms_l2l", "ms_l2p")},
+        "per_rank": per_rank,
+        "collectives": None if world == 1 else {"upward": "all-gather of multipoles" if op.split else "none (upward pass repeated)",
+                                                "result": op.y_collective},
         "plan_build_s": build_s, "near_assemble_s": st["build_assemble_ms"] * 1e-3,
         "host_lists_s": st["build_host_ms"] * 1e-3,
     }

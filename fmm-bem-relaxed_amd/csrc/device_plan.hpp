@@ -123,6 +123,8 @@ struct DevicePlan {
   // of x.  [panel (tree order)][ntab][s_max] complex, ntab = 1 (Laplace) or 4 (Stokes: moments of 1, x_q, y_q, z_q);
   // built once at p_max (kernels_far.hip p2m_table); the coefficients of order p are a prefix of every record.
   const double2* p2m_tab = nullptr;
+  int64_t p2m_tab_row0 = 0;                            // tree-order panel of the table's first record (a shard that runs P2M on
+                                                      // its own leaves only keeps only their records)
   // scratch
   double *xt, *yt;                                    // tree-order x and near result
 };
@@ -135,6 +137,8 @@ hipError_t launch_kernel_entries(const DevicePlan& d, int m, double* out, hipStr
 hipError_t launch_near_diag(const DevicePlan& d, const int* selfcol, double* out, hipStream_t s);
 hipError_t launch_near_matfree(const DevicePlan& d, hipStream_t s);
 hipError_t launch_scatter_y(const DevicePlan& d, double* y, hipStream_t s);
+hipError_t launch_assemble_slices(const DevicePlan& d, const double* slices, double* y, int world, const int64_t* d_cut, int64_t chunk,
+                                  hipStream_t s);
 hipError_t launch_p2m(const DevicePlan& d, int p, hipStream_t s);
 hipError_t launch_p2m_table(const DevicePlan& d, double2* tab, hipStream_t s);     // one-off: fills DevicePlan::p2m_tab's storage
 hipError_t launch_m2m_level(const DevicePlan& d, const ShiftOpDev& op, int p, int first, int count, hipStream_t s);

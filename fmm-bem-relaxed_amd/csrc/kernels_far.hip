@@ -255,7 +255,7 @@ __global__ __launch_bounds__(kWave) void p2m_table_kernel(DevicePlan d, double2*
     const double c0 = d.box_center[3 * box], c1 = d.box_center[3 * box + 1], c2 = d.box_center[3 * box + 2];
     for (int r = threadIdx.x; r < nrows; r += blockDim.x) {
       const int64_t i = row0 + r;
-      double2* out = tab + (size_t)i * NT * SM;
+      double2* out = tab + (size_t)(i - d.p2m_tab_row0) * NT * SM;
       const bool deriv = NT == 1 && d.bc[i] != 0;      // Laplace NORMAL_DERIV panel: (n . grad)(rho^n Ynm) moments (LaplaceSphericalBEM.hpp:331-343)
       const double n0 = d.nx[i], n1 = d.ny[i], n2 = d.nz[i];
       for (int q = 0; q < nq; ++q) {
@@ -318,7 +318,7 @@ template <int NT>
 __global__ __launch_bounds__(4 * kWave) void p2m_apply_kernel(DevicePlan d, const int P) {
   const int S = P * (P + 1) / 2, SM = d.s_max;
   const int lane = threadIdx.x & (kWave - 1);
-  const double2* __restrict__ tab = d.p2m_tab;
+  const double2* __restrict__ tab = d.p2m_tab - (size_t)d.p2m_tab_row0 * NT * SM;      // indexed by tree-order panel
   __shared__ double2 low_part[4][2 * kWave];
   for (int li = blockIdx.x * 4 + threadIdx.x / kWave; li < d.n_p2m; li += gridDim.x * 4) {
     const int leaf = d.p2m_leaf[li], box = d.leaf_box[leaf];
@@ -549,7 +549,8 @@ __global__ __launch_bounds__(kL2LWaves * kWave) void l2l_kernel(DevicePlan d, Sh
 // L2P: lane = panel centroid.  A leaf of the bench tree holds ~19 panels, so a wavefront takes a GROUP of consecutive
 // leaves (<= 64 rows, <= 8 leaves, DevicePlan::l2p_grp; a leaf with more rows is a group of its own and is walked in
 // chunks); the L of the group's leaves (active slots) is staged in LDS and every lane reads its own leaf's.
-// y[perm[i]] += r0 (POTENTIAL target) or -= r1 (NORMAL_DERIV target).
+// y_tree[i] += r0 (POTENTIAL target) or -= r1 (NORMAL_DERIV target): the far field joins the near field in TREE order
+// (coalesced; the one scatter to the caller's order comes after, plan.hip).
 // ---------------------------------------------------------------------------------------------
 constexpr int kL2PLeaves = 8, kL2PWaves = 4;
 __global__ __launch_bounds__(kL2PWaves * kWave) void l2p_kernel(DevicePlan d, const int P, double* __restrict__ y) {
@@ -610,8 +611,7 @@ __global__ __launch_bounds__(kL2PWaves * kWave) void l2p_kernel(DevicePlan d, co
         const double nr = er * s.cb - ei * s.sb, ni = er * s.sb + ei * s.cb;
         er = nr; ei = ni;
       }
-      const uint32_t o = d.perm[i];
-      y[o] += tb ? -r : r;
+      y[i] += tb ? -r : r;
     }
   }
 }
@@ -709,11 +709,10 @@ __global__ __launch_bounds__(kL2PWaves * kWave) void l2p_stokes_kernel(DevicePla
         const double f = e < 3 ? -tgt[e] : 1.0;
         res[0] += f * cx_; res[1] += f * cy_; res[2] += f * cz_;
       }
-      const uint32_t o = d.perm[i];
       const double sc = 1. / 2 / d.mu;
-      y[3 * (size_t)o] += sc * res[0];
-      y[3 * (size_t)o + 1] += sc * res[1];
-      y[3 * (size_t)o + 2] += sc * res[2];
+      y[3 * (size_t)i] += sc * res[0];
+      y[3 * (size_t)i + 1] += sc * res[1];
+      y[3 * (size_t)i + 2] += sc * res[2];
     }
   }
 }

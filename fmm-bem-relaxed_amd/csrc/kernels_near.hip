@@ -289,13 +289,55 @@ __device__ inline void stokes_self(V3 y1, V3 y2, V3 y3, V3 x, double* IU) {
         for (int j = 0; j < 3; ++j) IU[3 * i + j] += coef[a][b] * E[a][i] * E[b][j];
 }
 
-__device__ inline void stokes_entry(const DevicePlan& d, V3 t, int64_t j, double* out) {
+// one Gauss point of the traction (double-layer) integrand: res += w A (d . n) d d^T / r^5, d = target - point
+// (kernel/StokesSphericalBEM.hpp:205-225, 236-252)
+__device__ inline void stresslet_point(double* res, double wA, V3 t, V3 pnt, V3 nrm) {
+  const V3 dd = sub(t, pnt);
+  const double r2 = dd.x * dd.x + dd.y * dd.y + dd.z * dd.z;
+  double invR2 = 1. / r2;
+  if (r2 < 1e-8) invR2 = 0;
+  const double invR5 = invR2 * invR2 * sqrt(invR2);
+  const double dn = dd.x * nrm.x + dd.y * nrm.y + dd.z * nrm.z;
+  const double f = wA * dn * invR5;
+  const double dv[3] = {dd.x, dd.y, dd.z};
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) res[3 * i + j] += f * dv[i] * dv[j];
+}
+
+// tbc = the TARGET's flag (kernel/StokesSphericalBEM.hpp:377-389): 0 VELOCITY -> eval_velocity_integral (:260-375),
+// 1 TRACTION -> eval_traction_integral (:160-258): self 2 pi I, near K_fine, far K points, times -3, no 1/(2 mu)
+__device__ inline void stokes_entry(const DevicePlan& d, V3 t, int tbc, int64_t j, double* out) {
   const int64_t N = d.n;
   const V3 c = {d.cx[j], d.cy[j], d.cz[j]};
   const double A = d.area[j];
   const double dist = norm(sub(t, c));
 #pragma unroll
   for (int i = 0; i < 9; ++i) out[i] = 0;
+  if (tbc) {
+    if (fabs(dist) < 1e-8) { out[0] = out[4] = out[8] = 2 * M_PI; return; }
+    const V3 nrm = {d.nx[j], d.ny[j], d.nz[j]};
+    if (sqrt(2 * A) / dist >= 0.5) {
+      const V3 v0 = {d.vert[0 * N + j], d.vert[1 * N + j], d.vert[2 * N + j]};
+      const V3 v1 = {d.vert[3 * N + j], d.vert[4 * N + j], d.vert[5 * N + j]};
+      const V3 v2 = {d.vert[6 * N + j], d.vert[7 * N + j], d.vert[8 * N + j]};
+      for (int q = 0; q < d.nqf; ++q) {
+        const V3 pt = {v0.x * d.qf[q][0] + v1.x * d.qf[q][1] + v2.x * d.qf[q][2],
+                       v0.y * d.qf[q][0] + v1.y * d.qf[q][1] + v2.y * d.qf[q][2],
+                       v0.z * d.qf[q][0] + v1.z * d.qf[q][1] + v2.z * d.qf[q][2]};
+        stresslet_point(out, d.qf[q][3] * A, t, pt, nrm);
+      }
+    } else {
+      for (int q = 0; q < d.nq; ++q) {
+        const V3 qp = {d.quad[(q * 3 + 0) * N + j], d.quad[(q * 3 + 1) * N + j], d.quad[(q * 3 + 2) * N + j]};
+        stresslet_point(out, d.qw[q] * A, t, qp, nrm);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) out[i] *= -3.;
+    return;
+  }
   if (sqrt(2 * A) / dist >= 0.5) {
     const V3 v0 = {d.vert[0 * N + j], d.vert[1 * N + j], d.vert[2 * N + j]};
     const V3 v1 = {d.vert[3 * N + j], d.vert[4 * N + j], d.vert[5 * N + j]};
@@ -346,7 +388,7 @@ __global__ __launch_bounds__(256) void near_assemble_stokes_kernel(DevicePlan d)
         const int r = e / cw, c = e - r * cw;
         const int64_t i = row0 + r;
         double m[9];
-        stokes_entry(d, V3{d.cx[i], d.cy[i], d.cz[i]}, colmap[c], m);
+        stokes_entry(d, V3{d.cx[i], d.cy[i], d.cz[i]}, d.bc[i], colmap[c], m);
         if (sym) {                                     // the six entries (a <= b) of the symmetric block, three planes per panel row
           dvec2* row = sym + (int64_t)r * 3 * ncols + c0 + c;
           row[0] = dvec2{m[0], m[1]};
@@ -399,6 +441,53 @@ __global__ __launch_bounds__(256) void near_matfree_kernel(DevicePlan d) {
         for (int c = lane; c < cw; c += kWave) acc = fma(laplace_entry(d, tc, tbc, colmap[c]), xs[c], acc);
         acc = wave_sum(acc);
         if (lane == 0) d.yt[i] = c0 ? d.yt[i] + acc : acc;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// The same for StokesSphericalBEM (StokesBEM -disable_sparse): the 3x3 panel integral of every (target, source) pair of the
+// near list is recomputed and applied to the source's Vec<3,double> charge; one wavefront per target panel row.
+__global__ __launch_bounds__(256) void near_matfree_stokes_kernel(DevicePlan d) {
+  extern __shared__ double lds_d[];
+  double* xs = lds_d;                                          // [3][kAsmChunk / 2]
+  constexpr int kChunk = kAsmChunk / 2;
+  int* colmap = reinterpret_cast<int*>(xs + 3 * kChunk);       // [kChunk]
+  int* run_row0 = colmap + kChunk;
+  int* run_off = run_row0 + d.max_runs;
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, nwaves = blockDim.x / kWave;
+  for (int t = d.leaf_begin + blockIdx.x; t < d.leaf_end; t += gridDim.x) {
+    const int ncols = d.near_ncols[t], nrows = d.leaf_nrows[t];
+    const int row0 = d.leaf_row0[t];
+    const Runs runs = load_runs(d, t, run_row0, run_off);
+    for (int c0 = 0; c0 < ncols; c0 += kChunk) {
+      const int cw = ncols - c0 < kChunk ? ncols - c0 : kChunk;
+      if (c0) __syncthreads();
+      for (int c = threadIdx.x; c < cw; c += blockDim.x) {
+        const int j = column_to_row(runs, c0 + c);
+        colmap[c] = j;
+        xs[c] = d.xt[3 * (int64_t)j]; xs[kChunk + c] = d.xt[3 * (int64_t)j + 1]; xs[2 * kChunk + c] = d.xt[3 * (int64_t)j + 2];
+      }
+      __syncthreads();
+      for (int r = wave; r < nrows; r += nwaves) {
+        const int64_t i = row0 + r;
+        const V3 tc = {d.cx[i], d.cy[i], d.cz[i]};
+        const int tbc = d.bc[i];
+        double a0 = 0, a1 = 0, a2 = 0;
+        for (int c = lane; c < cw; c += kWave) {
+          double m[9];
+          stokes_entry(d, tc, tbc, colmap[c], m);
+          const double x0 = xs[c], x1 = xs[kChunk + c], x2 = xs[2 * kChunk + c];
+          a0 = fma(m[0], x0, fma(m[1], x1, fma(m[2], x2, a0)));
+          a1 = fma(m[3], x0, fma(m[4], x1, fma(m[5], x2, a1)));
+          a2 = fma(m[6], x0, fma(m[7], x1, fma(m[8], x2, a2)));
+        }
+        a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
+        if (lane == 0) {
+          double* y = d.yt + 3 * i;
+          y[0] = c0 ? y[0] + a0 : a0; y[1] = c0 ? y[1] + a1 : a1; y[2] = c0 ? y[2] + a2 : a2;
+        }
       }
     }
     __syncthreads();
@@ -808,7 +897,7 @@ __global__ void kernel_entries_kernel(DevicePlan d, int m, double* __restrict__ 
   const V3 t = {d.cx[i], d.cy[i], d.cz[i]};
   if (d.kernel == 1) {
     double b[9];
-    stokes_entry(d, t, (int64_t)m + i, b);
+    stokes_entry(d, t, d.bc[i], (int64_t)m + i, b);
 #pragma unroll
     for (int k = 0; k < 9; ++k) out[9 * (size_t)i + k] = b[k];
   } else {
@@ -848,6 +937,11 @@ hipError_t launch_near_assemble_stokes(const DevicePlan& d, hipStream_t s) {
 hipError_t launch_near_matfree(const DevicePlan& d, hipStream_t s) {
   const int nb = d.leaf_end - d.leaf_begin;
   if (nb <= 0) return hipSuccess;
+  if (d.dof == 3) {
+    const size_t lds3 = (size_t)(kAsmChunk / 2) * (3 * sizeof(double) + sizeof(int)) + 2 * (size_t)d.max_runs * sizeof(int);
+    hipLaunchKernelGGL(near_matfree_stokes_kernel, dim3(nb < 256 * 8 ? nb : 256 * 8), dim3(256), lds3, s, d);
+    return hipGetLastError();
+  }
   const size_t lds = (size_t)kAsmChunk * (sizeof(double) + sizeof(int)) + 2 * (size_t)d.max_runs * sizeof(int);
   hipLaunchKernelGGL(near_matfree_kernel, dim3(nb < 256 * 8 ? nb : 256 * 8), dim3(256), lds, s, d);
   return hipGetLastError();
@@ -883,6 +977,27 @@ hipError_t launch_near_spmv(const DevicePlan& d, hipStream_t s) {
   } else {
     hipLaunchKernelGGL((near_spmv_kernel<2, 4>), g, b, lds, s, d);
   }
+  return hipGetLastError();
+}
+
+// Result vectors assembled from per-shard slices (multi-GPU, include/fmmbem.h fmmbem_plan_assemble_slices_device): shard r
+// computed the tree-order rows [cut[r], cut[r+1]); its slice starts at slices + r * chunk.  One thread per unknown.
+__global__ void assemble_slices_kernel(const uint32_t* __restrict__ perm, const double* __restrict__ slices, double* __restrict__ y,
+                                       int64_t n, int dof, int world, const int64_t* __restrict__ cut, int64_t chunk) {
+  const int64_t u = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (u >= n * dof) return;
+  const int64_t i = u / dof;
+  const int a = (int)(u - i * dof);
+  int r = 0;
+  while (r + 1 < world && i >= cut[r + 1]) ++r;
+  y[(int64_t)perm[i] * dof + a] = slices[(int64_t)r * chunk + (i - cut[r]) * dof + a];
+}
+
+hipError_t launch_assemble_slices(const DevicePlan& d, const double* slices, double* y, int world, const int64_t* d_cut, int64_t chunk,
+                                  hipStream_t s) {
+  const int bs = 256;
+  hipLaunchKernelGGL(assemble_slices_kernel, dim3((unsigned)((d.n * d.dof + bs - 1) / bs)), dim3(bs), 0, s, d.perm, slices, y, d.n,
+                     d.dof, world, d_cut, chunk);
   return hipGetLastError();
 }
 

@@ -150,6 +150,8 @@ struct fmmbem_plan {
   bool split_upward = false;                                   // P2M/M2M sharded by owner, multipoles all-gathered by the caller
   unsigned pending_mask = 0;                                   // stages recorded by the upward half of a split execute
   bool pending_near = false;                                   // split execute: the near field already ran (fmmbem_plan_near_split_device)
+  bool result_slices = false;                                  // execute delivers the owned rows in tree order (fmmbem_plan_set_result_slices)
+  int64_t* d_cut = nullptr;                                    // tree-order row cuts of all shards, on the device
   std::vector<ShiftOpDev> up_ops, down_ops;                    // M2M / L2L operators, index p - 1
   int64_t near_bytes = 0;
   int64_t n_classes = 0;
@@ -607,7 +609,13 @@ int fmmbem_plan::to_device() {
   {
     const char* e = std::getenv("FMMBEM_P2M_TABLE");
     const size_t ntab = opts.kernel == FMMBEM_KERNEL_STOKES_BEM ? 4 : 1;
-    const size_t count = (size_t)hp.n * ntab * d.s_max;
+    // the panels of the leaves this plan runs P2M on: all of them, or -- upward pass sharded by owner -- the shard's own
+    // rows only (0.9 GB at N = 1M, p_max = 10 for the whole mesh: one eighth of that per GPU on an 8-GPU node)
+    int64_t r0 = hp.n, r1 = 0;
+    for (int b : hp.p2m_leaves) { r0 = std::min<int64_t>(r0, hp.box_body_begin[b]); r1 = std::max<int64_t>(r1, hp.box_body_end[b]); }
+    if (r1 < r0) r0 = r1 = 0;
+    d.p2m_tab_row0 = r0;
+    const size_t count = (size_t)(r1 - r0) * ntab * d.s_max;
     if (!(e && std::atoi(e) == 0) && hp.opt.evaluator == 0 && d.n_p2m > 0 && count * sizeof(double2) <= ((size_t)16 << 30)) {
       double2* tab = nullptr;
       TRY(alloc(count, &tab, true));
@@ -680,9 +688,20 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
     HIP_TRY(begin(1, ns));
     if (opts.sparse_local) HIP_TRY(launch_near_spmv(d, ns)); else HIP_TRY(launch_near_matfree(d, ns));
     HIP_TRY(end(1, ns));
+    return FMMBEM_OK;
+  };
+  // the result leaves the plan once, at the very end: the owned rows of y_tree (near + far field) scattered to the caller's
+  // panel order (zeros elsewhere when the plan is a shard), or -- result_slices -- copied as they are, tree order, to the
+  // head of d_y, for the caller's all-gather (fmmbem_plan_assemble_slices_device puts the gathered slices in panel order)
+  auto deliver = [&](hipStream_t ns) -> int {
     HIP_TRY(begin(2, ns));
-    if (hp.opt.shard_world > 1) HIP_TRY(hipMemsetAsync(d_y, 0, sizeof(double) * (size_t)hp.n * d.dof, ns));
-    HIP_TRY(launch_scatter_y(d, d_y, ns));
+    if (result_slices) {
+      HIP_TRY(hipMemcpyAsync(d_y, d.yt + d.row_begin * d.dof, sizeof(double) * (size_t)(d.row_end - d.row_begin) * d.dof,
+                             hipMemcpyDeviceToDevice, ns));
+    } else {
+      if (hp.opt.shard_world > 1) HIP_TRY(hipMemsetAsync(d_y, 0, sizeof(double) * (size_t)hp.n * d.dof, ns));
+      HIP_TRY(launch_scatter_y(d, d_y, ns));
+    }
     HIP_TRY(end(2, ns));
     return FMMBEM_OK;
   };
@@ -731,9 +750,10 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
     HIP_TRY(end(7, s));
     if (overlap) HIP_TRY(hipStreamWaitEvent(s, ev_join, 0));
     HIP_TRY(begin(8, s));
-    if (d.kernel == FMMBEM_KERNEL_STOKES_BEM) HIP_TRY(launch_l2p_stokes(d, p, d_y, s)); else HIP_TRY(launch_l2p(d, p, d_y, s));
+    if (d.kernel == FMMBEM_KERNEL_STOKES_BEM) HIP_TRY(launch_l2p_stokes(d, p, d.yt, s)); else HIP_TRY(launch_l2p(d, p, d.yt, s));
     HIP_TRY(end(8, s));
   }
+  TRY(deliver(s));
   last_p = p;
   if (tm) { ev_mask[ring] = mask; ++ev_count; }
   return FMMBEM_OK;
@@ -763,11 +783,13 @@ int fmmbem_plan_create(const fmmbem_options* opts, size_t n_panels, const double
   if (opts->kernel != FMMBEM_KERNEL_LAPLACE_BEM && opts->kernel != FMMBEM_KERNEL_STOKES_BEM)
     return fail(FMMBEM_ERR_UNSUPPORTED, "unknown kernel id");
   if (opts->kernel == FMMBEM_KERNEL_STOKES_BEM) {
-    if (!opts->sparse_local) return fail(FMMBEM_ERR_UNSUPPORTED, "Stokes: only the assembled near field (sparse_local=1)");
     if (!(opts->mu > 0)) return fail(FMMBEM_ERR_INVALID, "Stokes: viscosity mu must be positive");
-    if (bc)
+    // TRACTION panels: the near blocks are eval_traction_integral (kernel/StokesSphericalBEM.hpp:160-258) and every
+    // near-field-only operator is exact; the far field of the traction operator is refused -- the reference's own
+    // disagrees with its Direct sum by 50-75 %, there is nothing to be equal to
+    if (bc && opts->evaluator == FMMBEM_EVAL_FMM)
       for (size_t i = 0; i < n_panels; ++i)
-        if (bc[i]) return fail(FMMBEM_ERR_UNSUPPORTED, "Stokes: only VELOCITY panels (the traction far field of the reference is not reproducible)");
+        if (bc[i]) return fail(FMMBEM_ERR_UNSUPPORTED, "Stokes: TRACTION panels only with the near-field evaluators (LOCAL, BLOCK_DIAGONAL); the traction far field of the reference is not reproducible");
   }
   if (!vertices || n_panels == 0) return fail(FMMBEM_ERR_INVALID, "no panels");
   if (opts->l2l_rule != FMMBEM_L2L_COMPLETE && opts->l2l_rule != FMMBEM_L2L_REFERENCE) return fail(FMMBEM_ERR_INVALID, "unknown l2l_rule");
@@ -838,6 +860,39 @@ int fmmbem_plan_near_split_device(fmmbem_plan* plan, double* d_y, void* stream) 
   return plan->run(plan->last_p > 0 ? plan->last_p : 1, nullptr, d_y, static_cast<hipStream_t>(stream), false, 3, nullptr);
 }
 
+int fmmbem_plan_shard_rows(const fmmbem_plan* plan, int64_t* cut) {
+  if (!plan || !cut) return fail(FMMBEM_ERR_INVALID, "null argument");
+  const HostPlan& h = plan->hp;
+  std::vector<int> leaf_cut;
+  partition_leaves(h, h.opt.shard_world, leaf_cut);
+  for (int r = 0; r <= h.opt.shard_world; ++r)
+    cut[r] = leaf_cut[r] < h.nleaves() ? (int64_t)h.box_body_begin[h.leaf_box[leaf_cut[r]]] : h.n;
+  return FMMBEM_OK;
+}
+
+int fmmbem_plan_set_result_slices(fmmbem_plan* plan, int enabled) {
+  if (!plan) return fail(FMMBEM_ERR_INVALID, "null plan");
+  plan->result_slices = enabled != 0;
+  return FMMBEM_OK;
+}
+
+int fmmbem_plan_assemble_slices_device(fmmbem_plan* plan, const double* d_slices, size_t chunk_doubles, double* d_y, void* stream) {
+  if (!plan || !d_slices || !d_y) return fail(FMMBEM_ERR_INVALID, "null argument");
+  if (!plan->on_device) return fail(FMMBEM_ERR_NO_DEVICE, "plan was built host-only; there is no CPU execution path");
+  const int world = plan->hp.opt.shard_world;
+  DEVICE_SCOPE(plan->opts.device);
+  if (!plan->d_cut) {
+    std::vector<int64_t> cut((size_t)world + 1);
+    TRY(fmmbem_plan_shard_rows(plan, cut.data()));
+    for (int r = 0; r < world; ++r)
+      if ((size_t)(cut[r + 1] - cut[r]) * plan->d.dof > chunk_doubles) return fail(FMMBEM_ERR_INVALID, "chunk smaller than a shard's slice");
+    TRY(plan->alloc((size_t)world + 1, &plan->d_cut, false));
+    HIP_TRY(hipMemcpy(plan->d_cut, cut.data(), sizeof(int64_t) * cut.size(), hipMemcpyHostToDevice));
+  }
+  HIP_TRY(launch_assemble_slices(plan->d, d_slices, d_y, world, plan->d_cut, (int64_t)chunk_doubles, static_cast<hipStream_t>(stream)));
+  return FMMBEM_OK;
+}
+
 int fmmbem_plan_near_device(fmmbem_plan* plan, const double* d_x, double* d_y, void* stream) {
   if (!plan) return fail(FMMBEM_ERR_INVALID, "null plan");
   return plan->run(1, d_x, d_y, static_cast<hipStream_t>(stream), true);
@@ -895,6 +950,7 @@ int fmmbem_plan_stats(const fmmbem_plan* plan, fmmbem_stats* o) {
       const unsigned mask = plan->ev_mask[slot];
       int last = -1;
       for (int k = 0; k < NS; ++k) if (mask & (1u << k)) last = k;
+      if (mask & 4u) last = 2;                          // the delivery of the result (stage 2) is the last thing an execute does
       if (last < 0) continue;
       float f = 0;
       for (int k = 0; k < NS; ++k) {
@@ -1082,9 +1138,6 @@ int fmmbem_kernel_entries(const fmmbem_options* opts, size_t n, const double* ta
   if (stokes) {
     if (!quad_rule(opts->quad_k_fine, fine)) return fail(FMMBEM_ERR_INVALID, "invalid K_fine (valid: 1 3 4 7 13 17 19 25)");
     if (!(opts->mu > 0)) return fail(FMMBEM_ERR_INVALID, "Stokes: viscosity mu must be positive");
-    if (target_bc)
-      for (size_t i = 0; i < n; ++i)
-        if (target_bc[i]) return fail(FMMBEM_ERR_UNSUPPORTED, "Stokes: only VELOCITY targets");
   }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)

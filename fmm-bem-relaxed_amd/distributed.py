@@ -1,14 +1,17 @@
 """Multi-GPU form of the matvec: the target-leaf list is cut into contiguous shards, one per rank
 (one process per GPU); every rank builds the same tree, owns a slice of the near blocks and of the
-M2L/L2L/L2P work, and produces a result vector that is zero outside its rows.  An all-reduce(sum) of the
-N-vector over RCCL/xGMI makes the full result available on every rank (what GMRES needs for its next
-Arnoldi step).  The upward pass is either repeated by every rank (SURVEY.md section 8e as written: one
-collective per matvec) or -- shard_upward, the default -- computed by the owners of the boxes and shared
-with ONE all-gather of the multipoles (60 MB at N = 1M, p = 10) in front of M2L, overlapped with the near field.
+M2L/L2L/L2P work, and computes the result rows of its own leaves.  The rows of different shards are disjoint and,
+in tree order, contiguous, so the result is replicated by ONE all-gather of the shards' slices over RCCL/xGMI
+(N * dof * 8 bytes in total; what GMRES needs for its next Arnoldi step) followed by the un-permute to panel order --
+or, FMMBEM_Y_COLLECTIVE=allreduce, by the all-reduce(sum) of zero-padded vectors that BASELINE.json's north_star words
+(twice the bytes; the two produce the same bits).  The upward pass is either repeated by every rank (SURVEY.md section 8e
+as written: one collective per matvec) or -- shard_upward, the default -- computed by the owners of the boxes and shared
+with ONE all-gather of the multipoles (60 MB at N = 1M, p = 10) in front of M2L.
 
 The reference has no distributed code at all; this is the design of section 8(e).
 """
 import os
+import time
 
 import torch
 import torch.distributed as dist
@@ -25,7 +28,7 @@ class ShardedFMM:
     """
 
     def __init__(self, K, panels, opts=None, bc=None, p_max=None, group=None, device=None,
-                 host_only=False, local_execute=None, shard_upward=None, local_split=None):
+                 host_only=False, local_execute=None, shard_upward=None, local_split=None, y_collective=None):
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -48,6 +51,22 @@ class ShardedFMM:
         # such run should be a measurement of the plain path, not a debugging session.
         self._overlap = (self.split and dist.is_initialized() and dist.get_backend(group) == "nccl"
                          and os.environ.get("FMMBEM_OVERLAP_GATHER", "0") == "1")
+        # how y is replicated: all-gather of tree-order slices (HIP plans only) or all-reduce of zero-padded vectors
+        if y_collective is None:
+            y_collective = os.environ.get("FMMBEM_Y_COLLECTIVE", "allgather")
+        self.y_collective = "allreduce"
+        self._slices = None
+        if (y_collective == "allgather" and self.world > 1 and local_execute is None and local_split is None
+                and not host_only):
+            cut = self.plan.shard_rows(self.world)
+            self._cut = cut
+            self._chunk = int((cut[1:] - cut[:-1]).max()) * self.plan.dof
+            self.plan.set_result_slices(True)
+            self.y_collective = "allgather"
+        # instrumentation (bench.py): host-side seconds spent waiting in collectives, bytes moved per matvec
+        self.profile = False
+        self.collective_s = 0.0
+        self.calls = 0
 
     def kernel(self):
         return self.plan.kernel()
@@ -60,10 +79,49 @@ class ShardedFMM:
         s = self.plan.stats()
         return self.plan.perm()[s["owned_row_begin"]:s["owned_row_end"]]
 
+    def exchange_bytes(self, p=None):
+        """Bytes this rank RECEIVES per matvec in the two collectives: (multipole all-gather, result collective)."""
+        p = self.plan.kernel().P if p is None else p
+        up = self.plan.exchange_doubles(p) * 8 * (self.world - 1) if self.split and not self._split_fns else 0
+        nd = self.n * self.plan.dof * 8
+        if self.world == 1:
+            return 0, 0
+        if self.y_collective == "allgather":
+            return up, self._chunk * 8 * (self.world - 1)
+        return up, int(2 * nd * (self.world - 1) / self.world)          # ring all-reduce: reduce-scatter + all-gather
+
+    def _timed(self, fn, device):
+        """Run a collective; with profile on, bracket it with device syncs and add the wall time to collective_s."""
+        if not self.profile:
+            return fn()
+        if device is not None and device.type == "cuda":
+            torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        r = fn()
+        if device is not None and device.type == "cuda":
+            torch.cuda.synchronize(device)
+        self.collective_s += time.perf_counter() - t0
+        return r
+
     def execute(self, x, out=None):
         """x: full charge vector, replicated on every rank (torch tensor). Returns the full result."""
+        self.calls += 1
+        slices = self.y_collective == "allgather"
+        y = (torch.empty_like(x) if out is None else out)
+        if slices:
+            if self._slices is None:
+                self._slices = (torch.empty(self._chunk, dtype=x.dtype, device=x.device),
+                                torch.empty(self._chunk * self.world, dtype=x.dtype, device=x.device))
+            part = self._slices[0]
+        else:
+            part = y
         if not self.split:
-            y = self._local(x) if out is None else self._local(x, out=out)
+            if slices:
+                self._local(x, out=part)
+            elif out is None:
+                y = part = self._local(x)
+            else:
+                self._local(x, out=part)
         else:
             p = self.plan.kernel().P
             if p not in self._xbuf:
@@ -71,22 +129,30 @@ class ShardedFMM:
                 self._xbuf[p] = (torch.empty(per, dtype=torch.float64, device=x.device),
                                  torch.empty(per * self.world, dtype=torch.float64, device=x.device))
             send, recv = self._xbuf[p]
-            y = torch.empty_like(x) if out is None else out
             if self._split_fns:
                 self._split_fns[1](x, send)
                 dist.all_gather_into_tensor(recv, send, group=self.group)
-                self._split_fns[2](recv, y)
+                self._split_fns[2](recv, part)
             else:
                 stream = torch.cuda.current_stream(x.device).cuda_stream
                 self.plan.upward_device(x.data_ptr(), send.data_ptr(), stream, p)
                 if self._overlap:
                     # the near field (HBM-bound, needs no multipoles) streams while the multipoles travel over xGMI
                     work = dist.all_gather_into_tensor(recv, send, group=self.group, async_op=True)
-                    self.plan.near_split_device(y.data_ptr(), stream)
+                    self.plan.near_split_device(part.data_ptr(), stream)
                     work.wait()                           # RCCL: the current stream waits for the collective, the host does not
                 else:
-                    dist.all_gather_into_tensor(recv, send, group=self.group)
-                self.plan.downward_device(recv.data_ptr(), y.data_ptr(), stream, p)
+                    self._timed(lambda: dist.all_gather_into_tensor(recv, send, group=self.group), x.device)
+                self.plan.downward_device(recv.data_ptr(), part.data_ptr(), stream, p)
         if self.world > 1:
-            dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.group)
+            if slices:
+                gathered = self._slices[1]
+                self._timed(lambda: dist.all_gather_into_tensor(gathered, part, group=self.group), x.device)
+                self.plan.assemble_slices_device(gathered.data_ptr(), self._chunk, y.data_ptr(),
+                                                 torch.cuda.current_stream(x.device).cuda_stream)
+            else:
+                self._timed(lambda: dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.group), x.device)
         return y
+
+    # the solver (solver.gmres) looks for execute_torch first
+    execute_torch = execute

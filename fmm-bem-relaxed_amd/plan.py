@@ -272,6 +272,19 @@ class FMM_plan:
     def near_split_device(self, y_ptr, stream=0):
         _capi.check(_capi.lib().fmmbem_plan_near_split_device(self._h, C.c_void_p(y_ptr), C.c_void_p(stream)))
 
+    # ---- results as tree-order slices (multi-GPU all-gather instead of all-reduce, include/fmmbem.h) ----
+    def set_result_slices(self, on=True):
+        _capi.check(_capi.lib().fmmbem_plan_set_result_slices(self._h, 1 if on else 0))
+
+    def shard_rows(self, world):
+        cut = np.empty(world + 1, dtype=np.int64)
+        _capi.check(_capi.lib().fmmbem_plan_shard_rows(self._h, cut.ctypes.data_as(C.c_void_p)))
+        return cut
+
+    def assemble_slices_device(self, slices_ptr, chunk_doubles, y_ptr, stream=0):
+        _capi.check(_capi.lib().fmmbem_plan_assemble_slices_device(self._h, C.c_void_p(slices_ptr), int(chunk_doubles),
+                                                                  C.c_void_p(y_ptr), C.c_void_p(stream)))
+
     def near_device(self, x_ptr, y_ptr, stream=0):
         _capi.check(_capi.lib().fmmbem_plan_near_device(self._h, C.c_void_p(x_ptr), C.c_void_p(y_ptr), C.c_void_p(stream)))
 

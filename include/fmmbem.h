@@ -38,8 +38,11 @@ typedef enum {
 /* kernel ids: which reference Kernel class the plan stands in for */
 typedef enum {
   FMMBEM_KERNEL_LAPLACE_BEM = 0, /* kernel/LaplaceSphericalBEM.hpp: 1 unknown per panel                  */
-  FMMBEM_KERNEL_STOKES_BEM = 1   /* kernel/StokesSphericalBEM.hpp, VELOCITY boundary condition (stokeslet
-                                  * single layer): 3 unknowns per panel, x/y hold Vec<3,double> per panel  */
+  FMMBEM_KERNEL_STOKES_BEM = 1   /* kernel/StokesSphericalBEM.hpp: 3 unknowns per panel, x/y hold Vec<3,double> per panel.
+                                  * VELOCITY panels (stokeslet single layer, the operator the solve uses): everything.
+                                  * TRACTION panels (bc flag 1, eval_traction_integral :160-258): near-matrix entries,
+                                  * fmmbem_kernel_entries and the near-field evaluators (LOCAL, BLOCK_DIAGONAL); the FMM
+                                  * evaluator refuses them: the reference's traction far field disagrees with its own Direct */
 } fmmbem_kernel;
 
 /* boundary-condition flag per panel: LaplaceSphericalBEM::Panel::BoundaryType
@@ -184,6 +187,17 @@ int fmmbem_plan_downward_device(fmmbem_plan *plan, int p, const double *d_recv, 
 /* Optional, between the two: the near field of this shard (y = A_near x of the x given to upward; zero outside the owned
  * rows), so that it runs while the caller's all-gather is in flight.  downward then skips it and adds the far field. */
 int fmmbem_plan_near_split_device(fmmbem_plan *plan, double *d_y, void *stream);
+
+/* The result as a slice instead of a zero-padded vector (the shards' rows are disjoint and, in tree
+ * order, contiguous -- an all-gather moves half the bytes of the all-reduce).  With result slices enabled, every execute /
+ * downward call writes only the rows this shard owns, in TREE order, to d_y[0 .. rows * dof); the caller all-gathers the
+ * shards' slices into chunks of `chunk_doubles` (rank order; chunk >= the largest slice) and
+ * fmmbem_plan_assemble_slices_device puts them into ORIGINAL panel order: y[n_panels * dof].  The values are the ones the
+ * zero-padded form holds, bit for bit.  fmmbem_plan_shard_rows: cut[shard_world + 1], shard r owns tree rows
+ * [cut[r], cut[r+1]) (every rank builds the same tree, so every rank knows all cuts). */
+int fmmbem_plan_set_result_slices(fmmbem_plan *plan, int enabled);
+int fmmbem_plan_shard_rows(const fmmbem_plan *plan, int64_t *cut);
+int fmmbem_plan_assemble_slices_device(fmmbem_plan *plan, const double *d_slices, size_t chunk_doubles, double *d_y, void *stream);
 
 /* Multipole (which=0) or local (which=1) coefficients of the last execute for every box:
  * out[box][slot][p(p+1)/2][re,im]; Laplace: 2 slots (G, dG/dn); Stokes: 8 slots (M[2][4]). */

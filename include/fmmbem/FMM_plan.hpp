@@ -173,7 +173,8 @@ class StokesSphericalBEM {
   int p() const { return P; }
   int device = 0;
 
-  // the 3x3 block (1/2mu) int_source (I/r + d d^T/r^3) at the target centroid (:377-389, velocity targets)
+  // the 3x3 block at the target centroid (:377-389): VELOCITY target (1/2mu) int (I/r + d d^T/r^3), TRACTION target
+  // -3 int (d.n) d d^T / r^5 (self: 2 pi I)
   kernel_value_type operator()(const target_type& t, const source_type& s) const {
     fmmbem_options o;
     fmmbem_options_default(&o);
@@ -208,12 +209,12 @@ template <> struct KernelBinding<LaplaceSphericalBEM> {
   static double* out(std::vector<double>& v) { return v.data(); }
 };
 template <> struct KernelBinding<StokesSphericalBEM> {
-  static void fill(const StokesSphericalBEM& K, const FMMOptions&, fmmbem_options& o) {
+  static void fill(const StokesSphericalBEM& K, const FMMOptions& opts, fmmbem_options& o) {
     o.kernel = FMMBEM_KERNEL_STOKES_BEM;
     o.quad_k = (int)K.K;
     o.quad_k_fine = (int)K.K_fine;
     o.mu = K.Mu;
-    o.sparse_local = 1;                             // examples/StokesBEM.cpp:147 (the matrix-free evaluator is Laplace-only here)
+    o.sparse_local = opts.sparse_local ? 1 : 0;     // examples/StokesBEM.cpp:147 sets it, -disable_sparse (:197) clears it
   }
   // Vec<3,double> is three contiguous doubles: the vectors are the N x 3 arrays the C ABI expects
   static const double* in(const std::vector<Vec<3, double>>& v) { return v.data()->data(); }

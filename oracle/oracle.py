@@ -322,8 +322,11 @@ class StokesOracle(Oracle):
     """FMM_plan<StokesSphericalBEM>-equivalent on the CPU, velocity boundary condition only
     (kernel/StokesSphericalBEM.hpp:260-375, 391-432, 512-528; StokesSpherical.hpp:318-401)."""
 
-    def __init__(self, vertices, K=4, K_fine=19, mu=1e-3, theta=0.5, ncrit=64, evaluator=0, complete_l2l=False):
-        super().__init__(vertices, K=K, theta=theta, ncrit=ncrit, evaluator=evaluator, complete_l2l=complete_l2l)
+    def __init__(self, vertices, K=4, K_fine=19, mu=1e-3, theta=0.5, ncrit=64, evaluator=0, complete_l2l=False, bc=None):
+        """bc: per-panel flags, 0 VELOCITY / 1 TRACTION.  The target's flag picks the integral of a near-matrix entry
+        (StokesSphericalBEM.hpp:377-389); the far field is the velocity branch only, so matvec() refuses traction panels
+        unless the evaluator is near-field-only (1, 2)."""
+        super().__init__(vertices, bc=bc, K=K, theta=theta, ncrit=ncrit, evaluator=evaluator, complete_l2l=complete_l2l)
         if lib().orc_stokes_config(self._h, mu, K_fine):
             raise ValueError("invalid K_fine")
         self.mu = mu

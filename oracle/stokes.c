@@ -102,8 +102,41 @@ static void stokeslet_point(double res[9], double wA, const double t[3], const d
   for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) res[3*i + j] += f*((i == j ? r2 : 0.0) + d[i]*d[j]);
 }
 
-/* kernel/StokesSphericalBEM.hpp:260-375 (eval_velocity_integral) */
+/* one Gauss point of the traction (double-layer) integrand: res += w*A (d.n) d d^T / r^5, d = target - point
+ * (kernel/StokesSphericalBEM.hpp:205-225 with K_fine, :236-252 with the K stored points) */
+static void stresslet_point(double res[9], double wA, const double t[3], const double pnt[3], const double nrm[3]) {
+  double d[3] = { t[0]-pnt[0], t[1]-pnt[1], t[2]-pnt[2] };
+  double r2 = d[0]*d[0] + d[1]*d[1] + d[2]*d[2];
+  double invR2 = 1. / r2;
+  if (r2 < 1e-8) invR2 = 0;
+  double invR5 = invR2*invR2*sqrt(invR2);
+  double dn = d[0]*nrm[0] + d[1]*nrm[1] + d[2]*nrm[2];
+  double f = wA*dn*invR5;
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) res[3*i + j] += f*d[i]*d[j];
+}
+
+/* kernel/StokesSphericalBEM.hpp:160-258 (eval_traction_integral): self -> 2 pi I (:167-174); near -> K_fine rule; far -> the
+ * K stored points; times -3 (:227, :254).  No 1/(2 mu): the reference's traction kernel carries none. */
+static void stokes_traction_entry(const orc_ctx *c, const orc_panel *t, const orc_panel *s, double out[9]) {
+  double dd[3] = { t->c[0]-s->c[0], t->c[1]-s->c[1], t->c[2]-s->c[2] };
+  double d = norm3(dd);
+  memset(out, 0, sizeof(double)*9);
+  if (fabs(d) < 1e-8) { out[0] = out[4] = out[8] = 2*M_PI; return; }
+  if (sqrt(2*s->area)/d >= 0.5) {
+    for (int i = 0; i < c->nqf; ++i) {
+      double pnt[3];
+      for (int k = 0; k < 3; ++k) pnt[k] = s->v[0][k]*c->qfp[i][0] + s->v[1][k]*c->qfp[i][1] + s->v[2][k]*c->qfp[i][2];
+      stresslet_point(out, c->qfw[i]*s->area, t->c, pnt, s->n);
+    }
+  } else {
+    for (int i = 0; i < c->nq; ++i) stresslet_point(out, c->qw[i]*s->area, t->c, s->q[i], s->n);
+  }
+  for (int i = 0; i < 9; ++i) out[i] *= -3.;
+}
+
+/* kernel/StokesSphericalBEM.hpp:377-389 (operator(): the TARGET's flag picks the integral), :260-375 (eval_velocity_integral) */
 void orc_stokes_entry(const orc_ctx *c, const orc_panel *t, const orc_panel *s, double out[9]) {
+  if (t->bc) { stokes_traction_entry(c, t, s, out); return; }
   double dd[3] = { t->c[0]-s->c[0], t->c[1]-s->c[1], t->c[2]-s->c[2] };
   double d = norm3(dd);
   int self = d < 1e-8;
@@ -227,6 +260,9 @@ static void ensure_stokes_expansions(orc_ctx *c, int P) {
  * (M[1][..], zero for velocity panels).  faithful: all 8 slots are translated, as the reference does. */
 int orc_stokes_matvec(orc_ctx *c, int P, const double *x, double *y, int flags, double stage_s[8]) {
   if (P < 1 || P > ORC_PMAX) return -1;
+  /* the far field below is the VELOCITY branch only; the reference's traction far field disagrees with its own Direct sum
+   *  and is not restated: with traction panels only the near-field evaluators have an answer */
+  if (c->n_lr > 0) for (int i = 0; i < c->n; ++i) if (c->panels[i].bc) return -3;
   if (orc_stokes_build_near(c)) return -2;
   const int faithful = flags & ORC_FLAG_FAITHFUL;
   const int n = c->n, nb = c->nboxes, S = P*(P+1)/2, E = faithful ? 8 : 4;

@@ -160,3 +160,58 @@ def test_gpu_stokes_high_orders(fb, oracle_mod):
     for p in (13, 15, 16):
         K.set_p(p)
         assert rel_l2(pl.execute(x), o.matvec(x, p)) <= 1e-12
+
+
+@pytest.mark.gpu
+def test_gpu_stokes_traction_entries_and_near_field_operators(fb, oracle_mod):
+    """TRACTION targets (kernel/StokesSphericalBEM.hpp:160-258, 377-389): the 3x3 blocks -3 int (d.n) d d^T / r^5 against the
+    oracle's restatement (self 2 pi I, near K_fine, far K points), through fmmbem_kernel_entries and through the assembled
+    near matrix of the near-field-only evaluators (the operators with an answer: the FMM evaluator refuses traction panels,
+    test_gpu_stokes_rejects_traction).  The oracle's Direct sum over the same entries reproduces the double-layer identity
+    sum_j T_ij c = 4 pi c on a closed surface (12.5664)."""
+    v = oracle_mod.unit_sphere(5)
+    n = len(v)
+    bc = np.ones(n, dtype=np.uint8)
+    K = fb.StokesSphericalBEM(6, 4, 1e-3)
+    K.set_Kfine(19)
+    o = oracle_mod.StokesOracle(v, K=4, K_fine=19, mu=1e-3, bc=bc, evaluator=1)
+    rng = np.random.default_rng(13)
+    ti = np.concatenate([np.arange(30), rng.integers(0, n, 300)]).astype(np.int32)
+    sj = np.concatenate([np.arange(30), np.clip(ti[30:] + rng.integers(-40, 41, 300), 0, n - 1)]).astype(np.int32)
+    ref = o.kernel_entries(ti, sj)
+    got = fb.kernel_entries(K, v[ti], v[sj], target_bc=bc[ti])
+    assert np.max(np.abs(got - ref)) <= 1e-12 * np.max(np.abs(ref))
+    u = o.direct(np.tile([1.0, 0.0, 0.0], (n, 1)), rows=(0, 64))
+    assert np.max(np.abs(u[:, 0] - 4 * np.pi)) < 2e-2 and np.max(np.abs(u[:, 1:])) < 2e-2
+    x = drand48(3 * n, seed=8).reshape(n, 3)
+    for name, ev in (("local", 1), ("block", 2)):
+        oe = oracle_mod.StokesOracle(v, K=4, K_fine=19, mu=1e-3, bc=bc, evaluator=ev)
+        fo = fb.FMMOptions()
+        fo.lazy_evaluation = False
+        fo.local_evaluation, fo.block_diagonal = (ev == 1), (ev == 2)
+        pl = fb.FMM_plan(K, v, fo, bc=bc)
+        assert rel_l2(pl.execute(x), oe.matvec(x, 6)) <= 1e-13, name
+        oe.close()
+    # mixed flags: the target's flag picks the integral row by row
+    mixed = (np.arange(n) % 3 == 0).astype(np.uint8)
+    om = oracle_mod.StokesOracle(v, K=4, K_fine=19, mu=1e-3, bc=mixed, evaluator=1)
+    fo = fb.FMMOptions()
+    fo.lazy_evaluation, fo.local_evaluation = False, True
+    assert rel_l2(fb.FMM_plan(K, v, fo, bc=mixed).execute(x), om.matvec(x, 6)) <= 1e-13
+    om.close()
+    o.close()
+
+
+@pytest.mark.gpu
+def test_gpu_stokes_matrix_free_near_field(fb, stokes5):
+    """StokesBEM -disable_sparse (examples/StokesBEM.cpp:197; EvalInteractionLazy.hpp:239-252): the near field recomputed
+    every matvec equals the assembled one."""
+    v, o = stokes5
+    K = fb.StokesSphericalBEM(8, 4, 1e-3)
+    K.set_Kfine(19)
+    fo = fb.FMMOptions()
+    fo.sparse_local = False
+    pl = fb.FMM_plan(K, v, fo)
+    assert pl.stats()["near_bytes"] == 0
+    x = drand48(3 * o.n, seed=11).reshape(o.n, 3)
+    assert rel_l2(pl.execute(x), o.matvec(x, 8)) <= 1e-12
