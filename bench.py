@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--no-accuracy", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=45.0,
                     help="seconds of host time the cpu_baseline leg may spend on the full workload (else: quarter-size sample, extrapolated)")
+    ap.add_argument("--matrix-free", action="store_true",
+                    help="sparse_local = false: the near field recomputed every matvec (EvalInteractionLazy, SURVEY a8) "
+                         "instead of the assembled matrix; the roofline object then reports FP64 flop/s, not HBM GB/s")
     ap.add_argument("--workload", choices=["laplace", "stokes_rbc"], default="laplace",
                     help="laplace: the BASELINE metric workload (default); stokes_rbc: SURVEY 8(d) config 4 "
                          "(StokesSphericalBEM velocity BC on RedBloodCell(r), p=8, k=4, K_fine=19, mu=1e-3)")
@@ -118,6 +121,7 @@ def main():
     opts = fb.FMMOptions()
     opts.set_mac_theta(args.theta)
     opts.set_max_per_box(args.ncrit)
+    opts.sparse_local = not args.matrix_free
     t0 = time.time()
     op = fb.ShardedFMM(K, v, opts, device=local_rank)
     build_s = time.time() - t0
@@ -203,6 +207,14 @@ def main():
     m2l_flops = n_exp * st["m2l_pairs_owned"] * (2.0 * rot_fma + rot_mul) if rot_on else 0.70 * m2l_ref_flops
     m2l_tflops = m2l_flops / (st["ms_m2l"] * 1e-3) / 1e12 if st["ms_m2l"] > 0 else 0.0
 
+    if args.matrix_free:
+        # a matrix-free P2P has no meaningful HBM figure; report FP64 flop/s with its count,
+        # (3 rsqrt + 20 flop) * K per far panel pair (Laplace; the few near-regime pairs cost more and are not counted)
+        kq = 4 if stokes else 3
+        mf_flops = st["near_nnz"] * kq * 23.0 * (4 if stokes else 1)
+        mf = {"kernel": "near_matfree (P2P recomputed)", "bound": "fp64 vector + rsqrt", "achieved": mf_flops / (near_ms * 1e-3) / 1e12,
+              "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": mf_flops / (near_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+              "traffic": None, "algorithmic_flops_per_launch": mf_flops, "launch_ms": near_ms, "panel_pairs": st["near_nnz"]}
     out = {
         "metric": ("FMM matvecs/s (StokesBEM red blood cell, velocity BC) + achieved HBM GB/s on P2P" if stokes else
                    "FMM matvecs/s (LaplaceBEM sphere N=1e6 p=10) + achieved HBM GB/s on P2P"),
@@ -220,7 +232,8 @@ def main():
                                     "1 all-reduce of y per matvec"))),
                    "n_panels": n, "p": P, "near_nnz": st["near_nnz_total"], "m2l_pairs": st["m2l_pairs"],
                    "boxes": st["n_boxes"], "leaves": st["n_leaves"]},
-        "roofline": {"kernel": "near_spmv (P2P)", "bound": "hbm", "achieved": p2p_gbs, "peak": HBM_PEAK_GBS,
+        "roofline": mf if args.matrix_free else
+                    {"kernel": "near_spmv (P2P)", "bound": "hbm", "achieved": p2p_gbs, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": p2p_gbs / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": p2p_bytes, "launch_ms": near_ms,
                      "timed_launches": st["timed_executes"]},
