@@ -503,6 +503,7 @@ std::string HostPlan::build(const HostOptions& o, int64_t n_panels, const double
     }
   }
 
+  build_rot_items();
   mark("m2l csr + classes");
   // ---- panels in tree order, SoA (LaplaceSphericalBEM.hpp:64-97) ----
   PanelSoA& P = panels;
@@ -566,6 +567,43 @@ void partition_leaves(const HostPlan& hp, int world, std::vector<int>& cut) {
     while (r < world && acc >= total * r / world) cut[r++] = l + 1;
   }
   for (; r < world; ++r) cut[r] = nl;
+}
+
+// Packing of the M2L targets into 64-lane items.  A target's pairs stay together and in traversal order, so its sum -- four
+// interleaved chains over its own pair list -- does not depend on where the target lands: any packing produces the same bits
+// (and so do shards of one operator).  First fit over a window of open items, in box order: neighbouring targets, which share
+// most of their sources, stay within a few items of each other (the kernel keeps runs of items on one XCD's L2), and the
+// lane fill rises from 0.73 (next fit, what a plain cut of the CSR gives at N = 1M) to above 0.9.
+void HostPlan::build_rot_items() {
+  constexpr int kLanes = 64, kOpen = 16;
+  rot_src.clear(); rot_cls.clear(); rot_tgt.clear(); rot_empty.clear();
+  rot_item_ptr.assign(1, 0);
+  rot_passes = 0;
+  struct Bin { std::vector<int> tgt; int fill = 0; };
+  std::vector<Bin> open;
+  auto emit = [&](const Bin& bin) {
+    for (int b : bin.tgt)
+      for (int i = m2l_ptr[b]; i < m2l_ptr[b + 1]; ++i) { rot_src.push_back(m2l_src[i]); rot_cls.push_back(m2l_cls[i]); rot_tgt.push_back(b); }
+    rot_item_ptr.push_back((int)rot_src.size());
+    rot_passes += (bin.fill + kLanes - 1) / kLanes;
+  };
+  for (int b = 0; b < nboxes; ++b) {
+    if (!(has_L[b] && owned_L[b])) continue;
+    const int cnt = m2l_ptr[b + 1] - m2l_ptr[b];
+    if (cnt == 0) { rot_empty.push_back(b); continue; }
+    if (cnt >= kLanes) { Bin one; one.tgt.push_back(b); one.fill = cnt; emit(one); continue; }
+    size_t at = 0;
+    while (at < open.size() && open[at].fill + cnt > kLanes) ++at;
+    if (at == open.size()) {
+      if ((int)open.size() == kOpen) { emit(open.front()); open.erase(open.begin()); }
+      open.emplace_back();
+      at = open.size() - 1;
+    }
+    open[at].tgt.push_back(b);
+    open[at].fill += cnt;
+    if (open[at].fill == kLanes) { emit(open[at]); open.erase(open.begin() + (long)at); }
+  }
+  for (const Bin& bin : open) emit(bin);
 }
 
 }  // namespace fmmbem

@@ -102,6 +102,11 @@ struct HostPlan {
   std::vector<int> m2l_ptr;               // nboxes+1, by target box
   std::vector<int> m2l_src;               // source box
   std::vector<int> m2l_cls;               // translation class of the pair
+  // work list of the rotation M2L kernel (kernels_m2l_rot.hip): the owned pairs, whole targets packed into ITEMS of at most
+  // 64 pairs (one wavefront pass, lane = pair); a target with more than 64 sources is an item of its own (several passes)
+  std::vector<int> rot_src, rot_cls, rot_tgt, rot_item_ptr, rot_empty;   // rot_empty: owned targets with no source at all
+  int64_t rot_passes = 0;
+  void build_rot_items();
   std::vector<int32_t> m2l_class_vec;     // [class][3] integer translation (target - source), half-finest-cell units
   std::vector<int> m2l_class_rep;         // [class][2] representative (src,tgt) pair
   std::vector<int> m2m_parents;           // parents with need_M, deepest level first; m2m_level_ptr delimits levels

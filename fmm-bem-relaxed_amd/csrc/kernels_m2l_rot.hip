@@ -19,6 +19,8 @@
 #include "device_plan.hpp"
 #include "m2l_rot.hpp"
 
+#include <type_traits>
+
 namespace fmmbem {
 
 namespace {
@@ -26,11 +28,6 @@ namespace {
 constexpr int kWave = 64;
 constexpr int kTile = 8;                              // coefficients per reduction tile
 constexpr int kChains = 4;                            // partial sums per (target, coefficient)
-#ifndef FMMBEM_ROT_BATCH
-#define FMMBEM_ROT_BATCH 20
-#endif
-constexpr int kBatch = FMMBEM_ROT_BATCH;              // constants between two scheduling fences (2 SGPRs each)
-typedef __attribute__((address_space(4))) const double ConstD;      // wave-uniform constants: scalar loads
 
 #ifndef FMMBEM_ROT_XCD_CHUNK
 #define FMMBEM_ROT_XCD_CHUNK 32
@@ -44,45 +41,115 @@ __device__ __forceinline__ void wave_sync() {
 
 constexpr int idx_of(int n, int m) { return n * (n + 1) / 2 + m; }
 
-// The constants are loop-invariant: left alone, the compiler hoists all 700 scalar loads of a pass out of the pass loop and
-// spills them to VGPR lanes (5 000 v_readlane per pass at p = 10).  Forgetting the pointer's provenance at the head of
-// every block keeps each block's loads next to their uses.
-__device__ __forceinline__ ConstD* opaque(ConstD* p) {
-  uintptr_t v = reinterpret_cast<uintptr_t>(p);
-  asm volatile("" : "+s"(v));
-  return reinterpret_cast<ConstD*>(v);
+// ---- the constant stream ------------------------------------------------------------------------------------------------
+// Every FMA of the rotations and of the axial translation multiplies per-lane data by a WAVE-UNIFORM constant that is read
+// once per pass, in sequence (m2l_rot.hpp build_rot_stream).  As SGPR operands (the obvious path, measured first) hipcc
+// cannot hold them: 2 300 v_writelane + 2 300 v_readlane of spilled constants per pass at p = 10 beside 3 100 FMAs, whatever
+// the fencing.  So the constants travel in VGPRs, sixteen to a register pair -- one 8-byte load per lane, lane & 15, puts the
+// same sixteen numbers into every 16-lane row -- and the FMA takes lane k of its row as the multiplier:
+//     v_fmac_f64_dpp acc, cv, src row_newbcast:k
+// which issues at the rate of v_fma_f64 with an SGPR operand (tools/microbench/dpp64: 56.8 against 57.8 TFLOP/s).  No SGPR
+// pressure, no lane moves; kRotAhead groups are in flight, each load throttled by a data dependence on the accumulator of
+// the group that triggers it (the compiler would otherwise hoist all 110 loads of a pass to its head).
+// compile-time loop: f(std::integral_constant<int, i>) for i = B .. E-1 (the stream positions must be constant expressions:
+// they end up in the DPP control field of the instruction)
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(static_cast<F&&>(f));
+  }
 }
+#define FMMBEM_INLINE __attribute__((always_inline))
 
-// out = R in for the degree-n block, R = conj(X) (BACK = false) or X^T (BACK = true); coefficients at tab[rot_off(n) ...]
-template <int P, bool BACK>
-__device__ __forceinline__ void fixed_rotation(double (&a)[P * (P + 1) / 2], double (&b)[P * (P + 1) / 2], ConstD* tab_in) {
-#pragma unroll
-  for (int n = 1; n < P; ++n) {                       // degree 0 is the identity
-    double na[P], nb[P];
-    ConstD* tab = opaque(tab_in);
-    int ci = rot_off(n), fence_at = ci;
-#pragma unroll
-    for (int m = 0; m <= n; ++m) {
-      if (ci - fence_at >= kBatch) { __builtin_amdgcn_sched_barrier(0); fence_at = ci; }
-      double sa = 0, sb = 0;
-      bool ia = false, ib = false;                    // the first product initialises the sum
-#pragma unroll
-      for (int mp = 0; mp <= n; ++mp) {
-        if (!rot_live(n, m, mp)) continue;
-        const bool neg_back = BACK && ((m + mp) & 1);
-        const bool even = ((n + m) & 1) == 0;
-        const double src = (mp == 0 || even) ? a[idx_of(n, mp)] : b[idx_of(n, mp)];
-        const int kk = ((mp == 0 ? m : m + 3 * mp) + ((mp != 0 && !even) ? 1 : 0)) & 3;   // i^kk: 0 +Re, 1 +Im, 2 -Re, 3 -Im
-        const double c = ((kk >= 2) != neg_back) ? -tab[ci] : tab[ci];
-        ++ci;
-        if ((kk & 1) == 0) { sa = ia ? fma(c, src, sa) : c * src; ia = true; }
-        else { sb = ib ? fma(c, src, sb) : c * src; ib = true; }
-      }
-      na[m] = sa; nb[m] = sb;
+// Hazard the compiler cannot see inside the asm: a DPP source needs two wait states after a VALU write of that register
+// (wrong results from p = 8 when the constants were C++ loads that the register allocator parked in AGPRs and restored with
+// v_accvgpr_read right in front of their use).  With the loads in asm the ring is written by VMEM only and the allocator has
+// so far left it alone -- but nothing obliges it to, so the build CHECKS the generated code (tools/check_dpp_hazard.py, run
+// by the Makefile on every compile) and an order that shows the hazard is listed here to get "s_nop 1" in front of each FMA
+// (+30% M2L time at one wavefront per SIMD, where the s_nop takes an issue slot of its own).
+#ifndef FMMBEM_ROT_NOP_ORDERS
+#define FMMBEM_ROT_NOP_ORDERS 0u                      // bit p - 1
+#endif
+constexpr bool rot_needs_nop(int P) { return ((FMMBEM_ROT_NOP_ORDERS) >> (P - 1)) & 1u; }
+
+template <bool kNop>
+struct ConstFeed {
+  static constexpr int NB = kRotAhead + 1;
+  const double* base;                                 // this order's stream + (lane & 15)
+  double cv[NB];
+  // The loads are issued by hand: as plain C++ loads the compiler sinks each one to just in front of its first use
+  // ("global_load; s_waitcnt vmcnt(0); FMAs" -- a full L2 latency per sixteen FMAs, 1.2 ms of the 1.3 at p = 10).  As
+  // volatile asm they stay where they are written, kRotAhead groups ahead of their use; VMEM returns in order, so the wait in
+  // front of group g is vmcnt(kRotAhead) -- exactly the loads issued after g's.  (The compiler's own waits stay correct: more
+  // loads in flight than it counts can only make an in-order counter wait longer.)
+  // the group's address is the running pointer (moved every 32 groups) plus an immediate: as  base + 128 g  in C++ the
+  // compiler materialises, hoists and then spills a VGPR pair per group
+  static constexpr int kWindow = 32;                  // 32 groups x 128 bytes = the 12-bit immediate
+  template <int G>
+  __device__ __forceinline__ void issue() {
+    if constexpr (G % kWindow == 0 && G != 0) {
+      base += kWindow * kRotGroup;
+      asm volatile("" : "+v"(base));                  // one live pointer, not one per window
     }
+    asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=&v"(cv[G % NB]) : "v"(base), "n"((G % kWindow) * kRotGroup * 8));
+  }
+  __device__ __forceinline__ void start(const double* stream, int lane) {
+    base = stream + (lane & 15);
+    static_for<0, kRotAhead>([&](auto g) FMMBEM_INLINE { issue<decltype(g)::value>(); });
+  }
+  template <int K>
+  static __device__ __forceinline__ void dpp_fma(double& acc, double c, double src) {
+    if constexpr (kNop) asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(c), "v"(src), "n"(K));
+    else asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(c), "v"(src), "n"(K));
+  }
+  // acc += stream[E] * src; at the head of a group of sixteen: fetch the group kRotAhead further on, wait for this one
+  template <int E>
+  __device__ __forceinline__ void fma1(double& acc, double src) {
+    constexpr int g = E / kRotGroup, k = E % kRotGroup;
+    if constexpr (k == 0) {
+      issue<g + kRotAhead>();
+      asm volatile("s_waitcnt vmcnt(%1)" : "+v"(cv[g % NB]) : "n"(kRotAhead));
+    }
+    dpp_fma<k>(acc, cv[g % NB], src);
+  }
+  template <int E>
+  __device__ __forceinline__ void fma2(double& acc1, double src1, double& acc2, double src2) {   // one constant, two products
+    fma1<E>(acc1, src1);
+    constexpr int g = E / kRotGroup, k = E % kRotGroup;
+    dpp_fma<k>(acc2, cv[g % NB], src2);
+  }
+  // the loads issued past the end of the stream (into its padding) must land before their registers mean anything else
+  __device__ __forceinline__ void drain() {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(cv[0]), "+v"(cv[1]), "+v"(cv[2]), "+v"(cv[3]), "+v"(cv[4]), "+v"(cv[5]), "+v"(cv[6]),
+                 "+v"(cv[7]), "+v"(cv[8]));
+  }
+};
+static_assert(kRotAhead == 8, "ConstFeed::drain lists the ring");
+
+// out = R in for every degree-n block; STAGE picks the stream segment: conj(X) (0, 3) or X^T (1, 4), signs folded in
+template <int P, int STAGE, class Feed>
+__device__ __forceinline__ void fixed_rotation(double (&a)[P * (P + 1) / 2], double (&b)[P * (P + 1) / 2], Feed& cf) {
+  static_for<1, P>([&](auto N) FMMBEM_INLINE {         // degree 0 is the identity
+    constexpr int n = decltype(N)::value;
+    double na[P], nb[P];
+    static_for<0, n + 1>([&](auto M_) FMMBEM_INLINE {
+      constexpr int m = decltype(M_)::value;
+      double sa = 0, sb = 0;
+      static_for<0, n + 1>([&](auto Q) FMMBEM_INLINE {
+        constexpr int mp = decltype(Q)::value;
+        if constexpr (rot_live(n, m, mp)) {
+          constexpr int e = rot_stage_base(P, STAGE) + rot_index(n, m, mp);
+          constexpr bool even = ((n + m) & 1) == 0;
+          const double src = (mp == 0 || even) ? a[idx_of(n, mp)] : b[idx_of(n, mp)];
+          if constexpr ((rot_kk(n, m, mp) & 1) == 0) cf.template fma1<e>(sa, src); else cf.template fma1<e>(sb, src);
+        }
+      });
+      na[m] = sa; nb[m] = sb;
+    });
 #pragma unroll
     for (int m = 0; m <= n; ++m) { a[idx_of(n, m)] = na[m]; b[idx_of(n, m)] = nb[m]; }
-  }
+  });
 }
 
 // v[n,m] *= e^{i m g} for every degree, (c1, s1) = (cos g, sin g)
@@ -118,7 +185,6 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(rot_waves
   __shared__ double2 tile[kTile][kWave + 1];          // +1: the rows of one column sit in different banks
   __shared__ double2 carry[S];                        // a target spread over several passes
   __shared__ int seg_first[kWave + 1], seg_tgt[kWave];
-  ConstD* tab = reinterpret_cast<ConstD*>(reinterpret_cast<uintptr_t>(tab_g));
   const int lane = threadIdx.x;
   // workgroups are dealt round-robin to the 8 XCDs: keep runs of consecutive items (neighbouring targets, which share
   // sources) on one XCD's L2.  gridDim.x is a multiple of 8 * CH.
@@ -154,10 +220,13 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(rot_waves
       }
       const double* cr = d.rot_cls_rec + (size_t)cls * 8;
       const double inv_rho = cr[0], ca = cr[1], sa = cr[2], cb = cr[3], sb = cr[4];
+      ConstFeed<rot_needs_nop(P)> cf;
+#ifndef FMMBEM_ROT_EXP_NOARITH
+      cf.start(tab_g, lane);
       z_rotation<P>(a, b, cb, sb);
-      fixed_rotation<P, false>(a, b, tab);
+      fixed_rotation<P, 0>(a, b, cf);
       z_rotation<P>(a, b, ca, sa);
-      fixed_rotation<P, true>(a, b, tab);
+      fixed_rotation<P, 1>(a, b, cf);
       {                                               // M''[n,m] = rho^-n M'[n,m]
         double r = inv_rho;
 #pragma unroll
@@ -168,26 +237,23 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(rot_waves
         }
       }
       // axial translation, order by order: L'[j,k] = sum_{n>=k} Tz[j,n,k] M''[n,k]
-#pragma unroll
-      for (int k = 0; k < P; ++k) {
+      static_for<0, P>([&](auto K_) FMMBEM_INLINE {
+        constexpr int k = decltype(K_)::value;
         double la[P], lb[P];
-        ConstD* tabk = opaque(tab);
-        int ti = tz_off(P, k), fence_at = ti;
-#pragma unroll
-        for (int j = k; j < P; ++j) {
-          if (ti - fence_at >= kBatch) { __builtin_amdgcn_sched_barrier(0); fence_at = ti; }
+        static_for<k, P>([&](auto J) FMMBEM_INLINE {
+          constexpr int j = decltype(J)::value;
           double s1 = 0, s2 = 0;
-#pragma unroll
-          for (int n = k; n < P; ++n) {
-            const double t = tabk[ti++];
-            s1 = n == k ? t * a[idx_of(n, k)] : fma(t, a[idx_of(n, k)], s1);
-            if (k) s2 = n == k ? t * b[idx_of(n, k)] : fma(t, b[idx_of(n, k)], s2);
-          }
+          static_for<k, P>([&](auto N) FMMBEM_INLINE {
+            constexpr int n = decltype(N)::value;
+            constexpr int e = rot_stage_base(P, 2) + tz_index(P, k, j, n);
+            if constexpr (k != 0) cf.template fma2<e>(s1, a[idx_of(n, k)], s2, b[idx_of(n, k)]);
+            else cf.template fma1<e>(s1, a[idx_of(n, k)]);
+          });
           la[j] = s1; lb[j] = s2;
-        }
+        });
 #pragma unroll
         for (int j = k; j < P; ++j) { a[idx_of(j, k)] = la[j]; b[idx_of(j, k)] = lb[j]; }
-      }
+      });
       {                                               // L'[j,k] *= rho^-(j+1)
         double r = inv_rho;
 #pragma unroll
@@ -197,16 +263,31 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(rot_waves
           r *= inv_rho;
         }
       }
-      fixed_rotation<P, false>(a, b, tab);
+      fixed_rotation<P, 3>(a, b, cf);
       z_rotation<P>(a, b, ca, -sa);
-      fixed_rotation<P, true>(a, b, tab);
+      fixed_rotation<P, 4>(a, b, cf);
+      cf.drain();
       z_rotation<P>(a, b, cb, -sb);
+#else
+      a[0] += inv_rho + ca + sa + cb + sb;
+#endif
 
       // ---- add the lanes of each target, pair order, kChains interleaved partial sums ----
       wave_sync();                                    // segment tables written
       const bool first_pass = pb == ib, last_pass = pb + kWave >= ie;
+#ifdef FMMBEM_ROT_EXP_NOREDUCE
+      {
+        double sx = 0, sy = 0;
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
+        for (int i = 0; i < S; ++i) { sx += a[i]; sy += b[i]; }
+        if (sx == 1.2345 && sy == 5.4321) d.L[(size_t)tgt * d.nslots * d.s_max] = double2{sx, sy};
+      }
+      constexpr int NT_RUN = 0;
+#else
+      constexpr int NT_RUN = NT;
+#endif
+#pragma unroll
+      for (int t = 0; t < NT_RUN; ++t) {
 #pragma unroll
         for (int c = 0; c < kTile; ++c) {
           const int i = t * kTile + c;
@@ -267,8 +348,12 @@ hipError_t launch_m2l_rot(const DevicePlan& d, const DevicePlan* d_dev, int p, h
   const double* tab = d.rot_tab + d.rot_tab_off[p - 1];
 #define ROT_CASE(PP) case PP: hipLaunchKernelGGL((m2l_rot_kernel<PP>), dim3(grid), dim3(kWave), 0, s, d, tab); break;
   switch (p) {
+#ifdef FMMBEM_ROT_ONLY                                 // experiment builds (tools/rot_variant.sh): one order, 20 s instead of 3.5 min
+    ROT_CASE(FMMBEM_ROT_ONLY)
+#else
     ROT_CASE(1) ROT_CASE(2) ROT_CASE(3) ROT_CASE(4) ROT_CASE(5) ROT_CASE(6)
     ROT_CASE(7) ROT_CASE(8) ROT_CASE(9) ROT_CASE(10) ROT_CASE(11) ROT_CASE(12)
+#endif
     default: return hipErrorInvalidValue;
   }
 #undef ROT_CASE

@@ -93,4 +93,53 @@ inline void build_rot_table(int P, std::vector<double>& out) {
       }
 }
 
+// ---- the constants as ONE stream in the order the kernel consumes them, signs folded -------------------------------------
+//     [conj(X) rotation][X^T rotation][axial translation][conj(X) rotation][X^T rotation]
+// rotation entry (n, m, mp), rows m = 0..n, live mp = 0..n: the coefficient above times -1 where the routing phase i^kk has
+// kk >= 2, and for X^T times (-1)^{m+mp}: the kernel's FMA is always  acc += c * src.  Axial translation: Tz[j,n,k] for
+// k, then j >= k, then n >= k.  The kernel reads the stream sixteen at a time (one 8-byte load per lane, lane & 15) and
+// multiplies by lane k of every 16-lane row (v_fmac_f64_dpp row_newbcast:k); padded by kRotAhead groups for its prefetch.
+constexpr int kRotGroup = 16;
+constexpr int kRotAhead = 8;                        // groups in flight
+constexpr int rot_kk(int n, int m, int mp) {        // routing phase of entry (m, mp): 0 +Re, 1 +Im, 2 -Re, 3 -Im
+  return ((mp == 0 ? m : m + 3 * mp) + ((mp != 0 && ((n + m) & 1)) ? 1 : 0)) & 3;
+}
+// position of a constant in the stream: stage 0..4 = rotation, rotation, axial, rotation, rotation
+constexpr int rot_index(int n, int m, int mp) {     // within one rotation segment (degrees 1..P-1)
+  int c = rot_off(n) - 1;
+  for (int i = 0; i <= n; ++i)
+    for (int q = 0; q <= n; ++q) {
+      if (i == m && q == mp) return c;
+      c += rot_live(n, i, q) ? 1 : 0;
+    }
+  return c;
+}
+constexpr int tz_index(int P, int k, int j, int n) { return tz_off(P, k) - rot_off(P) + (j - k) * (P - k) + (n - k); }
+constexpr int rot_stage_base(int P, int stage) {
+  const int R = rot_off(P) - 1, T = tz_off(P, P) - rot_off(P);
+  return stage == 0 ? 0 : stage == 1 ? R : stage == 2 ? 2 * R : stage == 3 ? 2 * R + T : 3 * R + T;
+}
+constexpr int rot_stream_len(int P) { return 4 * (rot_off(P) - 1) + (tz_off(P, P) - rot_off(P)); }   // degree 0 is the identity
+constexpr int rot_stream_doubles(int P) { return ((rot_stream_len(P) + kRotGroup - 1) / kRotGroup + kRotAhead + 1) * kRotGroup; }
+
+inline void build_rot_stream(int P, std::vector<double>& out) {
+  std::vector<double> plain;
+  build_rot_table(P, plain);                        // [rotation coefficients, unsigned][Tz]
+  out.assign((size_t)rot_stream_doubles(P), 0.0);
+  size_t at = 0;
+  auto rotation = [&](bool back) {
+    size_t ci = (size_t)rot_off(1);
+    for (int n = 1; n < P; ++n)
+      for (int m = 0; m <= n; ++m)
+        for (int mp = 0; mp <= n; ++mp) {
+          if (!rot_live(n, m, mp)) continue;
+          const bool neg = (rot_kk(n, m, mp) >= 2) != (back && ((m + mp) & 1));
+          out[at++] = neg ? -plain[ci] : plain[ci];
+          ++ci;
+        }
+  };
+  auto axial = [&]() { for (int i = rot_off(P); i < tz_off(P, P); ++i) out[at++] = plain[(size_t)i]; };
+  rotation(false); rotation(true); axial(); rotation(false); rotation(true);
+}
+
 }  // namespace fmmbem

@@ -553,21 +553,10 @@ int fmmbem_plan::to_device() {
 
   // M2L by rotation (kernels_m2l_rot.hip): the owned pairs in CSR order by target, cut into items; class records; constants
   {
-    std::vector<int> rsrc, rcls, rtgt, item_ptr(1, 0), empty;
-    for (int b = 0; b < nb; ++b) {
-      if (!(hp.has_L[b] && hp.owned_L[b])) continue;
-      const int pb = hp.m2l_ptr[b], pe = hp.m2l_ptr[b + 1], cnt = pe - pb;
-      if (cnt == 0) { empty.push_back(b); continue; }
-      const int open = (int)rsrc.size() - item_ptr.back();          // pairs in the item being filled
-      if (open > 0 && open + cnt > 64) item_ptr.push_back((int)rsrc.size());
-      for (int i = pb; i < pe; ++i) { rsrc.push_back(hp.m2l_src[i]); rcls.push_back(hp.m2l_cls[i]); rtgt.push_back(b); }
-      if (cnt > 64) item_ptr.push_back((int)rsrc.size());           // a target with more than a wavefront of sources is an item of its own
-    }
-    if (item_ptr.back() != (int)rsrc.size()) item_ptr.push_back((int)rsrc.size());
-    d.n_rot_items = (int)item_ptr.size() - 1;
-    d.n_rot_empty = (int)empty.size();
-    TRY(upload(rsrc, &d.rot_src)); TRY(upload(rcls, &d.rot_cls)); TRY(upload(rtgt, &d.rot_tgt));
-    TRY(upload(item_ptr, &d.rot_item_ptr)); TRY(upload(empty, &d.rot_empty));
+    d.n_rot_items = (int)hp.rot_item_ptr.size() - 1;
+    d.n_rot_empty = (int)hp.rot_empty.size();
+    TRY(upload(hp.rot_src, &d.rot_src)); TRY(upload(hp.rot_cls, &d.rot_cls)); TRY(upload(hp.rot_tgt, &d.rot_tgt));
+    TRY(upload(hp.rot_item_ptr, &d.rot_item_ptr)); TRY(upload(hp.rot_empty, &d.rot_empty));
     std::vector<double> rec((size_t)n_classes * 8, 0.0);
     for (int64_t c = 0; c < n_classes; ++c) {
       double tr[3];
@@ -586,7 +575,7 @@ int fmmbem_plan::to_device() {
     std::vector<double> all, one;
     for (int p = 1; p <= kRotPmax; ++p) {
       d.rot_tab_off[p - 1] = (int)all.size();
-      build_rot_table(p, one);
+      build_rot_stream(p, one);
       all.insert(all.end(), one.begin(), one.end());
     }
     TRY(upload(all, &d.rot_tab));
@@ -934,6 +923,7 @@ int fmmbem_plan_stats(const fmmbem_plan* plan, fmmbem_stats* o) {
   o->owned_leaf_begin = h.leaf_begin; o->owned_leaf_end = h.leaf_end;
   o->owned_row_begin = h.row_begin; o->owned_row_end = h.row_end;
   o->near_bytes = plan->near_bytes;
+  o->m2l_items = (int64_t)h.rot_item_ptr.size() - 1; o->m2l_passes = h.rot_passes;
   o->expansions_active = (h.has_bc[0] ? 1 : 0) | (h.has_bc[1] ? 2 : 0);
   o->last_p = plan->last_p;
   o->build_host_ms = plan->build_host_ms; o->build_assemble_ms = plan->build_assemble_ms;
@@ -1008,7 +998,9 @@ int fmmbem_plan_get_pairs(const fmmbem_plan* plan, int which, int32_t* out, int6
         for (int c = h.box_child_begin[par]; c < h.box_child_end[par]; ++c) { flat.push_back(c); flat.push_back(par); }
       break;
     case 3: for (int c : h.l2l_children) { flat.push_back(h.box_parent[c]); flat.push_back(c); } break;
-    default: return fail(FMMBEM_ERR_INVALID, "which must be 0..3");
+    case 4: for (size_t i = 0; i < h.rot_src.size(); ++i) { flat.push_back(h.rot_src[i]); flat.push_back(h.rot_tgt[i]); } break;
+    case 5: for (size_t i = 0; i + 1 < h.rot_item_ptr.size(); ++i) { flat.push_back(h.rot_item_ptr[i]); flat.push_back(h.rot_item_ptr[i + 1]); } break;
+    default: return fail(FMMBEM_ERR_INVALID, "which must be 0..5");
   }
   *n = (int64_t)flat.size() / 2;
   if (out) std::memcpy(out, flat.data(), flat.size() * sizeof(int32_t));

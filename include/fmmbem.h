@@ -109,6 +109,8 @@ typedef struct {
   double  ms_total, ms_gather, ms_near, ms_scatter, ms_p2m, ms_m2m, ms_mh, ms_m2l, ms_l2l, ms_l2p;
   int64_t timed_executes;       /* how many executes the means cover                                 */
   int64_t l2l_reference_omitted;/* L2L edges FMMBEM_L2L_REFERENCE leaves out of this tree (0: the rules coincide) */
+  int64_t m2l_items, m2l_passes;/* rotation M2L: work items (one wavefront each) and 64-pair passes over them; pairs / (64 passes)
+                                 * is the lane fill                                                   */
 } fmmbem_stats;
 
 typedef struct fmmbem_plan fmmbem_plan;
@@ -154,7 +156,9 @@ int fmmbem_plan_get_perm(const fmmbem_plan *plan, uint32_t *out);
 int fmmbem_plan_get_boxes(const fmmbem_plan *plan, double *center, double *side, int32_t *level,
                           int32_t *is_leaf, int32_t *parent, int32_t *body_begin, int32_t *body_end);
 /* Pair lists; which: 0 = P2P (source leaf, target leaf), 1 = M2L (source box, target box),
- * 2 = M2M (child, parent), 3 = L2L (parent, child).  out may be NULL; returns the count via *n. */
+ * 2 = M2M (child, parent), 3 = L2L (parent, child); the work list of the rotation M2L kernel: 4 = its OWNED pairs (source
+ * box, target box) in the order the kernel takes them, 5 = its items as (first, one past last) positions in list 4.
+ * out may be NULL; returns the count via *n. */
 int fmmbem_plan_get_pairs(const fmmbem_plan *plan, int which, int32_t *out, int64_t *n);
 /* One assembled near-matrix row (tree-order index of the unknown, i.e. dof*panel + component; must be
  * owned): column indices (same numbering) and values, ascending columns.  cols/vals may be NULL; *n

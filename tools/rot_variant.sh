@@ -1,0 +1,11 @@
+#!/bin/bash
+# Experiment build of the rotation M2L kernel: tools/rot_variant.sh NAME [extra hipcc flags, e.g. -DFMMBEM_ROT_ONLY=10]
+# -> fmm-bem-relaxed_amd/variants/libfmmbem_hip_NAME.so (same ABI; select with FMMBEM_LIB=...).  Not part of the product build.
+set -e
+cd "$(dirname "$0")/../fmm-bem-relaxed_amd/csrc"
+name=$1; shift
+mkdir -p ../variants /tmp/rotvar
+/opt/rocm/bin/hipcc -std=c++17 -O3 -fPIC --offload-arch=gfx950 -mllvm -pragma-unroll-threshold=4000000 -mllvm -unroll-threshold=4000000 \
+  "$@" -c -o /tmp/rotvar/kr_$name.o kernels_m2l_rot.hip
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../variants/libfmmbem_hip_$name.so host_plan.o mesh_io.o kernels_near.o kernels_far.o kernels_m2l.o /tmp/rotvar/kr_$name.o plan.o
+echo built ../variants/libfmmbem_hip_$name.so
