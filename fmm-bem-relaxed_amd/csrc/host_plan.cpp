@@ -569,41 +569,46 @@ void partition_leaves(const HostPlan& hp, int world, std::vector<int>& cut) {
   for (; r < world; ++r) cut[r] = nl;
 }
 
-// Packing of the M2L targets into 64-lane items.  A target's pairs stay together and in traversal order, so its sum -- four
-// interleaved chains over its own pair list -- does not depend on where the target lands: any packing produces the same bits
-// (and so do shards of one operator).  First fit over a window of open items, in box order: neighbouring targets, which share
-// most of their sources, stay within a few items of each other (the kernel keeps runs of items on one XCD's L2), and the
-// lane fill rises from 0.73 (next fit, what a plain cut of the CSR gives at N = 1M) to above 0.9.
+// Work list of the rotation M2L kernel: the owned pairs in box order (a target's pairs together, traversal order), cut into
+// ITEMS -- runs of whole targets that one wavefront takes 64 pairs at a time.  A target may straddle the passes of its item
+// (the kernel carries its chain sums across, kernels_m2l_rot.hip), so the only idle lanes are those of an item's last pass:
+// each cut goes to the target boundary, among those around the nominal item length, that leaves the fewest.  Items of up to
+// kRotItemPasses passes when there are enough pairs to keep every SIMD of the chip busy several times over with them, shorter
+// ones on small operators.  Lane fill at N = 1M: 0.97 (0.73 for items of whole targets in at most one pass).
 void HostPlan::build_rot_items() {
-  constexpr int kLanes = 64, kOpen = 16;
+  constexpr int kLanes = 64, kItemsWanted = 4 * 1024;
+  int kRotItemPasses = 4;
+  if (const char* e = std::getenv("FMMBEM_ROT_ITEM_PASSES")) kRotItemPasses = std::max(1, std::atoi(e));   // tuning runs
   rot_src.clear(); rot_cls.clear(); rot_tgt.clear(); rot_empty.clear();
   rot_item_ptr.assign(1, 0);
   rot_passes = 0;
-  struct Bin { std::vector<int> tgt; int fill = 0; };
-  std::vector<Bin> open;
-  auto emit = [&](const Bin& bin) {
-    for (int b : bin.tgt)
-      for (int i = m2l_ptr[b]; i < m2l_ptr[b + 1]; ++i) { rot_src.push_back(m2l_src[i]); rot_cls.push_back(m2l_cls[i]); rot_tgt.push_back(b); }
-    rot_item_ptr.push_back((int)rot_src.size());
-    rot_passes += (bin.fill + kLanes - 1) / kLanes;
-  };
+  std::vector<int> tg;                                 // owned targets with sources, box order
   for (int b = 0; b < nboxes; ++b) {
     if (!(has_L[b] && owned_L[b])) continue;
-    const int cnt = m2l_ptr[b + 1] - m2l_ptr[b];
-    if (cnt == 0) { rot_empty.push_back(b); continue; }
-    if (cnt >= kLanes) { Bin one; one.tgt.push_back(b); one.fill = cnt; emit(one); continue; }
-    size_t at = 0;
-    while (at < open.size() && open[at].fill + cnt > kLanes) ++at;
-    if (at == open.size()) {
-      if ((int)open.size() == kOpen) { emit(open.front()); open.erase(open.begin()); }
-      open.emplace_back();
-      at = open.size() - 1;
-    }
-    open[at].tgt.push_back(b);
-    open[at].fill += cnt;
-    if (open[at].fill == kLanes) { emit(open[at]); open.erase(open.begin() + (long)at); }
+    if (m2l_ptr[b + 1] == m2l_ptr[b]) { rot_empty.push_back(b); continue; }
+    tg.push_back(b);
+    for (int i = m2l_ptr[b]; i < m2l_ptr[b + 1]; ++i) { rot_src.push_back(m2l_src[i]); rot_cls.push_back(m2l_cls[i]); rot_tgt.push_back(b); }
   }
-  for (const Bin& bin : open) emit(bin);
+  const int64_t want = (int64_t)rot_src.size() / ((int64_t)kLanes * kItemsWanted);
+  const int nominal = kLanes * (int)std::min<int64_t>(kRotItemPasses, std::max<int64_t>(1, want));
+  size_t i = 0;
+  while (i < tg.size()) {
+    // boundaries after targets i, i + 1, ...: take the one with the fewest idle lanes among the lengths in
+    // (nominal - 64, nominal + 64]; the first boundary at all if a single target is longer than that
+    int len = 0, best_len = 0, best_idle = kLanes;
+    size_t best = i, j = i;
+    while (j < tg.size()) {
+      len += m2l_ptr[tg[j] + 1] - m2l_ptr[tg[j]];
+      ++j;
+      if (len > nominal + kLanes && best > i) break;
+      const int idle = (kLanes - len % kLanes) % kLanes;
+      if (best == i || (len > nominal - kLanes && (best_len <= nominal - kLanes || idle <= best_idle))) { best = j; best_len = len; best_idle = idle; }
+      if (len > nominal + kLanes) break;
+    }
+    rot_item_ptr.push_back(rot_item_ptr.back() + best_len);
+    rot_passes += (best_len + kLanes - 1) / kLanes;
+    i = best;
+  }
 }
 
 }  // namespace fmmbem

@@ -12,10 +12,13 @@
 // The rotation and translation constants are wave-uniform: they stream through the scalar cache into SGPR operands of
 // v_fma_f64.  No LDS in the arithmetic, no barriers, no divergence; ~3 000 FMAs per pair at p = 10 (15 400 for the
 // reference's double sum, 280 x 55 in kernels_m2l.hip).
-// Reduction.  The lanes of one target are then added in pair order (four interleaved partial sums per coefficient,
-// combined in a fixed order: deterministic, and shards of one operator produce the same bits): eight coefficients at a time
-// go through a padded LDS tile [coefficient][lane]; a target spread over several passes accumulates in LDS.  Every L is
-// written exactly once -- no atomics.
+// Reduction.  The lanes of one target are then added in pair order as four interleaved chains -- chain h takes the target's
+// pairs h, h + 4, h + 8, ... one after the other -- combined (0 + 1) + (2 + 3) at the end.  An item is a run of whole
+// targets cut into passes of 64 pairs wherever they fall: a target that straddles a pass boundary carries its four chain sums
+// through LDS into the next pass and goes on adding, so the sequence of additions of a target does not depend on where in an
+// item it sits -- any cut of the list, and any shard of the operator, produces the same bits.  The coefficients go through
+// a padded LDS tile [coefficient][lane], as many at a time as the LDS share of a wavefront holds (two rounds at p = 10).
+// Every L is written exactly once -- no atomics.
 #include "device_plan.hpp"
 #include "m2l_rot.hpp"
 
@@ -26,8 +29,10 @@ namespace fmmbem {
 namespace {
 
 constexpr int kWave = 64;
-constexpr int kTile = 8;                              // coefficients per reduction tile
 constexpr int kChains = 4;                            // partial sums per (target, coefficient)
+// tile row: 64 lanes + 4.  A task group of four lanes (the chains of one coefficient) reads four consecutive double2; with
+// rows 4 double2 = 16 banks apart, the sixteen lanes that share an LDS cycle (4 coefficients x 4 chains) hit all 64 banks.
+constexpr int kRow = kWave + 4;
 
 #ifndef FMMBEM_ROT_XCD_CHUNK
 #define FMMBEM_ROT_XCD_CHUNK 32
@@ -40,6 +45,15 @@ __device__ __forceinline__ void wave_sync() {
 }
 
 constexpr int idx_of(int n, int m) { return n * (n + 1) / 2 + m; }
+
+// the value of another lane of the same quad (DPP quad_perm: 0xB1 = lanes 1 0 3 2, 0x4E = lanes 2 3 0 1): a VALU move per
+// half instead of the round trip through the LDS crossbar that __shfl_xor compiles to
+template <int CTRL>
+__device__ __forceinline__ double quad_swap(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
 
 // ---- the constant stream ------------------------------------------------------------------------------------------------
 // Every FMA of the rotations and of the axial translation multiplies per-lane data by a WAVE-UNIFORM constant that is read
@@ -65,7 +79,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 // Hazard the compiler cannot see inside the asm: a DPP source needs two wait states after a VALU write of that register
 // (wrong results from p = 8 when the constants were C++ loads that the register allocator parked in AGPRs and restored with
 // v_accvgpr_read right in front of their use).  With the loads in asm the ring is written by VMEM only and the allocator has
-// so far left it alone -- but nothing obliges it to, so the build CHECKS the generated code (tools/check_dpp_hazard.py, run
+// so far left it alone -- but nothing obliges it to, so the build CHECKS the generated code (tools/check_rot_isa.py, run
 // by the Makefile on every compile) and an order that shows the hazard is listed here to get "s_nop 1" in front of each FMA
 // (+30% M2L time at one wavefront per SIMD, where the s_nop takes an issue slot of its own).
 #ifndef FMMBEM_ROT_NOP_ORDERS
@@ -73,7 +87,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 #endif
 constexpr bool rot_needs_nop(int P) { return ((FMMBEM_ROT_NOP_ORDERS) >> (P - 1)) & 1u; }
 
-template <bool kNop>
+template <int NG, bool kNop>                          // NG: groups of sixteen in this order's stream
 struct ConstFeed {
   static constexpr int NB = kRotAhead + 1;
   const double* base;                                 // this order's stream + (lane & 15)
@@ -81,18 +95,22 @@ struct ConstFeed {
   // The loads are issued by hand: as plain C++ loads the compiler sinks each one to just in front of its first use
   // ("global_load; s_waitcnt vmcnt(0); FMAs" -- a full L2 latency per sixteen FMAs, 1.2 ms of the 1.3 at p = 10).  As
   // volatile asm they stay where they are written, kRotAhead groups ahead of their use; VMEM returns in order, so the wait in
-  // front of group g is vmcnt(kRotAhead) -- exactly the loads issued after g's.  (The compiler's own waits stay correct: more
-  // loads in flight than it counts can only make an in-order counter wait longer.)
+  // front of group g is vmcnt(number of groups issued after g) -- kRotAhead, fewer at the end of the stream: nothing is
+  // fetched past it, so the queue is empty when the last group has arrived and the kernel can put the NEXT pass's multipole
+  // loads behind it.  (The compiler's own waits stay correct: more loads in flight than it counts can only make an in-order
+  // counter wait longer.)
   // the group's address is the running pointer (moved every 32 groups) plus an immediate: as  base + 128 g  in C++ the
   // compiler materialises, hoists and then spills a VGPR pair per group
   static constexpr int kWindow = 32;                  // 32 groups x 128 bytes = the 12-bit immediate
   template <int G>
   __device__ __forceinline__ void issue() {
-    if constexpr (G % kWindow == 0 && G != 0) {
-      base += kWindow * kRotGroup;
-      asm volatile("" : "+v"(base));                  // one live pointer, not one per window
+    if constexpr (G < NG) {
+      if constexpr (G % kWindow == 0 && G != 0) {
+        base += kWindow * kRotGroup;
+        asm volatile("" : "+v"(base));                // one live pointer, not one per window
+      }
+      asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=&v"(cv[G % NB]) : "v"(base), "n"((G % kWindow) * kRotGroup * 8));
     }
-    asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=&v"(cv[G % NB]) : "v"(base), "n"((G % kWindow) * kRotGroup * 8));
   }
   __device__ __forceinline__ void start(const double* stream, int lane) {
     base = stream + (lane & 15);
@@ -109,7 +127,7 @@ struct ConstFeed {
     constexpr int g = E / kRotGroup, k = E % kRotGroup;
     if constexpr (k == 0) {
       issue<g + kRotAhead>();
-      asm volatile("s_waitcnt vmcnt(%1)" : "+v"(cv[g % NB]) : "n"(kRotAhead));
+      asm volatile("s_waitcnt vmcnt(%1)" : "+v"(cv[g % NB]) : "n"(NG - 1 - g < kRotAhead ? NG - 1 - g : kRotAhead));
     }
     dpp_fma<k>(acc, cv[g % NB], src);
   }
@@ -119,13 +137,7 @@ struct ConstFeed {
     constexpr int g = E / kRotGroup, k = E % kRotGroup;
     dpp_fma<k>(acc2, cv[g % NB], src2);
   }
-  // the loads issued past the end of the stream (into its padding) must land before their registers mean anything else
-  __device__ __forceinline__ void drain() {
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(cv[0]), "+v"(cv[1]), "+v"(cv[2]), "+v"(cv[3]), "+v"(cv[4]), "+v"(cv[5]), "+v"(cv[6]),
-                 "+v"(cv[7]), "+v"(cv[8]));
-  }
 };
-static_assert(kRotAhead == 8, "ConstFeed::drain lists the ring");
 
 // out = R in for every degree-n block; STAGE picks the stream segment: conj(X) (0, 3) or X^T (1, 4), signs folded in
 template <int P, int STAGE, class Feed>
@@ -178,13 +190,58 @@ __device__ __forceinline__ void z_rotation(double (&a)[P * (P + 1) / 2], double 
 #endif
 constexpr int rot_waves(int P) { return FMMBEM_ROT_OCC(P); }
 
+// The NEXT pass's operands, fetched while this pass is still busy.  At one wavefront per SIMD nothing hides a load: the chain
+// pair index -> source box -> 55 gathered 16-byte loads (every lane its own cache lines) + the class record cost a quarter of
+// the pass at p = 10.  The AGPRs are free once the last fixed rotation is through (the allocator parks values there during
+// the arithmetic only), the VMEM queue is empty behind the last group of constants, and the z rotation and the reduction that
+// follow use neither: the loads go out there, as asm so that they stay there, into AGPRs, and the next pass begins by waiting
+// for them and moving them over.  PF double2 of the multipole are fetched ahead (all of them up to p = 10; 60 x 4 AGPRs
+// above), the rest at the head of the pass.
+typedef double v2d __attribute__((ext_vector_type(2)));
+#ifndef FMMBEM_ROT_PF
+#define FMMBEM_ROT_PF(P) ((P) <= 9 ? 64 : (P) == 10 ? 36 : (P) == 11 ? 16 : 0)
+#endif
+constexpr int rot_prefetch(int P) { return rot_waves(P) > 1 ? 0 : (P * (P + 1) / 2 < FMMBEM_ROT_PF(P) ? P * (P + 1) / 2 : FMMBEM_ROT_PF(P)); }
+
+template <int PF>
+struct NextPass {
+  v2d m[PF > 0 ? PF : 1];                             // multipole of the lane's next pair
+  v2d r01, r23;                                       // its class record: 1/rho, cos a | sin a, cos b
+  double r4;                                          //                   sin b
+  const double2* from;
+  __device__ __forceinline__ void issue(const double2* M, const double* rec) {
+    from = M;                                         // (a member: asm operands inside a generic lambda do not capture locals)
+    static_for<0, PF>([&](auto I) FMMBEM_INLINE {
+      constexpr int i = decltype(I)::value;
+      asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=a"(m[i]) : "v"(from), "n"(i * 16));
+    });
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(r01) : "v"(rec));
+    asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=a"(r23) : "v"(rec));
+    asm volatile("global_load_dwordx2 %0, %1, off offset:32" : "=a"(r4) : "v"(rec));
+  }
+  __device__ __forceinline__ void wait() {            // everything after this in program order sees the loaded values
+    asm volatile("s_waitcnt vmcnt(0)" : "+a"(r01), "+a"(r23), "+a"(r4));
+    static_for<0, PF>([&](auto I) FMMBEM_INLINE { asm volatile("" : "+a"(m[decltype(I)::value])); });
+  }
+};
+
+// coefficients per reduction round: as many as fit the wavefront's share of the 160 KB of LDS at the occupancy asked for
+constexpr int rot_tile(int P) {
+  const int S = P * (P + 1) / 2, budget = 160 * 1024 / (4 * rot_waves(P)) - 2048;
+  for (int R = 1; R <= S; ++R) {
+    const int kt = (S + R - 1) / R;
+    if (kt * kRow * 16 + S * kChains * 16 + 1024 <= budget) return kt;
+  }
+  return 1;
+}
+
 template <int P>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(rot_waves(P), rot_waves(P)))) void m2l_rot_kernel(const DevicePlan d, const double* __restrict__ tab_g) {
   constexpr int S = P * (P + 1) / 2;
-  constexpr int NT = (S + kTile - 1) / kTile;
-  __shared__ double2 tile[kTile][kWave + 1];          // +1: the rows of one column sit in different banks
-  __shared__ double2 carry[S];                        // a target spread over several passes
-  __shared__ int seg_first[kWave + 1], seg_tgt[kWave];
+  constexpr int KT = rot_tile(P);
+  constexpr int NT = (S + KT - 1) / KT;
+  __shared__ double2 tile[KT][kRow];
+  __shared__ double2 carry[S][kChains];               // chain sums of a target that goes on in the next pass
   const int lane = threadIdx.x;
   // workgroups are dealt round-robin to the 8 XCDs: keep runs of consecutive items (neighbouring targets, which share
   // sources) on one XCD's L2.  gridDim.x is a multiple of 8 * CH.
@@ -193,34 +250,59 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(rot_waves
   const int item = (rnd / CH) * 8 * CH + xcd * CH + rnd % CH;
   if (item >= d.n_rot_items) return;
   const int ib = d.rot_item_ptr[item], ie = d.rot_item_ptr[item + 1];
-  const bool multi = ie - ib > kWave;                 // one target, several passes
 
+  constexpr int PF = rot_prefetch(P);
+  constexpr bool kAhead = rot_waves(P) == 1;          // fetch the next pass's operands ahead (NextPass); with several
+                                                      // wavefronts per SIMD the others cover the loads, and registers are scarce
   for (int q = 0; q < d.n_act; ++q) {
     const int slot = d.act[q];
+    const double2* Mslot = d.M + (size_t)slot * d.s_max;
+    const size_t box_stride = (size_t)d.nslots * d.s_max;
+    bool cont_in = false;                             // the first lane's target began in an earlier pass ...
+    int cont_q = 0;                                   // ... which took this many of its pairs
+    int pi = ib + lane < ie ? ib + lane : ie - 1;     // lanes past the end repeat the item's last pair
+    int src = d.rot_src[pi], cls = d.rot_cls[pi], tgt = d.rot_tgt[pi];
+    NextPass<PF> nx;
+    if constexpr (kAhead) nx.issue(Mslot + (size_t)src * box_stride, d.rot_cls_rec + (size_t)cls * 8);
     for (int pb = ib; pb < ie; pb += kWave) {
       const int cnt = ie - pb < kWave ? ie - pb : kWave;
       const bool live = lane < cnt;
-      const int pi = live ? pb + lane : ie - 1;
-      const int src = d.rot_src[pi], cls = d.rot_cls[pi], tgt = d.rot_tgt[pi];
-      // ---- segments (targets) of this pass ----
+      // ---- segments (targets) of this pass: bit l of smask = lane l begins a target ----
       const int prev = __shfl_up(tgt, 1, kWave);
-      const bool start = live && (lane == 0 || prev != tgt);
-      const unsigned long long smask = __ballot(start);
+      const unsigned long long smask = __ballot(live && (lane == 0 || prev != tgt));
       const int nseg = __popcll(smask);
-      const int segid = __popcll(smask & ((2ull << lane) - 1)) - 1;
-      if (start) { seg_first[segid] = lane; seg_tgt[segid] = tgt; }
-      if (lane == 0) seg_first[nseg] = cnt;
+      const int flast = 63 - __clzll(smask);          // first lane of the last segment
+      // the pairs of the next pass (the last pass reads its own again: nothing waits for that)
+      const bool more = pb + kWave < ie;
+      const int npi = more ? (pb + kWave + lane < ie ? pb + kWave + lane : ie - 1) : pi;
+      // asm: as C++ loads they would sink to their use, behind the arithmetic.  Into AGPRs: a VGPR destination the compiler,
+      // for which the asm has delivered when it is over, parks in an AGPR at once -- before the data is there
+      // (tools/check_rot_isa.py looks for exactly that in every build)
+      int nsrc, ncls, ntgt;
+      if constexpr (kAhead) {
+        asm volatile("global_load_dword %0, %1, off" : "=a"(nsrc) : "v"(d.rot_src + npi));
+        asm volatile("global_load_dword %0, %1, off" : "=a"(ncls) : "v"(d.rot_cls + npi));
+        asm volatile("global_load_dword %0, %1, off" : "=a"(ntgt) : "v"(d.rot_tgt + npi));
+      } else { nsrc = d.rot_src[npi]; ncls = d.rot_cls[npi]; ntgt = d.rot_tgt[npi]; }
 
       // ---- this lane's pair ----
       double a[S], b[S];
-      {
-        const double2* M = d.M + ((size_t)src * d.nslots + slot) * d.s_max;
+      if constexpr (PF < S) {                          // what was not fetched ahead
+        const double2* M = Mslot + (size_t)src * box_stride;
 #pragma unroll
-        for (int i = 0; i < S; ++i) { const double2 v = M[i]; a[i] = v.x; b[i] = v.y; }
+        for (int i = PF; i < S; ++i) { const double2 v = M[i]; a[i] = v.x; b[i] = v.y; }
       }
-      const double* cr = d.rot_cls_rec + (size_t)cls * 8;
-      const double inv_rho = cr[0], ca = cr[1], sa = cr[2], cb = cr[3], sb = cr[4];
-      ConstFeed<rot_needs_nop(P)> cf;
+      double inv_rho, ca, sa, cb, sb;
+      if constexpr (kAhead) {
+        nx.wait();
+#pragma unroll
+        for (int i = 0; i < PF; ++i) { a[i] = nx.m[i].x; b[i] = nx.m[i].y; }
+        inv_rho = nx.r01.x; ca = nx.r01.y; sa = nx.r23.x; cb = nx.r23.y; sb = nx.r4;
+      } else {
+        const double* cr = d.rot_cls_rec + (size_t)cls * 8;
+        inv_rho = cr[0]; ca = cr[1]; sa = cr[2]; cb = cr[3]; sb = cr[4];
+      }
+      ConstFeed<(rot_stream_len(P) + kRotGroup - 1) / kRotGroup, rot_needs_nop(P)> cf;
 #ifndef FMMBEM_ROT_EXP_NOARITH
       cf.start(tab_g, lane);
       z_rotation<P>(a, b, cb, sb);
@@ -266,15 +348,22 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(rot_waves
       fixed_rotation<P, 3>(a, b, cf);
       z_rotation<P>(a, b, ca, -sa);
       fixed_rotation<P, 4>(a, b, cf);
-      cf.drain();
+      if constexpr (kAhead) {
+        asm volatile("s_waitcnt vmcnt(0)" : "+a"(nsrc), "+a"(ncls), "+a"(ntgt));    // long since there
+        if (more) nx.issue(Mslot + (size_t)nsrc * box_stride, d.rot_cls_rec + (size_t)ncls * 8);
+      }
       z_rotation<P>(a, b, cb, -sb);
 #else
       a[0] += inv_rho + ca + sa + cb + sb;
+      if constexpr (kAhead) {
+        asm volatile("s_waitcnt vmcnt(0)" : "+a"(nsrc), "+a"(ncls), "+a"(ntgt));
+        if (more) nx.issue(Mslot + (size_t)nsrc * box_stride, d.rot_cls_rec + (size_t)ncls * 8);
+      }
 #endif
+      // does the last target go on in the next pass?  (lanes past cnt repeat the item's last pair: lane 63 is the last pair)
+      const bool cont_out = more && __builtin_amdgcn_readfirstlane(ntgt) == __shfl(tgt, kWave - 1, kWave);
 
-      // ---- add the lanes of each target, pair order, kChains interleaved partial sums ----
-      wave_sync();                                    // segment tables written
-      const bool first_pass = pb == ib, last_pass = pb + kWave >= ie;
+      // ---- add the lanes of each target: chain h of a target = its pairs h, h + 4, ... in order ----
 #ifdef FMMBEM_ROT_EXP_NOREDUCE
       {
         double sx = 0, sy = 0;
@@ -282,46 +371,73 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(rot_waves
         for (int i = 0; i < S; ++i) { sx += a[i]; sy += b[i]; }
         if (sx == 1.2345 && sy == 5.4321) d.L[(size_t)tgt * d.nslots * d.s_max] = double2{sx, sy};
       }
-      constexpr int NT_RUN = 0;
 #else
-      constexpr int NT_RUN = NT;
-#endif
+      static_for<0, NT>([&](auto T_) FMMBEM_INLINE {
+        constexpr int t = decltype(T_)::value;
+        constexpr int kt = S - t * KT < KT ? S - t * KT : KT;          // coefficients of this round
+        constexpr int NTASK = (kt * kChains + kWave - 1) / kWave;       // (coefficient, chain) tasks per lane and segment
 #pragma unroll
-      for (int t = 0; t < NT_RUN; ++t) {
-#pragma unroll
-        for (int c = 0; c < kTile; ++c) {
-          const int i = t * kTile + c;
-          if (i < S) tile[c][lane] = double2{a[i], b[i]};     // b[n,0] = 0 by construction
-        }
+        for (int c = 0; c < kt; ++c) tile[c][lane] = double2{a[t * KT + c], b[t * KT + c]};     // b[n,0] = 0 by construction
         wave_sync();
-        for (int task = lane; task < nseg * kTile * kChains; task += kWave) {
-          const int h = task & (kChains - 1), c = (task / kChains) & (kTile - 1), s = task / (kChains * kTile);
-          const int i = t * kTile + c;
-          const int f = seg_first[s], e = seg_first[s + 1];
-          double2 sum = {0, 0};
-          // at most 64 / kChains terms per chain: all loads issued, then added in order (a lane past the end adds zero)
-          double2 v[kWave / kChains];
+        // segment by segment (everything about a segment is wave-uniform: scalar registers, no tables); a lane takes NTASK
+        // tasks, all their loads are issued before the first addition
+        unsigned long long rest = smask;
+        for (int s = 0; s < nseg; ++s) {
+          const int f = __ffsll((long long)rest) - 1;
+          rest &= rest - 1;
+          const int e = rest ? __ffsll((long long)rest) - 1 : cnt;
+          const int stgt = __builtin_amdgcn_readlane(tgt, f);
+          const bool head = s == 0 && cont_in;                          // goes on from the previous pass
+          const bool tail = s == nseg - 1 && cont_out;                  // goes on in the next pass
+          const int q0 = head ? cont_q : 0;
+          double2* Ls = d.L + ((size_t)stgt * d.nslots + slot) * d.s_max + t * KT;
+          auto segment = [&](auto NU_) FMMBEM_INLINE {
+            constexpr int NU = decltype(NU_)::value;                    // terms per chain
+            double2 sum[NTASK], v[NTASK][NU];
+            bool valid[NTASK];
+            int cc[NTASK];
 #pragma unroll
-          for (int u = 0; u < kWave / kChains; ++u) {
-            const int l = f + h + u * kChains;
-            v[u] = l < e ? tile[c][l] : double2{0, 0};
-          }
+            for (int k = 0; k < NTASK; ++k) {
+              const int task = lane + k * kWave, h = task & (kChains - 1);
+              valid[k] = task < kt * kChains;
+              cc[k] = valid[k] ? task / kChains : kt - 1;
+              const int first = f + ((h - q0) & (kChains - 1));
+              sum[k] = head ? carry[t * KT + cc[k]][h] : double2{0, 0};
 #pragma unroll
-          for (int u = 0; u < kWave / kChains; ++u) { sum.x += v[u].x; sum.y += v[u].y; }
-          // chains 0..3 of one (target, coefficient) sit in four consecutive lanes: (0 + 1) + (2 + 3)
-          sum.x += __shfl_xor(sum.x, 1, kWave); sum.y += __shfl_xor(sum.y, 1, kWave);
-          sum.x += __shfl_xor(sum.x, 2, kWave); sum.y += __shfl_xor(sum.y, 2, kWave);
-          if (h == 0 && i < S) {
-            double2* L = d.L + ((size_t)seg_tgt[s] * d.nslots + slot) * d.s_max;
-            if (!multi) L[i] = sum;
-            else {
-              if (!first_pass) { const double2 old = carry[i]; sum.x += old.x; sum.y += old.y; }
-              if (last_pass) L[i] = sum; else carry[i] = sum;
+              for (int u = 0; u < NU; ++u) {
+                const int l = first + u * kChains;
+                v[k][u] = l < e ? tile[cc[k]][l] : double2{0, 0};     // a lane past the segment's end adds zero
+              }
             }
-          }
+#pragma unroll
+            for (int k = 0; k < NTASK; ++k) {
+#pragma unroll
+              for (int u = 0; u < NU; ++u) { sum[k].x += v[k][u].x; sum[k].y += v[k][u].y; }
+            }
+#pragma unroll
+            for (int k = 0; k < NTASK; ++k) {
+              const int h = lane & (kChains - 1);
+              if (tail) { if (valid[k]) carry[t * KT + cc[k]][h] = sum[k]; }      // keep the chains apart
+              else {
+                // chains 0..3 of one (target, coefficient) sit in four consecutive lanes: (0 + 1) + (2 + 3)
+                sum[k].x += quad_swap<0xB1>(sum[k].x); sum[k].y += quad_swap<0xB1>(sum[k].y);
+                sum[k].x += quad_swap<0x4E>(sum[k].x); sum[k].y += quad_swap<0x4E>(sum[k].y);
+                if (h == 0 && valid[k]) Ls[cc[k]] = sum[k];
+              }
+            }
+          };
+          const int len = e - f;
+          if (len <= 16) segment(std::integral_constant<int, 4>{});
+          else if (len <= 32) segment(std::integral_constant<int, 8>{});
+          else if (len <= 48) segment(std::integral_constant<int, 12>{});
+          else segment(std::integral_constant<int, 16>{});
         }
         wave_sync();
-      }
+      });
+#endif
+      cont_q = cont_out ? (nseg == 1 && cont_in ? cont_q : 0) + (cnt - flast) : 0;
+      cont_in = cont_out;
+      pi = npi; src = nsrc; cls = ncls; tgt = ntgt;
     }
   }
 }

@@ -101,10 +101,10 @@ def test_shards_partition_the_leaves(fb):
         assert pairs < 1.2 * full["m2l_pairs"]
 
 
-def test_rotation_m2l_work_list_packs_whole_targets():
+def test_rotation_m2l_work_list_items_are_runs_of_whole_targets():
     """The rotation M2L kernel's work list (HostPlan::build_rot_items): every owned M2L pair exactly once, a target's pairs
-    contiguous and in traversal order, items of at most 64 pairs unless they are one single target, and a lane fill well
-    above what cutting the CSR in order gives."""
+    contiguous and in traversal order, every item a run of WHOLE targets (no target is shared by two wavefronts), and few
+    idle lanes in the items' last passes."""
     import fmm_bem_relaxed_amd as fb
     v = fb.unit_sphere(5)
     K = fb.LaplaceSphericalBEM(5, 3)
@@ -131,10 +131,10 @@ def test_rotation_m2l_work_list_packs_whole_targets():
         assert got == ref
         passes = 0
         for b, e in items:
-            assert e > b and (e - b <= 64 or len(np.unique(work[b:e, 1])) == 1)
+            assert e > b
+            if b > 0:
+                assert work[b - 1, 1] != work[b, 1], "an item must begin with a new target"
             passes += (e - b + 63) // 64
         assert passes == st["m2l_passes"]
-        # two targets of 31..34 pairs share an item only when they sum to 64 or less: 0.73 on this small mesh, 0.84 - 0.89 on
-        # spheres of 32k - 131k panels; a plain in-order cut gives less
-        assert st["m2l_pairs_owned"] / (64.0 * passes) > 0.7
+        assert st["m2l_pairs_owned"] / (64.0 * passes) > 0.8
         plan.close()
