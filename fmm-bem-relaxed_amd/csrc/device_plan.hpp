@@ -150,6 +150,19 @@ hipError_t launch_mh_prep(const DevicePlan& d, int p, hipStream_t s);
 // instead of keeping them alive in SGPRs across its FMA region)
 hipError_t launch_m2l(const DevicePlan& d, const DevicePlan* d_dev, int p, hipStream_t s);
 bool m2l_rot_supported(int p);
+// One launch of the rotation kernel (kernels_m2l_rot.hip, compiled per operator): pairs (source box, class, target box) sorted by
+// target, cut into items of whole targets; class records of 8 doubles (1/rho, cos a, sin a, cos b, sin b, rho); the constant
+// stream of the operator at this order (m2l_rot.hpp).
+struct RotWork {
+  const int *src = nullptr, *cls = nullptr, *tgt = nullptr, *item_ptr = nullptr;
+  int n_items = 0;
+  const double* rec = nullptr;
+  const double* stream = nullptr;
+};
+constexpr int kShiftRotPmin = 5;                     // M2M / L2L by rotation from this order up
+bool shift_rot_supported(int p);
+hipError_t launch_m2m_rot(const DevicePlan& d, const RotWork& w, int p, hipStream_t s);   // M[tgt = parent] = sum over its children
+hipError_t launch_l2l_rot(const DevicePlan& d, const RotWork& w, int p, hipStream_t s);   // L[tgt = child] += shift of L[src = parent]
 hipError_t launch_m2l_rot(const DevicePlan& d, const DevicePlan* d_dev, int p, hipStream_t s);
 hipError_t launch_l2l_level(const DevicePlan& d, const ShiftOpDev& op, int p, int first, int count, hipStream_t s);
 hipError_t launch_l2p(const DevicePlan& d, int p, double* y, hipStream_t s);

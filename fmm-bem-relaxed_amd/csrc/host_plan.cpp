@@ -591,24 +591,35 @@ void HostPlan::build_rot_items() {
   }
   const int64_t want = (int64_t)rot_src.size() / ((int64_t)kLanes * kItemsWanted);
   const int nominal = kLanes * (int)std::min<int64_t>(kRotItemPasses, std::max<int64_t>(1, want));
+  std::vector<int> len(tg.size());
+  for (size_t i = 0; i < tg.size(); ++i) len[i] = m2l_ptr[tg[i] + 1] - m2l_ptr[tg[i]];
+  rot_item_ptr.clear();
+  rot_passes = cut_rot_items(len, nominal, 0, rot_item_ptr);
+}
+
+int64_t HostPlan::cut_rot_items(const std::vector<int>& seg_len, int nominal, int pair_base, std::vector<int>& item_ptr) {
+  constexpr int kLanes = 64;
+  int64_t passes = 0;
+  item_ptr.push_back(pair_base);
   size_t i = 0;
-  while (i < tg.size()) {
+  while (i < seg_len.size()) {
     // boundaries after targets i, i + 1, ...: take the one with the fewest idle lanes among the lengths in
     // (nominal - 64, nominal + 64]; the first boundary at all if a single target is longer than that
     int len = 0, best_len = 0, best_idle = kLanes;
     size_t best = i, j = i;
-    while (j < tg.size()) {
-      len += m2l_ptr[tg[j] + 1] - m2l_ptr[tg[j]];
+    while (j < seg_len.size()) {
+      len += seg_len[j];
       ++j;
       if (len > nominal + kLanes && best > i) break;
       const int idle = (kLanes - len % kLanes) % kLanes;
       if (best == i || (len > nominal - kLanes && (best_len <= nominal - kLanes || idle <= best_idle))) { best = j; best_len = len; best_idle = idle; }
       if (len > nominal + kLanes) break;
     }
-    rot_item_ptr.push_back(rot_item_ptr.back() + best_len);
-    rot_passes += (best_len + kLanes - 1) / kLanes;
+    item_ptr.push_back(item_ptr.back() + best_len);
+    passes += (best_len + kLanes - 1) / kLanes;
     i = best;
   }
+  return passes;
 }
 
 }  // namespace fmmbem

@@ -107,6 +107,9 @@ struct HostPlan {
   std::vector<int> rot_src, rot_cls, rot_tgt, rot_item_ptr, rot_empty;   // rot_empty: owned targets with no source at all
   int64_t rot_passes = 0;
   void build_rot_items();
+  // cut a run of targets (pairs per target in seg_len) into items of about `nominal` pairs; appends the boundaries, as
+  // positions in the pair list starting at pair_base, to item_ptr (n_items + 1 entries); returns the 64-pair passes
+  static int64_t cut_rot_items(const std::vector<int>& seg_len, int nominal, int pair_base, std::vector<int>& item_ptr);
   std::vector<int32_t> m2l_class_vec;     // [class][3] integer translation (target - source), half-finest-cell units
   std::vector<int> m2l_class_rep;         // [class][2] representative (src,tgt) pair
   std::vector<int> m2m_parents;           // parents with need_M, deepest level first; m2m_level_ptr delimits levels

@@ -28,6 +28,13 @@ namespace fmmbem {
 
 namespace {
 
+// This source is compiled three times (csrc/Makefile): FMMBEM_ROT_OP = 0 the M2L kernel, 1 the M2M and 2 the L2L of the tree
+// passes -- the same rotations around a different axial operator (m2l_rot.hpp), other source and destination arrays.
+#ifndef FMMBEM_ROT_OP
+#define FMMBEM_ROT_OP 0
+#endif
+constexpr int OP = FMMBEM_ROT_OP;
+
 constexpr int kWave = 64;
 constexpr int kChains = 4;                            // partial sums per (target, coefficient)
 // tile row: 64 lanes + 4.  A task group of four lanes (the chains of one coefficient) reads four consecutive double2; with
@@ -151,7 +158,7 @@ __device__ __forceinline__ void fixed_rotation(double (&a)[P * (P + 1) / 2], dou
       static_for<0, n + 1>([&](auto Q) FMMBEM_INLINE {
         constexpr int mp = decltype(Q)::value;
         if constexpr (rot_live(n, m, mp)) {
-          constexpr int e = rot_stage_base(P, STAGE) + rot_index(n, m, mp);
+          constexpr int e = rot_stage_base(P, STAGE, OP) + rot_index(n, m, mp);
           constexpr bool even = ((n + m) & 1) == 0;
           const double src = (mp == 0 || even) ? a[idx_of(n, mp)] : b[idx_of(n, mp)];
           if constexpr ((rot_kk(n, m, mp) & 1) == 0) cf.template fma1<e>(sa, src); else cf.template fma1<e>(sb, src);
@@ -201,13 +208,12 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 #ifndef FMMBEM_ROT_PF
 #define FMMBEM_ROT_PF(P) ((P) <= 9 ? 64 : (P) == 10 ? 36 : (P) == 11 ? 16 : 0)
 #endif
-constexpr int rot_prefetch(int P) { return rot_waves(P) > 1 ? 0 : (P * (P + 1) / 2 < FMMBEM_ROT_PF(P) ? P * (P + 1) / 2 : FMMBEM_ROT_PF(P)); }
+constexpr int rot_prefetch(int P) { return (rot_waves(P) > 1 || OP != kRotM2L) ? 0 : (P * (P + 1) / 2 < FMMBEM_ROT_PF(P) ? P * (P + 1) / 2 : FMMBEM_ROT_PF(P)); }
 
 template <int PF>
 struct NextPass {
   v2d m[PF > 0 ? PF : 1];                             // multipole of the lane's next pair
-  v2d r01, r23;                                       // its class record: 1/rho, cos a | sin a, cos b
-  double r4;                                          //                   sin b
+  v2d r01, r23, r45;                                  // its class record: 1/rho, cos a | sin a, cos b | sin b, rho
   const double2* from;
   __device__ __forceinline__ void issue(const double2* M, const double* rec) {
     from = M;                                         // (a member: asm operands inside a generic lambda do not capture locals)
@@ -217,10 +223,10 @@ struct NextPass {
     });
     asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(r01) : "v"(rec));
     asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=a"(r23) : "v"(rec));
-    asm volatile("global_load_dwordx2 %0, %1, off offset:32" : "=a"(r4) : "v"(rec));
+    asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=a"(r45) : "v"(rec));
   }
   __device__ __forceinline__ void wait() {            // everything after this in program order sees the loaded values
-    asm volatile("s_waitcnt vmcnt(0)" : "+a"(r01), "+a"(r23), "+a"(r4));
+    asm volatile("s_waitcnt vmcnt(0)" : "+a"(r01), "+a"(r23), "+a"(r45));
     static_for<0, PF>([&](auto I) FMMBEM_INLINE { asm volatile("" : "+a"(m[decltype(I)::value])); });
   }
 };
@@ -236,7 +242,7 @@ constexpr int rot_tile(int P) {
 }
 
 template <int P>
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(rot_waves(P), rot_waves(P)))) void m2l_rot_kernel(const DevicePlan d, const double* __restrict__ tab_g) {
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(rot_waves(P), rot_waves(P)))) void m2l_rot_kernel(const DevicePlan d, const RotWork w) {
   constexpr int S = P * (P + 1) / 2;
   constexpr int KT = rot_tile(P);
   constexpr int NT = (S + KT - 1) / KT;
@@ -248,22 +254,22 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(rot_waves
   constexpr int CH = FMMBEM_ROT_XCD_CHUNK;
   const int rnd = (int)(blockIdx.x >> 3), xcd = (int)(blockIdx.x & 7);
   const int item = (rnd / CH) * 8 * CH + xcd * CH + rnd % CH;
-  if (item >= d.n_rot_items) return;
-  const int ib = d.rot_item_ptr[item], ie = d.rot_item_ptr[item + 1];
+  if (item >= w.n_items) return;
+  const int ib = w.item_ptr[item], ie = w.item_ptr[item + 1];
 
   constexpr int PF = rot_prefetch(P);
-  constexpr bool kAhead = rot_waves(P) == 1;          // fetch the next pass's operands ahead (NextPass); with several
+  constexpr bool kAhead = rot_waves(P) == 1 && OP == kRotM2L;   // fetch the next pass's operands ahead (NextPass); with several
                                                       // wavefronts per SIMD the others cover the loads, and registers are scarce
   for (int q = 0; q < d.n_act; ++q) {
     const int slot = d.act[q];
-    const double2* Mslot = d.M + (size_t)slot * d.s_max;
+    const double2* Mslot = (OP == kRotL2L ? d.L : d.M) + (size_t)slot * d.s_max;      // the operand: M, or the parent's L
     const size_t box_stride = (size_t)d.nslots * d.s_max;
     bool cont_in = false;                             // the first lane's target began in an earlier pass ...
     int cont_q = 0;                                   // ... which took this many of its pairs
     int pi = ib + lane < ie ? ib + lane : ie - 1;     // lanes past the end repeat the item's last pair
-    int src = d.rot_src[pi], cls = d.rot_cls[pi], tgt = d.rot_tgt[pi];
+    int src = w.src[pi], cls = w.cls[pi], tgt = w.tgt[pi];
     NextPass<PF> nx;
-    if constexpr (kAhead) nx.issue(Mslot + (size_t)src * box_stride, d.rot_cls_rec + (size_t)cls * 8);
+    if constexpr (kAhead) nx.issue(Mslot + (size_t)src * box_stride, w.rec + (size_t)cls * 8);
     for (int pb = ib; pb < ie; pb += kWave) {
       const int cnt = ie - pb < kWave ? ie - pb : kWave;
       const bool live = lane < cnt;
@@ -280,10 +286,10 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(rot_waves
       // (tools/check_rot_isa.py looks for exactly that in every build)
       int nsrc, ncls, ntgt;
       if constexpr (kAhead) {
-        asm volatile("global_load_dword %0, %1, off" : "=a"(nsrc) : "v"(d.rot_src + npi));
-        asm volatile("global_load_dword %0, %1, off" : "=a"(ncls) : "v"(d.rot_cls + npi));
-        asm volatile("global_load_dword %0, %1, off" : "=a"(ntgt) : "v"(d.rot_tgt + npi));
-      } else { nsrc = d.rot_src[npi]; ncls = d.rot_cls[npi]; ntgt = d.rot_tgt[npi]; }
+        asm volatile("global_load_dword %0, %1, off" : "=a"(nsrc) : "v"(w.src + npi));
+        asm volatile("global_load_dword %0, %1, off" : "=a"(ncls) : "v"(w.cls + npi));
+        asm volatile("global_load_dword %0, %1, off" : "=a"(ntgt) : "v"(w.tgt + npi));
+      } else { nsrc = w.src[npi]; ncls = w.cls[npi]; ntgt = w.tgt[npi]; }
 
       // ---- this lane's pair ----
       double a[S], b[S];
@@ -292,42 +298,43 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(rot_waves
 #pragma unroll
         for (int i = PF; i < S; ++i) { const double2 v = M[i]; a[i] = v.x; b[i] = v.y; }
       }
-      double inv_rho, ca, sa, cb, sb;
+      double inv_rho, ca, sa, cb, sb, rho;
       if constexpr (kAhead) {
         nx.wait();
 #pragma unroll
         for (int i = 0; i < PF; ++i) { a[i] = nx.m[i].x; b[i] = nx.m[i].y; }
-        inv_rho = nx.r01.x; ca = nx.r01.y; sa = nx.r23.x; cb = nx.r23.y; sb = nx.r4;
+        inv_rho = nx.r01.x; ca = nx.r01.y; sa = nx.r23.x; cb = nx.r23.y; sb = nx.r45.x; rho = nx.r45.y;
       } else {
-        const double* cr = d.rot_cls_rec + (size_t)cls * 8;
-        inv_rho = cr[0]; ca = cr[1]; sa = cr[2]; cb = cr[3]; sb = cr[4];
+        const double* cr = w.rec + (size_t)cls * 8;
+        inv_rho = cr[0]; ca = cr[1]; sa = cr[2]; cb = cr[3]; sb = cr[4]; rho = cr[5];
       }
-      ConstFeed<(rot_stream_len(P) + kRotGroup - 1) / kRotGroup, rot_needs_nop(P)> cf;
+      ConstFeed<(rot_stream_len(P, OP) + kRotGroup - 1) / kRotGroup, rot_needs_nop(P)> cf;
 #ifndef FMMBEM_ROT_EXP_NOARITH
-      cf.start(tab_g, lane);
+      cf.start(w.stream, lane);
       z_rotation<P>(a, b, cb, sb);
       fixed_rotation<P, 0>(a, b, cf);
       z_rotation<P>(a, b, ca, sa);
       fixed_rotation<P, 1>(a, b, cf);
-      {                                               // M''[n,m] = rho^-n M'[n,m]
-        double r = inv_rho;
+      {                                               // M2L, M2M: M''[n,m] = rho^-n M'[n,m];  L2L: rho^n
+        const double base = OP == kRotL2L ? rho : inv_rho;
+        double r = base;
 #pragma unroll
         for (int n = 1; n < P; ++n) {
 #pragma unroll
           for (int m = 0; m <= n; ++m) { a[idx_of(n, m)] *= r; if (m) b[idx_of(n, m)] *= r; }
-          r *= inv_rho;
+          r *= base;
         }
       }
-      // axial translation, order by order: L'[j,k] = sum_{n>=k} Tz[j,n,k] M''[n,k]
+      // axial translation, order by order: out[j,k] = sum_n T[j,n,k] in[n,k], n over the operator's row (m2l_rot.hpp)
       static_for<0, P>([&](auto K_) FMMBEM_INLINE {
         constexpr int k = decltype(K_)::value;
         double la[P], lb[P];
         static_for<k, P>([&](auto J) FMMBEM_INLINE {
           constexpr int j = decltype(J)::value;
           double s1 = 0, s2 = 0;
-          static_for<k, P>([&](auto N) FMMBEM_INLINE {
+          static_for<axial_row_begin(P, OP, k, j), axial_row_end(P, OP, k, j)>([&](auto N) FMMBEM_INLINE {
             constexpr int n = decltype(N)::value;
-            constexpr int e = rot_stage_base(P, 2) + tz_index(P, k, j, n);
+            constexpr int e = rot_stage_base(P, 2, OP) + axial_index(P, OP, k, j, n);
             if constexpr (k != 0) cf.template fma2<e>(s1, a[idx_of(n, k)], s2, b[idx_of(n, k)]);
             else cf.template fma1<e>(s1, a[idx_of(n, k)]);
           });
@@ -336,13 +343,15 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(rot_waves
 #pragma unroll
         for (int j = k; j < P; ++j) { a[idx_of(j, k)] = la[j]; b[idx_of(j, k)] = lb[j]; }
       });
-      {                                               // L'[j,k] *= rho^-(j+1)
-        double r = inv_rho;
+      {                                               // M2L: L'[j,k] *= rho^-(j+1);  M2M: rho^j;  L2L: rho^-j
+        const double base = OP == kRotM2M ? rho : inv_rho;
+        double r = OP == kRotM2L ? base : 1.0;
 #pragma unroll
-        for (int j = 0; j < P; ++j) {
+        for (int j = OP == kRotM2L ? 0 : 1; j < P; ++j) {
+          if (OP != kRotM2L) r *= base;
 #pragma unroll
           for (int k = 0; k <= j; ++k) { a[idx_of(j, k)] *= r; if (k) b[idx_of(j, k)] *= r; }
-          r *= inv_rho;
+          if (OP == kRotM2L) r *= base;
         }
       }
       fixed_rotation<P, 3>(a, b, cf);
@@ -350,14 +359,14 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(rot_waves
       fixed_rotation<P, 4>(a, b, cf);
       if constexpr (kAhead) {
         asm volatile("s_waitcnt vmcnt(0)" : "+a"(nsrc), "+a"(ncls), "+a"(ntgt));    // long since there
-        if (more) nx.issue(Mslot + (size_t)nsrc * box_stride, d.rot_cls_rec + (size_t)ncls * 8);
+        if (more) nx.issue(Mslot + (size_t)nsrc * box_stride, w.rec + (size_t)ncls * 8);
       }
       z_rotation<P>(a, b, cb, -sb);
 #else
-      a[0] += inv_rho + ca + sa + cb + sb;
+      a[0] += inv_rho + ca + sa + cb + sb + rho;
       if constexpr (kAhead) {
         asm volatile("s_waitcnt vmcnt(0)" : "+a"(nsrc), "+a"(ncls), "+a"(ntgt));
-        if (more) nx.issue(Mslot + (size_t)nsrc * box_stride, d.rot_cls_rec + (size_t)ncls * 8);
+        if (more) nx.issue(Mslot + (size_t)nsrc * box_stride, w.rec + (size_t)ncls * 8);
       }
 #endif
       // does the last target go on in the next pass?  (lanes past cnt repeat the item's last pair: lane 63 is the last pair)
@@ -372,6 +381,41 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(rot_waves
         if (sx == 1.2345 && sy == 5.4321) d.L[(size_t)tgt * d.nslots * d.s_max] = double2{sx, sy};
       }
 #else
+      if constexpr (OP == kRotL2L) {
+        // every lane is a child of its own: L[child] += the shifted parent, straight from the registers (an item of the
+        // shifts is ONE pass -- plan.hip cuts them so -- and nothing is carried)
+        if (live) {
+          double2* own = d.L + ((size_t)tgt * d.nslots + slot) * d.s_max;
+#pragma unroll
+          for (int i = 0; i < S; ++i) { double2 v = own[i]; v.x += a[i]; v.y += b[i]; own[i] = v; }
+        }
+      } else if constexpr (OP == kRotM2M) {
+        // a parent has at most eight children, an item holds whole parents in one pass: lane = (parent, coefficient) adds the
+        // parent's children in the chain order of the general case -- (c0 + c4) + (c1 + c5) and so on -- eight LDS reads, no loop
+        __shared__ int seg_first[kWave + 1], seg_tgt[kWave];
+        const int segid = __popcll(smask & ((2ull << lane) - 1)) - 1;
+        if (live && (lane == 0 || prev != tgt)) { seg_first[segid] = lane; seg_tgt[segid] = tgt; }
+        if (lane == 0) seg_first[nseg] = cnt;
+        static_for<0, NT>([&](auto T_) FMMBEM_INLINE {
+          constexpr int t = decltype(T_)::value;
+          constexpr int kt = S - t * KT < KT ? S - t * KT : KT;
+#pragma unroll
+          for (int c = 0; c < kt; ++c) tile[c][lane] = double2{a[t * KT + c], b[t * KT + c]};
+          wave_sync();
+          for (int task = lane; task < nseg * kt; task += kWave) {
+            const int sg = task / kt, c = task - sg * kt;
+            const int f = seg_first[sg], e = seg_first[sg + 1];
+            double2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = f + u < e ? tile[c][f + u] : double2{0, 0};
+            double2 sum;
+            sum.x = ((v[0].x + v[4].x) + (v[1].x + v[5].x)) + ((v[2].x + v[6].x) + (v[3].x + v[7].x));
+            sum.y = ((v[0].y + v[4].y) + (v[1].y + v[5].y)) + ((v[2].y + v[6].y) + (v[3].y + v[7].y));
+            d.M[((size_t)seg_tgt[sg] * d.nslots + slot) * d.s_max + t * KT + c] = sum;
+          }
+          wave_sync();
+        });
+      } else
       static_for<0, NT>([&](auto T_) FMMBEM_INLINE {
         constexpr int t = decltype(T_)::value;
         constexpr int kt = S - t * KT < KT ? S - t * KT : KT;          // coefficients of this round
@@ -390,7 +434,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(rot_waves
           const bool head = s == 0 && cont_in;                          // goes on from the previous pass
           const bool tail = s == nseg - 1 && cont_out;                  // goes on in the next pass
           const int q0 = head ? cont_q : 0;
-          double2* Ls = d.L + ((size_t)stgt * d.nslots + slot) * d.s_max + t * KT;
+          double2* Ls = (OP == kRotM2M ? d.M : d.L) + ((size_t)stgt * d.nslots + slot) * d.s_max + t * KT;
           auto segment = [&](auto NU_) FMMBEM_INLINE {
             constexpr int NU = decltype(NU_)::value;                    // terms per chain
             double2 sum[NTASK], v[NTASK][NU];
@@ -422,7 +466,10 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(rot_waves
                 // chains 0..3 of one (target, coefficient) sit in four consecutive lanes: (0 + 1) + (2 + 3)
                 sum[k].x += quad_swap<0xB1>(sum[k].x); sum[k].y += quad_swap<0xB1>(sum[k].y);
                 sum[k].x += quad_swap<0x4E>(sum[k].x); sum[k].y += quad_swap<0x4E>(sum[k].y);
-                if (h == 0 && valid[k]) Ls[cc[k]] = sum[k];
+                if (h == 0 && valid[k]) {
+                  if constexpr (OP == kRotL2L) { const double2 own = Ls[cc[k]]; sum[k].x += own.x; sum[k].y += own.y; }   // L[child] += ...
+                  Ls[cc[k]] = sum[k];
+                }
               }
             }
           };
@@ -442,6 +489,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(rot_waves
   }
 }
 
+#if FMMBEM_ROT_OP == 0
 // boxes that hold a local expansion but have no M2L source of their own (they only inherit from the parent): L = 0
 __global__ void m2l_rot_zero_kernel(const DevicePlan d, int S) {
   const int box = d.rot_empty[blockIdx.x];
@@ -450,30 +498,47 @@ __global__ void m2l_rot_zero_kernel(const DevicePlan d, int S) {
     for (int i = threadIdx.x; i < S; i += blockDim.x) L[i] = double2{0, 0};
   }
 }
+#endif
 
-}  // namespace
-
-bool m2l_rot_supported(int p) { return p >= 1 && p <= kRotPmax; }
-
-hipError_t launch_m2l_rot(const DevicePlan& d, const DevicePlan* d_dev, int p, hipStream_t s) {
-  (void)d_dev;
-  if (d.n_rot_empty > 0) hipLaunchKernelGGL(m2l_rot_zero_kernel, dim3(d.n_rot_empty), dim3(kWave), 0, s, d, p * (p + 1) / 2);
-  if (d.n_rot_items <= 0) return hipGetLastError();
+hipError_t launch_rot(const DevicePlan& d, const RotWork& w, int p, hipStream_t s) {
+  if (w.n_items <= 0) return hipSuccess;
   constexpr int CH = FMMBEM_ROT_XCD_CHUNK;
-  const int grid = (d.n_rot_items + 8 * CH - 1) / (8 * CH) * (8 * CH);
-  const double* tab = d.rot_tab + d.rot_tab_off[p - 1];
-#define ROT_CASE(PP) case PP: hipLaunchKernelGGL((m2l_rot_kernel<PP>), dim3(grid), dim3(kWave), 0, s, d, tab); break;
+  const int grid = (w.n_items + 8 * CH - 1) / (8 * CH) * (8 * CH);
+#define ROT_CASE(PP) case PP: hipLaunchKernelGGL((m2l_rot_kernel<PP>), dim3(grid), dim3(kWave), 0, s, d, w); break;
   switch (p) {
 #ifdef FMMBEM_ROT_ONLY                                 // experiment builds (tools/rot_variant.sh): one order, 20 s instead of 3.5 min
     ROT_CASE(FMMBEM_ROT_ONLY)
-#else
+#elif FMMBEM_ROT_OP == 0
     ROT_CASE(1) ROT_CASE(2) ROT_CASE(3) ROT_CASE(4) ROT_CASE(5) ROT_CASE(6)
     ROT_CASE(7) ROT_CASE(8) ROT_CASE(9) ROT_CASE(10) ROT_CASE(11) ROT_CASE(12)
+#else                                                  // the shifts: below kShiftRotPmin the tree passes are launch-bound either way
+    ROT_CASE(5) ROT_CASE(6) ROT_CASE(7) ROT_CASE(8) ROT_CASE(9) ROT_CASE(10) ROT_CASE(11) ROT_CASE(12)
 #endif
     default: return hipErrorInvalidValue;
   }
 #undef ROT_CASE
   return hipGetLastError();
 }
+
+}  // namespace
+
+#if FMMBEM_ROT_OP == 0
+bool m2l_rot_supported(int p) { return p >= 1 && p <= kRotPmax; }
+
+hipError_t launch_m2l_rot(const DevicePlan& d, const DevicePlan* d_dev, int p, hipStream_t s) {
+  (void)d_dev;
+  if (d.n_rot_empty > 0) hipLaunchKernelGGL(m2l_rot_zero_kernel, dim3(d.n_rot_empty), dim3(kWave), 0, s, d, p * (p + 1) / 2);
+  RotWork w;
+  w.src = d.rot_src; w.cls = d.rot_cls; w.tgt = d.rot_tgt; w.item_ptr = d.rot_item_ptr; w.n_items = d.n_rot_items;
+  w.rec = d.rot_cls_rec; w.stream = d.rot_tab + d.rot_tab_off[p - 1];
+  if (hipError_t e = launch_rot(d, w, p, s); e != hipSuccess) return e;
+  return hipGetLastError();
+}
+#elif FMMBEM_ROT_OP == 1
+bool shift_rot_supported(int p) { return p >= kShiftRotPmin && p <= kRotPmax; }
+hipError_t launch_m2m_rot(const DevicePlan& d, const RotWork& w, int p, hipStream_t s) { return launch_rot(d, w, p, s); }
+#else
+hipError_t launch_l2l_rot(const DevicePlan& d, const RotWork& w, int p, hipStream_t s) { return launch_rot(d, w, p, s); }
+#endif
 
 }  // namespace fmmbem

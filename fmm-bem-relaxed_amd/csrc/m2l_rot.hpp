@@ -98,7 +98,7 @@ inline void build_rot_table(int P, std::vector<double>& out) {
 // rotation entry (n, m, mp), rows m = 0..n, live mp = 0..n: the coefficient above times -1 where the routing phase i^kk has
 // kk >= 2, and for X^T times (-1)^{m+mp}: the kernel's FMA is always  acc += c * src.  Axial translation: Tz[j,n,k] for
 // k, then j >= k, then n >= k.  The kernel reads the stream sixteen at a time (one 8-byte load per lane, lane & 15) and
-// multiplies by lane k of every 16-lane row (v_fmac_f64_dpp row_newbcast:k); padded by kRotAhead groups for its prefetch.
+// multiplies by lane k of every 16-lane row (v_fmac_f64_dpp row_newbcast:k).
 constexpr int kRotGroup = 16;
 constexpr int kRotAhead = 8;                        // groups in flight
 constexpr int rot_kk(int n, int m, int mp) {        // routing phase of entry (m, mp): 0 +Re, 1 +Im, 2 -Re, 3 -Im
@@ -114,18 +114,47 @@ constexpr int rot_index(int n, int m, int mp) {     // within one rotation segme
     }
   return c;
 }
-constexpr int tz_index(int P, int k, int j, int n) { return tz_off(P, k) - rot_off(P) + (j - k) * (P - k) + (n - k); }
-constexpr int rot_stage_base(int P, int stage) {
-  const int R = rot_off(P) - 1, T = tz_off(P, P) - rot_off(P);
+// The same factorisation serves the two shifts of the tree passes (reference: LaplaceSpherical::M2M :245-285, L2L :378-411):
+// in the frame where the translation vector is the z axis only the m = 0 harmonic of the shift survives, so
+//   M2M   M'[j,k] = sum_{n=k..j}   Tm[j,n,k] rho^(j-n) M[n,k],   Tm[j,n,k] = (-1)^(j-n) a(j-n,0) a(n,k) / a(j,k)
+//   L2L   L'[j,k] = sum_{n=j..P-1} Tl[j,n,k] rho^(n-j) L[n,k],   Tl[j,n,k] = a(n-j,0) a(j,k) / a(n,k)
+// with a(n,m) = (-1)^n / sqrt((n-m)!(n+m)!) (the reference's Anm without its 1/EPS, which cancels against the EPS the
+// operators multiply in), (rho, alpha, beta) = cart2sph(c_parent - c_child) for M2M and of (c_child - c_parent) for L2L, and
+// the rotations of M2L on either side (multipole and local coefficients transform alike).  Checked against the oracle's
+// operators to 5e-16 (tests/test_rot_operators.py).
+enum RotOp { kRotM2L = 0, kRotM2M = 1, kRotL2L = 2 };
+
+// axial block of order k: which (j, n) it holds, row by row (j), and where entry (j, n) sits in it
+constexpr int axial_row_begin(int P, int op, int k, int j) { (void)P; return op == kRotL2L ? j : k; }
+constexpr int axial_row_end(int P, int op, int k, int j) { (void)k; return op == kRotM2M ? j + 1 : P; }      // one past the last n
+constexpr int axial_block_len(int P, int op, int k) {
+  int c = 0;
+  for (int j = k; j < P; ++j) c += axial_row_end(P, op, k, j) - axial_row_begin(P, op, k, j);
+  return c;
+}
+constexpr int axial_len(int P, int op) {
+  int c = 0;
+  for (int k = 0; k < P; ++k) c += axial_block_len(P, op, k);
+  return c;
+}
+constexpr int axial_index(int P, int op, int k, int j, int n) {
+  int c = 0;
+  for (int i = 0; i < k; ++i) c += axial_block_len(P, op, i);
+  for (int jj = k; jj < j; ++jj) c += axial_row_end(P, op, k, jj) - axial_row_begin(P, op, k, jj);
+  return c + n - axial_row_begin(P, op, k, j);
+}
+constexpr int tz_index(int P, int k, int j, int n) { return axial_index(P, kRotM2L, k, j, n); }
+constexpr int rot_stage_base(int P, int stage, int op = kRotM2L) {
+  const int R = rot_off(P) - 1, T = axial_len(P, op);
   return stage == 0 ? 0 : stage == 1 ? R : stage == 2 ? 2 * R : stage == 3 ? 2 * R + T : 3 * R + T;
 }
-constexpr int rot_stream_len(int P) { return 4 * (rot_off(P) - 1) + (tz_off(P, P) - rot_off(P)); }   // degree 0 is the identity
-constexpr int rot_stream_doubles(int P) { return ((rot_stream_len(P) + kRotGroup - 1) / kRotGroup + kRotAhead + 1) * kRotGroup; }
+constexpr int rot_stream_len(int P, int op = kRotM2L) { return 4 * (rot_off(P) - 1) + axial_len(P, op); }   // degree 0 is the identity
+constexpr int rot_stream_doubles(int P, int op = kRotM2L) { return ((rot_stream_len(P, op) + kRotGroup - 1) / kRotGroup + 1) * kRotGroup; }
 
-inline void build_rot_stream(int P, std::vector<double>& out) {
+inline void build_rot_stream(int P, std::vector<double>& out, int op = kRotM2L) {
   std::vector<double> plain;
-  build_rot_table(P, plain);                        // [rotation coefficients, unsigned][Tz]
-  out.assign((size_t)rot_stream_doubles(P), 0.0);
+  build_rot_table(P, plain);                        // [rotation coefficients, unsigned][Tz of M2L]
+  out.assign((size_t)rot_stream_doubles(P, op), 0.0);
   size_t at = 0;
   auto rotation = [&](bool back) {
     size_t ci = (size_t)rot_off(1);
@@ -138,7 +167,16 @@ inline void build_rot_stream(int P, std::vector<double>& out) {
           ++ci;
         }
   };
-  auto axial = [&]() { for (int i = rot_off(P); i < tz_off(P, P); ++i) out[at++] = plain[(size_t)i]; };
+  auto fact = [](int k) { long double f = 1; for (int i = 2; i <= k; ++i) f *= i; return f; };
+  auto a = [&](int n, int m) { return ((n & 1) ? -1.0L : 1.0L) / std::sqrt(fact(n - m) * fact(n + m)); };
+  auto axial = [&]() {
+    if (op == kRotM2L) { for (int i = rot_off(P); i < tz_off(P, P); ++i) out[at++] = plain[(size_t)i]; return; }
+    for (int k = 0; k < P; ++k)
+      for (int j = k; j < P; ++j)
+        for (int n = axial_row_begin(P, op, k, j); n < axial_row_end(P, op, k, j); ++n)
+          out[at++] = op == kRotM2M ? (double)((((j - n) & 1) ? -1.0L : 1.0L) * a(j - n, 0) * a(n, k) / a(j, k))
+                                    : (double)(a(n - j, 0) * a(j, k) / a(n, k));
+  };
   rotation(false); rotation(true); axial(); rotation(false); rotation(true);
 }
 

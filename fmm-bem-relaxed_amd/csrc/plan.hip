@@ -146,6 +146,17 @@ struct fmmbem_plan {
   std::vector<void*> allocs;
   std::vector<std::pair<int, int>> m2m_launch, l2l_launch;     // (first, count) per level
   std::vector<std::pair<int, int>> m2m_shared_launch;          // sharded upward pass: parents spanning shards
+  // the same launches for the rotation kernels (kernels_m2l_rot.hip with FMMBEM_ROT_OP = 1, 2): (first item, items, pairs)
+  struct ShiftRot { int item_first = 0, n_items = 0, pairs = 0; };
+  std::vector<ShiftRot> m2m_rot, m2m_shared_rot, l2l_rot;
+  const int *up_rsrc = nullptr, *up_rcls = nullptr, *up_rtgt = nullptr, *up_ritem = nullptr;
+  const int *dn_rsrc = nullptr, *dn_rcls = nullptr, *dn_rtgt = nullptr, *dn_ritem = nullptr;
+  const double *up_rec = nullptr, *dn_rec = nullptr, *up_stream = nullptr, *dn_stream = nullptr;
+  int shift_stream_off[12] = {};
+  int shift_rot_min = 2048;                                    // pairs in a level from which the rotation kernels take it
+  bool shift_rot = true;
+  int m2m_level(int p, size_t i, bool shared, hipStream_t s);
+  int l2l_level(int p, size_t i, hipStream_t s);
   const DevicePlan* d_dev = nullptr;                            // copy of d in device memory
   bool split_upward = false;                                   // P2M/M2M sharded by owner, multipoles all-gathered by the caller
   unsigned pending_mask = 0;                                   // stages recorded by the upward half of a split execute
@@ -214,6 +225,18 @@ struct fmmbem_plan {
 };
 
 #define TRY(expr) do { int rc_ = (expr); if (rc_ != FMMBEM_OK) return rc_; } while (0)
+
+// class record of the rotation kernels: 1/rho, cos alpha, sin alpha, cos beta, sin beta, rho of a translation vector --
+// cart2sph of the reference (kernel/LaplaceSpherical.hpp:528-541): rho = |d| + EPS, alpha = acos(z / rho), and the azimuth
+// branches; kept as cosines and sines
+static void rot_record(const double tr[3], double* o) {
+  const double rho = std::sqrt(tr[0] * tr[0] + tr[1] * tr[1] + tr[2] * tr[2]) + kEps;
+  const double ca = tr[2] / rho;
+  o[0] = 1.0 / rho; o[1] = ca; o[2] = std::sqrt((1.0 - ca) * (1.0 + ca)); o[5] = rho; o[6] = o[7] = 0.0;
+  if (std::fabs(tr[0]) + std::fabs(tr[1]) < kEps) { o[3] = 1; o[4] = 0; }
+  else if (std::fabs(tr[0]) < kEps) { o[3] = 0; o[4] = tr[1] > 0 ? 1.0 : -1.0; }
+  else { const double h = 1.0 / std::sqrt(tr[0] * tr[0] + tr[1] * tr[1]); o[3] = tr[0] * h; o[4] = tr[1] * h; }
+}
 
 int fmmbem_plan::to_device() {
   int ndev = 0;
@@ -457,6 +480,7 @@ int fmmbem_plan::to_device() {
     std::vector<int> up_cls(nb, 0), down_cls(nb, 0);
     std::unordered_map<uint64_t, int> seen;
     std::vector<cplx> up_tab, down_tab, h;
+    std::vector<double> up_rec_h, dn_rec_h;              // records of the same classes for the rotation kernels
     for (int b = 1; b < nb; ++b) {
       const int par = hp.box_parent[b];
       const int32_t v[3] = {hp.box_icoord[3 * par] - hp.box_icoord[3 * b], hp.box_icoord[3 * par + 1] - hp.box_icoord[3 * b + 1],
@@ -467,6 +491,8 @@ int fmmbem_plan::to_device() {
       if (fresh) {
         double up[3], down[3];
         for (int k = 0; k < 3; ++k) { up[k] = 0.5 * hp.cell[k] * double(v[k]); down[k] = -up[k]; }
+        up_rec_h.resize(up_rec_h.size() + 8); dn_rec_h.resize(dn_rec_h.size() + 8);
+        rot_record(up, up_rec_h.data() + up_rec_h.size() - 8); rot_record(down, dn_rec_h.data() + dn_rec_h.size() - 8);
         // M2M: evalMultipole(rho, alpha, -beta) of (parent - child)   (LaplaceSpherical.hpp:253-254)
         SphHost s = cart2sph_host(up);
         harmonics(T, true, s.rho, s.alpha, -s.beta, pm, h);
@@ -487,6 +513,67 @@ int fmmbem_plan::to_device() {
       up_cls[b] = down_cls[b] = it->second;
     }
     TRY(upload(up_cls, &d.up_cls)); TRY(upload(down_cls, &d.down_cls));
+    // ---- M2M / L2L by rotation: pair lists per level launch, items, records, constant streams ----
+    {
+      TRY(upload(up_rec_h, &up_rec)); TRY(upload(dn_rec_h, &dn_rec));
+      std::vector<int> rs, rc, rt, ri, len;
+      // items of the shifts: whole targets, ONE pass (at most 64 pairs) -- the shift kernels carry nothing between passes
+      auto cut_single_pass = [](const std::vector<int>& seg_len, int pair_base, std::vector<int>& item_ptr) {
+        item_ptr.push_back(pair_base);
+        int fill = 0;
+        for (int l : seg_len) {
+          if (fill + l > 64) { item_ptr.push_back(item_ptr.back() + fill); fill = 0; }
+          fill += l;
+        }
+        if (fill > 0) item_ptr.push_back(item_ptr.back() + fill);
+      };
+      auto add_m2m = [&](const std::vector<std::pair<int, int>>& launches, std::vector<ShiftRot>& out) {
+        for (auto [first, count] : launches) {
+          ShiftRot sr;
+          sr.item_first = (int)ri.size();
+          const int base = (int)rs.size();
+          len.clear();
+          for (int i = first; i < first + count; ++i) {
+            const int par = hp.m2m_parents[i];
+            for (int c = hp.box_child_begin[par]; c < hp.box_child_end[par]; ++c) { rs.push_back(c); rc.push_back(up_cls[c]); rt.push_back(par); }
+            len.push_back(hp.box_child_end[par] - hp.box_child_begin[par]);
+          }
+          cut_single_pass(len, base, ri);
+          sr.n_items = (int)ri.size() - sr.item_first - 1;
+          sr.pairs = (int)rs.size() - base;
+          out.push_back(sr);
+        }
+      };
+      add_m2m(m2m_launch, m2m_rot);
+      add_m2m(m2m_shared_launch, m2m_shared_rot);
+      TRY(upload(rs, &up_rsrc)); TRY(upload(rc, &up_rcls)); TRY(upload(rt, &up_rtgt)); TRY(upload(ri, &up_ritem));
+      rs.clear(); rc.clear(); rt.clear(); ri.clear();
+      for (auto [first, count] : l2l_launch) {
+        ShiftRot sr;
+        sr.item_first = (int)ri.size();
+        const int base = (int)rs.size();
+        for (int i = first; i < first + count; ++i) {
+          const int c = hp.l2l_children[i];
+          rs.push_back(hp.box_parent[c]); rc.push_back(down_cls[c]); rt.push_back(c);
+        }
+        len.assign((size_t)count, 1);
+        cut_single_pass(len, base, ri);
+        sr.n_items = (int)ri.size() - sr.item_first - 1;
+        sr.pairs = count;
+        l2l_rot.push_back(sr);
+      }
+      TRY(upload(rs, &dn_rsrc)); TRY(upload(rc, &dn_rcls)); TRY(upload(rt, &dn_rtgt)); TRY(upload(ri, &dn_ritem));
+      std::vector<double> ups, dns, one;
+      for (int q = 1; q <= kRotPmax; ++q) {
+        shift_stream_off[q - 1] = (int)ups.size();
+        build_rot_stream(q, one, kRotM2M); ups.insert(ups.end(), one.begin(), one.end());
+        // both operators have the same number of axial terms: one offset table serves the two streams
+        build_rot_stream(q, one, kRotL2L); dns.insert(dns.end(), one.begin(), one.end());
+      }
+      TRY(upload(ups, &up_stream)); TRY(upload(dns, &dn_stream));
+      if (const char* e = std::getenv("FMMBEM_SHIFT_ROT")) shift_rot = std::atoi(e) != 0;
+      if (const char* e = std::getenv("FMMBEM_SHIFT_ROT_MIN")) shift_rot_min = std::atoi(e);
+    }
     const cplx *pu = nullptr, *pd = nullptr;
     TRY(upload(up_tab, &pu)); TRY(upload(down_tab, &pd));
     d.up_tab = reinterpret_cast<const double2*>(pu);
@@ -561,15 +648,7 @@ int fmmbem_plan::to_device() {
     for (int64_t c = 0; c < n_classes; ++c) {
       double tr[3];
       for (int k = 0; k < 3; ++k) tr[k] = 0.5 * hp.cell[k] * double(hp.m2l_class_vec[3 * c + k]);
-      // cart2sph of the reference (kernel/LaplaceSpherical.hpp:528-541): rho = |d| + EPS, alpha = acos(z / rho), and the
-      // azimuth branches; kept as cosines and sines
-      double* o = rec.data() + (size_t)c * 8;
-      const double rho = std::sqrt(tr[0] * tr[0] + tr[1] * tr[1] + tr[2] * tr[2]) + kEps;
-      const double ca = tr[2] / rho;
-      o[0] = 1.0 / rho; o[1] = ca; o[2] = std::sqrt((1.0 - ca) * (1.0 + ca));
-      if (std::fabs(tr[0]) + std::fabs(tr[1]) < kEps) { o[3] = 1; o[4] = 0; }
-      else if (std::fabs(tr[0]) < kEps) { o[3] = 0; o[4] = tr[1] > 0 ? 1.0 : -1.0; }
-      else { const double h = 1.0 / std::sqrt(tr[0] * tr[0] + tr[1] * tr[1]); o[3] = tr[0] * h; o[4] = tr[1] * h; }
+      rot_record(tr, rec.data() + (size_t)c * 8);
     }
     TRY(upload(rec, &d.rot_cls_rec));
     std::vector<double> all, one;
@@ -634,6 +713,32 @@ int fmmbem_plan::to_device() {
   return FMMBEM_OK;
 }
 
+// One level of the upward / downward pass: the rotation kernel where the level is big enough to fill the chip with lanes
+// (a pass of that kernel takes ~20 us at p = 10 whatever the number of lanes), the sparse-operator kernel of kernels_far.hip
+// for the few boxes near the root and below order kShiftRotPmin.
+int fmmbem_plan::m2m_level(int p, size_t i, bool shared, hipStream_t s) {
+  const auto [first, count] = shared ? m2m_shared_launch[i] : m2m_launch[i];
+  const ShiftRot& sr = shared ? m2m_shared_rot[i] : m2m_rot[i];
+  if (shift_rot && shift_rot_supported(p) && sr.pairs >= shift_rot_min) {
+    RotWork w;
+    w.src = up_rsrc; w.cls = up_rcls; w.tgt = up_rtgt; w.item_ptr = up_ritem + sr.item_first; w.n_items = sr.n_items;
+    w.rec = up_rec; w.stream = up_stream + shift_stream_off[p - 1];
+    HIP_TRY(launch_m2m_rot(d, w, p, s));
+  } else HIP_TRY(launch_m2m_level(d, up_ops[p - 1], p, first, count, s));
+  return FMMBEM_OK;
+}
+int fmmbem_plan::l2l_level(int p, size_t i, hipStream_t s) {
+  const auto [first, count] = l2l_launch[i];
+  const ShiftRot& sr = l2l_rot[i];
+  if (shift_rot && shift_rot_supported(p) && sr.pairs >= shift_rot_min) {
+    RotWork w;
+    w.src = dn_rsrc; w.cls = dn_rcls; w.tgt = dn_rtgt; w.item_ptr = dn_ritem + sr.item_first; w.n_items = sr.n_items;
+    w.rec = dn_rec; w.stream = dn_stream + shift_stream_off[p - 1];
+    HIP_TRY(launch_l2l_rot(d, w, p, s));
+  } else HIP_TRY(launch_l2l_level(d, down_ops[p - 1], p, first, count, s));
+  return FMMBEM_OK;
+}
+
 int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool near_only, int phase, double* xbuf) {
   if (!on_device) return fail(FMMBEM_ERR_NO_DEVICE, "plan was built host-only; there is no CPU execution path");
   if (p < 1 || p > hp.opt.p_max) return fail(FMMBEM_ERR_INVALID, "p outside [1, p_max]");
@@ -666,7 +771,7 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
     if (d.kernel == FMMBEM_KERNEL_STOKES_BEM) HIP_TRY(launch_p2m_stokes(d, p, s)); else HIP_TRY(launch_p2m(d, p, s));
     HIP_TRY(end(3, s));
     HIP_TRY(begin(4, s));
-    for (auto [first, count] : m2m_launch) HIP_TRY(launch_m2m_level(d, up_ops[p - 1], p, first, count, s));
+    for (size_t i = 0; i < m2m_launch.size(); ++i) TRY(m2m_level(p, i, false, s));
     HIP_TRY(launch_xch_pack(d, p, reinterpret_cast<double2*>(xbuf), s));
     HIP_TRY(end(4, s));
     pending_mask = mask;
@@ -714,13 +819,13 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
       if (d.kernel == FMMBEM_KERNEL_STOKES_BEM) HIP_TRY(launch_p2m_stokes(d, p, s)); else HIP_TRY(launch_p2m(d, p, s));
       HIP_TRY(end(3, s));
       HIP_TRY(begin(4, s));
-      for (auto [first, count] : m2m_launch) HIP_TRY(launch_m2m_level(d, up_ops[p - 1], p, first, count, s));
+      for (size_t i = 0; i < m2m_launch.size(); ++i) TRY(m2m_level(p, i, false, s));
       HIP_TRY(end(4, s));
     }
     HIP_TRY(begin(5, s));
     if (phase == 2) {                                  // the other shards' multipoles, then the boxes spanning shards
       HIP_TRY(launch_xch_unpack(d, p, reinterpret_cast<const double2*>(xbuf), s));
-      for (auto [first, count] : m2m_shared_launch) HIP_TRY(launch_m2m_level(d, up_ops[p - 1], p, first, count, s));
+      for (size_t i = 0; i < m2m_shared_launch.size(); ++i) TRY(m2m_level(p, i, true, s));
     }
     const bool rot = use_rot(p);
     if (!rot) HIP_TRY(launch_mh_prep(d, p, s));      // the rotation kernel reads M itself
@@ -735,7 +840,7 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
     if (rot) HIP_TRY(launch_m2l_rot(d, d_dev, p, s)); else HIP_TRY(launch_m2l(d, d_dev, p, s));
     HIP_TRY(end(6, s));
     HIP_TRY(begin(7, s));
-    for (auto [first, count] : l2l_launch) HIP_TRY(launch_l2l_level(d, down_ops[p - 1], p, first, count, s));
+    for (size_t i = 0; i < l2l_launch.size(); ++i) TRY(l2l_level(p, i, s));
     HIP_TRY(end(7, s));
     if (overlap) HIP_TRY(hipStreamWaitEvent(s, ev_join, 0));
     HIP_TRY(begin(8, s));

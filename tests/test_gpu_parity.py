@@ -244,3 +244,29 @@ def test_alternative_paths_match_oracle(fb, oracle_mod, monkeypatch, env):
         K.set_p(p)
         y, yo = pl.execute(x), o.matvec(x, p)
         assert np.linalg.norm(y - yo) <= 1e-12 * np.linalg.norm(yo)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("p", [5, 7, 8, 10, 12])
+def test_tree_passes_by_rotation_match_oracle(fb, oracle_mod, monkeypatch, p):
+    """M2M and L2L through the rotation kernels (kernels_m2l_rot.hip compiled with FMMBEM_ROT_OP = 1, 2).  By default only
+    levels of 2 048 pairs and more take that path, which no mesh of test size has: FMMBEM_SHIFT_ROT_MIN=0 sends every level
+    there.  Expansions and result against the oracle; mixed boundary conditions so that both expansion slots are live."""
+    monkeypatch.setenv("FMMBEM_SHIFT_ROT_MIN", "0")
+    v = np.concatenate([oracle_mod.unit_sphere(5), oracle_mod.unit_sphere(4, center=(2.5, 0.3, -0.2))])
+    rng = np.random.default_rng(11)
+    bc = (rng.random(len(v)) < 0.4).astype(np.uint8)
+    x = rng.standard_normal(len(v))
+    o = oracle_mod.Oracle(v, bc=bc)
+    K = fb.LaplaceSphericalBEM(p, 3)
+    pl = fb.FMM_plan(K, v, bc=bc)
+    y, yo = pl.execute(x), o.matvec(x, p)
+    for which in ("M", "L"):
+        got, ref = pl.expansions(which, p), o.expansions(p, which)
+        scale = np.abs(ref).max(axis=2, keepdims=True) + 1e-300
+        assert np.max(np.abs(got - ref) / scale) <= TOL_EXPANSION, which
+    assert rel_l2(y, yo) <= TOL_MATVEC
+    # the same operator as the sparse-operator kernels, to rounding
+    monkeypatch.setenv("FMMBEM_SHIFT_ROT", "0")
+    y2 = fb.FMM_plan(K, v, bc=bc).execute(x)
+    assert rel_l2(y, y2) <= 1e-14
