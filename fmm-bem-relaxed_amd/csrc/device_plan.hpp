@@ -159,7 +159,7 @@ struct RotWork {
   const double* rec = nullptr;
   const double* stream = nullptr;
 };
-constexpr int kShiftRotPmin = 5;                     // M2M / L2L by rotation from this order up
+constexpr int kShiftRotPmin = 1;                     // M2M / L2L by rotation from this order up
 bool shift_rot_supported(int p);
 hipError_t launch_m2m_rot(const DevicePlan& d, const RotWork& w, int p, hipStream_t s);   // M[tgt = parent] = sum over its children
 hipError_t launch_l2l_rot(const DevicePlan& d, const RotWork& w, int p, hipStream_t s);   // L[tgt = child] += shift of L[src = parent]

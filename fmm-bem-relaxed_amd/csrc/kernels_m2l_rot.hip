@@ -511,8 +511,9 @@ hipError_t launch_rot(const DevicePlan& d, const RotWork& w, int p, hipStream_t 
 #elif FMMBEM_ROT_OP == 0
     ROT_CASE(1) ROT_CASE(2) ROT_CASE(3) ROT_CASE(4) ROT_CASE(5) ROT_CASE(6)
     ROT_CASE(7) ROT_CASE(8) ROT_CASE(9) ROT_CASE(10) ROT_CASE(11) ROT_CASE(12)
-#else                                                  // the shifts: below kShiftRotPmin the tree passes are launch-bound either way
-    ROT_CASE(5) ROT_CASE(6) ROT_CASE(7) ROT_CASE(8) ROT_CASE(9) ROT_CASE(10) ROT_CASE(11) ROT_CASE(12)
+#else
+    ROT_CASE(1) ROT_CASE(2) ROT_CASE(3) ROT_CASE(4) ROT_CASE(5) ROT_CASE(6)
+    ROT_CASE(7) ROT_CASE(8) ROT_CASE(9) ROT_CASE(10) ROT_CASE(11) ROT_CASE(12)
 #endif
     default: return hipErrorInvalidValue;
   }
