@@ -314,6 +314,11 @@ __global__ __launch_bounds__(kWave) void p2m_table_kernel(DevicePlan d, double2*
   }
 }
 
+#ifndef FMMBEM_P2M_INFLIGHT
+#define FMMBEM_P2M_INFLIGHT 4
+#endif
+typedef double tvec2 __attribute__((ext_vector_type(2)));   // native 16-B vector (the nontemporal builtin needs it)
+
 template <int NT>
 __global__ __launch_bounds__(4 * kWave) void p2m_apply_kernel(DevicePlan d, const int P) {
   const int S = P * (P + 1) / 2, SM = d.s_max;
@@ -356,27 +361,26 @@ __global__ __launch_bounds__(4 * kWave) void p2m_apply_kernel(DevicePlan d, cons
     for (int idx = lane; idx < S; idx += kWave) {
       if (NT == 1) {
         double2 m0 = {0, 0}, m1 = {0, 0};              // G moments (POTENTIAL panels) / dG/dn moments (NORMAL_DERIV panels)
-        int r = 0;
-        constexpr int U = 4;                           // panels' records in flight (8: 0.231 against 0.214 ms at p = 10), added in panel order
-        for (; r + U <= nrows; r += U) {
+        constexpr int U = FMMBEM_P2M_INFLIGHT;         // panels' records in flight, added in panel order; the last batch of a leaf is
+                                                       // a masked one (one latency, not one per leftover panel).  The table is read
+                                                       // once per matvec and is 0.9 GB at N = 1M, p = 10: nontemporal, like the near blocks
+        for (int r = 0; r < nrows; r += U) {
           const int64_t i = row0 + r;
-          double2 t[U];
+          tvec2 t[U];
           double x[U];
           bool dn[U];
 #pragma unroll
-          for (int u = 0; u < U; ++u) { t[u] = tab[(size_t)(i + u) * SM + idx]; x[u] = d.xt[i + u]; dn[u] = d.bc[i + u] != 0; }
+          for (int u = 0; u < U; ++u) {
+            const bool ok = r + u < nrows;
+            const int64_t iu = ok ? i + u : i;
+            t[u] = ok ? __builtin_nontemporal_load(reinterpret_cast<const tvec2*>(tab + (size_t)iu * SM + idx)) : tvec2{0, 0};
+            x[u] = d.xt[iu]; dn[u] = d.bc[iu] != 0;
+          }
 #pragma unroll
           for (int u = 0; u < U; ++u) {
             if (dn[u]) { m1.x = fma(x[u], t[u].x, m1.x); m1.y = fma(x[u], t[u].y, m1.y); }
             else { m0.x = fma(x[u], t[u].x, m0.x); m0.y = fma(x[u], t[u].y, m0.y); }
           }
-        }
-        for (; r < nrows; ++r) {
-          const int64_t i = row0 + r;
-          const double2 t = tab[(size_t)i * SM + idx];
-          const double x = d.xt[i];
-          if (d.bc[i]) { m1.x = fma(x, t.x, m1.x); m1.y = fma(x, t.y, m1.y); }
-          else { m0.x = fma(x, t.x, m0.x); m0.y = fma(x, t.y, m0.y); }
         }
         for (int a = 0; a < d.n_act; ++a) {
           const int slot = a == 0 ? d.act[0] : d.act[1];
