@@ -2,16 +2,16 @@
 // Reference: LaplaceSpherical::M2L + evalLocal (kernel/LaplaceSpherical.hpp:296-329, 491-524), called once per LR_list pair
 // and expansion (executor/EvalInteractionLazySparse.hpp:269-283).  The algebra and the constant tables are in m2l_rot.hpp.
 //
-// Mapping.  The M2L pairs are kept in CSR order by target (traversal order inside a target, as the oracle sums them).  The
-// host cuts that list into ITEMS: runs of whole targets with at most 64 pairs, or one target with more.  A wavefront takes
-// an item 64 pairs at a time: lane = pair.  The lane loads its source's multipole (S complex, 16-byte loads straight from
-// M -- no rescaled copy, no mh_prep pass) and the five numbers of its translation class (1/rho, cos/sin alpha, cos/sin
-// beta), and then runs the SAME straight-line instruction stream as every other lane on its own registers:
+// Mapping.  The M2L pairs are kept in box order of their targets (traversal order inside a target, as the oracle sums them).
+// The host cuts that list into ITEMS: runs of whole targets of about 256 pairs (HostPlan::build_rot_items).  A wavefront takes
+// an item 64 pairs at a time: lane = pair.  The lane has its source's multipole (S complex, straight from M -- no rescaled
+// copy, no mh_prep pass) and the numbers of its translation class (1/rho, cos/sin alpha, cos/sin beta, rho), and runs the SAME
+// straight-line instruction stream as every other lane on its own registers:
 //     z-rotation by beta, fixed rotation, z-rotation by alpha, fixed rotation back, scale by rho^-n,
 //     axial translation, scale by rho^-(j+1), fixed rotation, z-rotation by -alpha, fixed rotation back, z-rotation by -beta
-// The rotation and translation constants are wave-uniform: they stream through the scalar cache into SGPR operands of
-// v_fma_f64.  No LDS in the arithmetic, no barriers, no divergence; ~3 000 FMAs per pair at p = 10 (15 400 for the
-// reference's double sum, 280 x 55 in kernels_m2l.hip).
+// The rotation and translation constants are wave-uniform: one stream, read sixteen at a time into a VGPR pair and applied by
+// v_fmac_f64_dpp row_newbcast (ConstFeed below).  No LDS in the arithmetic, no barriers, no divergence; ~3 000 FMAs per pair at
+// p = 10 (15 400 for the reference's double sum, 280 x 55 in kernels_m2l.hip).
 // Reduction.  The lanes of one target are then added in pair order as four interleaved chains -- chain h takes the target's
 // pairs h, h + 4, h + 8, ... one after the other -- combined (0 + 1) + (2 + 3) at the end.  An item is a run of whole
 // targets cut into passes of 64 pairs wherever they fall: a target that straddles a pass boundary carries its four chain sums
@@ -34,6 +34,14 @@ namespace {
 #define FMMBEM_ROT_OP 0
 #endif
 constexpr int OP = FMMBEM_ROT_OP;
+// one kernel name per operator, so that traces tell them apart
+#if FMMBEM_ROT_OP == 0
+#define ROT_KERNEL m2l_rot_kernel
+#elif FMMBEM_ROT_OP == 1
+#define ROT_KERNEL m2m_rot_kernel
+#else
+#define ROT_KERNEL l2l_rot_kernel
+#endif
 
 constexpr int kWave = 64;
 constexpr int kChains = 4;                            // partial sums per (target, coefficient)
@@ -70,8 +78,7 @@ __device__ __forceinline__ double quad_swap(double v) {
 // same sixteen numbers into every 16-lane row -- and the FMA takes lane k of its row as the multiplier:
 //     v_fmac_f64_dpp acc, cv, src row_newbcast:k
 // which issues at the rate of v_fma_f64 with an SGPR operand (tools/microbench/dpp64: 56.8 against 57.8 TFLOP/s).  No SGPR
-// pressure, no lane moves; kRotAhead groups are in flight, each load throttled by a data dependence on the accumulator of
-// the group that triggers it (the compiler would otherwise hoist all 110 loads of a pass to its head).
+// pressure, no lane moves; kRotAhead groups are in flight, their loads issued by hand (ConstFeed).
 // compile-time loop: f(std::integral_constant<int, i>) for i = B .. E-1 (the stream positions must be constant expressions:
 // they end up in the DPP control field of the instruction)
 template <int B, int E, class F>
@@ -242,7 +249,7 @@ constexpr int rot_tile(int P) {
 }
 
 template <int P>
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(rot_waves(P), rot_waves(P)))) void m2l_rot_kernel(const DevicePlan d, const RotWork w) {
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(rot_waves(P), rot_waves(P)))) void ROT_KERNEL(const DevicePlan d, const RotWork w) {
   constexpr int S = P * (P + 1) / 2;
   constexpr int KT = rot_tile(P);
   constexpr int NT = (S + KT - 1) / KT;
@@ -504,7 +511,7 @@ hipError_t launch_rot(const DevicePlan& d, const RotWork& w, int p, hipStream_t 
   if (w.n_items <= 0) return hipSuccess;
   constexpr int CH = FMMBEM_ROT_XCD_CHUNK;
   const int grid = (w.n_items + 8 * CH - 1) / (8 * CH) * (8 * CH);
-#define ROT_CASE(PP) case PP: hipLaunchKernelGGL((m2l_rot_kernel<PP>), dim3(grid), dim3(kWave), 0, s, d, w); break;
+#define ROT_CASE(PP) case PP: hipLaunchKernelGGL((ROT_KERNEL<PP>), dim3(grid), dim3(kWave), 0, s, d, w); break;
   switch (p) {
 #ifdef FMMBEM_ROT_ONLY                                 // experiment builds (tools/rot_variant.sh): one order, 20 s instead of 3.5 min
     ROT_CASE(FMMBEM_ROT_ONLY)

@@ -147,13 +147,13 @@ struct fmmbem_plan {
   std::vector<std::pair<int, int>> m2m_launch, l2l_launch;     // (first, count) per level
   std::vector<std::pair<int, int>> m2m_shared_launch;          // sharded upward pass: parents spanning shards
   // the same launches for the rotation kernels (kernels_m2l_rot.hip with FMMBEM_ROT_OP = 1, 2): (first item, items, pairs)
-  struct ShiftRot { int item_first = 0, n_items = 0, pairs = 0; };
+  struct ShiftRot { int item_first = 0, n_items = 0, pairs = 0, level_boxes = 0; };   // level_boxes: boxes of the child level in the WHOLE tree
   std::vector<ShiftRot> m2m_rot, m2m_shared_rot, l2l_rot;
   const int *up_rsrc = nullptr, *up_rcls = nullptr, *up_rtgt = nullptr, *up_ritem = nullptr;
   const int *dn_rsrc = nullptr, *dn_rcls = nullptr, *dn_rtgt = nullptr, *dn_ritem = nullptr;
   const double *up_rec = nullptr, *dn_rec = nullptr, *up_stream = nullptr, *dn_stream = nullptr;
   int shift_stream_off[12] = {};
-  int shift_rot_min = 2048;                                    // pairs in a level from which the rotation kernels take it
+  int shift_rot_min = 2048;                                    // boxes on a tree level from which the rotation kernels take it
   bool shift_rot = true;
   int m2m_level(int p, size_t i, bool shared, hipStream_t s);
   int l2l_level(int p, size_t i, hipStream_t s);
@@ -517,6 +517,7 @@ int fmmbem_plan::to_device() {
     {
       TRY(upload(up_rec_h, &up_rec)); TRY(upload(dn_rec_h, &dn_rec));
       std::vector<int> rs, rc, rt, ri, len;
+      auto level_boxes = [&](int l) { return l >= 0 && l < hp.nlevels ? hp.level_off[l + 1] - hp.level_off[l] : 0; };
       // items of the shifts: whole targets, ONE pass (at most 64 pairs) -- the shift kernels carry nothing between passes
       auto cut_single_pass = [](const std::vector<int>& seg_len, int pair_base, std::vector<int>& item_ptr) {
         item_ptr.push_back(pair_base);
@@ -541,6 +542,7 @@ int fmmbem_plan::to_device() {
           cut_single_pass(len, base, ri);
           sr.n_items = (int)ri.size() - sr.item_first - 1;
           sr.pairs = (int)rs.size() - base;
+          sr.level_boxes = count > 0 ? level_boxes(hp.box_level[hp.m2m_parents[first]] + 1) : 0;
           out.push_back(sr);
         }
       };
@@ -560,6 +562,7 @@ int fmmbem_plan::to_device() {
         cut_single_pass(len, base, ri);
         sr.n_items = (int)ri.size() - sr.item_first - 1;
         sr.pairs = count;
+        sr.level_boxes = count > 0 ? level_boxes(hp.box_level[hp.l2l_children[first]]) : 0;
         l2l_rot.push_back(sr);
       }
       TRY(upload(rs, &dn_rsrc)); TRY(upload(rc, &dn_rcls)); TRY(upload(rt, &dn_rtgt)); TRY(upload(ri, &dn_ritem));
@@ -715,11 +718,12 @@ int fmmbem_plan::to_device() {
 
 // One level of the upward / downward pass: the rotation kernel where the level is big enough to fill the chip with lanes
 // (a pass of that kernel takes ~20 us at p = 10 whatever the number of lanes), the sparse-operator kernel of kernels_far.hip
-// for the few boxes near the root and below order kShiftRotPmin.
+// for the few boxes near the root.  The rule looks at the number of boxes on the level in the WHOLE tree, not at what this
+// plan owns of it: the two kernels round differently, and shards of one operator must produce the bits of the whole.
 int fmmbem_plan::m2m_level(int p, size_t i, bool shared, hipStream_t s) {
   const auto [first, count] = shared ? m2m_shared_launch[i] : m2m_launch[i];
   const ShiftRot& sr = shared ? m2m_shared_rot[i] : m2m_rot[i];
-  if (shift_rot && shift_rot_supported(p) && sr.pairs >= shift_rot_min) {
+  if (shift_rot && shift_rot_supported(p) && sr.level_boxes >= shift_rot_min) {
     RotWork w;
     w.src = up_rsrc; w.cls = up_rcls; w.tgt = up_rtgt; w.item_ptr = up_ritem + sr.item_first; w.n_items = sr.n_items;
     w.rec = up_rec; w.stream = up_stream + shift_stream_off[p - 1];
@@ -730,7 +734,7 @@ int fmmbem_plan::m2m_level(int p, size_t i, bool shared, hipStream_t s) {
 int fmmbem_plan::l2l_level(int p, size_t i, hipStream_t s) {
   const auto [first, count] = l2l_launch[i];
   const ShiftRot& sr = l2l_rot[i];
-  if (shift_rot && shift_rot_supported(p) && sr.pairs >= shift_rot_min) {
+  if (shift_rot && shift_rot_supported(p) && sr.level_boxes >= shift_rot_min) {
     RotWork w;
     w.src = dn_rsrc; w.cls = dn_rcls; w.tgt = dn_rtgt; w.item_ptr = dn_ritem + sr.item_first; w.n_items = sr.n_items;
     w.rec = dn_rec; w.stream = dn_stream + shift_stream_off[p - 1];

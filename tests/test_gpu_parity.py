@@ -250,7 +250,7 @@ def test_alternative_paths_match_oracle(fb, oracle_mod, monkeypatch, env):
 @pytest.mark.parametrize("p", [1, 2, 3, 5, 7, 8, 10, 12])
 def test_tree_passes_by_rotation_match_oracle(fb, oracle_mod, monkeypatch, p):
     """M2M and L2L through the rotation kernels (kernels_m2l_rot.hip compiled with FMMBEM_ROT_OP = 1, 2).  By default only
-    levels of 2 048 pairs and more take that path, which no mesh of test size has: FMMBEM_SHIFT_ROT_MIN=0 sends every level
+    levels of 2 048 boxes and more take that path, which no mesh of test size has: FMMBEM_SHIFT_ROT_MIN=0 sends every level
     there.  Expansions and result against the oracle; mixed boundary conditions so that both expansion slots are live."""
     monkeypatch.setenv("FMMBEM_SHIFT_ROT_MIN", "0")
     v = np.concatenate([oracle_mod.unit_sphere(5), oracle_mod.unit_sphere(4, center=(2.5, 0.3, -0.2))])

@@ -1,0 +1,110 @@
+"""The factorisation behind csrc/kernels_m2l_rot.hip, checked on the CPU against the oracle's single operators
+(oracle/expansions.c: orc_m2l, orc_m2m, orc_l2l -- the reference's kernel/LaplaceSpherical.hpp:245-411 restated):
+
+    op(tr) = R(alpha, beta)^-1 . axial(rho) . R(alpha, beta),     (rho, alpha, beta) = cart2sph(tr)
+    R(alpha, beta) = X^T E(alpha) conj(X) E(beta),   X[m, m'] = i^(3|m| + |m'|) d^n_{m, m'}(pi / 2),   E(g) = diag(e^{i m g})
+
+for all three operators, with the closed forms of the M2M and L2L axial coefficients that csrc/m2l_rot.hpp tabulates
+(build_rot_stream).  Plain numpy on complex coefficient vectors; the device kernels use the same maps in real coordinates and
+are checked against the oracle end to end by the -m gpu tests."""
+from math import comb, factorial, sqrt
+
+import numpy as np
+import pytest
+
+
+def idx(n, m):
+    return n * (n + 1) // 2 + m
+
+
+def wigner_d_half(j, mp, m):
+    """d^j_{mp,m}(pi/2), the integer sum of csrc/m2l_rot.hpp wigner_d_half"""
+    tot = 0
+    for s in range(max(0, m - mp), min(j + m, j - mp) + 1):
+        tot += (-1) ** (mp - m + s) * comb(j + m, s) * comb(j - m, mp - m + s)
+    return tot * sqrt(factorial(j + mp) * factorial(j - mp) / (factorial(j + m) * factorial(j - m))) / 2 ** j
+
+
+def x_matrix(n):
+    X = np.zeros((2 * n + 1, 2 * n + 1), dtype=complex)
+    for m in range(-n, n + 1):
+        for mp in range(-n, n + 1):
+            X[m + n, mp + n] = 1j ** (3 * abs(m) + abs(mp)) * wigner_d_half(n, m, mp)
+    return X
+
+
+class Frame:
+    def __init__(self, P):
+        self.P, self.S = P, P * (P + 1) // 2
+        self.X = [x_matrix(n) for n in range(P)]
+
+    def full(self, v):                                   # stored orders m >= 0 -> all orders (negative by conjugation)
+        out = []
+        for n in range(self.P):
+            w = np.zeros(2 * n + 1, dtype=complex)
+            for m in range(n + 1):
+                w[n + m] = v[idx(n, m)]
+                w[n - m] = np.conj(v[idx(n, m)])
+            out.append(w)
+        return out
+
+    def stored(self, f):
+        v = np.zeros(self.S, dtype=complex)
+        for n in range(self.P):
+            for m in range(n + 1):
+                v[idx(n, m)] = f[n][n + m]
+        return v
+
+    @staticmethod
+    def E(n, g):
+        return np.diag(np.exp(1j * np.arange(-n, n + 1) * g))
+
+    def forward(self, v, a, b):
+        f = self.full(v)
+        return self.stored([self.X[n].T @ self.E(n, a) @ np.conj(self.X[n]) @ self.E(n, b) @ f[n] for n in range(self.P)])
+
+    def back(self, v, a, b):
+        f = self.full(v)
+        return self.stored([self.E(n, -b) @ self.X[n].T @ self.E(n, -a) @ np.conj(self.X[n]) @ f[n] for n in range(self.P)])
+
+
+def a_nm(n, m):                                          # the reference's Anm without its 1/EPS
+    return (-1) ** n / sqrt(factorial(n - m) * factorial(n + m))
+
+
+def axial(op, v, rho, P):
+    out = np.zeros_like(v)
+    for j in range(P):
+        for k in range(j + 1):
+            s = 0
+            if op == "m2m":                              # Tm[j,n,k] rho^(j-n), n = k..j
+                for n in range(k, j + 1):
+                    s += v[idx(n, k)] * ((-1) ** (j - n) * a_nm(j - n, 0) * a_nm(n, k) / a_nm(j, k) * rho ** (j - n))
+            elif op == "l2l":                            # Tl[j,n,k] rho^(n-j), n = j..P-1
+                for n in range(j, P):
+                    s += v[idx(n, k)] * (a_nm(n - j, 0) * a_nm(j, k) / a_nm(n, k) * rho ** (n - j))
+            else:                                        # Tz[j,n,k] rho^-(j+n+1), n = k..P-1
+                for n in range(k, P):
+                    tz = (-1) ** (k + j) * factorial(j + n) / sqrt(factorial(n - k) * factorial(n + k) * factorial(j - k) * factorial(j + k))
+                    s += v[idx(n, k)] * tz * rho ** -(j + n + 1)
+            out[idx(j, k)] = s
+    return out
+
+
+@pytest.mark.parametrize("P", [4, 7, 10])
+@pytest.mark.parametrize("op", ["m2l", "m2m", "l2l"])
+def test_rotation_factorisation_matches_the_reference_operator(oracle_mod, P, op):
+    T = oracle_mod.Tables(P)
+    fr = Frame(P)
+    rng = np.random.default_rng(5 + P)
+    v = rng.standard_normal(fr.S) + 1j * rng.standard_normal(fr.S)
+    for n in range(P):
+        v[idx(n, 0)] = v[idx(n, 0)].real                 # order 0 of a real field
+    for tr in ([0.3, -0.7, 0.45], [-1.0, 1.0, -1.0], [2.0, 0.5, 3.0]):
+        tr = np.array(tr)
+        if op != "m2l":
+            tr = 0.25 * tr                               # a child-parent offset: keeps rho^n tame
+        rho, alpha, beta = oracle_mod.cart2sph(tr)
+        ref = getattr(T, op)(v, tr)
+        got = fr.back(axial(op, fr.forward(v, alpha, beta), rho, P), alpha, beta)
+        assert np.linalg.norm(got - ref) <= 2e-13 * np.linalg.norm(ref), (op, P, tr)
