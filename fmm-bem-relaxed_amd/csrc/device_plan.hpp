@@ -49,6 +49,7 @@ struct DevicePlan {
   int nq = 0;
   int nboxes = 0, nleaves = 0;
   int p_max = 0, s_max = 0, p2_max = 0, y2_max = 0;   // S, P^2, (2P)^2 at p_max
+  int p2m_stride = 0;                                 // complex per record of p2m_tab: s_max rounded up to a cache line
   int leaf_begin = 0, leaf_end = 0;                   // owned target leaves
   int64_t row_begin = 0, row_end = 0;
   int max_ncols = 0;                                  // widest near row block (columns, padded even)
@@ -120,7 +121,7 @@ struct DevicePlan {
   const double* rot_tab = nullptr;  int rot_tab_off[12] = {};
   // P2M as a precomputed operator: the multipole of a leaf is linear in the charges, M = sum_panels x_i * T_i with the
   // panel's own moments T_i = sum_q w_q A_i Ynm(q - c_leaf) (G or, for NORMAL_DERIV panels, gradient moments) independent
-  // of x.  [panel (tree order)][ntab][s_max] complex, ntab = 1 (Laplace) or 4 (Stokes: moments of 1, x_q, y_q, z_q);
+  // of x.  [panel (tree order)][ntab][p2m_stride] complex, ntab = 1 (Laplace) or 4 (Stokes: moments of 1, x_q, y_q, z_q);
   // built once at p_max (kernels_far.hip p2m_table); the coefficients of order p are a prefix of every record.
   const double2* p2m_tab = nullptr;
   int64_t p2m_tab_row0 = 0;                            // tree-order panel of the table's first record (a shard that runs P2M on

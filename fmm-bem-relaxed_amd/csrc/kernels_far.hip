@@ -245,7 +245,7 @@ __device__ __forceinline__ void wave_lds_sync();     // below
 
 template <int NT>
 __global__ __launch_bounds__(kWave) void p2m_table_kernel(DevicePlan d, double2* __restrict__ tab) {
-  const int P = d.p_max, SM = d.s_max;
+  const int P = d.p_max, SM = d.p2m_stride;          // record stride of the table
   const ConstD4* steptab = reinterpret_cast<const ConstD4*>(reinterpret_cast<uintptr_t>(d.tabStep + (size_t)(P - 1) * (kSmax + 1) * 4));
   const int64_t N = d.n;
   const int nq = d.nq;
@@ -321,9 +321,9 @@ typedef double tvec2 __attribute__((ext_vector_type(2)));   // native 16-B vecto
 
 template <int NT>
 __global__ __launch_bounds__(4 * kWave) void p2m_apply_kernel(DevicePlan d, const int P) {
-  const int S = P * (P + 1) / 2, SM = d.s_max;
+  const int S = P * (P + 1) / 2, SM = d.s_max, TS = d.p2m_stride;      // strides of an expansion and of a table record
   const int lane = threadIdx.x & (kWave - 1);
-  const double2* __restrict__ tab = d.p2m_tab - (size_t)d.p2m_tab_row0 * NT * SM;      // indexed by tree-order panel
+  const double2* __restrict__ tab = d.p2m_tab - (size_t)d.p2m_tab_row0 * NT * TS;      // indexed by tree-order panel
   __shared__ double2 low_part[4][2 * kWave];
   for (int li = blockIdx.x * 4 + threadIdx.x / kWave; li < d.n_p2m; li += gridDim.x * 4) {
     const int leaf = d.p2m_leaf[li], box = d.leaf_box[leaf];
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(4 * kWave) void p2m_apply_kernel(DevicePlan d, cons
       if (g < G)
         for (int r = g; r < nrows; r += G) {
           const int64_t i = row0 + r;
-          const double2 t = tab[(size_t)i * SM + idx];
+          const double2 t = tab[(size_t)i * TS + idx];
           const double x = d.xt[i];
           if (d.bc[i]) { m1.x = fma(x, t.x, m1.x); m1.y = fma(x, t.y, m1.y); }
           else { m0.x = fma(x, t.x, m0.x); m0.y = fma(x, t.y, m0.y); }
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(4 * kWave) void p2m_apply_kernel(DevicePlan d, cons
           for (int u = 0; u < U; ++u) {
             const bool ok = r + u < nrows;
             const int64_t iu = ok ? i + u : i;
-            t[u] = ok ? __builtin_nontemporal_load(reinterpret_cast<const tvec2*>(tab + (size_t)iu * SM + idx)) : tvec2{0, 0};
+            t[u] = ok ? __builtin_nontemporal_load(reinterpret_cast<const tvec2*>(tab + (size_t)iu * TS + idx)) : tvec2{0, 0};
             x[u] = d.xt[iu]; dn[u] = d.bc[iu] != 0;
           }
 #pragma unroll
@@ -391,9 +391,9 @@ __global__ __launch_bounds__(4 * kWave) void p2m_apply_kernel(DevicePlan d, cons
 #pragma unroll 2
         for (int r = 0; r < nrows; ++r) {
           const int64_t i = row0 + r;
-          const double2* t = tab + (size_t)i * 4 * SM + idx;
+          const double2* t = tab + (size_t)i * 4 * TS + idx;
           const double f0 = d.xt[3 * i], f1 = d.xt[3 * i + 1], f2 = d.xt[3 * i + 2];
-          const double2 t0 = t[0], t1 = t[SM], t2 = t[2 * SM], t3 = t[3 * SM];
+          const double2 t0 = t[0], t1 = t[TS], t2 = t[2 * TS], t3 = t[3 * TS];
           m[0].x = fma(f0, t0.x, m[0].x); m[0].y = fma(f0, t0.y, m[0].y);
           m[1].x = fma(f1, t0.x, m[1].x); m[1].y = fma(f1, t0.y, m[1].y);
           m[2].x = fma(f2, t0.x, m[2].x); m[2].y = fma(f2, t0.y, m[2].y);
