@@ -55,7 +55,7 @@ struct DevicePlan {
   int max_ncols = 0;                                  // widest near row block (columns, padded even)
   int max_runs = 0;                                   // most source runs of any owned target leaf
   int n_act = 0;                                      // active expansion slots
-  int act[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int act[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   int nslots = 2;                                     // expansions per box: Laplace 2 (G, dG/dn), Stokes 2 x 4
   int kernel = 0;                                     // fmmbem_kernel
   int dof = 1;                                        // unknowns per panel (Stokes: 3, interleaved)
@@ -124,6 +124,9 @@ struct DevicePlan {
   // of x.  [panel (tree order)][ntab][p2m_stride] complex, ntab = 1 (Laplace) or 4 (Stokes: moments of 1, x_q, y_q, z_q);
   // built once at p_max (kernels_far.hip p2m_table); the coefficients of order p are a prefix of every record.
   const double2* p2m_tab = nullptr;
+  // Stokes double layer (TRACTION targets): [panel][3][p2m_stride], the components of sum_q w_q A grad(rho^n Ynm)
+  const double2* p2m_tab_g = nullptr;
+  int stokes_velocity_targets = 1, stokes_traction_targets = 0;   // which groups of Stokes expansions are live (slots 0..3 / 4..10)
   int64_t p2m_tab_row0 = 0;                            // tree-order panel of the table's first record (a shard that runs P2M on
                                                       // its own leaves only keeps only their records)
   // scratch
@@ -141,7 +144,8 @@ hipError_t launch_scatter_y(const DevicePlan& d, double* y, hipStream_t s);
 hipError_t launch_assemble_slices(const DevicePlan& d, const double* slices, double* y, int world, const int64_t* d_cut, int64_t chunk,
                                   hipStream_t s);
 hipError_t launch_p2m(const DevicePlan& d, int p, hipStream_t s);
-hipError_t launch_p2m_table(const DevicePlan& d, double2* tab, hipStream_t s);     // one-off: fills DevicePlan::p2m_tab's storage
+hipError_t launch_p2m_table(const DevicePlan& d, double2* tab, hipStream_t s);
+hipError_t launch_p2m_table_grad(const DevicePlan& d, double2* tab, hipStream_t s);     // one-off: fills DevicePlan::p2m_tab's storage
 hipError_t launch_m2m_level(const DevicePlan& d, const ShiftOpDev& op, int p, int first, int count, hipStream_t s);
 // multipoles of the boxes a shard owns -> send buffer [idx][active slot][S(p)]; all shards' buffers -> M (own slice skipped)
 hipError_t launch_xch_pack(const DevicePlan& d, int p, double2* send, hipStream_t s);

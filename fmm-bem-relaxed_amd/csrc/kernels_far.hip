@@ -256,7 +256,8 @@ __global__ __launch_bounds__(kWave) void p2m_table_kernel(DevicePlan d, double2*
     for (int r = threadIdx.x; r < nrows; r += blockDim.x) {
       const int64_t i = row0 + r;
       double2* out = tab + (size_t)(i - d.p2m_tab_row0) * NT * SM;
-      const bool deriv = NT == 1 && d.bc[i] != 0;      // Laplace NORMAL_DERIV panel: (n . grad)(rho^n Ynm) moments (LaplaceSphericalBEM.hpp:331-343)
+      const bool deriv = (NT == 1 && d.bc[i] != 0) || NT == 3;   // Laplace NORMAL_DERIV panel: (n . grad)(rho^n Ynm) moments (LaplaceSphericalBEM.hpp:331-343);
+                                                                  // NT == 3: the three components of that gradient, one record each (Stokes double layer, below)
       const double n0 = d.nx[i], n1 = d.ny[i], n2 = d.nz[i];
       for (int q = 0; q < nq; ++q) {
         const double qx = d.quad[(q * 3 + 0) * N + i], qy = d.quad[(q * 3 + 1) * N + i], qz = d.quad[(q * 3 + 2) * N + i];
@@ -291,14 +292,26 @@ __global__ __launch_bounds__(kWave) void p2m_table_kernel(DevicePlan d, double2*
               const double gzi = ca * bri - sa / rho * ti;
               vr = n0 * gxr + n1 * gyr + n2 * gzr;
               vi = n0 * gxi + n1 * gyi + n2 * gzi;
+              if constexpr (NT == 3) {
+                const int gidx = n * (n + 1) / 2 + m;
+                const double gr[3] = {gxr, gyr, gzr}, gi[3] = {gxi, gyi, gzi};
+#pragma unroll
+                for (int e = 0; e < 3; ++e) {
+                  double2 acc = q ? out[(size_t)e * SM + gidx] : double2{0, 0};
+                  acc.x += aw * gr[e]; acc.y += aw * gi[e];
+                  out[(size_t)e * SM + gidx] = acc;
+                }
+              }
             }
             const int idx = n * (n + 1) / 2 + m;
             const double wt[4] = {aw, aw * qx, aw * qy, aw * qz};      // Stokes: moments of 1 and of the ABSOLUTE point (StokesSphericalBEM.hpp:417-431)
+            if constexpr (NT != 3) {
 #pragma unroll
-            for (int e = 0; e < NT; ++e) {
-              double2 acc = q ? out[(size_t)e * SM + idx] : double2{0, 0};
-              acc.x += wt[e] * vr; acc.y += wt[e] * vi;
-              out[(size_t)e * SM + idx] = acc;
+              for (int e = 0; e < NT; ++e) {
+                double2 acc = q ? out[(size_t)e * SM + idx] : double2{0, 0};
+                acc.x += wt[e] * vr; acc.y += wt[e] * vi;
+                out[(size_t)e * SM + idx] = acc;
+              }
             }
             p1 = pcur; p = pnext;
             rhon *= s.rho;
@@ -386,6 +399,35 @@ __global__ __launch_bounds__(4 * kWave) void p2m_apply_kernel(DevicePlan d, cons
           const int slot = a == 0 ? d.act[0] : d.act[1];
           d.M[((size_t)box * d.nslots + slot) * SM + idx] = slot ? m1 : m0;
         }
+      } else if (NT == 3) {
+        // Stokes double layer (stresslet), the far field of TRACTION targets.  With phi = 1/|x - y| and the source's density g
+        // and normal n,   -3 (d.n) d_i (d.g) / r^5  =  x_k d_i Psi_k - d_i Psi_0 - Theta_i   (d = x - y, d_i = d/dx_i),
+        //   Psi_k = sum w A n_k (g . grad_y) phi,   Psi_0 = sum w A (y.n) (g . grad_y) phi,   Theta_i = sum w A g_i (n . grad_y) phi
+        // -- seven harmonic dipole potentials (from d_i d_j / r^5 = (d_i d_j phi + delta_ij / r^3) / 3).  Their multipoles are
+        // combinations of the panel's three gradient records G = sum_q w_q A grad(rho^n Ynm): slots 4..6 n_k (g.G), slot 7
+        // (c.n)(g.G) -- y.n is constant on a flat panel --, slots 8..10 g_i (n.G).
+        const double2* gtab = d.p2m_tab_g - (size_t)d.p2m_tab_row0 * 3 * TS;
+        double2 m[7] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
+#pragma unroll 2
+        for (int r = 0; r < nrows; ++r) {
+          const int64_t i = row0 + r;
+          const double2* t = gtab + (size_t)i * 3 * TS + idx;
+          const double f0 = d.xt[3 * i], f1 = d.xt[3 * i + 1], f2 = d.xt[3 * i + 2];
+          const double n0 = d.nx[i], n1 = d.ny[i], n2 = d.nz[i];
+          const double yn = d.cx[i] * n0 + d.cy[i] * n1 + d.cz[i] * n2;
+          const double2 t0 = t[0], t1 = t[TS], t2 = t[2 * TS];
+          const double2 gG = {fma(f0, t0.x, fma(f1, t1.x, f2 * t2.x)), fma(f0, t0.y, fma(f1, t1.y, f2 * t2.y))};
+          const double2 nG = {fma(n0, t0.x, fma(n1, t1.x, n2 * t2.x)), fma(n0, t0.y, fma(n1, t1.y, n2 * t2.y))};
+          m[0].x = fma(n0, gG.x, m[0].x); m[0].y = fma(n0, gG.y, m[0].y);
+          m[1].x = fma(n1, gG.x, m[1].x); m[1].y = fma(n1, gG.y, m[1].y);
+          m[2].x = fma(n2, gG.x, m[2].x); m[2].y = fma(n2, gG.y, m[2].y);
+          m[3].x = fma(yn, gG.x, m[3].x); m[3].y = fma(yn, gG.y, m[3].y);
+          m[4].x = fma(f0, nG.x, m[4].x); m[4].y = fma(f0, nG.y, m[4].y);
+          m[5].x = fma(f1, nG.x, m[5].x); m[5].y = fma(f1, nG.y, m[5].y);
+          m[6].x = fma(f2, nG.x, m[6].x); m[6].y = fma(f2, nG.y, m[6].y);
+        }
+#pragma unroll
+        for (int e = 0; e < 7; ++e) d.M[((size_t)box * d.nslots + 4 + e) * SM + idx] = m[e];
       } else {
         double2 m[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
 #pragma unroll 2
@@ -627,14 +669,18 @@ __global__ __launch_bounds__(kL2PWaves * kWave) void l2p_kernel(DevicePlan d, co
 // accumulated along the same recurrence as the Laplace L2P (Ynm and its theta derivative), then
 //   u_k = phi_k - x_0 d_k phi_0 - x_1 d_k phi_1 - x_2 d_k phi_2 + d_k phi_3   (Tornberg-Greengard)
 // ---------------------------------------------------------------------------------------------
+// TRAC: the rows of TRACTION targets, from the seven potentials of the double layer (p2m_apply_kernel<3>):
+//   t_i = x_k d_i Psi_k - d_i Psi_0 - Theta_i     (slots 4..6 Psi_k, 7 Psi_0: gradients; 8..10 Theta_i: values; no 1/(2 mu))
+template <bool TRAC>
 __global__ __launch_bounds__(kL2PWaves * kWave) void l2p_stokes_kernel(DevicePlan d, const int P, double* __restrict__ y) {
+  constexpr int NE = TRAC ? 7 : 4, SB = TRAC ? 4 : 0;   // potentials staged per leaf, first slot
   extern __shared__ double2 l2p_lds[];                  // as l2p_kernel: step tables, then [wave][leaf][4 potentials][S]
   const int S = P * (P + 1) / 2;
   double* sPref = reinterpret_cast<double*>(l2p_lds);
   double* sC1 = sPref + S;
   double* sC2 = sC1 + S;
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, nwaves = blockDim.x / kWave;
-  double2* Lw = l2p_lds + (3 * S + 1) / 2 + (size_t)wave * kL2PLeaves * 4 * S;
+  double2* Lw = l2p_lds + (3 * S + 1) / 2 + (size_t)wave * kL2PLeaves * NE * S;
   if (wave == 0) fill_step_tables(d, P, lane, sPref, sC1, sC2);
   __syncthreads();
   for (int gi = blockIdx.x * nwaves + wave; gi < d.n_l2p_grp; gi += gridDim.x * nwaves) {
@@ -643,9 +689,9 @@ __global__ __launch_bounds__(kL2PWaves * kWave) void l2p_stokes_kernel(DevicePla
     int g = -1, first = 0, total = 0;
     for (int k = 0; k < nl; ++k) {
       const int leaf = d.l2p_leaf[l0 + k], box = d.leaf_box[leaf], nr = d.leaf_nrows[leaf];
-      for (int e = 0; e < 4; ++e) {
-        const double2* src = d.L + ((size_t)box * d.nslots + e) * d.s_max;
-        for (int i = lane; i < S; i += kWave) Lw[(size_t)(k * 4 + e) * S + i] = src[i];
+      for (int e = 0; e < NE; ++e) {
+        const double2* src = d.L + ((size_t)box * d.nslots + SB + e) * d.s_max;
+        for (int i = lane; i < S; i += kWave) Lw[(size_t)(k * NE + e) * S + i] = src[i];
       }
       if (lane >= total && lane < total + nr) { g = k; first = total; }
       total += nr;
@@ -654,12 +700,13 @@ __global__ __launch_bounds__(kL2PWaves * kWave) void l2p_stokes_kernel(DevicePla
     if (nl == 1) { g = 0; first = 0; }
     const int leaf = d.l2p_leaf[l0 + (g < 0 ? 0 : g)], box = d.leaf_box[leaf];
     const int row0 = d.leaf_row0[leaf], nrows = d.leaf_nrows[leaf];
-    const double2* Ls = Lw + (size_t)(g < 0 ? 0 : g) * 4 * S;
+    const double2* Ls = Lw + (size_t)(g < 0 ? 0 : g) * NE * S;
     const double c0 = d.box_center[3 * box], c1 = d.box_center[3 * box + 1], c2 = d.box_center[3 * box + 2];
     for (int chunk = 0; chunk < total; chunk += kWave) {
       const int r_in_leaf = chunk + lane - first;
       if (g < 0 || r_in_leaf >= nrows) continue;
       const int64_t i = row0 + r_in_leaf;
+      if ((d.bc[i] != 0) != TRAC) continue;              // the target's flag picks the operator (StokesSphericalBEM.hpp:377-389)
       const double tx = d.cx[i], ty = d.cy[i], tz = d.cz[i];
       const Sph s = cart2sph(tx - c0, ty - c1, tz - c2);
       double val[3] = {0, 0, 0};               // potentials phi_0..2 at the target
@@ -684,13 +731,15 @@ __global__ __launch_bounds__(kL2PWaves * kWave) void l2p_stokes_kernel(DevicePla
           const double factor = 1. / s.rho * n;
           const int idx = n * (n + 1) / 2 + m;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
+          for (int e = 0; e < NE; ++e) {
             const double2 L = Ls[e * S + idx];
             const double re = L.x * yr - L.y * yi;                   // Re(L Ynm)
-            if (e < 3) val[e] += w * re;
-            g[e][0] += w * re * factor;
-            g[e][1] += w * (L.x * tr - L.y * ti);                    // Re(L YnmTheta)
-            if (m) g[e][2] += 2 * (-(L.x * yi + L.y * yr)) * m;      // Re(L Ynm i) m
+            if (TRAC ? e >= 4 : e < 3) val[TRAC ? e - 4 : e] += w * re;
+            if (e < 4) {
+              g[e][0] += w * re * factor;
+              g[e][1] += w * (L.x * tr - L.y * ti);                  // Re(L YnmTheta)
+              if (m) g[e][2] += 2 * (-(L.x * yi + L.y * yr)) * m;    // Re(L Ynm i) m
+            }
           }
           p1 = pcur; p = pnext;
           rhon *= s.rho;
@@ -703,17 +752,17 @@ __global__ __launch_bounds__(kL2PWaves * kWave) void l2p_stokes_kernel(DevicePla
       }
       // sph2cart (kernel/LaplaceSpherical.hpp:546-561) of each gradient, then the recombination
       const double r = s.rho, st = s.sa, ct = s.ca, cp = s.cb, sp = s.sb;
-      double res[3] = {val[0], val[1], val[2]};
+      double res[3] = {TRAC ? -val[0] : val[0], TRAC ? -val[1] : val[1], TRAC ? -val[2] : val[2]};
       const double tgt[3] = {tx, ty, tz};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const double cx_ = st * cp * g[e][0] + ct * cp / r * g[e][1] - sp / r / st * g[e][2];
         const double cy_ = st * sp * g[e][0] + ct * sp / r * g[e][1] + cp / r / st * g[e][2];
         const double cz_ = ct * g[e][0] - st / r * g[e][1];
-        const double f = e < 3 ? -tgt[e] : 1.0;
+        const double f = (TRAC ? -1.0 : 1.0) * (e < 3 ? -tgt[e] : 1.0);
         res[0] += f * cx_; res[1] += f * cy_; res[2] += f * cz_;
       }
-      const double sc = 1. / 2 / d.mu;
+      const double sc = TRAC ? 1.0 : 1. / 2 / d.mu;
       y[3 * (size_t)i] += sc * res[0];
       y[3 * (size_t)i + 1] += sc * res[1];
       y[3 * (size_t)i + 2] += sc * res[2];
@@ -743,7 +792,8 @@ hipError_t upload_constants_once() {
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(l2l_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     // L2P with one wavefront per workgroup at p = 16: 8 leaves x 4 potentials x 136 coefficients = 69.6 KB (Stokes)
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(l2p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(l2p_stokes_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(l2p_stokes_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(l2p_stokes_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     return e;
   }();
   if (st == hipSuccess) done[dev] = true;
@@ -758,6 +808,14 @@ hipError_t launch_p2m_table(const DevicePlan& d, double2* tab, hipStream_t s) {
   const dim3 g(d.n_p2m < 256 * 32 ? d.n_p2m : 256 * 32), b(kWave);
   if (d.kernel == 1) hipLaunchKernelGGL((p2m_table_kernel<4>), g, b, 0, s, d, tab);
   else hipLaunchKernelGGL((p2m_table_kernel<1>), g, b, 0, s, d, tab);
+  return hipGetLastError();
+}
+
+hipError_t launch_p2m_table_grad(const DevicePlan& d, double2* tab, hipStream_t s) {      // Stokes double layer: three gradient records per panel
+  if (hipError_t e = upload_constants_once(); e != hipSuccess) return e;
+  if (d.n_p2m <= 0) return hipSuccess;
+  const dim3 g(d.n_p2m < 256 * 32 ? d.n_p2m : 256 * 32), b(kWave);
+  hipLaunchKernelGGL((p2m_table_kernel<3>), g, b, 0, s, d, tab);
   return hipGetLastError();
 }
 
@@ -875,8 +933,10 @@ hipError_t launch_p2m_stokes(const DevicePlan& d, int p, hipStream_t s) {
   if (hipError_t e = upload_constants_once(); e != hipSuccess) return e;
   if (d.n_p2m <= 0) return hipSuccess;
   if (p < 1 || p > kPmaxDev) return hipErrorInvalidValue;
+  const int nb = (d.n_p2m + 3) / 4;
+  if (d.p2m_tab_g) hipLaunchKernelGGL((p2m_apply_kernel<3>), dim3(nb < 256 * 16 ? nb : 256 * 16), dim3(4 * kWave), 0, s, d, p);
+  if (!d.stokes_velocity_targets) return hipGetLastError();
   if (d.p2m_tab) {
-    const int nb = (d.n_p2m + 3) / 4;
     hipLaunchKernelGGL((p2m_apply_kernel<4>), dim3(nb < 256 * 16 ? nb : 256 * 16), dim3(4 * kWave), 0, s, d, p);
     return hipGetLastError();
   }
@@ -891,12 +951,16 @@ hipError_t launch_l2p_stokes(const DevicePlan& d, int p, double* y, hipStream_t 
   if (d.n_l2p <= 0) return hipSuccess;
   if (p < 1 || p > kPmaxDev) return hipErrorInvalidValue;
   const int S = p * (p + 1) / 2;
-  const size_t per_wave = sizeof(double2) * (size_t)kL2PLeaves * 4 * S;
-  int nw = (int)((48 * 1024) / per_wave);
-  nw = nw < 1 ? 1 : nw > kL2PWaves ? kL2PWaves : nw;
-  const int nblk = (d.n_l2p_grp + nw - 1) / nw;
-  const size_t lds = sizeof(double2) * (size_t)((3 * S + 1) / 2) + nw * per_wave;
-  hipLaunchKernelGGL(l2p_stokes_kernel, dim3(nblk < 256 * 8 ? nblk : 256 * 8), dim3(nw * kWave), lds, s, d, p, y);
+  for (int trac = 0; trac < 2; ++trac) {
+    if (!(trac ? d.stokes_traction_targets : d.stokes_velocity_targets)) continue;
+    const size_t per_wave = sizeof(double2) * (size_t)kL2PLeaves * (trac ? 7 : 4) * S;
+    int nw = (int)((48 * 1024) / per_wave);
+    nw = nw < 1 ? 1 : nw > kL2PWaves ? kL2PWaves : nw;
+    const int nblk = (d.n_l2p_grp + nw - 1) / nw;
+    const size_t lds = sizeof(double2) * (size_t)((3 * S + 1) / 2) + nw * per_wave;
+    if (trac) hipLaunchKernelGGL(l2p_stokes_kernel<true>, dim3(nblk < 256 * 8 ? nblk : 256 * 8), dim3(nw * kWave), lds, s, d, p, y);
+    else hipLaunchKernelGGL(l2p_stokes_kernel<false>, dim3(nblk < 256 * 8 ? nblk : 256 * 8), dim3(nw * kWave), lds, s, d, p, y);
+  }
   return hipGetLastError();
 }
 }  // namespace fmmbem

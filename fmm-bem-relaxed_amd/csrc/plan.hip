@@ -277,9 +277,16 @@ int fmmbem_plan::to_device() {
   d.kernel = opts.kernel;
   d.n_act = 0;
   if (opts.kernel == FMMBEM_KERNEL_STOKES_BEM) {
-    // StokesSphericalBEM: M[2][4] per box (kernel/StokesSphericalBEM.hpp:143-153); the velocity group is live
-    d.dof = 3; d.nslots = 8; d.mu = opts.mu;
-    for (int s = 0; s < 4; ++s) d.act[d.n_act++] = s;
+    // StokesSphericalBEM: M[2][4] per box (kernel/StokesSphericalBEM.hpp:143-153).  The TARGET's flag picks the operator
+    // (:377-389): velocity targets read the four potentials of the single layer (slots 0..3), TRACTION targets the seven of
+    // the double layer (slots 4..10, kernels_far.hip p2m_apply_kernel<3>); every source feeds the groups that have readers
+    d.dof = 3; d.mu = opts.mu;
+    d.stokes_velocity_targets = hp.has_bc[0] ? 1 : 0;
+    d.stokes_traction_targets = (hp.has_bc[1] && hp.opt.evaluator == 0) ? 1 : 0;
+    if (!d.stokes_velocity_targets && !d.stokes_traction_targets) d.stokes_velocity_targets = 1;
+    d.nslots = d.stokes_traction_targets ? 11 : 8;
+    if (d.stokes_velocity_targets) for (int s = 0; s < 4; ++s) d.act[d.n_act++] = s;
+    if (d.stokes_traction_targets) for (int s = 4; s < 11; ++s) d.act[d.n_act++] = s;
     QuadRule fine;
     if (!quad_rule(opts.quad_k_fine, fine)) return fail(FMMBEM_ERR_INVALID, "invalid K_fine (valid: 1 3 4 7 13 17 19 25)");
     d.nqf = fine.n;
@@ -692,7 +699,19 @@ int fmmbem_plan::to_device() {
     if (r1 < r0) r0 = r1 = 0;
     d.p2m_tab_row0 = r0;
     const size_t count = (size_t)(r1 - r0) * ntab * d.p2m_stride;
-    if (!(e && std::atoi(e) == 0) && hp.opt.evaluator == 0 && d.n_p2m > 0 && count * sizeof(double2) <= ((size_t)16 << 30)) {
+    const bool stokes = opts.kernel == FMMBEM_KERNEL_STOKES_BEM;
+    if (stokes && d.stokes_traction_targets && d.n_p2m > 0) {       // the double layer has no recurrence form here: records or nothing
+      const size_t count_g = (size_t)(r1 - r0) * 3 * d.p2m_stride;
+      if (count_g * sizeof(double2) > ((size_t)16 << 30)) return fail(FMMBEM_ERR_UNSUPPORTED, "Stokes TRACTION far field: the gradient records exceed 16 GB");
+      double2* tab = nullptr;
+      TRY(alloc(count_g, &tab, true));
+      HIP_TRY(hipDeviceSynchronize());
+      HIP_TRY(launch_p2m_table_grad(d, tab, own_stream));
+      HIP_TRY(hipStreamSynchronize(own_stream));
+      d.p2m_tab_g = tab;
+    }
+    const bool want = !stokes || d.stokes_velocity_targets;
+    if (want && !(e && std::atoi(e) == 0) && hp.opt.evaluator == 0 && d.n_p2m > 0 && count * sizeof(double2) <= ((size_t)16 << 30)) {
       double2* tab = nullptr;
       TRY(alloc(count, &tab, true));
       HIP_TRY(hipDeviceSynchronize());                 // the zero-fill ran on the NULL stream
@@ -837,6 +856,8 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
       for (size_t i = 0; i < m2m_shared_launch.size(); ++i) TRY(m2m_level(p, i, true, s));
     }
     const bool rot = use_rot(p);
+    if (!rot && d.kernel == FMMBEM_KERNEL_STOKES_BEM && d.stokes_traction_targets)
+      return fail(FMMBEM_ERR_UNSUPPORTED, "Stokes TRACTION far field needs the rotation M2L kernel (p <= 12, FMMBEM_M2L_ROT unset)");
     if (!rot) HIP_TRY(launch_mh_prep(d, p, s));      // the rotation kernel reads M itself
     HIP_TRY(end(5, s));
     if (overlap && !overlap_early) {                   // fork: the near field streams HBM while M2L saturates the FMA pipes
@@ -887,12 +908,13 @@ int fmmbem_plan_create(const fmmbem_options* opts, size_t n_panels, const double
     return fail(FMMBEM_ERR_UNSUPPORTED, "unknown kernel id");
   if (opts->kernel == FMMBEM_KERNEL_STOKES_BEM) {
     if (!(opts->mu > 0)) return fail(FMMBEM_ERR_INVALID, "Stokes: viscosity mu must be positive");
-    // TRACTION panels: the near blocks are eval_traction_integral (kernel/StokesSphericalBEM.hpp:160-258) and every
-    // near-field-only operator is exact; the far field of the traction operator is refused -- the reference's own
-    // disagrees with its Direct sum by 50-75 %, there is nothing to be equal to
-    if (bc && opts->evaluator == FMMBEM_EVAL_FMM)
+    // TRACTION panels: the near blocks are eval_traction_integral (kernel/StokesSphericalBEM.hpp:160-258).  Their far field
+    // is the double-layer decomposition of kernels_far.hip (seven dipole potentials), checked against the Direct sum -- the
+    // reference's own far field for this operator disagrees with its Direct sum by 50-75 %, so there
+    // is nothing of the reference's to be equal to beyond Direct.  It runs through the rotation M2L kernel: p_max <= 12.
+    if (bc && opts->evaluator == FMMBEM_EVAL_FMM && opts->p_max > kRotPmax)
       for (size_t i = 0; i < n_panels; ++i)
-        if (bc[i]) return fail(FMMBEM_ERR_UNSUPPORTED, "Stokes: TRACTION panels only with the near-field evaluators (LOCAL, BLOCK_DIAGONAL); the traction far field of the reference is not reproducible");
+        if (bc[i]) return fail(FMMBEM_ERR_UNSUPPORTED, "Stokes: the far field of TRACTION targets is built for p_max <= 12");
   }
   if (!vertices || n_panels == 0) return fail(FMMBEM_ERR_INVALID, "no panels");
   if (opts->l2l_rule != FMMBEM_L2L_COMPLETE && opts->l2l_rule != FMMBEM_L2L_REFERENCE) return fail(FMMBEM_ERR_INVALID, "unknown l2l_rule");
@@ -943,7 +965,7 @@ int fmmbem_plan_exchange_doubles(const fmmbem_plan* plan, int p, size_t* per_sha
   const HostPlan& h = plan->hp;
   size_t most = 0;
   for (size_t r = 0; r + 1 < h.xch_ptr.size(); ++r) most = std::max<size_t>(most, (size_t)(h.xch_ptr[r + 1] - h.xch_ptr[r]));
-  const size_t n_act = plan->opts.kernel == FMMBEM_KERNEL_STOKES_BEM ? 4 : (size_t)h.has_bc[0] + (size_t)h.has_bc[1];
+  const size_t n_act = plan->opts.kernel == FMMBEM_KERNEL_STOKES_BEM ? (size_t)plan->d.n_act : (size_t)h.has_bc[0] + (size_t)h.has_bc[1];
   *per_shard = (h.opt.shard_upward && h.opt.shard_world > 1) ? most * n_act * (size_t)(p * (p + 1) / 2) * 2 : 0;
   return FMMBEM_OK;
 }

@@ -78,3 +78,24 @@ def test_two_shards_sum_bitwise(fb, rbc):
         assert np.count_nonzero(yp) < 3 * plan.n
         total += yp
     assert np.array_equal(total, y)
+
+
+def test_traction_targets_at_full_size_against_direct(fb, oracle_mod):
+    """Config 4 read literally -- "(stresslet)": every target TRACTION, the double-layer far field of kernels_far.hip at
+    N = 524 288, p = 8, against the Direct sum over the reference's traction entries on sampled rows (the answer this
+    operator has: test_stokes.py); linear, and bitwise repeatable."""
+    v = fb.red_blood_cell(9)
+    bc = np.ones(len(v), dtype=np.uint8)
+    plan = fb.FMM_plan(_kernel(fb), v, p_max=P, bc=bc)
+    o = oracle_mod.StokesOracle(v, K=4, K_fine=19, mu=1e-3, bc=bc)
+    rng = np.random.default_rng(31)
+    x1, x2 = rng.random((plan.n, 3)), rng.standard_normal((plan.n, 3))
+    y1, y2 = plan.execute(x1), plan.execute(x2)
+    for lo in (0, 262144 - 32, 524288 - 64):
+        d = o.direct(x1, rows=(lo, lo + 64))
+        assert np.linalg.norm(y1[lo:lo + 64] - d) <= 1e-3 * np.linalg.norm(d)      # 5e-4 at p = 8 on the small meshes of test_stokes.py
+    y12 = plan.execute(0.5 * x1 + 3.0 * x2)
+    assert np.linalg.norm(y12 - (0.5 * y1 + 3.0 * y2)) <= 1e-13 * np.linalg.norm(y12)
+    assert np.array_equal(plan.execute(x1), y1)
+    o.close()
+    plan.close()

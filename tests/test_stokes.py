@@ -80,10 +80,45 @@ def test_gpu_stokes_red_blood_cell(fb, oracle_mod):
 
 
 @pytest.mark.gpu
-def test_gpu_stokes_rejects_traction(fb):
+def test_gpu_stokes_traction_far_field_against_direct(fb, oracle_mod):
+    """TRACTION targets through the FMM evaluator: near blocks as before, far field by the double-layer decomposition of
+    kernels_far.hip (seven dipole potentials: t_i = x_k d_i Psi_k - d_i Psi_0 - Theta_i).  The reference's own far field for
+    this operator is wrong, so the answer is the Direct sum over the reference's entries
+    (oracle: orc_stokes_entry, kernel/StokesSphericalBEM.hpp:160-258): the error must fall with the order like that of the
+    velocity operator, for all-traction targets and for mixed flags (the target's flag picks the row's operator)."""
+    v = np.concatenate([oracle_mod.unit_sphere(5), oracle_mod.unit_sphere(4, center=(2.6, 0.2, -0.3))])
+    n = len(v)
+    x = drand48(3 * n, seed=21).reshape(n, 3)
+    rows = (0, 96)
+    for name, bc in (("traction", np.ones(n, dtype=np.uint8)), ("mixed", (np.arange(n) % 2).astype(np.uint8))):
+        o = oracle_mod.StokesOracle(v, K=4, K_fine=19, mu=1e-3, bc=bc)
+        ref = o.direct(x, rows=rows)
+        errs = []
+        for p in (4, 8, 12):
+            K = fb.StokesSphericalBEM(p, 4, 1e-3)
+            K.set_Kfine(19)
+            pl = fb.FMM_plan(K, v, bc=bc)
+            assert pl.stats()["m2l_pairs"] > 0
+            y = pl.execute(x)[rows[0]:rows[1]]
+            errs.append(rel_l2(y, ref))
+            pl.close()
+        # measured: 7.6e-3, 5.0e-4, 6.8e-5 at p = 4, 8, 12 (a factor ~0.55 per order, one derivative worse than the single layer)
+        assert errs[0] < 2e-2 and errs[1] < 1e-3 and errs[2] < 1.5e-4 and errs[2] < errs[1] < errs[0], (name, errs)
+        # the rows of velocity targets of the mixed operator are the velocity operator's rows, bit for bit
+        if name == "mixed":
+            K = fb.StokesSphericalBEM(8, 4, 1e-3)
+            K.set_Kfine(19)
+            ym = fb.FMM_plan(K, v, bc=bc).execute(x)
+            yv = fb.FMM_plan(K, v).execute(x)
+            assert np.array_equal(ym[bc == 0], yv[bc == 0])
+        o.close()
+
+
+@pytest.mark.gpu
+def test_gpu_stokes_traction_far_field_needs_the_rotation_orders(fb):
     v = fb.unit_sphere(3)
     with pytest.raises(fb.FmmBemError) as e:
-        fb.FMM_plan(fb.StokesSphericalBEM(5, 3), v, bc=np.ones(len(v), dtype=np.uint8))
+        fb.FMM_plan(fb.StokesSphericalBEM(14, 3), v, bc=np.ones(len(v), dtype=np.uint8))
     assert e.value.status == 6
 
 
@@ -166,8 +201,7 @@ def test_gpu_stokes_high_orders(fb, oracle_mod):
 def test_gpu_stokes_traction_entries_and_near_field_operators(fb, oracle_mod):
     """TRACTION targets (kernel/StokesSphericalBEM.hpp:160-258, 377-389): the 3x3 blocks -3 int (d.n) d d^T / r^5 against the
     oracle's restatement (self 2 pi I, near K_fine, far K points), through fmmbem_kernel_entries and through the assembled
-    near matrix of the near-field-only evaluators (the operators with an answer: the FMM evaluator refuses traction panels,
-    test_gpu_stokes_rejects_traction).  The oracle's Direct sum over the same entries reproduces the double-layer identity
+    near matrix of the near-field-only evaluators.  The oracle's Direct sum over the same entries reproduces the double-layer identity
     sum_j T_ij c = 4 pi c on a closed surface (12.5664)."""
     v = oracle_mod.unit_sphere(5)
     n = len(v)
