@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """The reference's Stokes driver, examples/StokesBEM.cpp, on the MI355X library: same command-line flags (:80-97,
 :147-212), same steps -- unit sphere / red blood cell / mesh, unit velocity (1,0,0) on every panel, the right-hand side
-the driver ends up using (it computes A_traction * u by FMM and then OVERWRITES it with the analytic (4 pi, 0, 0),
-:262-277 -- the traction far field of the reference is wrong, SURVEY.md section 8a, and is not built here), the first-
+the driver ends up using (it computes A_traction * u by FMM, reports how far that is from 4 pi, and then OVERWRITES it with
+the analytic (4 pi, 0, 0), :262-277; the reference's own traction far field is wrong, SURVEY.md section 8a -- here the
+double-layer far field of csrc/kernels_far.hip evaluates that step, up to order 12), the first-
 kind stokeslet system solved by the relaxed GMRES of GMRES_Stokes.hpp (:307-330), and the same report: timing, drag
 against 6 pi mu, area and pointwise traction errors (:337-372).  All matvecs run in libfmmbem_hip.so.
 
@@ -119,17 +120,26 @@ def main(argv):
 
     print("generating RHS")
     tic = time.time()
-    # the reference runs the traction-BC plan on u = (1,0,0) here, prints how far the result is from 4 pi, and replaces it
-    b = torch.zeros((n, 3), dtype=torch.float64, device=dev)
-    b[:, 0] = 4 * math.pi
-    print("rhs error: not evaluated (traction operator not built; the driver uses the analytic value either way)")
-    print("done")
-    setup_time = time.time() - tic
-
     def kernel():
         K = fb.StokesSphericalBEM(p, k, mu)
         K.set_Kfine(kfine)
         return K
+
+    # the reference runs the traction-BC plan on u = (1,0,0) here (switch_BC on every panel), prints the summed relative
+    # distance of the result from 4 pi, and replaces it by the analytic value (:266-278)
+    b = torch.zeros((n, 3), dtype=torch.float64, device=dev)
+    if p <= 12:
+        rhs_plan = fb.FMM_plan(kernel(), v, opts, p_max=p, bc=np.ones(n, dtype=np.uint8))
+        u = torch.zeros((n, 3), dtype=torch.float64, device=dev)
+        u[:, 0] = 1.0
+        bt = rhs_plan.execute_torch(u.reshape(-1)).reshape(n, 3)
+        print("rhs error: %.4e" % float(((bt[:, 0] - 4 * math.pi).abs() / 4 / math.pi).sum()))
+        rhs_plan.close()
+    else:
+        print("rhs error: not evaluated (the far field of TRACTION targets is built for p <= 12)")
+    b[:, 0] = 4 * math.pi
+    print("done")
+    setup_time = time.time() - tic
 
     plan = fb.FMM_plan(kernel(), v, opts, p_max=p)
     # x(panels.size(), charge_type(1.)): Vec<3,double> with ONE argument is the zero vector

@@ -40,9 +40,10 @@ typedef enum {
   FMMBEM_KERNEL_LAPLACE_BEM = 0, /* kernel/LaplaceSphericalBEM.hpp: 1 unknown per panel                  */
   FMMBEM_KERNEL_STOKES_BEM = 1   /* kernel/StokesSphericalBEM.hpp: 3 unknowns per panel, x/y hold Vec<3,double> per panel.
                                   * VELOCITY panels (stokeslet single layer, the operator the solve uses): everything.
-                                  * TRACTION panels (bc flag 1, eval_traction_integral :160-258): near-matrix entries,
-                                  * fmmbem_kernel_entries and the near-field evaluators (LOCAL, BLOCK_DIAGONAL); the FMM
-                                  * evaluator refuses them: the reference's traction far field disagrees with its own Direct */
+                                  * TRACTION panels (bc flag 1, eval_traction_integral :160-258; the TARGET's flag picks the
+                                  * operator, :377-389): near-matrix entries, fmmbem_kernel_entries, the near-field evaluators
+                                  * (LOCAL, BLOCK_DIAGONAL), and through the FMM evaluator a double-layer far field checked
+                                  * against the Direct sum (the reference's own disagrees with its Direct); p_max <= 12 */
 } fmmbem_kernel;
 
 /* boundary-condition flag per panel: LaplaceSphericalBEM::Panel::BoundaryType

@@ -2,6 +2,7 @@
 // examples/LaplaceBEM.cpp:203-232): build panels, make a plan, execute, relax p, execute again.
 // Prints "<n> <p> <sum of results> <result[0]> <result[n-1]>" per execute for the Python test to compare
 // against the oracle.  usage: adapter_example <recursions>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -47,13 +48,23 @@ int main(int argc, char** argv) {
     for (const auto& r : u)
       for (int c = 0; c < 3; ++c) s3[c] += r[c];
     std::printf("stokes %zu %d %.17g %.17g %.17g\n", n, KS.p(), s3[0], s3[1], s3[2]);
-    // a traction panel is refused, not silently mis-evaluated
-    spanels[0].switch_BC();
+    // the driver's right-hand-side step (examples/StokesBEM.cpp:266-278): every panel switched to TRACTION, the plan run on
+    // u = (1,0,0); the double layer of a closed surface gives 4 pi u
+    for (auto& pnl : spanels) pnl.switch_BC();
+    {
+      FMM_plan<StokesSphericalBEM> rhs_plan(KS, spanels, opts, 8);
+      std::vector<StokesSphericalBEM::result_type> b = rhs_plan.execute(f);
+      double mean = 0, off = 0;
+      for (const auto& r : b) { mean += r[0]; off += std::fabs(r[1]) + std::fabs(r[2]); }
+      std::printf("traction accepted %.17g %.17g\n", mean / n / (4 * M_PI), off / n);
+    }
+    // ... which exists up to order 12: above, a plan with TRACTION targets is refused, not silently mis-evaluated
     try {
-      FMM_plan<StokesSphericalBEM> bad(KS, spanels, opts, 8);
-      std::printf("traction accepted\n");
+      StokesSphericalBEM K14(14, 3, 1e-3);
+      FMM_plan<StokesSphericalBEM> bad(K14, spanels, opts, 14);
+      std::printf("traction14 accepted\n");
     } catch (const fmmbem::Error& e) {
-      std::printf("traction refused %d\n", e.status);
+      std::printf("traction14 refused %d\n", e.status);
     }
   } catch (const fmmbem::Error& e) {
     std::printf("error %d %s\n", e.status, e.what());
