@@ -249,3 +249,27 @@ def test_gpu_stokes_matrix_free_near_field(fb, stokes5):
     assert pl.stats()["near_bytes"] == 0
     x = drand48(3 * o.n, seed=11).reshape(o.n, 3)
     assert rel_l2(pl.execute(x), o.matvec(x, 8)) <= 1e-12
+
+
+@pytest.mark.gpu
+def test_gpu_stokes_traction_shards_and_matrix_free(fb, oracle_mod):
+    """The double-layer operator through the other routes of the plan: shards over target leaves sum to the whole operator bit
+    for bit (a shard builds gradient records for its own P2M rows only when the upward pass is sharded too), and the
+    matrix-free near field gives the assembled operator."""
+    v = np.concatenate([oracle_mod.unit_sphere(4), oracle_mod.unit_sphere(4, center=(2.4, 0.0, 0.3))])
+    n = len(v)
+    bc = (np.arange(n) % 3 != 0).astype(np.uint8)                       # mostly TRACTION targets, some velocity
+    x = drand48(3 * n, seed=33).reshape(n, 3)
+    K = fb.StokesSphericalBEM(7, 4, 1e-3)
+    K.set_Kfine(19)
+    y = fb.FMM_plan(K, v, bc=bc).execute(x)
+    total = np.zeros_like(y)
+    for rank in range(3):
+        part = fb.FMM_plan(K, v, bc=bc, shard=(rank, 3))
+        total += part.execute(x)
+        part.close()
+    assert np.array_equal(total, y)
+    fo = fb.FMMOptions()
+    fo.sparse_local = False
+    ymf = fb.FMM_plan(K, v, fo, bc=bc).execute(x)
+    assert rel_l2(ymf, y) <= 1e-13
