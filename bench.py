@@ -231,9 +231,10 @@ def main():
                                ("LaplaceSphericalBEM, %d disjoint UnitSphere(r=%d), N=%d panels, p=%d, k=3, theta=%g, "
                                 "ncrit=%d, all POTENTIAL; target leaves sharded over %d GPU(s), %s"
                                 % (args.spheres, args.recursions, n, P, args.theta, args.ncrit, world,
-                                   ("1 all-gather of the multipoles + " if op.split else "") +
+                                   ((("1 all-to-all of the multipoles each shard reads + " if op.plan.exchange_mode == 2
+                                     else "1 all-gather of the multipoles + ") if op.split else "") +
                                    ("1 all-gather of the result slices per matvec" if op.y_collective == "allgather" else
-                                    "1 all-reduce of y per matvec"))),
+                                    "1 all-reduce of y per matvec")))),
                    "n_panels": n, "p": P, "near_nnz": st["near_nnz_total"], "m2l_pairs": st["m2l_pairs"],
                    "boxes": st["n_boxes"], "leaves": st["n_leaves"]},
         "roofline": mf if args.matrix_free else
@@ -249,7 +250,7 @@ def main():
         "stage_ms": {k[3:]: st[k] for k in ("ms_total", "ms_gather", "ms_near", "ms_scatter", "ms_p2m", "ms_m2m",
                                             "ms_mh", "ms_m2l", "ms_l2l", "ms_l2p")},
         "per_rank": per_rank,
-        "collectives": None if world == 1 else {"upward": "all-gather of multipoles" if op.split else "none (upward pass repeated)",
+        "collectives": None if world == 1 else {"upward": ("all-to-all of the multipoles each shard reads" if op.plan.exchange_mode == 2 else "all-gather of multipoles") if op.split else "none (upward pass repeated)",
                                                 "result": op.y_collective},
         "plan_build_s": build_s, "near_assemble_s": st["build_assemble_ms"] * 1e-3,
         "host_lists_s": st["build_host_ms"] * 1e-3,

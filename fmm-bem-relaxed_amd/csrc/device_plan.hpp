@@ -78,6 +78,9 @@ struct DevicePlan {
   const int* xch_box;                                // sharded upward pass: private need_M boxes of every shard, by shard
   int xch_ptr[9];                                    // ... xch_box[xch_ptr[r] .. xch_ptr[r+1]) belongs to shard r (<= 8 shards)
   int xch_rank, xch_world, xch_max;                  // this shard, number of shards, largest per-shard count
+  // shard_upward == 2 (selective exchange): the boxes this shard sends (all destinations, one after the other) and receives
+  const int *xsel_send_box = nullptr, *xsel_recv_box = nullptr;
+  int xsel_send_n = 0, xsel_recv_n = 0;
   const int4* near_items;                            // SpMV work items {leaf, first row, rows, column-split?}, largest first
   const NearItem* near_recs;                         // the same items as self-contained records (pipelined kernel)
   int near_nitems;

@@ -405,6 +405,7 @@ std::string HostPlan::build(const HostOptions& o, int64_t n_panels, const double
   mark("need/has + l2l rule");
   // ---- shard: contiguous range of target leaves ----
   std::vector<int> box_owner(nboxes, 0);                 // shard whose rows hold all of the box's bodies, -1 = spans shards
+  std::vector<int64_t> shard_rb;                         // first row of every shard, then n
   {
     std::vector<int> cut;
     partition_leaves(*this, o.shard_world, cut);
@@ -415,6 +416,7 @@ std::string HostPlan::build(const HostOptions& o, int64_t n_panels, const double
         const int r = int(std::upper_bound(rb.begin(), rb.end(), (int64_t)box_body_begin[b]) - rb.begin()) - 1;
         box_owner[b] = (box_body_end[b] <= rb[r + 1]) ? r : -1;
       }
+      shard_rb = rb;
     }
     leaf_begin = cut[o.shard_rank];
     leaf_end = cut[o.shard_rank + 1];
@@ -463,6 +465,31 @@ std::string HostPlan::build(const HostOptions& o, int64_t n_panels, const double
       for (int b = 0; b < nboxes; ++b)
         if (need_M[b] && box_owner[b] == r) xch_box.push_back(b);
       xch_ptr.push_back((int)xch_box.size());
+    }
+    // who READS which multipoles: shard q computes L of every box that overlaps its rows, from all of that box's sources
+    const int W = o.shard_world, me = o.shard_rank;
+    std::vector<std::vector<uint8_t>> need((size_t)W, std::vector<uint8_t>((size_t)nboxes, 0));
+    auto shard_of_row = [&](int64_t row) { return int(std::upper_bound(shard_rb.begin(), shard_rb.end(), row) - shard_rb.begin()) - 1; };
+    for (size_t i = 0; i < lr_tgt.size(); ++i) {
+      const int t = lr_tgt[i], s_ = lr_src[i];
+      if (box_body_end[t] <= box_body_begin[t]) continue;
+      const int q0 = shard_of_row(box_body_begin[t]), q1 = shard_of_row((int64_t)box_body_end[t] - 1);
+      for (int q = std::max(q0, 0); q <= q1 && q < W; ++q) need[(size_t)q][(size_t)s_] = 1;
+    }
+    for (int b = 0; b < nboxes; ++b)                     // the parents every shard translates read all their children
+      if (!box_leaf[b] && need_M[b] && box_owner[b] < 0)
+        for (int c = box_child_begin[b]; c < box_child_end[b]; ++c)
+          for (int q = 0; q < W; ++q) need[(size_t)q][(size_t)c] = 1;
+    xsel_send_ptr.assign(1, 0); xsel_recv_ptr.assign(1, 0);
+    for (int q = 0; q < W; ++q) {
+      if (q != me)
+        for (int b = 0; b < nboxes; ++b)
+          if (need_M[b] && box_owner[b] == me && need[(size_t)q][(size_t)b]) xsel_send_box.push_back(b);
+      xsel_send_ptr.push_back((int)xsel_send_box.size());
+      if (q != me)
+        for (int b = 0; b < nboxes; ++b)
+          if (need_M[b] && box_owner[b] == q && need[(size_t)me][(size_t)b]) xsel_recv_box.push_back(b);
+      xsel_recv_ptr.push_back((int)xsel_recv_box.size());
     }
   }
   l2l_level_ptr.assign(1, 0);

@@ -37,7 +37,7 @@ struct HostOptions {
   int shard_rank = 0, shard_world = 1;
   int evaluator = 0;           // 0 FMM, 1 local only, 2 block diagonal (executor/make_executor.hpp:24-60)
   bool reference_l2l = false;  // keep only the parent->child L2L edges the reference's lazy rule keeps (see host_plan.cpp)
-  bool shard_upward = false;   // shard_world > 1: P2M/M2M only for boxes this shard owns (+ the few spanning shards)
+  int shard_upward = 0;        // shard_world > 1: 1, 2 = P2M/M2M only for boxes this shard owns (+ the few spanning shards); 2 = selective exchange lists
 };
 
 // Panels in TREE order, structure-of-arrays (what the kernels stream).
@@ -129,6 +129,11 @@ struct HostPlan {
   // m2m_parents[m2m_shared_ptr[l] .. m2m_shared_ptr[l+1]) the shared parents of one level (deepest first), and
   // xch_box[xch_ptr[r] .. xch_ptr[r+1]) the private need_M boxes of shard r (what it sends in the all-gather).
   std::vector<int> m2m_shared_ptr, xch_ptr, xch_box;
+  // shard_upward == 2: the same exchange, but a shard sends another only the boxes that shard's lists READ (the sources of the
+  // M2L pairs of its targets, and the private children of the parents every shard translates): xsel_send_box[xsel_send_ptr[q]
+  // .. xsel_send_ptr[q+1]) go from this shard to shard q, xsel_recv_box[xsel_recv_ptr[r] ..) come from shard r, ascending box ids
+  // on both sides.  At N = 1M on 8 shards: 2-3 thousand boxes per shard instead of the 60 thousand of the all-gather.
+  std::vector<int> xsel_send_ptr, xsel_send_box, xsel_recv_ptr, xsel_recv_box;
   int64_t near_nnz_owned = 0, m2l_pairs_owned = 0;
 
   PanelSoA panels;                        // tree order

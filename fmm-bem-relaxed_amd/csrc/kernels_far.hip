@@ -877,7 +877,23 @@ __global__ void xch_unpack_kernel(DevicePlan d, const int P, const double2* __re
   d.M[((size_t)d.xch_box[g] * d.nslots + d.act[a]) * d.s_max + i] = recv[((size_t)r * d.xch_max + idx) * per + rem];
 }
 
+// selective exchange (shard_upward == 2): M of a list of boxes -> buffer, buffer -> M of a list of boxes; the buffer holds
+// [position in the list][active slot][S(p)] complex, the lists the boxes of all peers one peer after the other
+__global__ void xch_list_kernel(DevicePlan d, const int P, const int* __restrict__ boxes, int count, double2* __restrict__ buf, int to_buf) {
+  const int S = P * (P + 1) / 2, per = d.n_act * S;
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t >= (int64_t)count * per) return;
+  const int idx = (int)(t / per), rem = (int)(t - (int64_t)idx * per), a = rem / S, i = rem - a * S;
+  double2* m = d.M + ((size_t)boxes[idx] * d.nslots + d.act[a]) * d.s_max + i;
+  if (to_buf) buf[t] = *m; else *m = buf[t];
+}
+
 hipError_t launch_xch_pack(const DevicePlan& d, int p, double2* send, hipStream_t s) {
+  if (d.xsel_send_box) {
+    const int64_t n = (int64_t)d.xsel_send_n * d.n_act * (p * (p + 1) / 2);
+    if (n > 0) hipLaunchKernelGGL(xch_list_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d, p, d.xsel_send_box, d.xsel_send_n, send, 1);
+    return hipGetLastError();
+  }
   const int64_t n = (int64_t)(d.xch_ptr[d.xch_rank + 1] - d.xch_ptr[d.xch_rank]) * d.n_act * (p * (p + 1) / 2);
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(xch_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d, p, send);
@@ -885,6 +901,11 @@ hipError_t launch_xch_pack(const DevicePlan& d, int p, double2* send, hipStream_
 }
 
 hipError_t launch_xch_unpack(const DevicePlan& d, int p, const double2* recv, hipStream_t s) {
+  if (d.xsel_recv_box) {
+    const int64_t n = (int64_t)d.xsel_recv_n * d.n_act * (p * (p + 1) / 2);
+    if (n > 0) hipLaunchKernelGGL(xch_list_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d, p, d.xsel_recv_box, d.xsel_recv_n, const_cast<double2*>(recv), 0);
+    return hipGetLastError();
+  }
   const int64_t n = (int64_t)d.xch_ptr[d.xch_world] * d.n_act * (p * (p + 1) / 2);
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(xch_unpack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d, p, recv);

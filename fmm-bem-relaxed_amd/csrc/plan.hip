@@ -485,6 +485,10 @@ int fmmbem_plan::to_device() {
     for (int r = 0; r < hp.opt.shard_world; ++r) d.xch_max = std::max(d.xch_max, hp.xch_ptr[r + 1] - hp.xch_ptr[r]);
   }
   TRY(upload(hp.xch_box, &d.xch_box));
+  if (split_upward && hp.opt.shard_upward == 2) {      // selective exchange: only what the receiver reads
+    TRY(upload(hp.xsel_send_box, &d.xsel_send_box)); TRY(upload(hp.xsel_recv_box, &d.xsel_recv_box));
+    d.xsel_send_n = (int)hp.xsel_send_box.size(); d.xsel_recv_n = (int)hp.xsel_recv_box.size();
+  }
 
   mark("far-field lists");
   // parent<->child translation classes and their regular-harmonic tables
@@ -926,7 +930,7 @@ int fmmbem_plan_create(const fmmbem_options* opts, size_t n_panels, const double
   ho.p_max = opts->p_max; ho.quad_k = opts->quad_k; ho.theta = opts->theta; ho.ncrit = opts->ncrit;
   ho.shard_rank = opts->shard_rank; ho.shard_world = opts->shard_world < 1 ? 1 : opts->shard_world;
   ho.evaluator = opts->evaluator;
-  ho.shard_upward = opts->shard_upward != 0;
+  ho.shard_upward = opts->shard_upward < 0 ? 0 : opts->shard_upward > 2 ? 2 : opts->shard_upward;
   ho.reference_l2l = opts->l2l_rule == FMMBEM_L2L_REFERENCE;
   const double t0 = now_ms();
   std::string err;
@@ -967,6 +971,22 @@ int fmmbem_plan_exchange_doubles(const fmmbem_plan* plan, int p, size_t* per_sha
   for (size_t r = 0; r + 1 < h.xch_ptr.size(); ++r) most = std::max<size_t>(most, (size_t)(h.xch_ptr[r + 1] - h.xch_ptr[r]));
   const size_t n_act = plan->opts.kernel == FMMBEM_KERNEL_STOKES_BEM ? (size_t)plan->d.n_act : (size_t)h.has_bc[0] + (size_t)h.has_bc[1];
   *per_shard = (h.opt.shard_upward && h.opt.shard_world > 1) ? most * n_act * (size_t)(p * (p + 1) / 2) * 2 : 0;
+  return FMMBEM_OK;
+}
+
+int fmmbem_plan_exchange_counts(const fmmbem_plan* plan, int p, int64_t* send_doubles, int64_t* recv_doubles) {
+  if (!plan || !send_doubles || !recv_doubles) return fail(FMMBEM_ERR_INVALID, "null argument");
+  if (p < 1 || p > plan->hp.opt.p_max) return fail(FMMBEM_ERR_INVALID, "p outside [1, p_max]");
+  const HostPlan& h = plan->hp;
+  const int W = h.opt.shard_world;
+  const bool sel = h.opt.shard_upward == 2 && W > 1;
+  if (!sel) return fail(FMMBEM_ERR_INVALID, "plan was not created with shard_upward = 2");
+  const int64_t n_act = plan->opts.kernel == FMMBEM_KERNEL_STOKES_BEM ? (int64_t)(plan->on_device ? plan->d.n_act : 4) : (int64_t)h.has_bc[0] + (int64_t)h.has_bc[1];
+  const int64_t per = n_act * (int64_t)(p * (p + 1) / 2) * 2;
+  for (int q = 0; q < W; ++q) {
+    send_doubles[q] = (int64_t)(h.xsel_send_ptr[q + 1] - h.xsel_send_ptr[q]) * per;
+    recv_doubles[q] = (int64_t)(h.xsel_recv_ptr[q + 1] - h.xsel_recv_ptr[q]) * per;
+  }
   return FMMBEM_OK;
 }
 

@@ -6,7 +6,8 @@ in tree order, contiguous, so the result is replicated by ONE all-gather of the 
 or, FMMBEM_Y_COLLECTIVE=allreduce, by the all-reduce(sum) of zero-padded vectors that BASELINE.json's north_star words
 (twice the bytes; the two produce the same bits).  The upward pass is either repeated by every rank (SURVEY.md section 8e
 as written: one collective per matvec) or -- shard_upward, the default -- computed by the owners of the boxes and shared
-with ONE all-gather of the multipoles (60 MB at N = 1M, p = 10) in front of M2L.
+with ONE collective in front of M2L: by default an all-to-all in which every shard receives only the multipoles its own lists
+read (2-3 MB per shard at N = 1M, p = 10 on 8 shards; FMMBEM_XCH=allgather: all 60 MB to everybody).
 
 The reference has no distributed code at all; this is the design of section 8(e).
 """
@@ -36,12 +37,15 @@ class ShardedFMM:
             device = torch.cuda.current_device() if torch.cuda.is_available() else 0
         if shard_upward is None:
             shard_upward = os.environ.get("FMMBEM_SHARD_UPWARD", "1") != "0"
+        # how the multipoles travel when the upward pass is sharded: "alltoall" (default) = every shard sends every other only
+        # what that shard's lists read (2-3 thousand boxes per shard at N = 1M on 8 shards), "allgather" = everything to everybody
+        self.xch = os.environ.get("FMMBEM_XCH", "alltoall")
         # the owner-sharded upward pass carries at most 8 shards (DevicePlan::xch_ptr): larger groups repeat the upward pass
         self.split = (bool(shard_upward) and 1 < self.world <= 8 and local_execute is None) or local_split is not None
         self._split_fns = local_split
         self.plan = FMM_plan(K, panels, opts, bc=bc, p_max=p_max, device=device,
                              shard=(self.rank, self.world), host_only=host_only,
-                             shard_upward=self.split and self.world > 1)
+                             shard_upward=(2 if self.xch == "alltoall" and local_split is None else True) if (self.split and self.world > 1) else False)
         self.n = self.plan.n
         self._local = local_execute if local_execute is not None else self.plan.execute_torch
         self._xbuf = {}                                   # p -> (send, recv) exchange buffers
@@ -82,7 +86,10 @@ class ShardedFMM:
     def exchange_bytes(self, p=None):
         """Bytes this rank RECEIVES per matvec in the two collectives: (multipole all-gather, result collective)."""
         p = self.plan.kernel().P if p is None else p
-        up = self.plan.exchange_doubles(p) * 8 * (self.world - 1) if self.split and not self._split_fns else 0
+        if self.split and not self._split_fns:
+            up = int(self.plan.exchange_counts(p)[1].sum()) * 8 if self.plan.exchange_mode == 2 else self.plan.exchange_doubles(p) * 8 * (self.world - 1)
+        else:
+            up = 0
         nd = self.n * self.plan.dof * 8
         if self.world == 1:
             return 0, 0
@@ -102,6 +109,29 @@ class ShardedFMM:
             torch.cuda.synchronize(device)
         self.collective_s += time.perf_counter() - t0
         return r
+
+    def _all_to_all(self, recv, send, recv_counts, send_counts):
+        """One all-to-all with uneven counts.  RCCL takes device tensors; gloo (CPU rehearsals of the N > 1 path on a one-GPU
+        box) has no all-to-all at all: there the segments go through the host, point to point."""
+        ns, nr = sum(send_counts), sum(recv_counts)
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_to_all_single(recv[:nr], send[:ns], recv_counts, send_counts, group=self.group)
+            return
+        hs, hr = send[:ns].cpu(), torch.empty(nr, dtype=send.dtype)
+        outs = list(hr.split(recv_counts)) if nr else [hr[:0] for _ in recv_counts]
+        ins = list(hs.split(send_counts)) if ns else [hs[:0] for _ in send_counts]
+        peer = (lambda q: q) if self.group is None else (lambda q: dist.get_global_rank(self.group, q))
+        reqs = []
+        for q in range(self.world):                       # gloo has no all-to-all: point-to-point, receives posted first
+            if q != self.rank and recv_counts[q]:
+                reqs.append(dist.irecv(outs[q], src=peer(q), group=self.group))
+        for q in range(self.world):
+            if q != self.rank and send_counts[q]:
+                reqs.append(dist.isend(ins[q].contiguous(), dst=peer(q), group=self.group))
+        for r in reqs:
+            r.wait()
+        if nr:
+            recv[:nr].copy_(hr)
 
     def execute(self, x, out=None):
         """x: full charge vector, replicated on every rank (torch tensor). Returns the full result."""
@@ -124,11 +154,18 @@ class ShardedFMM:
                 self._local(x, out=part)
         else:
             p = self.plan.kernel().P
+            a2a = not self._split_fns and self.plan.exchange_mode == 2
             if p not in self._xbuf:
-                per = self._split_fns[0] if self._split_fns else self.plan.exchange_doubles(p)
-                self._xbuf[p] = (torch.empty(per, dtype=torch.float64, device=x.device),
-                                 torch.empty(per * self.world, dtype=torch.float64, device=x.device))
-            send, recv = self._xbuf[p]
+                if a2a:
+                    sc, rc = self.plan.exchange_counts(p)
+                    self._xbuf[p] = (torch.empty(max(int(sc.sum()), 1), dtype=torch.float64, device=x.device),
+                                     torch.empty(max(int(rc.sum()), 1), dtype=torch.float64, device=x.device),
+                                     [int(c) for c in sc], [int(c) for c in rc])
+                else:
+                    per = self._split_fns[0] if self._split_fns else self.plan.exchange_doubles(p)
+                    self._xbuf[p] = (torch.empty(per, dtype=torch.float64, device=x.device),
+                                     torch.empty(per * self.world, dtype=torch.float64, device=x.device))
+            send, recv = self._xbuf[p][0], self._xbuf[p][1]
             if self._split_fns:
                 self._split_fns[1](x, send)
                 dist.all_gather_into_tensor(recv, send, group=self.group)
@@ -136,11 +173,14 @@ class ShardedFMM:
             else:
                 stream = torch.cuda.current_stream(x.device).cuda_stream
                 self.plan.upward_device(x.data_ptr(), send.data_ptr(), stream, p)
-                if self._overlap:
+                if self._overlap and not a2a:
                     # the near field (HBM-bound, needs no multipoles) streams while the multipoles travel over xGMI
                     work = dist.all_gather_into_tensor(recv, send, group=self.group, async_op=True)
                     self.plan.near_split_device(part.data_ptr(), stream)
                     work.wait()                           # RCCL: the current stream waits for the collective, the host does not
+                elif a2a:
+                    sc, rc = self._xbuf[p][2], self._xbuf[p][3]
+                    self._timed(lambda: self._all_to_all(recv, send, rc, sc), x.device)
                 else:
                     self._timed(lambda: dist.all_gather_into_tensor(recv, send, group=self.group), x.device)
                 self.plan.downward_device(recv.data_ptr(), part.data_ptr(), stream, p)

@@ -215,8 +215,11 @@ class FMM_plan:
             o.quad_k_fine = K.K_fine
             self.dof = 3
         o.shard_rank, o.shard_world = int(shard[0]), int(shard[1])
-        o.shard_upward = 1 if (shard_upward and int(shard[1]) > 1) else 0
+        self._shard_world = int(shard[1])
+        # shard_upward: False / True (1: all-gather of the multipoles) / 2 (all-to-all of the ones each receiver reads)
+        o.shard_upward = (2 if shard_upward == 2 else 1) if (shard_upward and int(shard[1]) > 1) else 0
         self.shard_upward = bool(o.shard_upward)
+        self.exchange_mode = int(o.shard_upward)
         self.p_max = o.p_max
         bcp = None
         if bc is not None:
@@ -256,6 +259,14 @@ class FMM_plan:
                                                            C.c_void_p(x_ptr), C.c_void_p(y_ptr), C.c_void_p(stream)))
 
     # ---- split execute of a plan that shards the upward pass (include/fmmbem.h) ----
+    def exchange_counts(self, p=None):
+        """shard_upward = 2: (send, recv) int64 arrays of doubles per peer shard at order p (fmmbem_plan_exchange_counts)."""
+        w = self._shard_world
+        send, recv = np.zeros(w, dtype=np.int64), np.zeros(w, dtype=np.int64)
+        _capi.check(_capi.lib().fmmbem_plan_exchange_counts(self._h, self._K.P if p is None else int(p),
+                                                             send.ctypes.data_as(C.c_void_p), recv.ctypes.data_as(C.c_void_p)))
+        return send, recv
+
     def exchange_doubles(self, p=None):
         n = C.c_size_t(0)
         _capi.check(_capi.lib().fmmbem_plan_exchange_doubles(self._h, self._K.P if p is None else int(p), C.byref(n)))

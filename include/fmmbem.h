@@ -89,8 +89,10 @@ typedef struct {
   int32_t  evaluator;         /* fmmbem_evaluator: which branch of make_evaluators the plan takes   */
   double   mu;                /* Stokes: viscosity (StokesSphericalBEM(p,k,mu), :131)               */
   int32_t  shard_upward;      /* shard_world > 1: also shard P2M/M2M by owner; the multipoles are exchanged by ONE
-                               * all-gather the caller performs between fmmbem_plan_upward_device and
-                               * fmmbem_plan_downward_device (0: every shard repeats the whole upward pass)   */
+                               * collective the caller performs between fmmbem_plan_upward_device and
+                               * fmmbem_plan_downward_device: 1 = an all-gather of every shard's multipoles, 2 = an
+                               * all-to-all of the ones each receiver reads (fmmbem_plan_exchange_counts);
+                               * 0: every shard repeats the whole upward pass                                  */
   int32_t  l2l_rule;          /* fmmbem_l2l_rule: which parent->child L2L edges the downward pass applies              */
 } fmmbem_options;
 
@@ -187,6 +189,13 @@ int fmmbem_kernel_entries(const fmmbem_options *opts, size_t n, const double *ta
  *             [meanwhile, optionally: near_split -> y]
  *   downward: d_recv -> the remaining M2M, M2L, L2L, L2P and the near field -> y (zero outside the owned rows) */
 int fmmbem_plan_exchange_doubles(const fmmbem_plan *plan, int p, size_t *per_shard);
+/* shard_upward = 2: the same split execute, but the caller's collective is ONE all-to-all with uneven counts that carries,
+ * for every pair of shards, only the multipoles the receiver's lists read (the M2L sources of its targets and the private
+ * children of the few parents every shard translates): 2-3 thousand boxes per shard instead of 60 thousand at N = 1M on 8
+ * shards.  send_doubles[q] / recv_doubles[q], q < shard_world: doubles this shard sends to / receives from shard q at order p
+ * (0 for itself); d_send / d_recv of upward / downward hold the peers' segments one after the other, rank order -- the
+ * layout of MPI_Alltoallv / torch.distributed.all_to_all_single with split sizes. */
+int fmmbem_plan_exchange_counts(const fmmbem_plan *plan, int p, int64_t *send_doubles, int64_t *recv_doubles);
 int fmmbem_plan_upward_device(fmmbem_plan *plan, int p, const double *d_x, double *d_send, void *stream);
 int fmmbem_plan_downward_device(fmmbem_plan *plan, int p, const double *d_recv, double *d_y, void *stream);
 /* Optional, between the two: the near field of this shard (y = A_near x of the x given to upward; zero outside the owned

@@ -138,3 +138,34 @@ def test_rotation_m2l_work_list_items_are_runs_of_whole_targets():
         assert passes == st["m2l_passes"]
         assert st["m2l_pairs_owned"] / (64.0 * passes) > 0.8
         plan.close()
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_selective_exchange_lists_cover_what_a_shard_reads(world):
+    """shard_upward = 2 (HostPlan::xsel_*): what shard r sends shard q is what q expects from r, nothing goes to oneself, and
+    every multipole a shard's M2L work list reads is either its own, translated by every shard (a box spanning shards), or on
+    its receive list -- counted here through fmmbem_plan_exchange_counts against the shard's own work list."""
+    import fmm_bem_relaxed_amd as fb
+    v = np.concatenate([fb.unit_sphere(5), fb.unit_sphere(4, center=(2.5, 0.0, 0.0))])
+    K = fb.LaplaceSphericalBEM(6, 3)
+    plans = [fb.FMM_plan(K, v, host_only=True, shard=(r, world), shard_upward=2) for r in range(world)]
+    per = 2 * (6 * 7 // 2)                                    # doubles per box: one live expansion (all POTENTIAL), order 6
+    counts = [pl.exchange_counts(6) for pl in plans]
+    cut = plans[0].shard_rows(world)
+    B = plans[0].boxes()
+    owner = np.full(len(B["bb"]), -1)
+    for r in range(world):
+        owner[(B["bb"] >= cut[r]) & (B["be"] <= cut[r + 1])] = r
+    for r in range(world):
+        assert counts[r][0][r] == 0 and counts[r][1][r] == 0
+        for q in range(world):
+            assert counts[r][0][q] == counts[q][1][r] and counts[r][0][q] % per == 0
+        src = np.unique(plans[r].pairs("m2l_work")[:, 0])
+        for q in range(world):
+            if q != r:                                        # at least the M2L sources private to q (plus children of spanning parents)
+                assert counts[r][1][q] // per >= np.count_nonzero(owner[src] == q)
+    # less than everything to everybody
+    gather = fb.FMM_plan(K, v, host_only=True, shard=(0, world), shard_upward=True).exchange_doubles(6) * (world - 1)
+    assert max(int(c[1].sum()) for c in counts) < gather
+    for pl in plans:
+        pl.close()

@@ -1,5 +1,6 @@
 """The N > 1 path with the REAL per-shard work: two ranks (gloo, both on GPU 0 -- this box has one card) run
-ShardedFMM.execute through the HIP plan's split entry points (upward -> all-gather of multipoles -> downward) and both
+ShardedFMM.execute through the HIP plan's split entry points (upward -> exchange of multipoles, selective all-to-all or
+all-gather -> downward) and both
 result collectives (all-gather of tree-order slices + assembly; all-reduce of zero-padded vectors), and the replicated
 result must equal the single plan's bit for bit; the relaxed GMRES then runs on the sharded operator.  (The collectives go
 through the host under gloo: this is a correctness rehearsal of what bench.py --gpus N does over RCCL, not a measurement.)"""
@@ -35,20 +36,26 @@ def _worker(rank, world, port, out):
         x = torch.from_numpy(np.random.default_rng(3).random(n)).to(dev)
         ok = {}
         single = fb.FMM_plan(fb.LaplaceSphericalBEM(10, 3), v, p_max=10) if rank == 0 else None
-        for split in (True, False):
+        ups = {}
+        for split, xch in ((True, "alltoall"), (True, "allgather"), (False, "alltoall")):
+            os.environ["FMMBEM_XCH"] = xch                # how the multipoles travel: only what the receiver reads / everything
             for coll in ("allgather", "allreduce"):
                 K = fb.LaplaceSphericalBEM(10, 3)
                 op = fb.ShardedFMM(K, v, p_max=10, device=0, shard_upward=split, y_collective=coll)
                 assert op.split == split and op.y_collective == coll
+                assert op.plan.exchange_mode == ((2 if xch == "alltoall" else 1) if split else 0)
                 for p in (10, 3):
                     K.set_p(p)
                     y = op.execute(x)
                     if rank == 0:
                         ref = single.execute_torch(x, p=p)
-                        ok[(split, coll, p)] = bool(torch.equal(y, ref))
+                        ok[(split, xch, coll, p)] = bool(torch.equal(y, ref))
                 up, down = op.exchange_bytes(10)
                 assert down > 0 and (up > 0) == split
+                ups[(split, xch)] = up
                 op.plan.close()
+        assert ups[(True, "alltoall")] < ups[(True, "allgather")]
+        os.environ.pop("FMMBEM_XCH")
         # Stokes, three unknowns per panel, slices of Vec<3,double>
         vs = fb.unit_sphere(5)
         KS = fb.StokesSphericalBEM(6, 4, 1e-3)
@@ -78,6 +85,9 @@ def _worker(rank, world, port, out):
             ok["gmres"] = (bool(torch.equal(b, b1)) and it == it1 and [q for _, q, _ in log] == [q for _, q, _ in log1]
                            and bool(torch.equal(xg, x1)))
             out.put(ok)
+    except BaseException as e:                              # the parent should fail now, not after its queue timeout
+        out.put({"error in rank %d: %r" % (rank, e): False})
+        raise
     finally:
         dist.destroy_process_group()
 

@@ -85,3 +85,53 @@ def test_mixed_bc_and_stokes_split(fb):
         torch.cuda.synchronize()
         total += y
     assert np.array_equal(total.cpu().numpy(), fulls)
+
+
+@pytest.mark.parametrize("world,p,traction", [(2, 10, False), (3, 8, False), (8, 5, False), (4, 6, True)])
+def test_selective_exchange_sums_bitwise(fb, world, p, traction):
+    """shard_upward = 2: every shard sends every other only the multipoles that shard's lists read, in one all-to-all with
+    uneven counts (emulated here by copying the segments between the shards' buffers on one GPU).  The receive buffers are
+    filled with NaN first: a box a shard reads but was not sent would poison its result.  The shards' results add up bitwise
+    to the single plan's, and the traffic is a fraction of the all-gather's."""
+    import torch
+    v = np.concatenate([fb.unit_sphere(6), fb.unit_sphere(5, center=(3.0, 0.0, 0.0))])
+    rng = np.random.default_rng(31)
+    n = len(v)
+
+    def kernel():
+        if not traction:
+            return fb.LaplaceSphericalBEM(p, 3)
+        K = fb.StokesSphericalBEM(p, 4, 1e-3)
+        K.set_Kfine(19)
+        return K
+    bc = (np.arange(n) % 2).astype(np.uint8) if traction else None      # Stokes: velocity and TRACTION targets, 11 slots
+    x = rng.standard_normal((n, 3) if traction else n)
+    full = fb.FMM_plan(kernel(), v, p_max=p, bc=bc).execute(x)
+    xd = torch.from_numpy(x).cuda().reshape(-1)
+    plans = [fb.FMM_plan(kernel(), v, p_max=p, bc=bc, shard=(r, world), shard_upward=2) for r in range(world)]
+    counts = [pl.exchange_counts(p) for pl in plans]
+    for r in range(world):
+        assert counts[r][0][r] == 0 and counts[r][1][r] == 0
+        for q in range(world):
+            assert counts[r][0][q] == counts[q][1][r]                    # what r sends q is what q expects from r
+    s = torch.cuda.current_stream().cuda_stream
+    send = [torch.full((max(int(c[0].sum()), 1),), float("nan"), dtype=torch.float64, device="cuda") for c in counts]
+    recv = [torch.full((max(int(c[1].sum()), 1),), float("nan"), dtype=torch.float64, device="cuda") for c in counts]
+    for r, pl in enumerate(plans):
+        pl.upward_device(xd.data_ptr(), send[r].data_ptr(), s, p)
+    torch.cuda.synchronize()
+    for r in range(world):                                              # the all-to-all
+        so = np.concatenate([[0], np.cumsum(counts[r][0])])
+        for q in range(world):
+            ro = np.concatenate([[0], np.cumsum(counts[q][1])])
+            recv[q][ro[r]:ro[r + 1]] = send[r][so[q]:so[q + 1]]
+    total = torch.zeros_like(xd)
+    for r, pl in enumerate(plans):
+        y = torch.empty_like(xd)
+        pl.downward_device(recv[r].data_ptr(), y.data_ptr(), s, p)
+        total += y
+    torch.cuda.synchronize()
+    assert np.array_equal(total.cpu().numpy().reshape(full.shape), full)
+    # against everything-to-everybody (shard_upward = 1)
+    gather = fb.FMM_plan(kernel(), v, p_max=p, bc=bc, shard=(0, world), shard_upward=True).exchange_doubles(p) * (world - 1)
+    assert max(int(c[1].sum()) for c in counts) < gather
