@@ -196,9 +196,10 @@ __device__ __forceinline__ void z_rotation(double (&a)[P * (P + 1) / 2], double 
 }
 
 // Registers: a pair's data alone is 2 S doubles = 4 S VGPRs (112 at p = 7, 220 at p = 10), plus a degree block of
-// temporaries.  Wavefronts per SIMD asked of the compiler, measured at N = 1M (M2L ms, Laplace): p = 7: two 0.41, one 0.50;
-// p = 8: two 0.72, one 0.70; p = 9..12: two 1.00 / 1.51 / 3.28 / 5.59 (1-2 KB of scratch per lane), one 0.96 / 1.29 / 2.07 /
-// 2.73 (the overflow goes to AGPRs: no scratch up to p = 10).
+// temporaries.  Wavefronts per SIMD asked of the compiler: four up to p = 4, three at 5-6, two at 7, ONE from p = 8, where the
+// overflow goes to AGPRs (no scratch up to p = 11).  Measured with the first (SGPR-constant) kernel at N = 1M, M2L ms: p = 7:
+// two 0.41, one 0.50; p = 8: two 0.72, one 0.70; p = 9..12: two 1.00 / 1.51 / 3.28 / 5.59, one 0.96 / 1.29 / 2.07 / 2.73; with the
+// present one at p = 10: two 1.27, one 1.07 (before the later steps that took it to 0.56).
 #ifndef FMMBEM_ROT_OCC
 #define FMMBEM_ROT_OCC(P) ((P) <= 4 ? 4 : (P) <= 6 ? 3 : (P) <= 7 ? 2 : 1)
 #endif
@@ -209,8 +210,10 @@ constexpr int rot_waves(int P) { return FMMBEM_ROT_OCC(P); }
 // the pass at p = 10.  The AGPRs are free once the last fixed rotation is through (the allocator parks values there during
 // the arithmetic only), the VMEM queue is empty behind the last group of constants, and the z rotation and the reduction that
 // follow use neither: the loads go out there, as asm so that they stay there, into AGPRs, and the next pass begins by waiting
-// for them and moving them over.  PF double2 of the multipole are fetched ahead (all of them up to p = 10; 60 x 4 AGPRs
-// above), the rest at the head of the pass.
+// for them and moving them over.  PF double2 of the multipole are fetched ahead -- all of them at p = 8, 9, 36 of 55 at p = 10,
+// 16 at p = 11, none at p = 12: what the AGPRs hold beside the allocator's own use of them (more: the prefetched values are
+// spilled to scratch at once, which tools/check_rot_isa.py reports) -- and the rest at the head of the pass.  The tree-pass
+// operators (OP != M2L) take items of one pass and fetch nothing ahead.
 typedef double v2d __attribute__((ext_vector_type(2)));
 #ifndef FMMBEM_ROT_PF
 #define FMMBEM_ROT_PF(P) ((P) <= 9 ? 64 : (P) == 10 ? 36 : (P) == 11 ? 16 : 0)
