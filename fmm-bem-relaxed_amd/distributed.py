@@ -173,9 +173,13 @@ class ShardedFMM:
             else:
                 stream = torch.cuda.current_stream(x.device).cuda_stream
                 self.plan.upward_device(x.data_ptr(), send.data_ptr(), stream, p)
-                if self._overlap and not a2a:
+                if self._overlap:
                     # the near field (HBM-bound, needs no multipoles) streams while the multipoles travel over xGMI
-                    work = dist.all_gather_into_tensor(recv, send, group=self.group, async_op=True)
+                    if a2a:
+                        sc, rc = self._xbuf[p][2], self._xbuf[p][3]
+                        work = dist.all_to_all_single(recv[:sum(rc)], send[:sum(sc)], rc, sc, group=self.group, async_op=True)
+                    else:
+                        work = dist.all_gather_into_tensor(recv, send, group=self.group, async_op=True)
                     self.plan.near_split_device(part.data_ptr(), stream)
                     work.wait()                           # RCCL: the current stream waits for the collective, the host does not
                 elif a2a:
