@@ -247,7 +247,7 @@ def test_alternative_paths_match_oracle(fb, oracle_mod, monkeypatch, env):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("p", [1, 2, 3, 5, 7, 8, 10, 12])
+@pytest.mark.parametrize("p", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
 def test_tree_passes_by_rotation_match_oracle(fb, oracle_mod, monkeypatch, p):
     """M2M and L2L through the rotation kernels (kernels_m2l_rot.hip compiled with FMMBEM_ROT_OP = 1, 2).  By default only
     levels of 2 048 boxes and more take that path, which no mesh of test size has: FMMBEM_SHIFT_ROT_MIN=0 sends every level
