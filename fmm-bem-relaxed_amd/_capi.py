@@ -55,7 +55,7 @@ _lib = None
 # every symbol include/fmmbem.h declares (tests check that the library exports all of them)
 SYMBOLS = (
     "fmmbem_options_default", "fmmbem_plan_create", "fmmbem_plan_destroy", "fmmbem_plan_execute",
-    "fmmbem_plan_execute_device", "fmmbem_plan_exchange_doubles", "fmmbem_plan_exchange_counts", "fmmbem_plan_upward_device",
+    "fmmbem_mgs_column_device", "fmmbem_mgs_scratch_doubles", "fmmbem_plan_execute_device", "fmmbem_plan_exchange_doubles", "fmmbem_plan_exchange_counts", "fmmbem_plan_upward_device",
     "fmmbem_plan_downward_device", "fmmbem_plan_near_split_device", "fmmbem_plan_near_device", "fmmbem_plan_set_result_slices", "fmmbem_plan_shard_rows",
     "fmmbem_plan_assemble_slices_device", "fmmbem_plan_set_timing", "fmmbem_plan_stats",
     "fmmbem_plan_get_perm", "fmmbem_plan_get_boxes", "fmmbem_plan_get_pairs", "fmmbem_plan_get_near_row",
@@ -93,6 +93,8 @@ def lib():
     L.fmmbem_plan_near_split_device.argtypes = [vp, vp, vp]
     L.fmmbem_plan_exchange_doubles.argtypes = [vp, i32, C.POINTER(C.c_size_t)]
     L.fmmbem_plan_exchange_counts.argtypes = [vp, i32, vp, vp]
+    L.fmmbem_mgs_column_device.argtypes = [C.c_int64, vp, vp, C.c_int64, i32, vp, vp, vp, vp]
+    L.fmmbem_mgs_scratch_doubles.argtypes = [i32]
     L.fmmbem_plan_upward_device.argtypes = [vp, i32, vp, vp, vp]
     L.fmmbem_plan_downward_device.argtypes = [vp, i32, vp, vp, vp]
     L.fmmbem_plan_set_result_slices.argtypes = [vp, i32]

@@ -7,6 +7,7 @@ per iteration ONE device->host transfer brings the new Hessenberg column to the 
 update.  The vector algebra (dot/axpy/norm) is torch plumbing around the operator, not part of the hot path.
 """
 import math
+import os
 
 import torch
 
@@ -48,6 +49,38 @@ def _apply(execute, z, out):
         return out
 
 
+class _Mgs:
+    """Buffers of the fused orthogonalisation (csrc/krylov.hip, fmmbem_mgs_column_device): the column of H on the device and
+    the reduction scratch, zeroed once."""
+
+    def __init__(self, restart, like):
+        from . import _capi
+        self.lib = _capi.lib()
+        self.h = torch.empty(restart + 2, dtype=like.dtype, device=like.device)
+        self.scratch = torch.zeros(int(self.lib.fmmbem_mgs_scratch_doubles(restart + 1)), dtype=like.dtype, device=like.device)
+
+
+def _mgs_column(w, V, i, mgs):
+    """h_k = <w, V_k>, w -= h_k V_k for k <= i; h_{i+1} = |w|; V_{i+1} = w / h_{i+1}.  Returns the i + 2 numbers on the host.
+    Device vectors go through ONE library call (i + 3 launches); anything else (the CPU tests drive this solver with the
+    oracle as the operator) takes the same steps as torch calls."""
+    if mgs is not None and w.is_cuda and w.is_contiguous() and V.is_contiguous():
+        from . import _capi
+        _capi.check(mgs.lib.fmmbem_mgs_column_device(w.numel(), w.data_ptr(), V.data_ptr(), V.stride(0), i + 1, mgs.h.data_ptr(),
+                                                      V[i + 1].data_ptr(), mgs.scratch.data_ptr(),
+                                                      torch.cuda.current_stream(w.device).cuda_stream))
+        return mgs.h[:i + 2].tolist()
+    hs = []
+    for k in range(i + 1):
+        hk = torch.dot(w, V[k])
+        hs.append(hk)
+        w.addcmul_(V[k], hk, value=-1.0)                  # w -= hk * V[k]
+    hn = torch.linalg.vector_norm(w)
+    hs.append(hn)
+    torch.div(w, hn, out=V[i + 1])
+    return torch.stack(hs).tolist()
+
+
 def _generate_plane_rotation(dx, dy):          # GMRES.hpp:88-105
     if dy == 0.0:
         return 1.0, 0.0
@@ -73,6 +106,7 @@ def gmres(MV, x, b, opts, M=None, log=None, stokes=False):
     R, n = opts.restart, x.numel()
     V = torch.empty((R + 1, n), dtype=x.dtype, device=x.device)
     wbuf = torch.empty(n, dtype=x.dtype, device=x.device)
+    mgs = _Mgs(R, x) if (x.is_cuda and os.environ.get("FMMBEM_FUSED_MGS", "1") != "0") else None
     H = [[0.0] * R for _ in range(R + 1)]
     cs, sn, s = [0.0] * R, [0.0] * R, [0.0] * (R + 1)
     normb = float(torch.linalg.vector_norm(b))
@@ -96,15 +130,7 @@ def gmres(MV, x, b, opts, M=None, log=None, stokes=False):
             K.set_p(p)
             z = V[i] if M is None else M(V[i])
             w = _apply(execute, z, wbuf)
-            hs = []
-            for k in range(i + 1):                        # modified Gram-Schmidt, :203-208 (two launches per k)
-                hk = torch.dot(w, V[k])
-                hs.append(hk)
-                w.addcmul_(V[k], hk, value=-1.0)          # w -= hk * V[k]
-            hn = torch.linalg.vector_norm(w)
-            hs.append(hn)
-            torch.div(w, hn, out=V[i + 1])
-            col = torch.stack(hs).tolist()                # the one sync of the iteration
+            col = _mgs_column(w, V, i, mgs)               # modified Gram-Schmidt, :203-212; the one sync of the iteration
             for k in range(i + 2):
                 H[k][i] = col[k]
             for k in range(i):                            # PlaneRotation, :108-117
@@ -146,6 +172,7 @@ def fgmres(MV, x, b, opts, M, log=None, stokes=False):
     V = torch.empty((R + 1, n), dtype=x.dtype, device=x.device)
     wbuf = torch.empty(n, dtype=x.dtype, device=x.device)
     Z = torch.empty((R, n), dtype=x.dtype, device=x.device)
+    mgs = _Mgs(R, x) if (x.is_cuda and os.environ.get("FMMBEM_FUSED_MGS", "1") != "0") else None
     H = [[0.0] * R for _ in range(R + 1)]
     cs, sn, s = [0.0] * R, [0.0] * R, [0.0] * (R + 1)
     normb = float(torch.linalg.vector_norm(b))
@@ -168,15 +195,7 @@ def fgmres(MV, x, b, opts, M, log=None, stokes=False):
             K.set_p(p)
             Z[i] = M(V[i])
             w = _apply(execute, Z[i], wbuf)
-            hs = []
-            for k in range(i + 1):
-                hk = torch.dot(w, V[k])
-                hs.append(hk)
-                w.addcmul_(V[k], hk, value=-1.0)
-            hn = torch.linalg.vector_norm(w)
-            hs.append(hn)
-            torch.div(w, hn, out=V[i + 1])
-            col = torch.stack(hs).tolist()
+            col = _mgs_column(w, V, i, mgs)               # modified Gram-Schmidt, :203-212; the one sync of the iteration
             for k in range(i + 2):
                 H[k][i] = col[k]
             for k in range(i):

@@ -182,6 +182,16 @@ int fmmbem_plan_get_diagonal(const fmmbem_plan *plan, double *out);
 int fmmbem_kernel_entries(const fmmbem_options *opts, size_t n, const double *target_vertices, const uint8_t *target_bc,
                           const double *source_vertices, double *out);
 
+/* ---- the orthogonalisation step of the callers above the matvec (examples/BEM/GMRES.hpp:203-212: modified Gram-Schmidt of
+ * w against V_0 .. V_{ncols-1}, then the normalised next basis vector), device vectors, ONE call per Arnoldi column:
+ *   for k < ncols:  h[k] = <w, V_k>;  w -= h[k] V_k;      h[ncols] = |w|;   vnext = w / h[ncols]
+ * d_V: ncols vectors of n doubles, ldv apart; d_h: ncols + 1 doubles on the device; d_scratch:
+ * fmmbem_mgs_scratch_doubles(largest ncols) doubles, ZEROED once by the caller and then reused; asynchronous on `stream`.
+ * The sums are formed in a fixed order. */
+int fmmbem_mgs_column_device(int64_t n, double *d_w, const double *d_V, int64_t ldv, int ncols, double *d_h, double *d_vnext,
+                             double *d_scratch, void *stream);
+int fmmbem_mgs_scratch_doubles(int max_cols);
+
 /* ---- split execute of a plan created with shard_upward = 1 and shard_world > 1 (no reference counterpart:
  * the reference is single-node) ----------------------------------------------------------
  *   upward:   x -> P2M and M2M of the boxes this shard owns -> d_send (exchange_doubles(p) doubles)
