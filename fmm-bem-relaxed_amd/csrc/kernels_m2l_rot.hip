@@ -196,13 +196,14 @@ __device__ __forceinline__ void z_rotation(double (&a)[P * (P + 1) / 2], double 
 }
 
 // Registers: a pair's data alone is 2 S doubles = 4 S VGPRs (112 at p = 7, 220 at p = 10), plus a degree block of
-// temporaries.  Wavefronts per SIMD asked of the compiler: four up to p = 4, three at 5-6, two at 7-8, ONE from p = 9, where the
-// overflow goes to AGPRs (no scratch up to p = 11).  Same box, present kernel: p = 8 two 0.337, one 0.399; p = 9 two 0.472, one
-// 0.461; p = 7 two 0.236, one 0.284.  Measured with the first (SGPR-constant) kernel at N = 1M, M2L ms: p = 7:
+// temporaries.  Wavefronts per SIMD asked of the compiler: four up to p = 4, two at 5-8, ONE from p = 9, where the overflow goes
+// to AGPRs (no scratch up to p = 11).  Same box, present kernel, M2L ms at N = 1M: p = 4 four 0.091, three 0.093, five 0.180;
+// p = 5 two 0.111, three 0.120, four 0.161; p = 6 two 0.169, three 0.180; p = 7 one 0.284, two 0.236, three 0.367; p = 8 one
+// 0.399, two 0.337; p = 9 one 0.461, two 0.472.  Measured with the first (SGPR-constant) kernel at N = 1M, M2L ms: p = 7:
 // two 0.41, one 0.50; p = 8: two 0.72, one 0.70; p = 9..12: two 1.00 / 1.51 / 3.28 / 5.59, one 0.96 / 1.29 / 2.07 / 2.73; with the
 // present one at p = 10: two 1.27, one 1.07 (before the later steps that took it to 0.56).
 #ifndef FMMBEM_ROT_OCC
-#define FMMBEM_ROT_OCC(P) ((P) <= 4 ? 4 : (P) <= 6 ? 3 : (P) <= 8 ? 2 : 1)
+#define FMMBEM_ROT_OCC(P) ((P) <= 4 ? 4 : (P) <= 8 ? 2 : 1)
 #endif
 constexpr int rot_waves(int P) { return FMMBEM_ROT_OCC(P); }
 
