@@ -23,6 +23,12 @@ __device__ inline double wave_sum(double v) {
   return v;
 }
 
+__device__ inline void wave_lds_fence() {             // LDS writes of this wavefront visible to its other lanes
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 struct V3 { double x, y, z; };
 __device__ inline V3 sub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 __device__ inline V3 cross(V3 u, V3 v) { return {u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x}; }
@@ -444,6 +450,157 @@ __global__ __launch_bounds__(256) void near_matfree_kernel(DevicePlan d) {
       }
     }
     __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// near_matfree, second form (one unknown per panel; the default).  The first form above repeats the reference's arithmetic
+// entry by entry: every entry re-reads its source panel (14 doubles from L2), takes a square root and a division per
+// quadrature point, and a wavefront that meets ONE near-regime pair walks the whole semi-analytic integral (three edges,
+// atan2, cos, five-point rules) with the other lanes idle: 45 ms at N = 1M against 0.7 ms for the assembled matrix.  Here
+// (15.5 ms: about 6 of it the far regime, 9 the semi-analytic integrals of the 4.5 % of pairs in the near regimes)
+//   * a wavefront takes a work item of near_spmv (a row range of a target leaf, 64 rows at a time) and walks its columns 64 at a
+//     time: lane = SOURCE panel, read once into registers and applied to every row of the block (the row's centroid is an LDS
+//     broadcast); the lane keeps its share of every row's sum in registers and the lanes are added once, at the end;
+//   * the far regime -- all but ~5 % of the pairs -- is K reciprocal square roots per pair, no division;
+//   * pairs that are, or might be, in a near regime (the reference's test sqrt(2A)/d >= 0.5, taken here as d^2 <= 8A with
+//     a guard band) are not evaluated where they turn up: they go to a queue in LDS and are worked off with all lanes busy,
+//     one queued pair per lane, by the same laplace_entry the assembled path uses (which repeats the exact regime test);
+//   * a row's sum is formed in a fixed order: column groups in order, the queue's contributions in queue order at each flush.
+// ---------------------------------------------------------------------------------------------
+constexpr int kMfRows = 64, kMfQueue = 512;
+
+// 1 / sqrt(x) for a positive, normal x (a squared distance between distinct points): the hardware estimate (2^-26) and one
+// Newton step carried to second order -- five FMAs instead of the library's two steps plus special-case handling
+__device__ __forceinline__ double rsqrt_pos(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double e = fma(-x * y, y, 1.0);                 // 1 - x y^2
+  return fma(y * e, fma(0.375, e, 0.5), y);
+}
+
+// the queue of near_matfree2: every lane takes queued pairs (the full laplace_entry), then lane = row adds its pairs' values
+// in queue order.  Not inlined: the row loop of the kernel is unrolled 64 times around its call.
+__device__ __noinline__ void mf_flush(const DevicePlan& d, int lane, int nr, int qn, const double* tcx, const double* tcy, const double* tcz,
+                                      const int* tbc, const short* qrow, const int* qj, double* qval, double* racc) {
+  wave_lds_fence();
+  for (int k = lane; k < qn; k += kWave) {
+    const int r = qrow[k];
+#ifdef FMMBEM_MF_EXP_NOSLOW
+    qval[k] *= 1e-300 * r;
+#else
+    qval[k] *= laplace_entry(d, V3{tcx[r], tcy[r], tcz[r]}, tbc[r], qj[k]);          // qval held x_j
+#endif
+  }
+  wave_lds_fence();
+  if (lane < nr) {
+    double a = *racc;
+    for (int k = 0; k < qn; ++k) if (qrow[k] == lane) a += qval[k];
+    *racc = a;
+  }
+  wave_lds_fence();
+}
+
+// far regime with more than three quadrature points (K = 4 .. 25): the points are read again for every row
+__device__ __noinline__ double mf_far_general(const DevicePlan& d, int64_t j, double tx, double ty, double tz, int dn, double A,
+                                              double nx, double ny, double nz) {
+  const int64_t N = d.n;
+  double v = 0;
+  for (int q = 0; q < d.nq; ++q) {
+    const double ex = d.quad[(q * 3 + 0) * N + j] - tx, ey = d.quad[(q * 3 + 1) * N + j] - ty, ez = d.quad[(q * 3 + 2) * N + j] - tz;
+    const double ir = rsqrt(ex * ex + ey * ey + ez * ez);
+    v += dn ? d.qw[q] * A * (ex * nx + ey * ny + ez * nz) * (ir * ir * ir) : d.qw[q] * A * ir;
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(kWave) void near_matfree2_kernel(DevicePlan d) {
+  extern __shared__ int mf_lds[];
+  __shared__ double tcx[kMfRows], tcy[kMfRows], tcz[kMfRows], qval[kMfQueue];
+  __shared__ int tbc[kMfRows], qj[kMfQueue];
+  __shared__ short qrow[kMfQueue];
+  int* run_row0 = mf_lds;
+  int* run_off = run_row0 + d.max_runs;
+  const int lane = threadIdx.x;
+  const int64_t N = d.n;
+  const int nq = d.nq;
+  // work units: the row ranges near_spmv streams (plan.hip: a leaf's rows cut so that no unit exceeds 256 KB of matrix, largest
+  // first) -- one coarse leaf of the bench tree is 58 rows x 16 031 columns, a wavefront alone on it would finish milliseconds
+  // after everyone else
+  for (int item = blockIdx.x; item < d.near_nitems; item += gridDim.x) {
+    const int4 it = d.near_items[item];
+    const int t = it.x;
+    const int ncols = d.near_ncols[t], nrows_all = it.z, row0 = d.leaf_row0[t] + it.y;
+    __builtin_amdgcn_wave_barrier();
+    const Runs runs = load_runs(d, t, run_row0, run_off);
+    wave_lds_fence();
+    for (int rb = 0; rb < nrows_all; rb += kMfRows) {
+      const int nr = nrows_all - rb < kMfRows ? nrows_all - rb : kMfRows;
+      if (lane < nr) {
+        const int64_t i = row0 + rb + lane;
+        tcx[lane] = d.cx[i]; tcy[lane] = d.cy[i]; tcz[lane] = d.cz[i]; tbc[lane] = d.bc[i];
+      }
+      double racc = 0;                                   // lane = row: the row's sum
+      double acc[kMfRows];                               // lane = column: this lane's columns' share of every row (registers: the
+#pragma unroll                                           // row loop below is unrolled; a wave_sum per row and column group, the
+      for (int r = 0; r < kMfRows; ++r) acc[r] = 0;      // first attempt, cost three times the arithmetic)
+      int qn = 0;                                        // queued pairs (wave-uniform)
+      wave_lds_fence();
+      for (int c0 = 0; c0 < ncols; c0 += kWave) {
+        const int c = c0 + lane;
+        const bool valid = c < ncols;
+        const int j = valid ? column_to_row(runs, c) : 0;
+        // this lane's source panel, once for all rows
+        const double sx = d.cx[j], sy = d.cy[j], sz = d.cz[j], A = d.area[j], xj = valid ? d.xt[j] : 0.0;
+        const double nx = d.nx[j], ny = d.ny[j], nz = d.nz[j];
+        double qx[3], qy[3], qz[3], wA[3];               // up to three far-regime points in registers (K = 1, 3); more: reloaded
+        const int nqr = nq <= 3 ? nq : 0;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const bool have = q < nqr;
+          qx[q] = have ? d.quad[(q * 3 + 0) * N + j] : 0.0; qy[q] = have ? d.quad[(q * 3 + 1) * N + j] : 0.0;
+          qz[q] = have ? d.quad[(q * 3 + 2) * N + j] : 1.0; wA[q] = have ? d.qw[q] * A : 0.0;
+        }
+        const double near2 = 8.0 * A * (1.0 + 1e-9);      // d^2 <= 8 A  <=>  sqrt(2 A) / d >= 0.5; the band goes to the exact test
+#pragma unroll
+        for (int r = 0; r < kMfRows; ++r) {
+          if (r < nr) {                                    // wave-uniform
+            if (qn > kMfQueue - kWave) { mf_flush(d, lane, nr, qn, tcx, tcy, tcz, tbc, qrow, qj, qval, &racc); qn = 0; }
+            const double tx = tcx[r], ty = tcy[r], tz = tcz[r];
+            const int dn = __builtin_amdgcn_readfirstlane(tbc[r]);      // the row's operator: a scalar branch, not a select per point
+            const double dx = tx - sx, dy = ty - sy, dz = tz - sz;
+            const double d2 = dx * dx + dy * dy + dz * dz;
+            const bool slow = valid && d2 <= near2;
+            double v = 0;
+            if (nqr) {                                     // K <= 3: straight-line, the slow lanes' values are dropped below
+#pragma unroll
+              for (int q = 0; q < 3; ++q) {
+                const double ex = qx[q] - tx, ey = qy[q] - ty, ez = qz[q] - tz;
+                const double ir = rsqrt_pos(fma(ex, ex, fma(ey, ey, ez * ez)));
+                if (dn) v = fma(wA[q] * fma(ex, nx, fma(ey, ny, ez * nz)), ir * ir * ir, v); else v = fma(wA[q], ir, v);
+              }
+            } else if (valid && !slow) v = mf_far_general(d, j, tx, ty, tz, dn, A, nx, ny, nz);
+            const unsigned long long m = __ballot(slow);
+            if (m) {
+              if (slow) {
+                const int k = qn + __popcll(m & ((1ull << lane) - 1));
+                qrow[k] = (short)r; qj[k] = j; qval[k] = xj;
+              }
+              qn += __popcll(m);
+            }
+            acc[r] = fma(slow ? 0.0 : v, xj, acc[r]);      // (xj = 0 in lanes past the last column)
+          }
+        }
+      }
+      mf_flush(d, lane, nr, qn, tcx, tcy, tcz, tbc, qrow, qj, qval, &racc);
+#pragma unroll
+      for (int r = 0; r < kMfRows; ++r)
+        if (r < nr) {
+          const double srow = wave_sum(acc[r]);
+          if (lane == r) racc += srow;
+        }
+      if (lane < nr) d.yt[row0 + rb + lane] = racc;
+      wave_lds_fence();
+    }
   }
 }
 
@@ -940,6 +1097,12 @@ hipError_t launch_near_matfree(const DevicePlan& d, hipStream_t s) {
   if (d.dof == 3) {
     const size_t lds3 = (size_t)(kAsmChunk / 2) * (3 * sizeof(double) + sizeof(int)) + 2 * (size_t)d.max_runs * sizeof(int);
     hipLaunchKernelGGL(near_matfree_stokes_kernel, dim3(nb < 256 * 8 ? nb : 256 * 8), dim3(256), lds3, s, d);
+    return hipGetLastError();
+  }
+  const char* v1 = getenv("FMMBEM_MATFREE_V1");                       // the literal form (A/B)
+  if (!(v1 && atoi(v1) != 0)) {
+    const size_t lds2 = 2 * (size_t)d.max_runs * sizeof(int);
+    hipLaunchKernelGGL(near_matfree2_kernel, dim3(d.near_nitems < 256 * 16 ? d.near_nitems : 256 * 16), dim3(kWave), lds2, s, d);
     return hipGetLastError();
   }
   const size_t lds = (size_t)kAsmChunk * (sizeof(double) + sizeof(int)) + 2 * (size_t)d.max_runs * sizeof(int);
