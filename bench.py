@@ -155,7 +155,7 @@ def main():
     elapsed = time.perf_counter() - t0
     st = plan.stats()
     plan.set_timing(False)
-    per_rank = None
+    per_rank, replicas_equal = None, None
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -175,6 +175,12 @@ def main():
         keys = ("kernels_ms", "near_ms", "upward_ms", "m2l_ms", "downward_ms", "collectives_ms_synced", "multipole_bytes_in",
                 "result_bytes_in", "near_nnz", "m2l_pairs")
         per_rank = [dict(zip(keys, t.tolist())) for t in allr]
+        # every rank must hold the same replicated result
+        sig = torch.stack([y.sum(), y.abs().max(), y[::4097].sum()])
+        lo, hi = sig.clone(), sig.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        replicas_equal = bool(torch.equal(lo, hi))
     ms_per_step = elapsed / args.steps * 1e3
 
     if rank != 0:
@@ -249,7 +255,7 @@ def main():
                          "reference_equivalent_tflops": m2l_ref_flops / (st["ms_m2l"] * 1e-3) / 1e12 if st["ms_m2l"] > 0 else 0.0},
         "stage_ms": {k[3:]: st[k] for k in ("ms_total", "ms_gather", "ms_near", "ms_scatter", "ms_p2m", "ms_m2m",
                                             "ms_mh", "ms_m2l", "ms_l2l", "ms_l2p")},
-        "per_rank": per_rank,
+        "per_rank": per_rank, "replicas_equal": replicas_equal,
         "collectives": None if world == 1 else {"upward": ("all-to-all of the multipoles each shard reads" if op.plan.exchange_mode == 2 else "all-gather of multipoles") if op.split else "none (upward pass repeated)",
                                                 "result": op.y_collective},
         "plan_build_s": build_s, "near_assemble_s": st["build_assemble_ms"] * 1e-3,
@@ -259,7 +265,7 @@ def main():
     # The oracle is only ever touched in this CPU leg of the bench (rank 0, N = 1): as the checker of the result just
     # computed (Direct sum on a row sample) and as the timed CPU baseline -- never inside the timed region.
     cpu_leg = world == 1 and not args.no_cpu_baseline
-    check_leg = world == 1 and not args.no_accuracy           # the Direct-sum check does not depend on the baseline switch
+    check_leg = not args.no_accuracy                          # the Direct-sum check (rank 0, any N: the result is replicated) does not depend on the baseline switch
     if check_leg and stokes:
         from oracle import oracle as O
         o = O.StokesOracle(v, K=4, K_fine=19, mu=1e-3, theta=args.theta, ncrit=args.ncrit, bc=bc)
