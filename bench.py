@@ -43,8 +43,15 @@ def parse():
     ap.add_argument("--ncrit", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-accuracy", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=45.0,
-                    help="seconds of host time the cpu_baseline leg may spend on the full workload (else: quarter-size sample, extrapolated)")
+    ap.add_argument("--cpu-budget", type=float, default=150.0,
+                    help="seconds of host time the cpu_baseline leg may spend on the full workload (else: quarter-size sample, "
+                         "extrapolated); the full N = 1M Laplace workload takes ~45 s on a 128-core host, Stokes config 4 ~100 s")
+    ap.add_argument("--collectives", choices=["default", "plain"], default="default",
+                    help="N > 1: default = upward pass sharded by owner + one all-to-all of the multipoles each shard reads + "
+                         "all-gather of the result slices; plain = upward pass repeated by every rank + ONE all-reduce of y "
+                         "(BASELINE.json's wording; the fallback of the preflight)")
+    ap.add_argument("--preflight-timeout", type=float, default=240.0,
+                    help="N > 1: seconds the preflight (first contact with RCCL) may take before rank 0 prints an error line and the job exits")
     ap.add_argument("--matrix-free", action="store_true",
                     help="sparse_local = false: the near field recomputed every matvec (EvalInteractionLazy, SURVEY a8) "
                          "instead of the assembled matrix; the roofline object then reports FP64 flop/s, not HBM GB/s")
@@ -77,8 +84,109 @@ def cpu_baseline(args, stokes):
     return json.loads(out.strip().splitlines()[-1])
 
 
+STAGE = ["start"]                 # where this rank is: printed by the error line and by the watchdog
+
+
+def stage(rank, what):
+    """Breadcrumb on stderr (every rank) so that a hang or a crash on first contact with RCCL says where it happened."""
+    STAGE[0] = what
+    print("[bench rank %d] %s" % (rank, what), file=sys.stderr, flush=True)
+
+
+def die(rank, world, msg, code=1):
+    """One self-explaining JSON line instead of a bare traceback, then a hard exit (a rank stuck in a collective would
+    otherwise keep the job alive until the launcher's timeout)."""
+    print(json.dumps({"error": msg, "stage": STAGE[0], "rank": rank, "n_gpus": world, "metric": "FMM matvecs/s", "value": None}), flush=True)
+    sys.stderr.flush()
+    os._exit(code)
+
+
+def direct_check(args, np, v, x, y, stokes, bc):
+    """north_star gate: relative L2 of the result against the O(N^2) Direct sum on a row sample (the oracle as checker)."""
+    from oracle import oracle as O
+    n = len(v)
+    lo = n // 3
+    if stokes:
+        o = O.StokesOracle(v, K=4, K_fine=19, mu=1e-3, theta=args.theta, ncrit=args.ncrit, bc=bc)
+        d = o.direct(x.cpu().numpy().reshape(n, 3), rows=(lo, lo + 128))
+        ys = y.cpu().numpy().reshape(n, 3)[lo:lo + 128]
+    else:
+        o = O.Oracle(v, K=3, theta=args.theta, ncrit=args.ncrit)
+        d = o.direct(x.cpu().numpy(), rows=(lo, lo + 256))
+        ys = y.cpu().numpy()[lo:lo + 256]
+    o.close()
+    return float(np.linalg.norm(ys - d) / np.linalg.norm(d))
+
+
+def preflight(args, fb, make_op, x, v, stokes, bc, rank, world, dev):
+    """N > 1, BEFORE the timed region and in the same processes: the first collectives this code ever issues on a backend
+    should produce a verdict, not a hang inside the measurement.  In order of first execution:
+      1. all_reduce of one double                       (communicator bring-up)
+      2. the PLAIN path: upward pass repeated on every rank, ONE all_reduce(sum) of zero-padded result vectors
+      3. rank 0 checks that result against the Direct sum; the verdict is all-reduced
+      4. the DEFAULT path (unless --collectives plain): all_gather of the exchange count vectors and their symmetry
+         (what r sends q == what q expects from r), then a matvec through all_to_all_single (uneven splits) +
+         all_gather_into_tensor of the result slices; torch.equal against the plain result, verdict all-reduced
+    A default path that disagrees (or raises) makes the run fall back to the plain path and says so; a plain path that
+    disagrees with Direct is an error line and a non-zero exit.  Returns (the operator to time, the preflight record)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    info = {"backend": dist.get_backend(), "requested": args.collectives}
+    stage(rank, "preflight 1/4: all_reduce of one double")
+    one = torch.ones(1, dtype=torch.float64, device=dev)
+    dist.all_reduce(one)
+    if int(one.item()) != world:
+        die(rank, world, "all_reduce of ones returned %r on %d ranks" % (one.item(), world))
+    stage(rank, "preflight 2/4: plain path (replicated upward pass + all_reduce of y)")
+    op_plain = make_op("plain")
+    y_plain = op_plain.execute(x).clone()
+    torch.cuda.synchronize()
+    stage(rank, "preflight 3/4: Direct-sum check of the plain result on rank 0")
+    flag = torch.zeros(2, dtype=torch.float64, device=dev)
+    if rank == 0 and not args.no_accuracy:
+        flag[0] = direct_check(args, np, v, x, y_plain, stokes, bc)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    info["direct_rel_l2"] = None if args.no_accuracy else float(flag[0].item())
+    gate = 1e-3                      # not the north-star gate (reported as is): a wrong collective gives O(1), p = 8 Stokes 3e-5
+    if not args.no_accuracy and not (flag[0].item() < gate):
+        die(rank, world, "plain path (all_reduce) disagrees with the Direct sum: rel L2 %.3e" % flag[0].item())
+    if args.collectives == "plain":
+        info.update(paths_equal=None, used="plain")
+        return op_plain, info
+    stage(rank, "preflight 4/4: default path (count symmetry, all_to_all_single, all_gather_into_tensor)")
+    verdict = torch.ones(1, dtype=torch.float64, device=dev)
+    why = None
+    op = None
+    try:
+        op = make_op("default")
+        info["exchange_symmetric"] = op.check_exchange_symmetry() if op.split else None
+        if info["exchange_symmetric"] is False:
+            raise RuntimeError("exchange counts are not symmetric across ranks")
+        y_def = op.execute(x)
+        torch.cuda.synchronize()
+        if not torch.equal(y_def, y_plain):
+            verdict[0] = 0
+            why = "default path result differs from the plain path on rank %d (max abs diff %.3e)" % (rank, float((y_def - y_plain).abs().max()))
+    except Exception as e:                     # a collective that raised leaves the communicator in an unknown state:
+        die(rank, world, "default collectives path raised: %r (rerun with --collectives plain)" % (e,))
+    dist.all_reduce(verdict, op=dist.ReduceOp.MIN)
+    info["paths_equal"] = bool(verdict.item() == 1)
+    if info["paths_equal"]:
+        op_plain.plan.close()
+        info["used"] = "default"
+        return op, info
+    if why:
+        print("[bench rank %d] %s" % (rank, why), file=sys.stderr, flush=True)
+    op.plan.close()
+    info.update(used="plain", fallback="default path disagreed with the plain path (see stderr); timed the plain path")
+    return op_plain, info
+
+
 def main():
     args = parse()
+    import datetime
+    import threading
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -90,18 +198,26 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU execution path")
     # one rank per GPU over RCCL.  FMMBEM_BENCH_BACKEND=gloo is a rehearsal aid for a one-GPU box: the ranks then share
-    # device 0 and the all-reduce goes through the host (numbers from such a run mean nothing).
+    # device 0 and the collectives go through the host (numbers from such a run mean nothing).
     backend = os.environ.get("FMMBEM_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    watchdog = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        stage(rank, "init_process_group(%s)" % backend)
+        # a stuck collective fails after two minutes instead of the launcher's limit
+        tmo = datetime.timedelta(seconds=120)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
+        watchdog = threading.Timer(args.preflight_timeout, lambda: die(
+            rank, world, "preflight did not finish in %.0f s" % args.preflight_timeout, 3))
+        watchdog.daemon = True
+        watchdog.start()
 
     stokes = args.workload in ("stokes_rbc", "stokes_rbc_traction")
     traction = args.workload == "stokes_rbc_traction"       # config 4 read literally: the double layer (stresslet), every target TRACTION
@@ -124,16 +240,36 @@ def main():
     opts.set_mac_theta(args.theta)
     opts.set_max_per_box(args.ncrit)
     opts.sparse_local = not args.matrix_free
-    t0 = time.time()
     if traction:
         bc = np.ones(len(v), dtype=np.uint8)
-    op = fb.ShardedFMM(K, v, opts, bc=bc, device=local_rank)
-    build_s = time.time() - t0
-    plan = op.plan
+
+    build = {}
+
+    def make_op(which):
+        t_b = time.time()
+        if which == "plain":                                 # upward pass repeated, ONE all_reduce(sum) of y per matvec
+            o = fb.ShardedFMM(K, v, opts, bc=bc, device=local_rank, shard_upward=False, y_collective="allreduce")
+        else:                                                # distributed.py's defaults (the FMMBEM_* switches apply)
+            o = fb.ShardedFMM(K, v, opts, bc=bc, device=local_rank)
+        build[id(o)] = time.time() - t_b
+        return o
 
     g = torch.Generator(device="cpu").manual_seed(1234)
     x = torch.rand(n * dof, dtype=torch.float64, generator=g).to(dev)
     y = torch.empty_like(x)
+    pre = None
+    if world > 1:
+        try:
+            op, pre = preflight(args, fb, make_op, x, v, stokes, bc, rank, world, dev)
+        except Exception as e:
+            die(rank, world, "preflight raised: %r" % (e,))
+        watchdog.cancel()
+        torch.cuda.empty_cache()
+        stage(rank, "preflight done: timing the %s path" % pre["used"])
+    else:
+        op = make_op("default")
+    build_s = build[id(op)]
+    plan = op.plan
 
     def step():
         op.execute(x, out=y)                                 # local matvec + the collective(s) of fmm-bem-relaxed_amd/distributed.py
@@ -147,12 +283,18 @@ def main():
         torch.cuda.synchronize()
 
     plan.set_timing(True)                                    # HIP events around each kernel, no added syncs
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
+    stage(rank, "timed region: %d steps" % args.steps)
+    try:
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        elapsed = time.perf_counter() - t0
+    except Exception as e:
+        if world == 1:
+            raise
+        die(rank, world, "timed region raised: %r" % (e,))
     st = plan.stats()
     plan.set_timing(False)
     per_rank, replicas_equal = None, None
@@ -255,36 +397,18 @@ def main():
                          "reference_equivalent_tflops": m2l_ref_flops / (st["ms_m2l"] * 1e-3) / 1e12 if st["ms_m2l"] > 0 else 0.0},
         "stage_ms": {k[3:]: st[k] for k in ("ms_total", "ms_gather", "ms_near", "ms_scatter", "ms_p2m", "ms_m2m",
                                             "ms_mh", "ms_m2l", "ms_l2l", "ms_l2p")},
-        "per_rank": per_rank, "replicas_equal": replicas_equal,
+        "per_rank": per_rank, "replicas_equal": replicas_equal, "preflight": pre,
         "collectives": None if world == 1 else {"upward": ("all-to-all of the multipoles each shard reads" if op.plan.exchange_mode == 2 else "all-gather of multipoles") if op.split else "none (upward pass repeated)",
                                                 "result": op.y_collective},
         "plan_build_s": build_s, "near_assemble_s": st["build_assemble_ms"] * 1e-3,
         "host_lists_s": st["build_host_ms"] * 1e-3,
     }
 
-    # The oracle is only ever touched in this CPU leg of the bench (rank 0, N = 1): as the checker of the result just
+    # The oracle is only ever touched in this CPU leg of the bench (rank 0): as the checker of the result just
     # computed (Direct sum on a row sample) and as the timed CPU baseline -- never inside the timed region.
     cpu_leg = world == 1 and not args.no_cpu_baseline
-    check_leg = not args.no_accuracy                          # the Direct-sum check (rank 0, any N: the result is replicated) does not depend on the baseline switch
-    if check_leg and stokes:
-        from oracle import oracle as O
-        o = O.StokesOracle(v, K=4, K_fine=19, mu=1e-3, theta=args.theta, ncrit=args.ncrit, bc=bc)
-        xs = x.cpu().numpy().reshape(n, 3)
-        lo = n // 3
-        dd = o.direct(xs, rows=(lo, lo + 128))
-        ys = y.cpu().numpy().reshape(n, 3)[lo:lo + 128]
-        out["rel_l2_vs_direct_sample"] = float(np.linalg.norm(ys - dd) / np.linalg.norm(dd))
-        o.close()
-    if check_leg and not stokes:
-        # north_star gate at full size: relative L2 vs the O(N^2) Direct sum on a 256-target sample (oracle as checker)
-        from oracle import oracle as O
-        o = O.Oracle(v, K=3, theta=args.theta, ncrit=args.ncrit)
-        xs = x.cpu().numpy()
-        lo = n // 3
-        d = o.direct(xs, rows=(lo, lo + 256))
-        ys = y.cpu().numpy()[lo:lo + 256]
-        out["rel_l2_vs_direct_sample"] = float(np.linalg.norm(ys - d) / np.linalg.norm(d))
-        o.close()
+    if not args.no_accuracy:                                  # rank 0, any N (the result is replicated); independent of the baseline switch
+        out["rel_l2_vs_direct_sample"] = direct_check(args, np, v, x, y, stokes, bc)
     if cpu_leg and traction:
         # the oracle restates the reference, whose far field for this operator is wrong: there is no CPU FMM to time
         out["cpu_baseline"] = None

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("FMMBEM_LIB") or os.path.join(_HERE, "libfmmbem_hip.so
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC, ERR_TREE, ERR_UNSUPPORTED, ERR_IO = range(8)
 PMAX = 16
+MAX_QUAD = 79          # FMMBEM_MAX_QUAD
 KERNEL_LAPLACE_BEM, KERNEL_STOKES_BEM = 0, 1
 EVAL_FMM, EVAL_LOCAL, EVAL_BLOCK_DIAGONAL = 0, 1, 2
 L2L_COMPLETE, L2L_REFERENCE = 0, 1

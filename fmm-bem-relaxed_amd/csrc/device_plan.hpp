@@ -61,13 +61,13 @@ struct DevicePlan {
   int dof = 1;                                        // unknowns per panel (Stokes: 3, interleaved)
   double mu = 1.0;                                    // Stokes viscosity
   int nqf = 0;                                        // Stokes near-regime rule K_fine: barycentric points + weight
-  double qf[25][4];
+  const double* qf = nullptr;                         // [nqf][4] in device memory (by value it would not fit the kernel arguments at K_fine = 79)
 
   // panels
   const double *cx, *cy, *cz, *nx, *ny, *nz, *area, *quad, *vert;
   const uint8_t* bc;
   const uint32_t* perm;
-  double qw[25];
+  double qw[79];                                      // weights of the far-regime rule K (at most FMMBEM_MAX_QUAD points)
   // leaves
   const int *leaf_row0, *leaf_nrows, *leaf_box;
   const int64_t* near_ptr;

@@ -71,6 +71,27 @@ bool quad_rule(int key, QuadRule& out) {
       b.perm(0.025003534762686, 0.246672560639903, 0.728323904597411, 0.028327242531057);
       b.perm(0.009540815400299, 0.066803251012200, 0.923655933587500, 0.009421666963733);
       return true;
+    case 79:                          // GaussQuadrature.hpp:186-272 (negative weights and one point outside the triangle included)
+      b.centroid(0.033057055541624);
+      b.rot(-0.001900928704400, 0.500950464352200, 0.000867019185663);
+      b.rot(0.023574084130543, 0.488212957934729, 0.011660052716448);
+      b.rot(0.089726636099435, 0.455136681950283, 0.022876936356421);
+      b.rot(0.196007481363421, 0.401996259318289, 0.030448982673938);
+      b.rot(0.488214180481157, 0.255892909759421, 0.030624891725355);
+      b.rot(0.647023488009788, 0.176488255995106, 0.024368057676800);
+      b.rot(0.791658289326483, 0.104170855336758, 0.015997432032024);
+      b.rot(0.893862072318140, 0.053068963840930, 0.007698301815602);
+      b.rot(0.916762569607942, 0.041618715196029, -0.000632060497488);
+      b.rot(0.976836157186356, 0.011581921406822, 0.001751134301193);
+      b.perm(0.048741583664839, 0.344855770229001, 0.606402646106160, 0.016465839189576);
+      b.perm(0.006314115948605, 0.377843269594854, 0.615842614456541, 0.004839033540485);
+      b.perm(0.134316520547348, 0.306635479062357, 0.559048000390295, 0.025804906534650);
+      b.perm(0.013973893962392, 0.249419362774742, 0.736606743262866, 0.008471091054441);
+      b.perm(0.075549132909764, 0.212775724802802, 0.711675142287434, 0.018354914106280);
+      b.perm(-0.008368153208227, 0.146965436053239, 0.861402717154987, 0.000704404677908);
+      b.perm(0.026686063258714, 0.137726978828923, 0.835586957912363, 0.010112684927462);
+      b.perm(0.010547719294141, 0.059696109149007, 0.929756171556853, 0.003573909385950);
+      return true;
     default: return false;
   }
 }
@@ -179,7 +200,7 @@ std::string HostPlan::build(const HostOptions& o, int64_t n_panels, const double
   n = n_panels;
   if (n <= 0 || !vertices) return "no panels";
   if (n > (int64_t(1) << 31) - 1) return "too many panels";
-  if (!quad_rule(o.quad_k, rule)) return "invalid quadrature key (valid: 1 3 4 7 13 17 19 25)";
+  if (!quad_rule(o.quad_k, rule)) return "invalid quadrature key (valid: 1 3 4 7 13 17 19 25 79)";
   if (o.p_max < 1 || o.p_max > kPmax) return "p_max out of range";
   if (!(o.theta > 0)) return "theta must be positive";
   if (o.shard_world < 1 || o.shard_rank < 0 || o.shard_rank >= o.shard_world) return "bad shard";

@@ -19,7 +19,7 @@
 namespace fmmbem {
 
 constexpr int kPmax = 16;
-constexpr int kMaxQuad = 25;
+constexpr int kMaxQuad = 79;       // FMMBEM_MAX_QUAD: the largest rule of examples/BEM/GaussQuadrature.hpp
 
 struct QuadRule {            // triangle Gauss rule: barycentric points + weights
   int n = 0;

@@ -329,10 +329,10 @@ __device__ inline void stokes_entry(const DevicePlan& d, V3 t, int tbc, int64_t 
       const V3 v1 = {d.vert[3 * N + j], d.vert[4 * N + j], d.vert[5 * N + j]};
       const V3 v2 = {d.vert[6 * N + j], d.vert[7 * N + j], d.vert[8 * N + j]};
       for (int q = 0; q < d.nqf; ++q) {
-        const V3 pt = {v0.x * d.qf[q][0] + v1.x * d.qf[q][1] + v2.x * d.qf[q][2],
-                       v0.y * d.qf[q][0] + v1.y * d.qf[q][1] + v2.y * d.qf[q][2],
-                       v0.z * d.qf[q][0] + v1.z * d.qf[q][1] + v2.z * d.qf[q][2]};
-        stresslet_point(out, d.qf[q][3] * A, t, pt, nrm);
+        const V3 pt = {v0.x * d.qf[4 * q + 0] + v1.x * d.qf[4 * q + 1] + v2.x * d.qf[4 * q + 2],
+                       v0.y * d.qf[4 * q + 0] + v1.y * d.qf[4 * q + 1] + v2.y * d.qf[4 * q + 2],
+                       v0.z * d.qf[4 * q + 0] + v1.z * d.qf[4 * q + 1] + v2.z * d.qf[4 * q + 2]};
+        stresslet_point(out, d.qf[4 * q + 3] * A, t, pt, nrm);
       }
     } else {
       for (int q = 0; q < d.nq; ++q) {
@@ -352,10 +352,10 @@ __device__ inline void stokes_entry(const DevicePlan& d, V3 t, int tbc, int64_t 
       stokes_self(v0, v1, v2, t, out);
     } else {
       for (int q = 0; q < d.nqf; ++q) {
-        const V3 pt = {v0.x * d.qf[q][0] + v1.x * d.qf[q][1] + v2.x * d.qf[q][2],
-                       v0.y * d.qf[q][0] + v1.y * d.qf[q][1] + v2.y * d.qf[q][2],
-                       v0.z * d.qf[q][0] + v1.z * d.qf[q][1] + v2.z * d.qf[q][2]};
-        stokeslet_point(out, d.qf[q][3] * A, t, pt);
+        const V3 pt = {v0.x * d.qf[4 * q + 0] + v1.x * d.qf[4 * q + 1] + v2.x * d.qf[4 * q + 2],
+                       v0.y * d.qf[4 * q + 0] + v1.y * d.qf[4 * q + 1] + v2.y * d.qf[4 * q + 2],
+                       v0.z * d.qf[4 * q + 0] + v1.z * d.qf[4 * q + 1] + v2.z * d.qf[4 * q + 2]};
+        stokeslet_point(out, d.qf[4 * q + 3] * A, t, pt);
       }
     }
   } else {
@@ -587,7 +587,9 @@ __global__ __launch_bounds__(kWave) void near_matfree2_kernel(DevicePlan d) {
               }
               qn += __popcll(m);
             }
-            acc[r] = fma(slow ? 0.0 : v, xj, acc[r]);      // (xj = 0 in lanes past the last column)
+            // lanes past the last column ran the arithmetic against panel 0: its value may be inf/NaN (K = 1: the only point of
+            // panel 0 IS the centroid of row 0) and NaN * 0 is NaN -- masked by validity, not by xj = 0
+            acc[r] = fma((slow || !valid) ? 0.0 : v, xj, acc[r]);
           }
         }
       }

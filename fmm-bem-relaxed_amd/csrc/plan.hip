@@ -288,9 +288,11 @@ int fmmbem_plan::to_device() {
     if (d.stokes_velocity_targets) for (int s = 0; s < 4; ++s) d.act[d.n_act++] = s;
     if (d.stokes_traction_targets) for (int s = 4; s < 11; ++s) d.act[d.n_act++] = s;
     QuadRule fine;
-    if (!quad_rule(opts.quad_k_fine, fine)) return fail(FMMBEM_ERR_INVALID, "invalid K_fine (valid: 1 3 4 7 13 17 19 25)");
+    if (!quad_rule(opts.quad_k_fine, fine)) return fail(FMMBEM_ERR_INVALID, "invalid K_fine (valid: 1 3 4 7 13 17 19 25 79)");
     d.nqf = fine.n;
-    for (int q = 0; q < fine.n; ++q) { for (int k = 0; k < 3; ++k) d.qf[q][k] = fine.pts[q][k]; d.qf[q][3] = fine.w[q]; }
+    std::vector<double> qf((size_t)fine.n * 4);
+    for (int q = 0; q < fine.n; ++q) { for (int k = 0; k < 3; ++k) qf[4 * q + k] = fine.pts[q][k]; qf[4 * q + 3] = fine.w[q]; }
+    TRY(upload(qf, &d.qf));
   } else {
     d.dof = 1; d.nslots = 2;
     for (int s = 0; s < 2; ++s) if (hp.has_bc[s]) d.act[d.n_act++] = s;
@@ -962,6 +964,16 @@ int fmmbem_plan_execute_device(fmmbem_plan* plan, int p, const double* d_x, doub
   return plan->run(p, d_x, d_y, static_cast<hipStream_t>(stream), false);
 }
 
+// expansion slots an exchange carries per box, from the HOST lists (a host-only plan answers too): Laplace one per boundary
+// condition present; Stokes four potentials for velocity targets, seven for TRACTION targets (to_device, d.act)
+static int64_t active_slots(const fmmbem_plan* plan) {
+  const HostPlan& h = plan->hp;
+  if (plan->opts.kernel != FMMBEM_KERNEL_STOKES_BEM) return (int64_t)h.has_bc[0] + (int64_t)h.has_bc[1];
+  const bool trac = h.has_bc[1] && h.opt.evaluator == 0;
+  const bool vel = h.has_bc[0] || !trac;
+  return (vel ? 4 : 0) + (trac ? 7 : 0);
+}
+
 int fmmbem_plan_exchange_doubles(const fmmbem_plan* plan, int p, size_t* per_shard) {
   if (!plan || !per_shard) return fail(FMMBEM_ERR_INVALID, "null argument");
   if (p < 1 || p > plan->hp.opt.p_max) return fail(FMMBEM_ERR_INVALID, "p outside [1, p_max]");
@@ -969,7 +981,7 @@ int fmmbem_plan_exchange_doubles(const fmmbem_plan* plan, int p, size_t* per_sha
   const HostPlan& h = plan->hp;
   size_t most = 0;
   for (size_t r = 0; r + 1 < h.xch_ptr.size(); ++r) most = std::max<size_t>(most, (size_t)(h.xch_ptr[r + 1] - h.xch_ptr[r]));
-  const size_t n_act = plan->opts.kernel == FMMBEM_KERNEL_STOKES_BEM ? (size_t)plan->d.n_act : (size_t)h.has_bc[0] + (size_t)h.has_bc[1];
+  const size_t n_act = (size_t)active_slots(plan);
   *per_shard = (h.opt.shard_upward && h.opt.shard_world > 1) ? most * n_act * (size_t)(p * (p + 1) / 2) * 2 : 0;
   return FMMBEM_OK;
 }
@@ -981,7 +993,7 @@ int fmmbem_plan_exchange_counts(const fmmbem_plan* plan, int p, int64_t* send_do
   const int W = h.opt.shard_world;
   const bool sel = h.opt.shard_upward == 2 && W > 1;
   if (!sel) return fail(FMMBEM_ERR_INVALID, "plan was not created with shard_upward = 2");
-  const int64_t n_act = plan->opts.kernel == FMMBEM_KERNEL_STOKES_BEM ? (int64_t)(plan->on_device ? plan->d.n_act : 4) : (int64_t)h.has_bc[0] + (int64_t)h.has_bc[1];
+  const int64_t n_act = active_slots(plan);
   const int64_t per = n_act * (int64_t)(p * (p + 1) / 2) * 2;
   for (int q = 0; q < W; ++q) {
     send_doubles[q] = (int64_t)(h.xsel_send_ptr[q + 1] - h.xsel_send_ptr[q]) * per;
@@ -1047,6 +1059,8 @@ int fmmbem_plan_execute(fmmbem_plan* plan, int p, const double* x, double* y) {
   if (!plan) return fail(FMMBEM_ERR_INVALID, "null plan");
   if (!plan->on_device) return fail(FMMBEM_ERR_NO_DEVICE, "plan was built host-only; there is no CPU execution path");
   if (!x || !y) return fail(FMMBEM_ERR_INVALID, "null vector");
+  if (plan->result_slices)         // the owned rows in tree order at the head of y are only meaningful to the device-side all-gather
+    return fail(FMMBEM_ERR_INVALID, "plan delivers result slices (fmmbem_plan_set_result_slices): use the device entry points");
   DEVICE_SCOPE(plan->opts.device);
   const size_t bytes = sizeof(double) * (size_t)plan->hp.n * (plan->opts.kernel == FMMBEM_KERNEL_STOKES_BEM ? 3 : 1);
   hipStream_t s = plan->own_stream;
@@ -1282,9 +1296,9 @@ int fmmbem_kernel_entries(const fmmbem_options* opts, size_t n, const double* ta
   if (n > ((size_t)1 << 30)) return fail(FMMBEM_ERR_INVALID, "too many pairs");
   const bool stokes = opts->kernel == FMMBEM_KERNEL_STOKES_BEM;
   QuadRule rule, fine;
-  if (!quad_rule(opts->quad_k, rule)) return fail(FMMBEM_ERR_INVALID, "invalid quadrature key (valid: 1 3 4 7 13 17 19 25)");
+  if (!quad_rule(opts->quad_k, rule)) return fail(FMMBEM_ERR_INVALID, "invalid quadrature key (valid: 1 3 4 7 13 17 19 25 79)");
   if (stokes) {
-    if (!quad_rule(opts->quad_k_fine, fine)) return fail(FMMBEM_ERR_INVALID, "invalid K_fine (valid: 1 3 4 7 13 17 19 25)");
+    if (!quad_rule(opts->quad_k_fine, fine)) return fail(FMMBEM_ERR_INVALID, "invalid K_fine (valid: 1 3 4 7 13 17 19 25 79)");
     if (!(opts->mu > 0)) return fail(FMMBEM_ERR_INVALID, "Stokes: viscosity mu must be positive");
   }
   int ndev = 0;
@@ -1318,13 +1332,15 @@ int fmmbem_kernel_entries(const fmmbem_options* opts, size_t n, const double* ta
   DevicePlan d{};
   d.n = N; d.nq = rule.n; d.kernel = opts->kernel; d.dof = stokes ? 3 : 1; d.mu = opts->mu;
   for (int q = 0; q < rule.n; ++q) d.qw[q] = rule.w[q];
+  std::vector<double> qf((size_t)fine.n * 4);
   if (stokes) {
     d.nqf = fine.n;
-    for (int q = 0; q < fine.n; ++q) { for (int k = 0; k < 3; ++k) d.qf[q][k] = fine.pts[q][k]; d.qf[q][3] = fine.w[q]; }
+    for (int q = 0; q < fine.n; ++q) { for (int k = 0; k < 3; ++k) qf[4 * q + k] = fine.pts[q][k]; qf[4 * q + 3] = fine.w[q]; }
   }
 #define UP(field, vec) HIP_TRY(up(vec.data(), vec.size() * sizeof(vec[0]), reinterpret_cast<const void**>(&d.field)))
   UP(cx, P.cx); UP(cy, P.cy); UP(cz, P.cz); UP(nx, P.nx); UP(ny, P.ny); UP(nz, P.nz);
   UP(area, P.area); UP(quad, P.quad); UP(vert, P.vert); UP(bc, P.bc);
+  if (stokes) UP(qf, qf);
 #undef UP
   const size_t per = stokes ? 9 : 1;
   double* d_out = nullptr;

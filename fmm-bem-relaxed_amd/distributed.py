@@ -97,6 +97,22 @@ class ShardedFMM:
             return up, self._chunk * 8 * (self.world - 1)
         return up, int(2 * nd * (self.world - 1) / self.world)          # ring all-reduce: reduce-scatter + all-gather
 
+    def check_exchange_symmetry(self, p=None):
+        """Collective, once, before the first all-to-all: all-gather the (send, recv) count vectors of every rank and check
+        that what r sends q is what q expects from r, and that nobody sends to itself.  A mismatch inside
+        all_to_all_single would be a hang or a silent overrun; here it is a False.  None when there is no all-to-all."""
+        if not (self.split and not self._split_fns and self.plan.exchange_mode == 2 and self.world > 1):
+            return None
+        p = self.plan.kernel().P if p is None else p
+        sc, rc = self.plan.exchange_counts(p)
+        dev = torch.device("cuda", self.plan.device) if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
+        mine = torch.tensor([list(map(int, sc)), list(map(int, rc))], dtype=torch.int64, device=dev)
+        everyone = [torch.zeros_like(mine) for _ in range(self.world)]
+        dist.all_gather(everyone, mine, group=self.group)
+        t = torch.stack(everyone).cpu()                   # [rank][send|recv][peer]
+        send, recv = t[:, 0, :], t[:, 1, :]
+        return bool(torch.equal(send, recv.t()) and int(send.diagonal().abs().sum()) == 0)
+
     def _timed(self, fn, device):
         """Run a collective; with profile on, bracket it with device syncs and add the wall time to collective_s."""
         if not self.profile:

@@ -91,7 +91,7 @@ def unit_sphere(recursions, center=(0.0, 0.0, 0.0)):
 
 def quadrature(key):
     """Triangle Gauss rule of examples/BEM/GaussQuadrature.hpp: (barycentric points (n, 3), weights (n,))."""
-    pts, w, n = np.empty((25, 3)), np.empty(25), C.c_int(0)
+    pts, w, n = np.empty((_capi.MAX_QUAD, 3)), np.empty(_capi.MAX_QUAD), C.c_int(0)
     _capi.check(_capi.lib().fmmbem_quadrature(int(key), pts.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p), C.byref(n)))
     return pts[:n.value].copy(), w[:n.value].copy()
 

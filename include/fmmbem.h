@@ -240,7 +240,9 @@ int fmmbem_mesh_red_blood_cell(int recursions, double *vertices, size_t *n_panel
 int fmmbem_mesh_red_blood_cells(int recursions, int cells, const double *placement, double *vertices, size_t *n_panels);
 
 /* Triangle Gauss rule `key` of examples/BEM/GaussQuadrature.hpp:15-274 (what BEMConfig hands the kernels): barycentric
- * points[n][3] and weights[n] (at most 25); either array may be NULL. */
+ * points[n][3] and weights[n], n <= FMMBEM_MAX_QUAD (size the buffers for that); either array may be NULL.
+ * Keys: 1 3 4 7 (alias of 4, :58-59) 13 17 (16 points) 19 25 79. */
+#define FMMBEM_MAX_QUAD 79
 int fmmbem_quadrature(int key, double *points, double *weights, int *n);
 
 /* ---- mesh files of the reference's drivers ------------------------------------------------ */

@@ -19,6 +19,8 @@
 #include <cmath>
 #include <complex>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <limits>
 #include <stdexcept>
 #include <string>
@@ -62,7 +64,7 @@ struct PanelT {
     const point_type c(L0[1] * L1[2] - L0[2] * L1[1], -(L0[0] * L1[2] - L0[2] * L1[0]), L0[0] * L1[1] - L0[1] * L1[0]);
     Area = 0.5 * norm(c);
     normal = c / 2 / Area;
-    double pts[25][3], w[25];
+    double pts[FMMBEM_MAX_QUAD][3], w[FMMBEM_MAX_QUAD];
     int k = 0;
     check(fmmbem_quadrature((int)config_K(), &pts[0][0], w, &k));
     quad_points.resize(k);
@@ -74,22 +76,38 @@ struct PanelT {
 
 }  // namespace fmmbem
 
-// include/FMMOptions.hpp:9-60 -- the fields and setters the hot path reads
+// include/FMMOptions.hpp:9-106 -- every field, setter and getter of the reference's class, and get_options(argc, argv)
 class FMMOptions {
  public:
   bool lazy_evaluation = true, local_evaluation = false, sparse_local = false, block_diagonal = false;
   enum EvalType { FMM, TREECODE };
   EvalType evaluator = FMM;
-  double theta = 0.5;
+  // FMMOptions.hpp:19-31: accept a pair of boxes iff |c1 - c2|^2 > ((r1 + r2) / theta)^2, r = half the box side.  The plan
+  // applies this rule on the host (csrc/host_plan.cpp, mac_accepts); the functor is here for callers that use it themselves
+  struct DefaultMAC {
+    double theta_;
+    DefaultMAC(double theta) : theta_(theta) {}
+    template <typename BOX>
+    bool operator()(const BOX& b1, const BOX& b2) const {
+      const double r0_normSq = normSq(b1.center() - b2.center());
+      const double rhs = (b1.radius() + b2.radius()) / theta_;
+      return r0_normSq > rhs * rhs;
+    }
+  };
+  DefaultMAC MAC_ = DefaultMAC(0.5);
   unsigned NCRIT_ = 64;
+  bool printTree = false;             // FMMOptions.hpp:38,67-68,100-101: set by -printtree, read by nothing in the reference either
   // Not in the reference.  Its lazy evaluator never queues L2L into a child that was an M2L target earlier in the
   // traversal than its parent (EvalInteractionLazySparse.hpp:199-237); on the meshes its generators produce no such child
   // exists and the two rules are one list, on clustered meshes the reference's list loses far field.
   // false (default): every child of a box that holds L;  true: exactly the reference's list.
   bool reference_l2l = false;
-  void set_mac_theta(double t) { theta = t; }
+  void set_mac_theta(double t) { MAC_ = DefaultMAC(t); }
+  DefaultMAC MAC() { return MAC_; }
   void set_max_per_box(unsigned n) { NCRIT_ = n; }
   unsigned max_per_box() const { return NCRIT_; }
+  void print_tree(bool v) { printTree = v; }
+  bool print_tree() const { return printTree; }
   // executor/make_executor.hpp:24-60: lazy_evaluation wins, then local_evaluation, then block_diagonal; the
   // non-lazy upward/interact/downward evaluators compute the same operator as the lazy ones
   int c_evaluator() const {
@@ -98,6 +116,26 @@ class FMMOptions {
     return local_evaluation ? FMMBEM_EVAL_LOCAL : block_diagonal ? FMMBEM_EVAL_BLOCK_DIAGONAL : FMMBEM_EVAL_FMM;
   }
 };
+
+// FMMOptions.hpp:74-106: -theta <t>, -eval FMM|TREE, -lazy_eval, -ncrit <n>, -printtree; everything else is left to the
+// caller's own parser (the drivers scan argv again for their flags).  `inline`: the reference defines it in the header
+// without it, which is why its headers admit one translation unit only.
+inline FMMOptions get_options(int argc, char** argv) {
+  FMMOptions opts = FMMOptions();
+  for (int i = 1; i < argc; ++i) {
+    const std::string a = argv[i];
+    if (a == "-theta" && i + 1 < argc) opts.set_mac_theta(std::atof(argv[++i]));
+    else if (a == "-eval" && i + 1 < argc) {
+      const std::string e = argv[++i];
+      if (e == "FMM") opts.evaluator = FMMOptions::FMM;
+      else if (e == "TREE") opts.evaluator = FMMOptions::TREECODE;
+      else std::printf("[W]: Unknown evaluator type: \"%s\"\n", e.c_str());
+    } else if (a == "-lazy_eval") opts.lazy_evaluation = true;
+    else if (a == "-ncrit" && i + 1 < argc) opts.set_max_per_box((unsigned)std::atoi(argv[++i]));
+    else if (a == "-printtree") opts.print_tree(true);
+  }
+  return opts;
+}
 
 // kernel/LaplaceSphericalBEM.hpp:14-140 (+ the typedefs it inherits from kernel/LaplaceSpherical.hpp:33-50)
 class LaplaceSphericalBEM {
@@ -233,31 +271,15 @@ class PlanAdapter {
   typedef typename kernel_type::result_type result_type;
   typedef typename std::vector<source_type>::const_iterator body_source_iterator;
 
-  // p_max: largest order a later kernel().set_p() may ask for.  The reference accepts any p at any time
-  // (LaplaceSpherical::set_p resizes its tables, kernel/LaplaceSpherical.hpp:119-128), so the default is the largest
-  // pre-compiled order, which is also SolverOptions::max_p's default (examples/BEM/SolverOptions.hpp:22).
-  PlanAdapter(const kernel_type& k, const std::vector<source_type>& source, FMMOptions& opts, int p_max = FMMBEM_PMAX,
-              int device = 0)
-      : K(k), opts_(opts), sources_(source), n_(source.size()) {
+  // p_max: the order the plan's expansions, tables and stored P2M moments are sized for.  The reference accepts any p at any
+  // time (LaplaceSpherical::set_p resizes its tables, kernel/LaplaceSpherical.hpp:119-128); so does this class: the default
+  // is the kernel's order at construction -- what the drivers pass as SolverOptions::max_p too (LaplaceBEM.cpp:160-168) --
+  // and an execute() at a higher order re-creates the plan for it, once (sizing every plan for the largest pre-compiled
+  // order instead would cost 2.5x the memory at p = 10 and refuse Stokes TRACTION plans outright).
+  PlanAdapter(const kernel_type& k, const std::vector<source_type>& source, FMMOptions& opts, int p_max = 0, int device = 0)
+      : K(k), opts_(opts), sources_(source), n_(source.size()), device_(device) {
     K.device = device;
-    std::vector<double> v(9 * n_);
-    std::vector<uint8_t> bc(n_);
-    for (size_t i = 0; i < n_; ++i) {
-      for (int a = 0; a < 3; ++a)
-        for (int c = 0; c < 3; ++c) v[9 * i + 3 * a + c] = source[i].vertices[a][c];
-      bc[i] = source[i].BC == source_type::BC1;
-    }
-    fmmbem_options o;
-    fmmbem_options_default(&o);
-    KernelBinding<Kernel>::fill(K, opts, o);
-    o.p_max = p_max;
-    o.theta = opts.theta;
-    o.ncrit = opts.NCRIT_;
-    o.device = device;
-    o.evaluator = opts.c_evaluator();
-    o.l2l_rule = opts.reference_l2l ? FMMBEM_L2L_REFERENCE : FMMBEM_L2L_COMPLETE;
-    sparse_ = o.sparse_local != 0;
-    check(fmmbem_plan_create(&o, n_, v.data(), bc.data(), &plan_));
+    create(p_max > 0 ? p_max : K.p());
   }
   ~PlanAdapter() { fmmbem_plan_destroy(plan_); }
   PlanAdapter(const PlanAdapter&) = delete;
@@ -270,6 +292,7 @@ class PlanAdapter {
   std::vector<result_type> execute(const std::vector<charge_type>& charges) {
     if (charges.size() != n_) throw Error(FMMBEM_ERR_INVALID, "charges.size() != number of panels");
     std::vector<result_type> results(charges.size());
+    if (K.p() > p_max_) create(K.p());                  // set_p above what the plan was sized for: grow, as set_p does
     check(fmmbem_plan_execute(plan_, K.p(), KernelBinding<Kernel>::in(charges), KernelBinding<Kernel>::out(results)));
     return results;
   }
@@ -282,8 +305,34 @@ class PlanAdapter {
   body_source_iterator source_end() { tree_sources(); return tree_.end(); }
 
   fmmbem_plan* handle() { return plan_; }
+  int p_max() const { return p_max_; }
 
  private:
+  void create(int p_max) {
+    std::vector<double> v(9 * n_);
+    std::vector<uint8_t> bc(n_);
+    for (size_t i = 0; i < n_; ++i) {
+      for (int a = 0; a < 3; ++a)
+        for (int c = 0; c < 3; ++c) v[9 * i + 3 * a + c] = sources_[i].vertices[a][c];
+      bc[i] = sources_[i].BC == source_type::BC1;
+    }
+    fmmbem_options o;
+    fmmbem_options_default(&o);
+    KernelBinding<Kernel>::fill(K, opts_, o);
+    o.p_max = p_max;
+    o.theta = opts_.MAC().theta_;
+    o.ncrit = opts_.NCRIT_;
+    o.device = device_;
+    o.evaluator = opts_.c_evaluator();
+    o.l2l_rule = opts_.reference_l2l ? FMMBEM_L2L_REFERENCE : FMMBEM_L2L_COMPLETE;
+    sparse_ = o.sparse_local != 0;
+    fmmbem_plan* fresh = nullptr;
+    check(fmmbem_plan_create(&o, n_, v.data(), bc.data(), &fresh));
+    if (plan_) fmmbem_plan_destroy(plan_);
+    plan_ = fresh;
+    p_max_ = p_max;
+  }
+
   void tree_sources() {
     if (!tree_.empty() || n_ == 0) return;
     std::vector<uint32_t> perm(n_);
@@ -304,6 +353,7 @@ class PlanAdapter {
   FMMOptions opts_;
   std::vector<source_type> sources_, tree_;
   size_t n_;
+  int device_ = 0, p_max_ = 0;
   bool sparse_ = false;
   fmmbem_plan* plan_ = nullptr;
 };

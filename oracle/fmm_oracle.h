@@ -27,7 +27,7 @@
 #error "the oracle is plain C"
 #endif
 
-#define ORC_MAXK 32      /* max stored quadrature points per panel            */
+#define ORC_MAXK 80      /* max stored quadrature points per panel            */
 #define ORC_PMAX 20      /* max expansion order the stack buffers allow       */
 #define ORC_EPS 1e-12    /* kernel/LaplaceSpherical.hpp:30                     */
 

@@ -70,6 +70,27 @@ int orc_quadrature(int key, double pts[][3], double *w) {
       n = perm3(pts, w, n, 0.025003534762686, 0.246672560639903, 0.728323904597411, 0.028327242531057);
       n = perm3(pts, w, n, 0.009540815400299, 0.066803251012200, 0.923655933587500, 0.009421666963733);
       break;
+    case 79: /* :186-272: centroid, ten rotation triples b..k, eight permutation sextets l..s, weights wa..ws */
+      n = one(pts, w, n, 0.033057055541624);
+      n = rot3(pts, w, n, -0.001900928704400, 0.500950464352200, 0.000867019185663);
+      n = rot3(pts, w, n, 0.023574084130543, 0.488212957934729, 0.011660052716448);
+      n = rot3(pts, w, n, 0.089726636099435, 0.455136681950283, 0.022876936356421);
+      n = rot3(pts, w, n, 0.196007481363421, 0.401996259318289, 0.030448982673938);
+      n = rot3(pts, w, n, 0.488214180481157, 0.255892909759421, 0.030624891725355);
+      n = rot3(pts, w, n, 0.647023488009788, 0.176488255995106, 0.024368057676800);
+      n = rot3(pts, w, n, 0.791658289326483, 0.104170855336758, 0.015997432032024);
+      n = rot3(pts, w, n, 0.893862072318140, 0.053068963840930, 0.007698301815602);
+      n = rot3(pts, w, n, 0.916762569607942, 0.041618715196029, -0.000632060497488);
+      n = rot3(pts, w, n, 0.976836157186356, 0.011581921406822, 0.001751134301193);
+      n = perm3(pts, w, n, 0.048741583664839, 0.344855770229001, 0.606402646106160, 0.016465839189576);
+      n = perm3(pts, w, n, 0.006314115948605, 0.377843269594854, 0.615842614456541, 0.004839033540485);
+      n = perm3(pts, w, n, 0.134316520547348, 0.306635479062357, 0.559048000390295, 0.025804906534650);
+      n = perm3(pts, w, n, 0.013973893962392, 0.249419362774742, 0.736606743262866, 0.008471091054441);
+      n = perm3(pts, w, n, 0.075549132909764, 0.212775724802802, 0.711675142287434, 0.018354914106280);
+      n = perm3(pts, w, n, -0.008368153208227, 0.146965436053239, 0.861402717154987, 0.000704404677908);
+      n = perm3(pts, w, n, 0.026686063258714, 0.137726978828923, 0.835586957912363, 0.010112684927462);
+      n = perm3(pts, w, n, 0.010547719294141, 0.059696109149007, 0.929756171556853, 0.003573909385950);
+      break;
     default: return -1;
   }
   return n;

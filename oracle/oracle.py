@@ -120,8 +120,8 @@ def semi_analytical(y0, y1, y2, x, same=False):
 
 
 def quadrature(key):
-    pts = np.zeros((32, 3))
-    w = np.zeros(32)
+    pts = np.zeros((80, 3))            # ORC_MAXK
+    w = np.zeros(80)
     n = lib().orc_quadrature(key, _p(pts), _p(w))
     if n < 0:
         raise ValueError("invalid quadrature key %d" % key)

@@ -52,6 +52,46 @@ def test_adapter_compiles_and_reports_missing_device(tmp_path, gpu_available):
     assert r.returncode == 2 and "no HIP device" in r.stdout       # fails loudly, no CPU fallback
 
 
+OPT_FLAGS = ["-theta", "0.4", "-ncrit", "32", "-printtree", "-eval", "FMM", "-lazy_eval"]
+
+
+def test_options_surface_compiles_and_parses(tmp_path, gpu_available):
+    """get_options(argc, argv), FMMOptions::MAC() / MAC_ / print_tree (include/FMMOptions.hpp:19-106) exist with the
+    reference's meaning in the stand-alone header; the flags are parsed before any device is needed."""
+    exe = _build(tmp_path, "options_and_defaults")
+    r = subprocess.run([exe, "3"] + OPT_FLAGS, capture_output=True, text=True)
+    first = r.stdout.splitlines()[0].split()
+    # theta, ncrit, printtree, lazy, evaluator == FMM, MAC accepts (0,0,0)-(2.1,0,0) with radii .5 at theta .4 (d^2 = 4.41 <= 6.25: no)
+    assert first[0] == "options" and float(first[1]) == 0.4 and first[2:6] == ["32", "1", "1", "1"]
+    assert first[6:] == ["0", "0"]
+    d = subprocess.run([exe, "3"], capture_output=True, text=True).stdout.splitlines()[0].split()
+    assert float(d[1]) == 0.5 and d[2:6] == ["64", "0", "1", "1"] and d[6:] == ["1", "0"]    # defaults; 4.41 > 4: accepted, 3.61: not
+    if not gpu_available:
+        assert r.returncode == 2 and "no HIP device" in r.stdout
+
+
+@pytest.mark.gpu
+def test_adapter_defaults_grow_with_set_p_and_accept_the_traction_rhs_plan(tmp_path, oracle_mod):
+    """FMM_plan<K>(K, panels, opts) with no p_max: sized for K's order; kernel().set_p above it re-creates the plan (the
+    reference's set_p resizes its tables, LaplaceSpherical.hpp:119-128) and earlier orders give the same bits afterwards;
+    the right-hand-side step of StokesBEM.cpp:266-270 -- every panel TRACTION, default arguments -- is accepted."""
+    exe = _build(tmp_path, "options_and_defaults")
+    r = subprocess.run([exe, "5"] + OPT_FLAGS, capture_output=True, text=True, check=True)
+    out = [ln.split() for ln in r.stdout.strip().splitlines()]
+    v = oracle_mod.unit_sphere(5)
+    o = oracle_mod.Oracle(v, theta=0.4, ncrit=32)
+    one = np.ones(o.n)
+    lap = [ln for ln in out if ln[0] == "laplace"]
+    assert [(int(ln[2]), int(ln[3])) for ln in lap] == [(6, 6), (4, 6), (9, 9), (6, 9)]
+    for ln in lap:
+        y = o.matvec(one, int(ln[2]))
+        assert abs(float(ln[4]) - y.sum()) / abs(y.sum()) < 1e-12
+        assert abs(float(ln[5]) - y[0]) / abs(y[0]) < 1e-11 and abs(float(ln[6]) - y[-1]) / abs(y[-1]) < 1e-11
+    assert lap[0][4:] == lap[3][4:]                                # p = 6 before and after the plan grew: the same digits
+    tr = [ln for ln in out if ln[0] == "traction"][0]
+    assert int(tr[3]) == 8 and abs(float(tr[4]) - 1.0) < 2e-2 and float(tr[5]) < 2e-2
+
+
 @pytest.mark.gpu
 def test_adapter_matches_oracle(tmp_path, oracle_mod):
     exe = _build(tmp_path)

@@ -132,6 +132,17 @@ def _split_worker(rank, world, port, out):
         x = torch.from_numpy(np.random.default_rng(8).random(n))
         y = op.execute(x)
         ok = np.array_equal(y.numpy(), orc.matvec(x.numpy(), K.P)) and sizes[0].item() == sizes[1].item()
+        # the selective exchange (all-to-all with uneven counts): host-only plans answer the count queries, and the collective
+        # check bench.py's preflight runs before the first all_to_all_single holds -- Laplace and Stokes with both target kinds
+        sel = fb.ShardedFMM(K, v, host_only=True)
+        ok = ok and sel.split and sel.plan.exchange_mode == 2 and sel.check_exchange_symmetry(6) is True
+        bcs = np.zeros(n, dtype=np.uint8)
+        bcs[::3] = 1
+        KS = fb.StokesSphericalBEM(6, 4, 1e-3)
+        for flags, slots in ((None, 4), (np.ones(n, dtype=np.uint8), 7), (bcs, 11)):
+            ss = fb.ShardedFMM(KS, v, bc=flags, host_only=True)
+            sc, rc = ss.plan.exchange_counts(6)
+            ok = ok and ss.check_exchange_symmetry(6) is True and int(sc.sum()) > 0 and int(sc.sum()) % (slots * 21 * 2) == 0
         if rank == 0:
             out.put(bool(ok))
     finally:

@@ -58,7 +58,7 @@ def test_near_field_only(case6):
     assert rel_l2(yd.cpu().numpy(), o.near_only(x)) <= 1e-14
 
 
-@pytest.mark.parametrize("p", [1, 2, 3, 4, 5, 6, 10, 11, 12, 16])
+@pytest.mark.parametrize("p", [1, 2, 3, 4, 5, 6, 10, 11, 12, 13, 14, 15, 16])
 def test_expansions_and_matvec_vs_oracle(case6, p):
     _, K, pl, o, x = case6
     K.set_p(p)
@@ -71,6 +71,27 @@ def test_expansions_and_matvec_vs_oracle(case6, p):
     scaleL = np.abs(Lo[:, 0]).max(axis=1, keepdims=True) + 1e-300
     assert np.max(np.abs(M[:, 0] - Mo[:, 0]) / scaleM) <= TOL_EXPANSION
     assert np.max(np.abs(L[:, 0] - Lo[:, 0]) / scaleL) <= TOL_EXPANSION
+    assert rel_l2(y, yo) <= TOL_MATVEC
+
+
+@pytest.mark.parametrize("p", [2, 7, 10, 12, 13, 14, 15, 16])
+def test_expansions_all_slots_mixed_bc(fb, oracle_mod, p):
+    """Both expansion slots live (POTENTIAL and NORMAL_DERIV panels mixed): every slot of M and L against the oracle, every
+    order family -- rotation kernels (p <= 12) and the double-sum kernels (13 ... 16)."""
+    v = oracle_mod.unit_sphere(5)
+    rng = np.random.default_rng(17)
+    bc = (rng.random(len(v)) < 0.5).astype(np.uint8)
+    x = rng.standard_normal(len(v))
+    o = oracle_mod.Oracle(v, bc=bc)
+    K = fb.LaplaceSphericalBEM(p, 3)
+    pl = fb.FMM_plan(K, v, bc=bc)
+    y, yo = pl.execute(x), o.matvec(x, p)
+    for which in ("M", "L"):
+        got, ref = pl.expansions(which, p), o.expansions(p, which)
+        assert got.shape == ref.shape and got.shape[1] == 2
+        scale = np.abs(ref).max(axis=2, keepdims=True) + 1e-300
+        assert np.max(np.abs(got - ref) / scale) <= TOL_EXPANSION, which
+        assert np.abs(ref[:, 0]).max() > 0 and np.abs(ref[:, 1]).max() > 0
     assert rel_l2(y, yo) <= TOL_MATVEC
 
 
@@ -128,7 +149,7 @@ def test_boundary_condition_variants(fb, oracle_mod, bc_kind):
         assert np.max(np.abs(vals - ref) / np.abs(ref)) <= TOL_ENTRY
 
 
-@pytest.mark.parametrize("theta,ncrit,k", [(0.4, 64, 3), (0.6, 32, 4), (0.5, 125, 7), (0.5, 200, 1), (0.5, 64, 13)])
+@pytest.mark.parametrize("theta,ncrit,k", [(0.4, 64, 3), (0.6, 32, 4), (0.5, 125, 7), (0.5, 200, 1), (0.5, 64, 13), (0.5, 64, 79)])
 def test_option_variants(fb, oracle_mod, theta, ncrit, k):
     v = fb.unit_sphere(5)
     opts = fb.FMMOptions()
@@ -208,20 +229,24 @@ def test_larger_case_r8_properties(fb, oracle_mod):
     assert rel_l2(y[rows[0]:rows[1]], d) < 2e-6
 
 
-@pytest.mark.parametrize("bc_val", [0, 1])
-def test_matrix_free_near_field(fb, oracle_mod, bc_val):
-    """sparse_local = false: EvalInteractionLazy recomputes the panel integrals every matvec."""
+@pytest.mark.parametrize("bc_val,quad_k", [(0, 3), (1, 3), (0, 1), (1, 1), (0, 4), (1, 13)])
+def test_matrix_free_near_field(fb, oracle_mod, bc_val, quad_k):
+    """sparse_local = false: EvalInteractionLazy recomputes the panel integrals every matvec.
+    K = 1: the only quadrature point of a panel is its centroid, so a lane past the last column that runs the far-regime
+    arithmetic against tree panel 0 meets distance zero in row 0 -- its NaN must not reach the row's sum (round-2 advisory);
+    K > 3: the far regime re-reads the quadrature points (mf_far_general)."""
     v = fb.unit_sphere(5)
     n = len(v)
     bc = np.full(n, bc_val, dtype=np.uint8)
     opts = fb.FMMOptions()
     opts.sparse_local = False
-    K = fb.LaplaceSphericalBEM(10, 3)
+    K = fb.LaplaceSphericalBEM(10, quad_k)
     pl = fb.FMM_plan(K, v, opts, bc=bc)
     assert pl.stats()["near_bytes"] == 0
     x = drand48(n, seed=5)
     y = pl.execute(x)
-    assert rel_l2(y, oracle_mod.Oracle(v, bc=bc).matvec(x, 10)) <= TOL_MATVEC
+    assert np.isfinite(y).all()
+    assert rel_l2(y, oracle_mod.Oracle(v, K=quad_k, bc=bc).matvec(x, 10)) <= TOL_MATVEC
     dense = fb.FMM_plan(K, v, bc=bc).execute(x)
     assert rel_l2(y, dense) <= 1e-14
 

@@ -94,12 +94,24 @@ def test_analytic_identities(oracle_mod):
     assert abs(abs(np.mean(yd)) - 4 * np.pi) / (4 * np.pi) < 2e-2 or abs(np.mean(yd)) < 0.3
 
 
-def test_quadrature_rules(oracle_mod):
-    for key, npts in [(1, 1), (3, 3), (4, 4), (7, 4), (13, 13), (17, 16), (19, 19), (25, 25)]:
+def test_quadrature_rules(oracle_mod, fb):
+    """Every key of examples/BEM/GaussQuadrature.hpp:15-274: point counts (key 7 aliases the 4-point rule, key 17 has 16
+    nodes), weights summing to one, barycentric points; each rule integrates the monomials of its degree over the
+    reference triangle (int x^a y^b = a! b! / (a+b+2)!, area 1/2 -> weights sum to 1: factor 2) -- a mistyped node or weight
+    shows at once; and the product's table (fmmbem_quadrature) is the oracle's, digit for digit."""
+    from math import factorial
+    degree = {1: 1, 3: 2, 4: 3, 7: 3, 13: 7, 17: 8, 19: 9, 25: 10, 79: 20}
+    for key, npts in [(1, 1), (3, 3), (4, 4), (7, 4), (13, 13), (17, 16), (19, 19), (25, 25), (79, 79)]:
         pts, w = oracle_mod.quadrature(key)
         assert len(w) == npts
         assert abs(w.sum() - 1) < 2e-9
         assert np.allclose(pts.sum(axis=1), 1, atol=2e-9)
+        for a in range(degree[key] + 1):
+            for b in range(degree[key] + 1 - a):
+                exact = 2.0 * factorial(a) * factorial(b) / factorial(a + b + 2)
+                assert abs((w * pts[:, 0] ** a * pts[:, 1] ** b).sum() - exact) < 5e-9, (key, a, b)
+        gp, gw = fb.quadrature(key)
+        assert np.array_equal(gp, pts) and np.array_equal(gw, w)
     with pytest.raises(ValueError):
         oracle_mod.quadrature(2)
 

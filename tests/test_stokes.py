@@ -183,6 +183,25 @@ def test_gpu_stokes_alternative_paths(fb, stokes5, monkeypatch, env):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("k,kfine", [(4, 79), (13, 25), (79, 79)])
+def test_gpu_stokes_other_rules(fb, oracle_mod, k, kfine):
+    """The other keys of GaussQuadrature.hpp as K and K_fine, up to the 79-point rule (:186-272): near blocks and matvec."""
+    v = oracle_mod.unit_sphere(3)
+    o = oracle_mod.StokesOracle(v, K=k, K_fine=kfine, mu=1e-3)
+    K = fb.StokesSphericalBEM(6, k, 1e-3)
+    K.set_Kfine(kfine)
+    pl = fb.FMM_plan(K, v)
+    rp, col, val = o.near_csr()
+    for row in (0, o.n - 1):
+        for a in range(3):
+            _, vals = pl.near_row(3 * row + a)
+            ref = val[rp[row]:rp[row + 1], a, :].reshape(-1)
+            assert np.max(np.abs(vals - ref)) / np.abs(ref).max() <= 1e-13
+    x = drand48(3 * o.n, seed=12).reshape(o.n, 3)
+    assert rel_l2(pl.execute(x), o.matvec(x, 6)) <= 1e-12
+
+
+@pytest.mark.gpu
 def test_gpu_stokes_high_orders(fb, oracle_mod):
     """p = 13..16: the Stokes L2P stages 8 leaves x 4 potentials x S(p) coefficients per wavefront, 69.6 KB at p = 16 --
     above the 64 KB a kernel gets without hipFuncAttributeMaxDynamicSharedMemorySize."""
