@@ -48,15 +48,21 @@ __device__ __forceinline__ double block_total(const double* __restrict__ partial
 // w -= h_prev * v_prev (when v_prev; h_prev = the total of part_prev, formed by every workgroup for itself -- no atomics, no
 // device-wide fences: on this part a device-scope fence per workgroup writes the L2 back and cost 30 us per sweep), then this
 // workgroup's share of <w, v_dot> (v_dot == nullptr: <w, w>) into part_out[blockIdx.x]
+// vec: every vector of the call starts on a 16-byte boundary (the host checks the pointers and the stride); otherwise -- an odd
+// ldv with Laplace's one unknown per panel puts every other row of V on an 8-byte boundary -- the whole sweep is scalar
 __global__ __launch_bounds__(kThreads) void mgs_step_kernel(int64_t n, double* __restrict__ w, const double* __restrict__ v_prev,
                                                              const double* __restrict__ part_prev, const double* __restrict__ v_dot,
-                                                             double* __restrict__ part_out) {
+                                                             double* __restrict__ part_out, int vec) {
   __shared__ double wsum[kThreads / 64];
   const double hp = v_prev ? block_total(part_prev, wsum) : 0.0;
   double acc = 0;
+  // the slots of this row no workgroup of this grid writes are part of every total: zero them here, every call (a scratch
+  // reused after a call with a larger n would otherwise add stale partial sums)
+  if (blockIdx.x == 0)
+    for (int k = gridDim.x + threadIdx.x; k < kBlocks; k += kThreads) part_out[k] = 0.0;
   // four consecutive elements per thread and step, as two 16-byte vectors per array: all loads of a step are in flight before
   // the first FMA
-  const int64_t n4 = n >> 2;
+  const int64_t n4 = vec ? n >> 2 : 0;
   typedef double dv2 __attribute__((ext_vector_type(2)));
   dv2* w2 = reinterpret_cast<dv2*>(w);
   const dv2* p2 = reinterpret_cast<const dv2*>(v_prev);
@@ -91,17 +97,17 @@ __global__ __launch_bounds__(kThreads) void mgs_step_kernel(int64_t n, double* _
 
 // v_next = w / |w|, |w|^2 = the total of part_norm
 __global__ __launch_bounds__(kThreads) void mgs_scale_kernel(int64_t n, const double* __restrict__ w, const double* __restrict__ part_norm,
-                                                              double* __restrict__ v_next) {
+                                                              double* __restrict__ v_next, int vec) {
   __shared__ double wsum[kThreads / 64];
   const double inv = 1.0 / sqrt(block_total(part_norm, wsum));
   typedef double dv2 __attribute__((ext_vector_type(2)));
-  const int64_t n2 = n >> 1;
+  const int64_t n2 = vec ? n >> 1 : 0;
   for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n2; q += (int64_t)gridDim.x * blockDim.x) {
     dv2 v = reinterpret_cast<const dv2*>(w)[q];
     v.x *= inv; v.y *= inv;
     reinterpret_cast<dv2*>(v_next)[q] = v;
   }
-  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) v_next[n - 1] = w[n - 1] * inv;
+  for (int64_t i = (n2 << 1) + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) v_next[i] = w[i] * inv;
 }
 
 // h[k] = total of the k-th row of partial sums, k <= ncols; the last one is |w|^2 -> |w|
@@ -119,14 +125,16 @@ extern "C" int fmmbem_mgs_column_device(int64_t n, double* d_w, const double* d_
     return fmmbem::fail(FMMBEM_ERR_INVALID, "fmmbem_mgs_column_device: bad argument");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int64_t want = (n / 4 + kThreads - 1) / kThreads + 1;
-  const int grid = (int)(want < kBlocks ? want : kBlocks);          // slots grid .. kBlocks-1 of a row stay zero (the caller zeroed the scratch)
+  const int grid = (int)(want < kBlocks ? want : kBlocks);          // slots grid .. kBlocks-1 of a row are zeroed by the sweep itself
+  const auto a16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  const int vec = a16(d_w) && a16(d_V) && a16(d_vnext) && (ldv & 1) == 0;
   for (int k = 0; k <= ncols; ++k) {
     const double* v_prev = k ? d_V + (int64_t)(k - 1) * ldv : nullptr;
     const double* v_dot = k < ncols ? d_V + (int64_t)k * ldv : nullptr;
     hipLaunchKernelGGL(mgs_step_kernel, dim3(grid), dim3(kThreads), 0, s, n, d_w, v_prev, k ? d_scratch + (size_t)(k - 1) * kBlocks : nullptr,
-                       v_dot, d_scratch + (size_t)k * kBlocks);
+                       v_dot, d_scratch + (size_t)k * kBlocks, vec);
   }
-  hipLaunchKernelGGL(mgs_scale_kernel, dim3(grid), dim3(kThreads), 0, s, n, d_w, d_scratch + (size_t)ncols * kBlocks, d_vnext);
+  hipLaunchKernelGGL(mgs_scale_kernel, dim3(grid), dim3(kThreads), 0, s, n, d_w, d_scratch + (size_t)ncols * kBlocks, d_vnext, vec);
   hipLaunchKernelGGL(mgs_finish_kernel, dim3(ncols + 1), dim3(kThreads), 0, s, d_scratch, ncols, d_h);
   return hipGetLastError() == hipSuccess ? FMMBEM_OK : fmmbem::fail(FMMBEM_ERR_HIP, "fmmbem_mgs_column_device: launch failed");
 }

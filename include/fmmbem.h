@@ -186,8 +186,9 @@ int fmmbem_kernel_entries(const fmmbem_options *opts, size_t n, const double *ta
  * w against V_0 .. V_{ncols-1}, then the normalised next basis vector), device vectors, ONE call per Arnoldi column:
  *   for k < ncols:  h[k] = <w, V_k>;  w -= h[k] V_k;      h[ncols] = |w|;   vnext = w / h[ncols]
  * d_V: ncols vectors of n doubles, ldv apart; d_h: ncols + 1 doubles on the device; d_scratch:
- * fmmbem_mgs_scratch_doubles(largest ncols) doubles, ZEROED once by the caller and then reused; asynchronous on `stream`.
- * The sums are formed in a fixed order. */
+ * fmmbem_mgs_scratch_doubles(largest ncols) doubles of work space (no initial contents assumed; reusable across calls and
+ * sizes); asynchronous on `stream`.  The sums are formed in a fixed order.  Vectors that start on 16-byte boundaries with an
+ * even ldv take the vector path; anything else is correct but scalar. */
 int fmmbem_mgs_column_device(int64_t n, double *d_w, const double *d_V, int64_t ldv, int ncols, double *d_h, double *d_vnext,
                              double *d_scratch, void *stream);
 int fmmbem_mgs_scratch_doubles(int max_cols);
