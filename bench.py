@@ -282,7 +282,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    plan.set_timing(True)                                    # HIP events around each kernel, no added syncs
+    # HIP events around the near-field kernel only (the roofline kernel), no added syncs: events around every stage put a
+    # packet between every two kernels and cost 85 us per matvec (profiles/r03b_p10_timeline.md); the per-stage breakdown
+    # (`stage_ms`) comes from a second, fully instrumented pass OUTSIDE the timed region
+    plan.set_timing(2)
     stage(rank, "timed region: %d steps" % args.steps)
     try:
         fence()
@@ -295,7 +298,12 @@ def main():
         if world == 1:
             raise
         die(rank, world, "timed region raised: %r" % (e,))
-    st = plan.stats()
+    st_near = plan.stats()
+    plan.set_timing(1)
+    for _ in range(min(args.steps, 10)):
+        step()
+    fence()
+    st = plan.stats()                                        # every stage bracketed: the breakdown, not the throughput
     plan.set_timing(False)
     per_rank, replicas_equal = None, None
     if world > 1:
@@ -335,7 +343,7 @@ def main():
     rows = st["owned_row_end"] - st["owned_row_begin"]
     # Stokes: the 3x3 block of a panel pair is symmetric and is streamed as 6 values, not the 9 of SURVEY 8d
     p2p_bytes = st["near_nnz"] * 8 * (6 if stokes else 1) + n * 8 * dof + rows * 8 * dof
-    near_ms = st["ms_near"]
+    near_ms = st_near["ms_near"]                              # measured live over the timed region, on the launch stream
     p2p_gbs = p2p_bytes / (near_ms * 1e-3) / 1e9 if near_ms > 0 else 0.0
     traffic = None
     try:                                                     # PMC traffic comes from a separate rocprofv3 --pmc pass
@@ -389,7 +397,7 @@ def main():
                     {"kernel": "near_spmv (P2P)", "bound": "hbm", "achieved": p2p_gbs, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": p2p_gbs / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": p2p_bytes, "launch_ms": near_ms,
-                     "timed_launches": st["timed_executes"]},
+                     "timed_launches": st_near["timed_executes"]},
         "roofline_m2l": {"kernel": "m2l_rot" if rot_on else "m2l", "bound": "fp64 vector FMA", "achieved": m2l_tflops,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": m2l_tflops / FP64_PEAK_TFLOPS,
                          "executed_flops_per_launch": m2l_flops, "launch_ms": st["ms_m2l"],
@@ -397,6 +405,8 @@ def main():
                          "reference_equivalent_tflops": m2l_ref_flops / (st["ms_m2l"] * 1e-3) / 1e12 if st["ms_m2l"] > 0 else 0.0},
         "stage_ms": {k[3:]: st[k] for k in ("ms_total", "ms_gather", "ms_near", "ms_scatter", "ms_p2m", "ms_m2m",
                                             "ms_mh", "ms_m2l", "ms_l2l", "ms_l2p")},
+        "stage_ms_note": "a second pass of %d matvecs with HIP events around every stage, outside the timed region (the events "
+                         "themselves lengthen such a matvec; `ms_per_step` is the un-instrumented figure)" % min(args.steps, 10),
         "per_rank": per_rank, "replicas_equal": replicas_equal, "preflight": pre,
         "collectives": None if world == 1 else {"upward": ("all-to-all of the multipoles each shard reads" if op.plan.exchange_mode == 2 else "all-gather of multipoles") if op.split else "none (upward pass repeated)",
                                                 "result": op.y_collective},

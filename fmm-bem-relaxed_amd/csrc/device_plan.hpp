@@ -134,16 +134,18 @@ struct DevicePlan {
                                                       // its own leaves only keeps only their records)
   // scratch
   double *xt, *yt;                                    // tree-order x and near result
+  double* yfar = nullptr;                             // tree-order far-field result when the near field runs beside the far field (rows L2P never
+                                                      // writes stay zero from the plan's creation on)
 };
 
 // ---- launchers (kernels_near.hip / kernels_far.hip); all asynchronous on `s` ----
 hipError_t launch_near_assemble(const DevicePlan& d, hipStream_t s);
 hipError_t launch_gather_x(const DevicePlan& d, const double* x, hipStream_t s);
-hipError_t launch_near_spmv(const DevicePlan& d, hipStream_t s);
+hipError_t launch_near_spmv(const DevicePlan& d, hipStream_t s, int wgs_per_cu = 0);
 hipError_t launch_kernel_entries(const DevicePlan& d, int m, double* out, hipStream_t s);   // panels [0,m) targets, [m,2m) sources
 hipError_t launch_near_diag(const DevicePlan& d, const int* selfcol, double* out, hipStream_t s);
 hipError_t launch_near_matfree(const DevicePlan& d, hipStream_t s);
-hipError_t launch_scatter_y(const DevicePlan& d, double* y, hipStream_t s);
+hipError_t launch_scatter_y(const DevicePlan& d, double* y, hipStream_t s, const double* add = nullptr, bool slices = false);
 hipError_t launch_assemble_slices(const DevicePlan& d, const double* slices, double* y, int world, const int64_t* d_cut, int64_t chunk,
                                   hipStream_t s);
 hipError_t launch_p2m(const DevicePlan& d, int p, hipStream_t s);
@@ -173,9 +175,9 @@ hipError_t launch_m2m_rot(const DevicePlan& d, const RotWork& w, int p, hipStrea
 hipError_t launch_l2l_rot(const DevicePlan& d, const RotWork& w, int p, hipStream_t s);   // L[tgt = child] += shift of L[src = parent]
 hipError_t launch_m2l_rot(const DevicePlan& d, const DevicePlan* d_dev, int p, hipStream_t s);
 hipError_t launch_l2l_level(const DevicePlan& d, const ShiftOpDev& op, int p, int first, int count, hipStream_t s);
-hipError_t launch_l2p(const DevicePlan& d, int p, double* y, hipStream_t s);
+hipError_t launch_l2p(const DevicePlan& d, int p, double* y, hipStream_t s, bool store = false);
 hipError_t launch_near_assemble_stokes(const DevicePlan& d, hipStream_t s);
 hipError_t launch_p2m_stokes(const DevicePlan& d, int p, hipStream_t s);
-hipError_t launch_l2p_stokes(const DevicePlan& d, int p, double* y, hipStream_t s);
+hipError_t launch_l2p_stokes(const DevicePlan& d, int p, double* y, hipStream_t s, bool store = false);
 
 }  // namespace fmmbem

@@ -449,6 +449,61 @@ __global__ __launch_bounds__(4 * kWave) void p2m_apply_kernel(DevicePlan d, cons
   }
 }
 
+// p2m_apply, one expansion per box (every panel the same boundary condition: the reference's drivers) and more than 32
+// coefficients: the streaming form.  The kernel above spends three vector loads per panel (record, charge, flag) where one
+// carries data, waits for every batch of four records before asking for the next, and finds its leaf through a chain of four
+// dependent vector loads.  Here everything that is the same for all lanes is scalar -- the leaf index is wave-uniform by
+// construction (readfirstlane), leaf record, row range and the charges come through the scalar cache (constant address
+// space: the M stores of this kernel would otherwise count as clobbers), the NEXT leaf's record is fetched while this leaf
+// streams -- and the only vector loads are the 16-byte table entries, kP2MStream panels' worth in flight per lane.
+constexpr int kP2MStream = 8;
+typedef __attribute__((address_space(4))) int ConstInt;
+typedef __attribute__((address_space(4))) double ConstDouble;
+template <class T, class U>
+__device__ __forceinline__ const T* as_const_space(const U* p) { return reinterpret_cast<const T*>(reinterpret_cast<uintptr_t>(p)); }
+
+__global__ __launch_bounds__(4 * kWave) void p2m_stream_kernel(DevicePlan d, const int P) {
+  const int S = P * (P + 1) / 2, SM = d.s_max, TS = d.p2m_stride;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const double2* __restrict__ tab = d.p2m_tab - (size_t)d.p2m_tab_row0 * TS;      // indexed by tree-order panel
+  const ConstInt* leaf_of = as_const_space<ConstInt>(d.p2m_leaf);
+  const ConstInt* box_of = as_const_space<ConstInt>(d.leaf_box);
+  const ConstInt* row0_of = as_const_space<ConstInt>(d.leaf_row0);
+  const ConstInt* nrows_of = as_const_space<ConstInt>(d.leaf_nrows);
+  const ConstDouble* xt = as_const_space<ConstDouble>(d.xt);
+  const int slot = d.act[0], stride = gridDim.x * 4, n = d.n_p2m;
+  int li = blockIdx.x * 4 + wv;
+  if (li >= n) return;
+  int leaf = leaf_of[li];
+  int box = box_of[leaf], row0 = row0_of[leaf], nrows = nrows_of[leaf];
+  for (; li < n; li += stride) {
+    // the next leaf's record, on its way while this one streams
+    const int nl = li + stride < n ? li + stride : li;
+    const int nleaf = leaf_of[nl];
+    const int nbox = box_of[nleaf], nrow0 = row0_of[nleaf], nnrows = nrows_of[nleaf];
+    for (int idx = lane; idx < S; idx += kWave) {
+      double2 m = {0, 0};
+      constexpr int U = kP2MStream;
+      for (int r = 0; r < nrows; r += U) {
+        tvec2 t[U];
+        double x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {                    // a leaf's last batch is a masked one: the row test is scalar
+          const bool ok = r + u < nrows;
+          const int64_t iu = (int64_t)row0 + (ok ? r + u : r);
+          t[u] = __builtin_nontemporal_load(reinterpret_cast<const tvec2*>(tab + (size_t)iu * TS + idx));
+          x[u] = ok ? xt[iu] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { m.x = fma(x[u], t[u].x, m.x); m.y = fma(x[u], t[u].y, m.y); }   // panel order, as p2m_apply_kernel
+      }
+      d.M[((size_t)box * d.nslots + slot) * SM + idx] = m;
+    }
+    leaf = nleaf; box = nbox; row0 = nrow0; nrows = nnrows;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // M2M, one tree level per launch.  A workgroup = kShiftWaves wavefronts takes one parent box; wavefront w
 // translates child w (children are the <= 8 occupied octants) with the precomputed sparse operator
@@ -502,7 +557,10 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// (Round 3 tried the levels near the root as ONE launch with a device-wide barrier between the levels: a barrier through L2
+// atomics costs ~10 us, a dependent launch 4.5 us including the kernel -- profiles/r03e_fused_levels_and_p2m_stream.txt.)
 __global__ __launch_bounds__(kShiftWaves * kWave) void m2m_kernel(DevicePlan d, ShiftOpDev op, const int P, int first, int count) {
+  const int slot_i = blockIdx.y, wg = blockIdx.x, nwg = gridDim.x;
   extern __shared__ double2 lds2[];
   const int S = P * (P + 1) / 2, P2 = P * P, SM = d.s_max, W = S + P2 + op.V;
   const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
@@ -510,8 +568,8 @@ __global__ __launch_bounds__(kShiftWaves * kWave) void m2m_kernel(DevicePlan d, 
   double2* Y = Ms + S;                                // ... its translation harmonics
   double2* pv = Y + P2;                               // ... and its per-piece partial sums
   double2* part = lds2 + (size_t)kShiftWaves * W + (size_t)w * S;
-  const int slot = d.act[blockIdx.y];
-  for (int it = blockIdx.x; it < count; it += gridDim.x) {
+  const int slot = d.act[slot_i];
+  for (int it = wg; it < count; it += nwg) {
     const int parent = d.m2m_parent[first + it];
     const int cb = d.box_child_begin[parent], nchild = d.box_child_end[parent] - cb;
     if (w < nchild) {
@@ -563,14 +621,15 @@ __global__ __launch_bounds__(kWave) void mh_prep_kernel(DevicePlan d, const int 
 // ---------------------------------------------------------------------------------------------
 constexpr int kL2LWaves = FMMBEM_L2L_WAVES;            // independent children per workgroup (LDS: 10.7 KB each at p = 10)
 __global__ __launch_bounds__(kL2LWaves * kWave) void l2l_kernel(DevicePlan d, ShiftOpDev op, const int P, int first, int count) {
+  const int slot_i = blockIdx.y, wg = blockIdx.x, nwg = gridDim.x;
   extern __shared__ double2 lds2[];
   const int S = P * (P + 1) / 2, P2 = P * P, SM = d.s_max, W = S + P2 + op.V;
   const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
   double2* Ls = lds2 + (size_t)w * W;
   double2* Y = Ls + S;
   double2* pv = Y + P2;
-  const int slot = d.act[blockIdx.y];
-  for (int it = blockIdx.x * kL2LWaves + w; it < count; it += gridDim.x * kL2LWaves) {
+  const int slot = d.act[slot_i];
+  for (int it = wg * kL2LWaves + w; it < count; it += nwg * kL2LWaves) {
     const int child = d.l2l_child[first + it];
     const int parent = d.box_parent[child];
     const double2* src = d.L + ((size_t)parent * d.nslots + slot) * SM;
@@ -599,7 +658,9 @@ __global__ __launch_bounds__(kL2LWaves * kWave) void l2l_kernel(DevicePlan d, Sh
 // (coalesced; the one scatter to the caller's order comes after, plan.hip).
 // ---------------------------------------------------------------------------------------------
 constexpr int kL2PLeaves = 8, kL2PWaves = 4;
-__global__ __launch_bounds__(kL2PWaves * kWave) void l2p_kernel(DevicePlan d, const int P, double* __restrict__ y) {
+// store: y[i] = the far field (the near field runs beside this on another stream and the two meet in the delivery kernel)
+// instead of y[i] += (the near field is already there).
+__global__ __launch_bounds__(kL2PWaves * kWave) void l2p_kernel(DevicePlan d, const int P, double* __restrict__ y, const int store) {
   extern __shared__ double2 l2p_lds[];                  // step tables (3 S doubles), then [wave][leaf][active slot][S]
   const int S = P * (P + 1) / 2, na = d.n_act;
   double* sPref = reinterpret_cast<double*>(l2p_lds);
@@ -657,7 +718,7 @@ __global__ __launch_bounds__(kL2PWaves * kWave) void l2p_kernel(DevicePlan d, co
         const double nr = er * s.cb - ei * s.sb, ni = er * s.sb + ei * s.cb;
         er = nr; ei = ni;
       }
-      y[i] += tb ? -r : r;
+      y[i] = (store ? 0.0 : y[i]) + (tb ? -r : r);
     }
   }
 }
@@ -672,7 +733,7 @@ __global__ __launch_bounds__(kL2PWaves * kWave) void l2p_kernel(DevicePlan d, co
 // TRAC: the rows of TRACTION targets, from the seven potentials of the double layer (p2m_apply_kernel<3>):
 //   t_i = x_k d_i Psi_k - d_i Psi_0 - Theta_i     (slots 4..6 Psi_k, 7 Psi_0: gradients; 8..10 Theta_i: values; no 1/(2 mu))
 template <bool TRAC>
-__global__ __launch_bounds__(kL2PWaves * kWave) void l2p_stokes_kernel(DevicePlan d, const int P, double* __restrict__ y) {
+__global__ __launch_bounds__(kL2PWaves * kWave) void l2p_stokes_kernel(DevicePlan d, const int P, double* __restrict__ y, const int store) {
   constexpr int NE = TRAC ? 7 : 4, SB = TRAC ? 4 : 0;   // potentials staged per leaf, first slot
   extern __shared__ double2 l2p_lds[];                  // as l2p_kernel: step tables, then [wave][leaf][4 potentials][S]
   const int S = P * (P + 1) / 2;
@@ -763,9 +824,9 @@ __global__ __launch_bounds__(kL2PWaves * kWave) void l2p_stokes_kernel(DevicePla
         res[0] += f * cx_; res[1] += f * cy_; res[2] += f * cz_;
       }
       const double sc = TRAC ? 1.0 : 1. / 2 / d.mu;
-      y[3 * (size_t)i] += sc * res[0];
-      y[3 * (size_t)i + 1] += sc * res[1];
-      y[3 * (size_t)i + 2] += sc * res[2];
+      y[3 * (size_t)i] = (store ? 0.0 : y[3 * (size_t)i]) + sc * res[0];
+      y[3 * (size_t)i + 1] = (store ? 0.0 : y[3 * (size_t)i + 1]) + sc * res[1];
+      y[3 * (size_t)i + 2] = (store ? 0.0 : y[3 * (size_t)i + 2]) + sc * res[2];
     }
   }
 }
@@ -825,7 +886,12 @@ hipError_t launch_p2m(const DevicePlan& d, int p, hipStream_t s) {
   if (p < 1 || p > kPmaxDev) return hipErrorInvalidValue;
   if (d.p2m_tab) {
     const int nb = (d.n_p2m + 3) / 4;
-    hipLaunchKernelGGL((p2m_apply_kernel<1>), dim3(nb < 256 * 16 ? nb : 256 * 16), dim3(4 * kWave), 0, s, d, p);
+    const char* se = std::getenv("FMMBEM_P2M_STREAM");               // read per launch: tests switch it per plan
+    const bool stream_off = se && std::atoi(se) == 0;
+    if (d.n_act == 1 && p * (p + 1) / 2 > kWave / 2 && !stream_off)      // one expansion per box, more than 32 coefficients
+      hipLaunchKernelGGL(p2m_stream_kernel, dim3(nb < 256 * 8 ? nb : 256 * 8), dim3(4 * kWave), 0, s, d, p);
+    else
+      hipLaunchKernelGGL((p2m_apply_kernel<1>), dim3(nb < 256 * 16 ? nb : 256 * 16), dim3(4 * kWave), 0, s, d, p);
     return hipGetLastError();
   }
   const int nblk = (d.n_p2m + kP2MWaves - 1) / kP2MWaves;
@@ -933,7 +999,7 @@ hipError_t launch_l2l_level(const DevicePlan& d, const ShiftOpDev& op, int p, in
   return hipGetLastError();
 }
 
-hipError_t launch_l2p(const DevicePlan& d, int p, double* y, hipStream_t s) {
+hipError_t launch_l2p(const DevicePlan& d, int p, double* y, hipStream_t s, bool store) {
   if (hipError_t e = upload_constants_once(); e != hipSuccess) return e;
   if (d.n_l2p <= 0) return hipSuccess;
   if (p < 1 || p > kPmaxDev) return hipErrorInvalidValue;
@@ -943,7 +1009,7 @@ hipError_t launch_l2p(const DevicePlan& d, int p, double* y, hipStream_t s) {
   nw = nw < 1 ? 1 : nw > kL2PWaves ? kL2PWaves : nw;
   const int nblk = (d.n_l2p_grp + nw - 1) / nw;
   const size_t lds = sizeof(double2) * (size_t)((3 * S + 1) / 2) + nw * per_wave;
-  hipLaunchKernelGGL(l2p_kernel, dim3(nblk < 256 * 8 ? nblk : 256 * 8), dim3(nw * kWave), lds, s, d, p, y);
+  hipLaunchKernelGGL(l2p_kernel, dim3(nblk < 256 * 8 ? nblk : 256 * 8), dim3(nw * kWave), lds, s, d, p, y, store ? 1 : 0);
   return hipGetLastError();
 }
 
@@ -967,7 +1033,7 @@ hipError_t launch_p2m_stokes(const DevicePlan& d, int p, hipStream_t s) {
   return hipGetLastError();
 }
 
-hipError_t launch_l2p_stokes(const DevicePlan& d, int p, double* y, hipStream_t s) {
+hipError_t launch_l2p_stokes(const DevicePlan& d, int p, double* y, hipStream_t s, bool store) {
   if (hipError_t e = upload_constants_once(); e != hipSuccess) return e;
   if (d.n_l2p <= 0) return hipSuccess;
   if (p < 1 || p > kPmaxDev) return hipErrorInvalidValue;
@@ -979,8 +1045,8 @@ hipError_t launch_l2p_stokes(const DevicePlan& d, int p, double* y, hipStream_t 
     nw = nw < 1 ? 1 : nw > kL2PWaves ? kL2PWaves : nw;
     const int nblk = (d.n_l2p_grp + nw - 1) / nw;
     const size_t lds = sizeof(double2) * (size_t)((3 * S + 1) / 2) + nw * per_wave;
-    if (trac) hipLaunchKernelGGL(l2p_stokes_kernel<true>, dim3(nblk < 256 * 8 ? nblk : 256 * 8), dim3(nw * kWave), lds, s, d, p, y);
-    else hipLaunchKernelGGL(l2p_stokes_kernel<false>, dim3(nblk < 256 * 8 ? nblk : 256 * 8), dim3(nw * kWave), lds, s, d, p, y);
+    if (trac) hipLaunchKernelGGL(l2p_stokes_kernel<true>, dim3(nblk < 256 * 8 ? nblk : 256 * 8), dim3(nw * kWave), lds, s, d, p, y, store ? 1 : 0);
+    else hipLaunchKernelGGL(l2p_stokes_kernel<false>, dim3(nblk < 256 * 8 ? nblk : 256 * 8), dim3(nw * kWave), lds, s, d, p, y, store ? 1 : 0);
   }
   return hipGetLastError();
 }

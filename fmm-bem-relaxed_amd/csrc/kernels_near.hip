@@ -660,10 +660,17 @@ __global__ void gather_x_kernel(const uint32_t* __restrict__ perm, const double*
   if (u < n * dof) { const int64_t i = u / dof; const int a = (int)(u - i * dof); xt[u] = x[(int64_t)perm[i] * dof + a]; }
 }
 
-__global__ void scatter_y_kernel(const uint32_t* __restrict__ perm, const double* __restrict__ yt,
-                                 double* __restrict__ y, int64_t row_begin, int64_t row_end, int dof) {
+// add: a second tree-order vector summed in (the far field, when it was computed beside the near field); slices: the owned
+// rows stay in tree order at the head of y (a shard's contribution to the all-gather) instead of going to panel order
+__global__ void scatter_y_kernel(const uint32_t* __restrict__ perm, const double* __restrict__ yt, const double* __restrict__ add,
+                                 double* __restrict__ y, int64_t row_begin, int64_t row_end, int dof, int slices) {
   const int64_t u = row_begin * dof + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (u < row_end * dof) { const int64_t i = u / dof; const int a = (int)(u - i * dof); y[(int64_t)perm[i] * dof + a] = yt[u]; }
+  if (u < row_end * dof) {
+    const int64_t i = u / dof;
+    const int a = (int)(u - i * dof);
+    const double v = add ? yt[u] + add[u] : yt[u];
+    y[slices ? u - row_begin * dof : (int64_t)perm[i] * dof + a] = v;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -790,18 +797,29 @@ __global__ __launch_bounds__(kSpmvWaves * kWave, kSpmvOcc) void near_spmv_kernel
 constexpr int kSpmvPipeChunk = 1024;                  // columns per x buffer (2 x 8 KiB)
 constexpr int kSpmvPre = kSpmvPipeChunk / (kSpmvWaves * kWave);       // x values a thread prefetches
 
+// the item records through the constant address space: scalar loads whatever else the kernel stores (6 VGPRs fewer than
+// through the generic pointer)
+typedef __attribute__((address_space(4))) NearItem ConstNearItem;
+__device__ __forceinline__ NearItem load_item(const ConstNearItem* r) {
+  NearItem o;
+  o.val_off = r->val_off; o.run_begin = r->run_begin; o.nruns = r->nruns; o.yrow = r->yrow; o.nrows = r->nrows;
+  o.ncols = r->ncols; o.stride = r->stride; o.colsplit = r->colsplit; o.pad[0] = o.pad[1] = 0;
+  return o;
+}
+
+// the pipelined loop over items first, first + step, ... < end of one workgroup; LDS: xs_all [2][kSpmvPipeChunk] doubles then
+// runbuf [2][2][max_runs] ints, part [kSpmvWaves][kColRows]
 template <int kRows, int kVecs>
-__global__ __launch_bounds__(kSpmvWaves * kWave, kSpmvOcc) void near_spmv_pipe_kernel(DevicePlan d) {
-  extern __shared__ double xs_all[];                  // [2][kSpmvPipeChunk] doubles, then [2][2][max_runs] ints
-  __shared__ double part[kSpmvWaves][kColRows];
+__device__ __forceinline__ void spmv_pipe_run(const DevicePlan& d, double* xs_all, double (*part)[kColRows], int first, int step, int end) {
   int* const runbuf = reinterpret_cast<int*>(xs_all + 2 * kSpmvPipeChunk);
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-  const int mr = d.max_runs, nitems = d.near_nitems, step = gridDim.x, tid = threadIdx.x;
+  const int mr = d.max_runs, nitems = end, tid = threadIdx.x;
+  const ConstNearItem* recs = reinterpret_cast<const ConstNearItem*>(reinterpret_cast<uintptr_t>(d.near_recs));
 
-  int item = blockIdx.x;
+  int item = first;
   if (item >= nitems) return;
-  NearItem it = d.near_recs[item];
-  NearItem nx = d.near_recs[item + step < nitems ? item + step : nitems - 1];
+  NearItem it = load_item(recs + item);
+  NearItem nx = load_item(recs + (item + step < nitems ? item + step : nitems - 1));
   // prologue: runs of the first two items, x of the first
   for (int i = tid; i < it.nruns; i += blockDim.x) { runbuf[i] = d.near_run_row0[it.run_begin + i]; runbuf[mr + i] = d.near_run_off[it.run_begin + i]; }
   for (int i = tid; i < nx.nruns; i += blockDim.x) { runbuf[2 * mr + i] = d.near_run_row0[nx.run_begin + i]; runbuf[3 * mr + i] = d.near_run_off[nx.run_begin + i]; }
@@ -816,7 +834,7 @@ __global__ __launch_bounds__(kSpmvWaves * kWave, kSpmvOcc) void near_spmv_pipe_k
   for (;; item += step) {
     const bool more = item + step < nitems;
     const int i2 = item + 2 * step;
-    const NearItem nn = d.near_recs[i2 < nitems ? i2 : nitems - 1];
+    const NearItem nn = load_item(recs + (i2 < nitems ? i2 : nitems - 1));
     // ---- set-up of the following items, in flight while this item's rows stream ----
     // (issued behind the first matrix loads instead: the staging array lands in scratch, 0.91 ms)
     double px[kSpmvPre];
@@ -917,6 +935,18 @@ __global__ __launch_bounds__(kSpmvWaves * kWave, kSpmvOcc) void near_spmv_pipe_k
     __syncthreads();
     it = nx; nx = nn; xb ^= 1; rb ^= 1;
   }
+}
+
+// Static deal: item blockIdx.x, + gridDim.x, ...  (A work queue -- batches of eight items drawn from an atomic counter, so
+// that the grid could be any size and a workgroup that shares its CU simply takes fewer -- was built and measured in round 3:
+// inside the pipelined loop it costs the loop its scalar registers (spills, 1.44 ms); with the pipeline restarted per batch
+// every restart is an atomic and three dependent loads at the latency of a saturated memory system, ~60 us: 1.15 ms against
+// 0.70.  profiles/r03d_overlap_near_far.txt.)
+template <int kRows, int kVecs>
+__global__ __launch_bounds__(kSpmvWaves * kWave, kSpmvOcc) void near_spmv_pipe_kernel(DevicePlan d) {
+  extern __shared__ double xs_all[];
+  __shared__ double part[kSpmvWaves][kColRows];
+  spmv_pipe_run<kRows, kVecs>(d, xs_all, part, blockIdx.x, gridDim.x, d.near_nitems);
 }
 
 }  // namespace
@@ -1118,7 +1148,7 @@ hipError_t launch_gather_x(const DevicePlan& d, const double* x, hipStream_t s) 
   return hipGetLastError();
 }
 
-hipError_t launch_near_spmv(const DevicePlan& d, hipStream_t s) {
+hipError_t launch_near_spmv(const DevicePlan& d, hipStream_t s, int wgs_per_cu) {
   if (d.near_nitems <= 0) return hipSuccess;
   if (d.dof == 3 && d.near_sym) {
     const size_t lds3 = 3 * (size_t)kSymChunk * sizeof(double) + 2 * (size_t)d.max_runs * sizeof(int);
@@ -1138,7 +1168,9 @@ hipError_t launch_near_spmv(const DevicePlan& d, hipStream_t s) {
   const bool pipe = !(pe && atoi(pe) == 0);
   if (d.dof == 1 && d.max_runs <= kSpmvWaves * kWave && pipe) {
     const size_t lds2 = 2 * (size_t)kSpmvPipeChunk * sizeof(double) + 4 * (size_t)d.max_runs * sizeof(int);
-    hipLaunchKernelGGL((near_spmv_pipe_kernel<2, 4>), g, b, lds2, s, d);
+    // wgs_per_cu: fewer resident workgroups when the far field runs beside this kernel (plan.hip, FMMBEM_OVERLAP_NEAR)
+    const dim3 gp(wgs_per_cu > 0 ? std::min(d.near_nitems, 256 * std::min(wgs_per_cu, kSpmvOcc)) : g.x);
+    hipLaunchKernelGGL((near_spmv_pipe_kernel<2, 4>), gp, b, lds2, s, d);
   } else {
     hipLaunchKernelGGL((near_spmv_kernel<2, 4>), g, b, lds, s, d);
   }
@@ -1166,12 +1198,12 @@ hipError_t launch_assemble_slices(const DevicePlan& d, const double* slices, dou
   return hipGetLastError();
 }
 
-hipError_t launch_scatter_y(const DevicePlan& d, double* y, hipStream_t s) {
+hipError_t launch_scatter_y(const DevicePlan& d, double* y, hipStream_t s, const double* add, bool slices) {
   const int64_t rows = (d.row_end - d.row_begin) * d.dof;
   if (rows <= 0) return hipSuccess;
   const int bs = 256;
-  hipLaunchKernelGGL(scatter_y_kernel, dim3((unsigned)((rows + bs - 1) / bs)), dim3(bs), 0, s, d.perm, d.yt, y,
-                     d.row_begin, d.row_end, d.dof);
+  hipLaunchKernelGGL(scatter_y_kernel, dim3((unsigned)((rows + bs - 1) / bs)), dim3(bs), 0, s, d.perm, d.yt, add, y,
+                     d.row_begin, d.row_end, d.dof, slices ? 1 : 0);
   return hipGetLastError();
 }
 

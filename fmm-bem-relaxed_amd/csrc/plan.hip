@@ -155,8 +155,8 @@ struct fmmbem_plan {
   int shift_stream_off[12] = {};
   int shift_rot_min = 2048;                                    // boxes on a tree level from which the rotation kernels take it
   bool shift_rot = true;
-  int m2m_level(int p, size_t i, bool shared, hipStream_t s);
-  int l2l_level(int p, size_t i, hipStream_t s);
+  int m2m_pass(int p, bool shared, hipStream_t s);
+  int l2l_pass(int p, hipStream_t s);
   const DevicePlan* d_dev = nullptr;                            // copy of d in device memory
   bool split_upward = false;                                   // P2M/M2M sharded by owner, multipoles all-gathered by the caller
   unsigned pending_mask = 0;                                   // stages recorded by the upward half of a split execute
@@ -168,15 +168,18 @@ struct fmmbem_plan {
   int64_t n_classes = 0;
   double build_host_ms = 0, build_assemble_ms = 0;
   // execute state
-  bool timing = false;
+  int timing = 0;                                              // 0 off, 1 events around every stage, 2 around the near-field kernel only
   int last_p = 0;
   static constexpr int kStages = 9, kRing = 64;                // gather spmv scatter p2m m2m mh m2l l2l l2p
   std::vector<hipEvent_t> ev;                                  // kRing sets of 2*kStages events (begin, end)
   unsigned ev_mask[kRing] = {};                                // stages actually recorded in each set
-  // Near field on its own stream beside M2L: measured +4% matvecs/s at N=1M (M2L fills the wavefront slots
-  // first and the streaming kernel is starved: 1.0 -> 3.6 ms), so it is off unless FMMBEM_OVERLAP_NEAR=1.
+  // The near field beside the far field (FMMBEM_OVERLAP_NEAR=1; OFF): forked right after the gather onto a stream of its own
+  // with fewer resident workgroups (near_wgs per CU, FMMBEM_NEAR_WGS) so that the far field's kernels find registers; L2P
+  // stores the far field in yfar and the delivery adds the two -- the same bits as the serial schedule.  Measured in rounds
+  // 1, 2 and 3 and slower every time (p = 2: 1.01 ms against 0.87): beside the saturated memory system of the near field
+  // every dependent access of the latency-bound far kernels takes 10-70x longer (profiles/r03d_overlap_near_far.txt).
   bool overlap_near = false;
-  bool overlap_early = false;                                  // FMMBEM_OVERLAP_NEAR=2: fork right after the gather (beside P2M/M2M) instead of beside M2L
+  int near_wgs = 3;
   int64_t ev_count = 0;                                        // executes recorded since timing was enabled
   double *stage_x = nullptr, *stage_y = nullptr;               // device staging for host-pointer execute
   hipStream_t own_stream = nullptr;
@@ -339,7 +342,8 @@ int fmmbem_plan::to_device() {
   if (const char* e = getenv("FMMBEM_M2L_ROT")) { if (atoi(e) == 0) rot_max = 0; }
   if (const char* e = getenv("FMMBEM_M2L_ROT_MIN")) rot_min = atoi(e);
   if (const char* e = getenv("FMMBEM_M2L_ROT_MAX")) rot_max = atoi(e);
-  if (const char* ov = getenv("FMMBEM_OVERLAP_NEAR")) { overlap_near = atoi(ov) != 0; overlap_early = atoi(ov) == 2; }
+  if (const char* ov = getenv("FMMBEM_OVERLAP_NEAR")) overlap_near = atoi(ov) != 0;
+  if (const char* nw = getenv("FMMBEM_NEAR_WGS")) near_wgs = std::max(1, std::min(8, atoi(nw)));
   d.max_ncols = max_cols;
   near_bytes = total * (int64_t)sizeof(double);
   TRY(upload(leaf_row0, &d.leaf_row0)); TRY(upload(leaf_nrows, &d.leaf_nrows)); TRY(upload(hp.leaf_box, &d.leaf_box));
@@ -684,6 +688,7 @@ int fmmbem_plan::to_device() {
   mark("m2l class tables");
   TRY(alloc((size_t)hp.n * dof, &d.xt, true));
   TRY(alloc((size_t)hp.n * dof, &d.yt, true));
+  TRY(alloc((size_t)hp.n * dof, &d.yfar, true));
   TRY(alloc((size_t)hp.n * dof, &stage_x, true));
   TRY(alloc((size_t)hp.n * dof, &stage_y, true));
 
@@ -750,26 +755,32 @@ int fmmbem_plan::to_device() {
 // (a pass of that kernel takes ~20 us at p = 10 whatever the number of lanes), the sparse-operator kernel of kernels_far.hip
 // for the few boxes near the root.  The rule looks at the number of boxes on the level in the WHOLE tree, not at what this
 // plan owns of it: the two kernels round differently, and shards of one operator must produce the bits of the whole.
-int fmmbem_plan::m2m_level(int p, size_t i, bool shared, hipStream_t s) {
-  const auto [first, count] = shared ? m2m_shared_launch[i] : m2m_launch[i];
-  const ShiftRot& sr = shared ? m2m_shared_rot[i] : m2m_rot[i];
-  if (shift_rot && shift_rot_supported(p) && sr.level_boxes >= shift_rot_min) {
-    RotWork w;
-    w.src = up_rsrc; w.cls = up_rcls; w.tgt = up_rtgt; w.item_ptr = up_ritem + sr.item_first; w.n_items = sr.n_items;
-    w.rec = up_rec; w.stream = up_stream + shift_stream_off[p - 1];
-    HIP_TRY(launch_m2m_rot(d, w, p, s));
-  } else HIP_TRY(launch_m2m_level(d, up_ops[p - 1], p, first, count, s));
+int fmmbem_plan::m2m_pass(int p, bool shared, hipStream_t s) {
+  const auto& launches = shared ? m2m_shared_launch : m2m_launch;
+  const auto& rots = shared ? m2m_shared_rot : m2m_rot;
+  for (size_t i = 0; i < launches.size(); ++i) {
+    const auto [first, count] = launches[i];
+    const ShiftRot& sr = rots[i];
+    if (shift_rot && shift_rot_supported(p) && sr.level_boxes >= shift_rot_min) {
+      RotWork w;
+      w.src = up_rsrc; w.cls = up_rcls; w.tgt = up_rtgt; w.item_ptr = up_ritem + sr.item_first; w.n_items = sr.n_items;
+      w.rec = up_rec; w.stream = up_stream + shift_stream_off[p - 1];
+      HIP_TRY(launch_m2m_rot(d, w, p, s));
+    } else HIP_TRY(launch_m2m_level(d, up_ops[p - 1], p, first, count, s));
+  }
   return FMMBEM_OK;
 }
-int fmmbem_plan::l2l_level(int p, size_t i, hipStream_t s) {
-  const auto [first, count] = l2l_launch[i];
-  const ShiftRot& sr = l2l_rot[i];
-  if (shift_rot && shift_rot_supported(p) && sr.level_boxes >= shift_rot_min) {
-    RotWork w;
-    w.src = dn_rsrc; w.cls = dn_rcls; w.tgt = dn_rtgt; w.item_ptr = dn_ritem + sr.item_first; w.n_items = sr.n_items;
-    w.rec = dn_rec; w.stream = dn_stream + shift_stream_off[p - 1];
-    HIP_TRY(launch_l2l_rot(d, w, p, s));
-  } else HIP_TRY(launch_l2l_level(d, down_ops[p - 1], p, first, count, s));
+int fmmbem_plan::l2l_pass(int p, hipStream_t s) {
+  for (size_t i = 0; i < l2l_launch.size(); ++i) {
+    const auto [first, count] = l2l_launch[i];
+    const ShiftRot& sr = l2l_rot[i];
+    if (shift_rot && shift_rot_supported(p) && sr.level_boxes >= shift_rot_min) {
+      RotWork w;
+      w.src = dn_rsrc; w.cls = dn_rcls; w.tgt = dn_rtgt; w.item_ptr = dn_ritem + sr.item_first; w.n_items = sr.n_items;
+      w.rec = dn_rec; w.stream = dn_stream + shift_stream_off[p - 1];
+      HIP_TRY(launch_l2l_rot(d, w, p, s));
+    } else HIP_TRY(launch_l2l_level(d, down_ops[p - 1], p, first, count, s));
+  }
   return FMMBEM_OK;
 }
 
@@ -781,20 +792,24 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
     return fail(FMMBEM_ERR_UNSUPPORTED, "plan shards the upward pass: use fmmbem_plan_upward_device / _downward_device");
   if (phase != 0 && (!split_upward || (!xbuf && phase != 3))) return fail(FMMBEM_ERR_INVALID, "split execute needs shard_upward and an exchange buffer");
   DEVICE_SCOPE(opts.device);
-  const bool tm = timing;
+  const int tm = timing;
   const int64_t ring = ev_count % kRing;
   hipEvent_t* set = tm ? &ev[(size_t)ring * 2 * kStages] : nullptr;
   unsigned mask = phase >= 2 ? pending_mask : 0;
-  // stage i runs on stream st: begin/end events bracket exactly that kernel (or level sequence)
-  auto begin = [&](int i, hipStream_t st) -> hipError_t { return tm ? hipEventRecord(set[2 * i], st) : hipSuccess; };
+  // stage i runs on stream st: begin/end events bracket exactly that kernel (or level sequence).  An event record is a
+  // packet of its own between two kernels (~5 us each on this part: a fully instrumented matvec is 85 us longer than a bare
+  // one), so a throughput measurement brackets the one kernel it needs (mode 2: the near field, stage 1) and nothing else.
+  auto rec = [&](int i) { return tm == 1 || (tm == 2 && i == 1); };
+  auto begin = [&](int i, hipStream_t st) -> hipError_t { return rec(i) ? hipEventRecord(set[2 * i], st) : hipSuccess; };
   auto end = [&](int i, hipStream_t st) -> hipError_t {
+    if (!rec(i)) return hipSuccess;
     mask |= 1u << i;
-    return tm ? hipEventRecord(set[2 * i + 1], st) : hipSuccess;
+    return hipEventRecord(set[2 * i + 1], st);
   };
   // Stage order of the reference (EvalInteractionLazySparse.hpp:120-168): near-field SpMV, then P2M, M2M,
   // M2L, L2L, L2P.  The near field only meets the far field in y, so it is launched on a second stream next
   // to M2L (an HBM-bound kernel beside an FMA-bound one); the two are joined before L2P adds into y.
-  const bool overlap = overlap_near && !near_only && phase == 0;
+  const bool overlap = overlap_near && !near_only && phase == 0 && opts.sparse_local;
   if (phase < 2) {
     HIP_TRY(begin(0, s));
     HIP_TRY(launch_gather_x(d, d_x, s));
@@ -805,7 +820,7 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
     if (d.kernel == FMMBEM_KERNEL_STOKES_BEM) HIP_TRY(launch_p2m_stokes(d, p, s)); else HIP_TRY(launch_p2m(d, p, s));
     HIP_TRY(end(3, s));
     HIP_TRY(begin(4, s));
-    for (size_t i = 0; i < m2m_launch.size(); ++i) TRY(m2m_level(p, i, false, s));
+    TRY(m2m_pass(p, false, s));
     HIP_TRY(launch_xch_pack(d, p, reinterpret_cast<double2*>(xbuf), s));
     HIP_TRY(end(4, s));
     pending_mask = mask;
@@ -814,7 +829,7 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
   }
   auto near_field = [&](hipStream_t ns) -> int {
     HIP_TRY(begin(1, ns));
-    if (opts.sparse_local) HIP_TRY(launch_near_spmv(d, ns)); else HIP_TRY(launch_near_matfree(d, ns));
+    if (opts.sparse_local) HIP_TRY(launch_near_spmv(d, ns, overlap ? near_wgs : 0)); else HIP_TRY(launch_near_matfree(d, ns));
     HIP_TRY(end(1, ns));
     return FMMBEM_OK;
   };
@@ -823,12 +838,14 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
   // head of d_y, for the caller's all-gather (fmmbem_plan_assemble_slices_device puts the gathered slices in panel order)
   auto deliver = [&](hipStream_t ns) -> int {
     HIP_TRY(begin(2, ns));
+    const double* far = overlap ? d.yfar : nullptr;   // computed beside the near field: the two meet here
     if (result_slices) {
-      HIP_TRY(hipMemcpyAsync(d_y, d.yt + d.row_begin * d.dof, sizeof(double) * (size_t)(d.row_end - d.row_begin) * d.dof,
-                             hipMemcpyDeviceToDevice, ns));
+      if (far) HIP_TRY(launch_scatter_y(d, d_y, ns, far, true));
+      else HIP_TRY(hipMemcpyAsync(d_y, d.yt + d.row_begin * d.dof, sizeof(double) * (size_t)(d.row_end - d.row_begin) * d.dof,
+                                  hipMemcpyDeviceToDevice, ns));
     } else {
       if (hp.opt.shard_world > 1) HIP_TRY(hipMemsetAsync(d_y, 0, sizeof(double) * (size_t)hp.n * d.dof, ns));
-      HIP_TRY(launch_scatter_y(d, d_y, ns));
+      HIP_TRY(launch_scatter_y(d, d_y, ns, far));
     }
     HIP_TRY(end(2, ns));
     return FMMBEM_OK;
@@ -841,7 +858,7 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
   }
   if (!overlap && !(phase == 2 && pending_near)) TRY(near_field(s));
   pending_near = false;
-  if (overlap && overlap_early) {
+  if (overlap) {
     HIP_TRY(hipEventRecord(ev_fork, s));
     HIP_TRY(hipStreamWaitEvent(near_stream, ev_fork, 0));
     TRY(near_field(near_stream));
@@ -853,35 +870,30 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
       if (d.kernel == FMMBEM_KERNEL_STOKES_BEM) HIP_TRY(launch_p2m_stokes(d, p, s)); else HIP_TRY(launch_p2m(d, p, s));
       HIP_TRY(end(3, s));
       HIP_TRY(begin(4, s));
-      for (size_t i = 0; i < m2m_launch.size(); ++i) TRY(m2m_level(p, i, false, s));
+      TRY(m2m_pass(p, false, s));
       HIP_TRY(end(4, s));
     }
     HIP_TRY(begin(5, s));
     if (phase == 2) {                                  // the other shards' multipoles, then the boxes spanning shards
       HIP_TRY(launch_xch_unpack(d, p, reinterpret_cast<const double2*>(xbuf), s));
-      for (size_t i = 0; i < m2m_shared_launch.size(); ++i) TRY(m2m_level(p, i, true, s));
+      TRY(m2m_pass(p, true, s));
     }
     const bool rot = use_rot(p);
     if (!rot && d.kernel == FMMBEM_KERNEL_STOKES_BEM && d.stokes_traction_targets)
       return fail(FMMBEM_ERR_UNSUPPORTED, "Stokes TRACTION far field needs the rotation M2L kernel (p <= 12, FMMBEM_M2L_ROT unset)");
     if (!rot) HIP_TRY(launch_mh_prep(d, p, s));      // the rotation kernel reads M itself
     HIP_TRY(end(5, s));
-    if (overlap && !overlap_early) {                   // fork: the near field streams HBM while M2L saturates the FMA pipes
-      HIP_TRY(hipEventRecord(ev_fork, s));
-      HIP_TRY(hipStreamWaitEvent(near_stream, ev_fork, 0));
-      TRY(near_field(near_stream));
-      HIP_TRY(hipEventRecord(ev_join, near_stream));
-    }
     HIP_TRY(begin(6, s));
     if (rot) HIP_TRY(launch_m2l_rot(d, d_dev, p, s)); else HIP_TRY(launch_m2l(d, d_dev, p, s));
     HIP_TRY(end(6, s));
     HIP_TRY(begin(7, s));
-    for (size_t i = 0; i < l2l_launch.size(); ++i) TRY(l2l_level(p, i, s));
+    TRY(l2l_pass(p, s));
     HIP_TRY(end(7, s));
-    if (overlap) HIP_TRY(hipStreamWaitEvent(s, ev_join, 0));
     HIP_TRY(begin(8, s));
-    if (d.kernel == FMMBEM_KERNEL_STOKES_BEM) HIP_TRY(launch_l2p_stokes(d, p, d.yt, s)); else HIP_TRY(launch_l2p(d, p, d.yt, s));
+    if (d.kernel == FMMBEM_KERNEL_STOKES_BEM) HIP_TRY(launch_l2p_stokes(d, p, overlap ? d.yfar : d.yt, s, overlap));
+    else HIP_TRY(launch_l2p(d, p, overlap ? d.yfar : d.yt, s, overlap));
     HIP_TRY(end(8, s));
+    if (overlap) HIP_TRY(hipStreamWaitEvent(s, ev_join, 0));
   }
   TRY(deliver(s));
   last_p = p;
@@ -1074,7 +1086,7 @@ int fmmbem_plan_execute(fmmbem_plan* plan, int p, const double* x, double* y) {
 
 int fmmbem_plan_set_timing(fmmbem_plan* plan, int enabled) {
   if (!plan) return fail(FMMBEM_ERR_INVALID, "null plan");
-  plan->timing = enabled != 0 && plan->on_device;
+  plan->timing = plan->on_device ? (enabled == 2 ? 2 : enabled != 0) : 0;
   plan->ev_count = 0;
   return FMMBEM_OK;
 }
@@ -1108,8 +1120,8 @@ int fmmbem_plan_stats(const fmmbem_plan* plan, fmmbem_stats* o) {
       const int64_t slot = (plan->ev_count - 1 - i) % NR;
       const hipEvent_t* set = &plan->ev[(size_t)slot * 2 * NS];
       const unsigned mask = plan->ev_mask[slot];
-      int last = -1;
-      for (int k = 0; k < NS; ++k) if (mask & (1u << k)) last = k;
+      int last = -1, first = -1;
+      for (int k = 0; k < NS; ++k) if (mask & (1u << k)) { last = k; if (first < 0) first = k; }
       if (mask & 4u) last = 2;                          // the delivery of the result (stage 2) is the last thing an execute does
       if (last < 0) continue;
       float f = 0;
@@ -1119,7 +1131,7 @@ int fmmbem_plan_stats(const fmmbem_plan* plan, fmmbem_stats* o) {
         HIP_TRY(hipEventElapsedTime(&f, set[2 * k], set[2 * k + 1]));
         sum[k] += f;
       }
-      HIP_TRY(hipEventElapsedTime(&f, set[0], set[2 * last + 1]));      // both on the caller's stream
+      HIP_TRY(hipEventElapsedTime(&f, set[2 * first], set[2 * last + 1]));      // both on the caller's stream
       sum[NS] += f;
       ++used;
     }

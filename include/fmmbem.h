@@ -148,7 +148,7 @@ int fmmbem_plan_near_device(fmmbem_plan *plan, const double *d_x, double *d_y, v
  * kernel on the stream it runs on (no synchronisation is added); fmmbem_plan_stats() waits for the
  * recorded events and reports the mean stage times of up to the last 64 executes.  Enabling resets
  * the record.  Default off. */
-int fmmbem_plan_set_timing(fmmbem_plan *plan, int enabled);
+int fmmbem_plan_set_timing(fmmbem_plan *plan, int enabled);      /* 0 off; 1 every stage; 2 the near-field kernel only */
 
 int fmmbem_plan_stats(const fmmbem_plan *plan, fmmbem_stats *out);
 

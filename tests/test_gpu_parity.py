@@ -252,10 +252,12 @@ def test_matrix_free_near_field(fb, oracle_mod, bc_val, quad_k):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{"FMMBEM_P2M_TABLE": "0"}, {"FMMBEM_SPMV_PIPE": "0"}, {"FMMBEM_OVERLAP_NEAR": "2"}])
+@pytest.mark.parametrize("env", [{"FMMBEM_P2M_TABLE": "0"}, {"FMMBEM_SPMV_PIPE": "0"},
+                                 {"FMMBEM_OVERLAP_NEAR": "1"}, {"FMMBEM_OVERLAP_NEAR": "1", "FMMBEM_NEAR_WGS": "1"}])
 def test_alternative_paths_match_oracle(fb, oracle_mod, monkeypatch, env):
     """The switches that select the older / optional kernels (recurrence P2M instead of the stored moments, the plain
-    near_spmv kernel, the near field forked beside P2M/M2M) give the same operator."""
+    near_spmv kernel, the near field beside the far field on a stream of its own) give the same operator -- the two schedules
+    bit for bit."""
     for k, val in env.items():
         monkeypatch.setenv(k, val)
     v = oracle_mod.unit_sphere(5)
@@ -265,10 +267,50 @@ def test_alternative_paths_match_oracle(fb, oracle_mod, monkeypatch, env):
     o = oracle_mod.Oracle(v, bc=bc)
     K = fb.LaplaceSphericalBEM(10, 3)
     pl = fb.FMM_plan(K, v, bc=bc)
+    res = {}
     for p in (10, 3):
         K.set_p(p)
         y, yo = pl.execute(x), o.matvec(x, p)
         assert np.linalg.norm(y - yo) <= 1e-12 * np.linalg.norm(yo)
+        res[p] = y
+    if "FMMBEM_OVERLAP_NEAR" in env:                            # a schedule, not other arithmetic: the same bits
+        for k in env:
+            monkeypatch.delenv(k)
+        monkeypatch.setenv("FMMBEM_OVERLAP_NEAR", "0")
+        K2 = fb.LaplaceSphericalBEM(10, 3)
+        pl2 = fb.FMM_plan(K2, v, bc=bc)
+        for p in (10, 3):
+            K2.set_p(p)
+            assert np.array_equal(pl2.execute(x), res[p])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bc_val", [0, 1])
+def test_p2m_streaming_kernel(fb, oracle_mod, monkeypatch, bc_val):
+    """One expansion per box and more than 32 coefficients: the streaming P2M contraction (scalar leaf records and charges,
+    eight table entries in flight) -- M per box against the oracle at p = 8 ... 16 (two passes over the coefficients from
+    p = 11), and bit for bit the kernel it replaces (same panel order of the additions)."""
+    v = np.concatenate([oracle_mod.unit_sphere(5), oracle_mod.unit_sphere(3, center=(2.5, 0.3, -0.2))])   # leaves of 1 ... 64 panels
+    bc = np.full(len(v), bc_val, dtype=np.uint8)
+    x = np.random.default_rng(21).standard_normal(len(v))
+    o = oracle_mod.Oracle(v, bc=bc)
+    K = fb.LaplaceSphericalBEM(16, 3)
+    pl = fb.FMM_plan(K, v, bc=bc)
+    got = {}
+    for p in (8, 10, 11, 12, 16):
+        K.set_p(p)
+        pl.execute(x)
+        o.matvec(x, p)
+        M, Mo = pl.expansions("M", p), o.expansions(p, "M")
+        scale = np.abs(Mo[:, bc_val]).max(axis=1, keepdims=True) + 1e-300
+        assert np.abs(Mo[:, bc_val]).max() > 0
+        assert np.max(np.abs(M[:, bc_val] - Mo[:, bc_val]) / scale) <= TOL_EXPANSION
+        got[p] = M
+    monkeypatch.setenv("FMMBEM_P2M_STREAM", "0")
+    for p in got:
+        K.set_p(p)
+        pl.execute(x)
+        assert np.array_equal(pl.expansions("M", p), got[p]), p
 
 
 @pytest.mark.gpu

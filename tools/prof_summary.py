@@ -3,6 +3,7 @@
 
   python tools/prof_summary.py kernel-stats <dir> <out.md>        (from --kernel-trace --stats)
   python tools/prof_summary.py pmc <fetch_dir> <write_dir> <out.json> <n_panels> <n_gpus>
+  python tools/prof_summary.py timeline <dir> <out.md> [first kernel]   (from --kernel-trace: one matvec, dispatch by dispatch)
 PMC units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and
 WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming
 read, so the read side of the streaming near_spmv kernel is doubled.
@@ -70,8 +71,38 @@ def pmc(fetch_dir, write_dir, out, n_panels, n_gpus):
     print(json.dumps(res, indent=1))
 
 
+def timeline(d, out, first="gather_x", last_n=8):
+    """One matvec as the GPU saw it (from --kernel-trace): per dispatch its start relative to the matvec's first kernel, its
+    duration and the idle gap in front of it, averaged over the last `last_n` matvecs of the trace (a matvec = from one
+    `first` kernel to the next; FMMBEM graphs and fused kernels change the dispatch list, not this definition)."""
+    f = glob.glob(os.path.join(d, "**", "*_kernel_trace.csv"), recursive=True)[0]
+    rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])) for r in csv.DictReader(open(f))]
+    rows.sort()
+    starts = [i for i, r in enumerate(rows) if r[2].startswith(first)]
+    if len(starts) < last_n + 2:
+        raise SystemExit("fewer than %d matvecs in the trace" % (last_n + 2))
+    runs = [rows[starts[k]:starts[k + 1]] for k in range(len(starts) - 1 - last_n, len(starts) - 1)]
+    n = min(len(r) for r in runs)
+    runs = [r for r in runs if len(r) == n]
+    with open(out, "w") as o:
+        o.write("| # | kernel | start us | duration us | gap before us |\n|---|---|---|---|---|\n")
+        tot_k = tot_g = 0.0
+        for i in range(n):
+            st = sum(r[i][0] - r[0][0] for r in runs) / len(runs) / 1e3
+            du = sum(r[i][1] - r[i][0] for r in runs) / len(runs) / 1e3
+            gap = sum((r[i][0] - r[i - 1][1]) if i else 0 for r in runs) / len(runs) / 1e3
+            tot_k += du
+            tot_g += gap
+            o.write("| %d | %s | %.1f | %.1f | %.1f |\n" % (i, runs[0][i][2], st, du, gap))
+        span = sum(r[-1][1] - r[0][0] for r in runs) / len(runs) / 1e3
+        o.write("\n%d dispatches per matvec; kernels %.1f us + gaps %.1f us = span %.1f us (mean of %d matvecs)\n" % (n, tot_k, tot_g, span, len(runs)))
+    print(open(out).read())
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "kernel-stats":
         kernel_stats(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "timeline":
+        timeline(sys.argv[2], sys.argv[3], *sys.argv[4:5])
     else:
         pmc(*sys.argv[2:7])
