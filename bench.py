@@ -363,7 +363,9 @@ def main():
     rot_fma = 4 * sum(n * n + n + 1 for n in range(1, P)) + sum((P - k) ** 2 * (2 if k else 1) for k in range(P))
     rot_mul = 4 * 2 * sum(P - m for m in range(1, P)) + 2 * (P * P - 1)        # z rotations (2 mul + 2 FMA per coefficient), powers of rho
     rot_fma += 4 * 2 * sum(P - m for m in range(1, P))
-    rot_on = os.environ.get("FMMBEM_M2L_ROT", "1") != "0" and P <= 12
+    rot_on = st["m2l_kernel"] == 1                           # which kernel the plan launched (fmmbem_stats), not a guess from the environment
+    # the double-sum kernels (p > 12, FMMBEM_M2L_ROT=0) execute 280 of the reference's 400 real FMAs per output and source at
+    # p = 10 (real radial table x complex phase, kernels_m2l.hip header): 0.70 of the reference's count
     m2l_flops = n_exp * st["m2l_pairs_owned"] * (2.0 * rot_fma + rot_mul) if rot_on else 0.70 * m2l_ref_flops
     m2l_tflops = m2l_flops / (st["ms_m2l"] * 1e-3) / 1e12 if st["ms_m2l"] > 0 else 0.0
 
@@ -398,7 +400,7 @@ def main():
                      "unit": "GB/s", "frac": p2p_gbs / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": p2p_bytes, "launch_ms": near_ms,
                      "timed_launches": st_near["timed_executes"]},
-        "roofline_m2l": {"kernel": "m2l_rot" if rot_on else "m2l", "bound": "fp64 vector FMA", "achieved": m2l_tflops,
+        "roofline_m2l": {"kernel": {1: "m2l_rot", 2: "m2l (double sum)", 3: "m2l_small (double sum, lanes = sources)"}.get(st["m2l_kernel"], "?"), "bound": "fp64 vector FMA", "achieved": m2l_tflops,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": m2l_tflops / FP64_PEAK_TFLOPS,
                          "executed_flops_per_launch": m2l_flops, "launch_ms": st["ms_m2l"],
                          "reference_flops_per_launch": m2l_ref_flops,

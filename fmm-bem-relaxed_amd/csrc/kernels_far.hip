@@ -22,7 +22,7 @@
 // The inner loop is then a plain complex correlation: one wavefront per target box, lanes over the
 // (j,k) outputs, Yh staged in LDS, Mh read through the scalar cache (wave-uniform), L accumulated
 // in registers over the whole source list and written once -- no atomics, fixed summation order.
-#include "device_plan.hpp"
+#include "device_launch.hpp"
 
 #include <mutex>
 
@@ -456,6 +456,10 @@ __global__ __launch_bounds__(4 * kWave) void p2m_apply_kernel(DevicePlan d, cons
 // construction (readfirstlane), leaf record, row range and the charges come through the scalar cache (constant address
 // space: the M stores of this kernel would otherwise count as clobbers), the NEXT leaf's record is fetched while this leaf
 // streams -- and the only vector loads are the 16-byte table entries, kP2MStream panels' worth in flight per lane.
+// 0.219 -> 0.194 ms at N = 1M, p = 10 (0.94 GB: 4.8 TB/s).  What it does NOT respond to (profiles/r03f, r03g): 4, 12 or 16
+// entries in flight (0.192 / 0.203 / 0.208), 4 to 16 workgroups per CU (0.197 ... 0.192), contiguous leaf ranges per
+// workgroup instead of the strided deal (0.194): 57 MB are in flight at 8 192 wavefronts x 7 KB, the memory system returns
+// 4.8 TB/s for this pattern whatever the kernel asks.
 constexpr int kP2MStream = 8;
 typedef __attribute__((address_space(4))) int ConstInt;
 typedef __attribute__((address_space(4))) double ConstDouble;
@@ -463,6 +467,7 @@ template <class T, class U>
 __device__ __forceinline__ const T* as_const_space(const U* p) { return reinterpret_cast<const T*>(reinterpret_cast<uintptr_t>(p)); }
 
 __global__ __launch_bounds__(4 * kWave) void p2m_stream_kernel(DevicePlan d, const int P) {
+  constexpr int U = kP2MStream;
   const int S = P * (P + 1) / 2, SM = d.s_max, TS = d.p2m_stride;
   const int lane = threadIdx.x & (kWave - 1);
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
@@ -484,7 +489,6 @@ __global__ __launch_bounds__(4 * kWave) void p2m_stream_kernel(DevicePlan d, con
     const int nbox = box_of[nleaf], nrow0 = row0_of[nleaf], nnrows = nrows_of[nleaf];
     for (int idx = lane; idx < S; idx += kWave) {
       double2 m = {0, 0};
-      constexpr int U = kP2MStream;
       for (int r = 0; r < nrows; r += U) {
         tvec2 t[U];
         double x[U];

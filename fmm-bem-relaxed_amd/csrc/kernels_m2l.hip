@@ -21,7 +21,7 @@
 //   * Mh[n,m] and Z^m are wave-uniform and come through the scalar cache straight into the SGPR operands of
 //     v_fma_f64; Z^k is one 16-byte vector load per lane, prefetched with the table.
 // One instantiation per p = 1..16: the solver's per-iteration relaxation of p only picks among them.
-#include "device_plan.hpp"
+#include "device_launch.hpp"
 #include "m2l_layout.hpp"
 
 #include <type_traits>

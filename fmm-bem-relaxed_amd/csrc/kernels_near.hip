@@ -5,7 +5,7 @@
 //   gather_x        x_tree[i] = x[perm[i]]        (EvalInteractionLazySparse.hpp:137-138)
 //   near_spmv       y_tree = A_near * x_tree      (Matvec<>, include/Matvec.hpp:14-33) -- HBM-bound hot kernel
 //   scatter_y       y[perm[i]] = y_tree[i]        (EvalInteractionLazySparse.hpp:146-148)
-#include "device_plan.hpp"
+#include "device_launch.hpp"
 
 #include <algorithm>
 #include <cstdlib>
@@ -454,21 +454,28 @@ __global__ __launch_bounds__(256) void near_matfree_kernel(DevicePlan d) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// near_matfree, second form (one unknown per panel; the default).  The first form above repeats the reference's arithmetic
+// near_matfree, third form (one unknown per panel; the default).  The first form above repeats the reference's arithmetic
 // entry by entry: every entry re-reads its source panel (14 doubles from L2), takes a square root and a division per
 // quadrature point, and a wavefront that meets ONE near-regime pair walks the whole semi-analytic integral (three edges,
-// atan2, cos, five-point rules) with the other lanes idle: 45 ms at N = 1M against 0.7 ms for the assembled matrix.  Here
-// (15.5 ms: about 6 of it the far regime, 9 the semi-analytic integrals of the 4.5 % of pairs in the near regimes)
-//   * a wavefront takes a work item of near_spmv (a row range of a target leaf, 64 rows at a time) and walks its columns 64 at a
-//     time: lane = SOURCE panel, read once into registers and applied to every row of the block (the row's centroid is an LDS
-//     broadcast); the lane keeps its share of every row's sum in registers and the lanes are added once, at the end;
-//   * the far regime -- all but ~5 % of the pairs -- is K reciprocal square roots per pair, no division;
-//   * pairs that are, or might be, in a near regime (the reference's test sqrt(2A)/d >= 0.5, taken here as d^2 <= 8A with
-//     a guard band) are not evaluated where they turn up: they go to a queue in LDS and are worked off with all lanes busy,
-//     one queued pair per lane, by the same laplace_entry the assembled path uses (which repeats the exact regime test);
-//   * a row's sum is formed in a fixed order: column groups in order, the queue's contributions in queue order at each flush.
+// atan2, cos, five-point rules) with the other lanes idle: 45 ms at N = 1M against 0.7 ms for the assembled matrix.  The
+// second form (round 2: lane = source panel applied to 64 rows out of registers, near-regime pairs queued in LDS and worked
+// off with all lanes busy) took 15.5 ms, 9 of them the semi-analytic integrals of the 4.5 % of pairs in the near regimes --
+// the same numbers every matvec.  Here the point of sparse_local = 0 is kept (no 4.1 GB matrix) and those are not recomputed:
+//   * plan creation: the pairs that are, or might be, in a near regime (the reference's test sqrt(2A)/d >= 0.5, taken as
+//     d^2 <= 8A with a guard band) are listed per target row (mf_sweep<COUNT>, <FILL>: columns ascending) and evaluated ONCE by
+//     the laplace_entry the assembled path uses, one thread per pair (mf_side_eval_kernel): DevicePlan::side_ptr/col/val,
+//     ~23 M entries = 280 MB at N = 1M;
+//   * every matvec (mf_sweep<APPLY>): a wavefront takes a work item of near_spmv (a row range of a target leaf, kMfRows rows at a
+//     time) and walks its columns 64 at a time: lane = SOURCE panel, read once into registers and applied to every row of the
+//     block (the row's centroid is an LDS broadcast); the far regime is K reciprocal square roots per pair, no division; a
+//     listed pair contributes nothing here (same predicate as at creation: same code).  The lane keeps its share of every
+//     row's sum in registers, the lanes are added once at the end, then lane = row adds the row's listed entries in order.
+//   * a row's sum is formed in a fixed order: column groups in order, then the lanes' tree sum, then the list.
 // ---------------------------------------------------------------------------------------------
-constexpr int kMfRows = 64, kMfQueue = 512;
+#ifndef FMMBEM_MF_ROWS
+#define FMMBEM_MF_ROWS 32
+#endif
+constexpr int kMfRows = FMMBEM_MF_ROWS;               // rows per block: their partial sums live in registers (2 VGPRs each)
 
 // 1 / sqrt(x) for a positive, normal x (a squared distance between distinct points): the hardware estimate (2^-26) and one
 // Newton step carried to second order -- five FMAs instead of the library's two steps plus special-case handling
@@ -478,29 +485,7 @@ __device__ __forceinline__ double rsqrt_pos(double x) {
   return fma(y * e, fma(0.375, e, 0.5), y);
 }
 
-// the queue of near_matfree2: every lane takes queued pairs (the full laplace_entry), then lane = row adds its pairs' values
-// in queue order.  Not inlined: the row loop of the kernel is unrolled 64 times around its call.
-__device__ __noinline__ void mf_flush(const DevicePlan& d, int lane, int nr, int qn, const double* tcx, const double* tcy, const double* tcz,
-                                      const int* tbc, const short* qrow, const int* qj, double* qval, double* racc) {
-  wave_lds_fence();
-  for (int k = lane; k < qn; k += kWave) {
-    const int r = qrow[k];
-#ifdef FMMBEM_MF_EXP_NOSLOW
-    qval[k] *= 1e-300 * r;
-#else
-    qval[k] *= laplace_entry(d, V3{tcx[r], tcy[r], tcz[r]}, tbc[r], qj[k]);          // qval held x_j
-#endif
-  }
-  wave_lds_fence();
-  if (lane < nr) {
-    double a = *racc;
-    for (int k = 0; k < qn; ++k) if (qrow[k] == lane) a += qval[k];
-    *racc = a;
-  }
-  wave_lds_fence();
-}
-
-// far regime with more than three quadrature points (K = 4 .. 25): the points are read again for every row
+// far regime with more than three quadrature points (K = 4 .. 79): the points are read again for every row
 __device__ __noinline__ double mf_far_general(const DevicePlan& d, int64_t j, double tx, double ty, double tz, int dn, double A,
                                               double nx, double ny, double nz) {
   const int64_t N = d.n;
@@ -513,11 +498,15 @@ __device__ __noinline__ double mf_far_general(const DevicePlan& d, int64_t j, do
   return v;
 }
 
-__global__ __launch_bounds__(kWave) void near_matfree2_kernel(DevicePlan d) {
+enum MfMode { kMfCount = 0, kMfFill = 1, kMfApply = 2 };
+
+// side_cnt (COUNT): listed pairs per tree-order row; side_ptr / side_col (FILL): the CSR being filled; APPLY: d.side_*
+template <int MODE>
+__global__ __launch_bounds__(kWave) void mf_sweep_kernel(DevicePlan d, int* __restrict__ side_cnt, const int64_t* __restrict__ side_ptr,
+                                                         int* __restrict__ side_col) {
   extern __shared__ int mf_lds[];
-  __shared__ double tcx[kMfRows], tcy[kMfRows], tcz[kMfRows], qval[kMfQueue];
-  __shared__ int tbc[kMfRows], qj[kMfQueue];
-  __shared__ short qrow[kMfQueue];
+  __shared__ double tcx[kMfRows], tcy[kMfRows], tcz[kMfRows];
+  __shared__ int tbc[kMfRows];
   int* run_row0 = mf_lds;
   int* run_off = run_row0 + d.max_runs;
   const int lane = threadIdx.x;
@@ -539,71 +528,202 @@ __global__ __launch_bounds__(kWave) void near_matfree2_kernel(DevicePlan d) {
         const int64_t i = row0 + rb + lane;
         tcx[lane] = d.cx[i]; tcy[lane] = d.cy[i]; tcz[lane] = d.cz[i]; tbc[lane] = d.bc[i];
       }
-      double racc = 0;                                   // lane = row: the row's sum
-      double acc[kMfRows];                               // lane = column: this lane's columns' share of every row (registers: the
+      double acc[kMfRows];                               // APPLY, lane = column: this lane's columns' share of every row (registers: the
 #pragma unroll                                           // row loop below is unrolled; a wave_sum per row and column group, the
       for (int r = 0; r < kMfRows; ++r) acc[r] = 0;      // first attempt, cost three times the arithmetic)
-      int qn = 0;                                        // queued pairs (wave-uniform)
+      int listed = 0;                                    // COUNT / FILL, lane = row: listed pairs of the row so far
       wave_lds_fence();
       for (int c0 = 0; c0 < ncols; c0 += kWave) {
         const int c = c0 + lane;
         const bool valid = c < ncols;
         const int j = valid ? column_to_row(runs, c) : 0;
         // this lane's source panel, once for all rows
-        const double sx = d.cx[j], sy = d.cy[j], sz = d.cz[j], A = d.area[j], xj = valid ? d.xt[j] : 0.0;
-        const double nx = d.nx[j], ny = d.ny[j], nz = d.nz[j];
+        const double sx = d.cx[j], sy = d.cy[j], sz = d.cz[j], A = d.area[j];
+        const double near2 = 8.0 * A * (1.0 + 1e-9);      // d^2 <= 8 A  <=>  sqrt(2 A) / d >= 0.5; the band goes to the exact test
+        double xj = 0, nx = 0, ny = 0, nz = 0;
         double qx[3], qy[3], qz[3], wA[3];               // up to three far-regime points in registers (K = 1, 3); more: reloaded
         const int nqr = nq <= 3 ? nq : 0;
+        if constexpr (MODE == kMfApply) {
+          xj = valid ? d.xt[j] : 0.0;
+          nx = d.nx[j]; ny = d.ny[j]; nz = d.nz[j];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
+          for (int q = 0; q < 3; ++q) {
+            const bool have = q < nqr;
+            qx[q] = have ? d.quad[(q * 3 + 0) * N + j] : 0.0; qy[q] = have ? d.quad[(q * 3 + 1) * N + j] : 0.0;
+            qz[q] = have ? d.quad[(q * 3 + 2) * N + j] : 1.0; wA[q] = have ? d.qw[q] * A : 0.0;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < kMfRows; ++r) {
+          if (r < nr) {                                    // wave-uniform
+            const double tx = tcx[r], ty = tcy[r], tz = tcz[r];
+            const double dx = tx - sx, dy = ty - sy, dz = tz - sz;
+            const double d2 = dx * dx + dy * dy + dz * dz;
+            const bool slow = valid && d2 <= near2;       // a listed pair: the SAME expression at creation and in every matvec
+            if constexpr (MODE == kMfApply) {
+              const int dn = __builtin_amdgcn_readfirstlane(tbc[r]);      // the row's operator: a scalar branch, not a select per point
+              double v = 0;
+              if (nqr) {                                   // K <= 3: straight-line, the listed lanes' values are dropped below
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                  const double ex = qx[q] - tx, ey = qy[q] - ty, ez = qz[q] - tz;
+                  const double ir = rsqrt_pos(fma(ex, ex, fma(ey, ey, ez * ez)));
+                  if (dn) v = fma(wA[q] * fma(ex, nx, fma(ey, ny, ez * nz)), ir * ir * ir, v); else v = fma(wA[q], ir, v);
+                }
+              } else if (valid && !slow) v = mf_far_general(d, j, tx, ty, tz, dn, A, nx, ny, nz);
+              // lanes past the last column ran the arithmetic against panel 0: its value may be inf/NaN (K = 1: the only point of
+              // panel 0 IS the centroid of row 0) and NaN * 0 is NaN -- masked by validity, not by xj = 0
+              acc[r] = fma((slow || !valid) ? 0.0 : v, xj, acc[r]);
+              // one row after the other: left to itself the scheduler interleaves all rows of the unrolled loop (every LDS
+              // broadcast hoisted, 512 registers and 2.4 KB of scratch per lane)
+              __builtin_amdgcn_sched_barrier(0);
+            } else {
+              const unsigned long long m = __ballot(slow);
+              if (m) {
+                if constexpr (MODE == kMfFill)
+                  if (slow) side_col[side_ptr[row0 + rb + r] + __builtin_amdgcn_readlane(listed, r) + __popcll(m & ((1ull << lane) - 1))] = j;
+                if (lane == r) listed += __popcll(m);
+              }
+            }
+          }
+        }
+      }
+      if constexpr (MODE == kMfApply) {
+        double racc = 0;                                   // lane = row: the row's sum
+#pragma unroll
+        for (int r = 0; r < kMfRows; ++r)
+          if (r < nr) {
+            const double srow = wave_sum(acc[r]);
+            if (lane == r) racc = srow;
+          }
+        if (lane < nr) {
+          const int64_t i = row0 + rb + lane;
+          for (int64_t k = d.side_ptr[i]; k < d.side_ptr[i + 1]; ++k) racc = fma(d.side_val[k], d.xt[d.side_col[k]], racc);
+          d.yt[i] = racc;
+        }
+      } else if constexpr (MODE == kMfCount) {
+        if (lane < nr) side_cnt[row0 + rb + lane] = listed;
+      }
+      wave_lds_fence();
+    }
+  }
+}
+
+// The same sweep for StokesSphericalBEM (three unknowns per panel; StokesBEM -disable_sparse): the far regime of a pair applied
+// to the source's Vec<3,double> charge WITHOUT forming the 3 x 3 block --
+//   velocity target   (1/2mu) sum_q w_q A [ x / r + d (d.x) / r^3 ]          d = target - point q   (StokesSphericalBEM.hpp:352-369)
+//   TRACTION target   -3 sum_q w_q A (d.n)(d.x) d / r^5                       (:236-252; n = the source's normal)
+// one reciprocal square root per point; listed pairs (near regime: the K_fine rule; self: Fata's closed form / 2 pi I) come
+// from the list with their 3 x 3 blocks.  Rows in blocks of kMfRows3 (three partial sums each in registers).
+#ifndef FMMBEM_MF_ROWS3
+#define FMMBEM_MF_ROWS3 16
+#endif
+constexpr int kMfRows3 = FMMBEM_MF_ROWS3;
+__global__ __launch_bounds__(kWave) void mf_sweep3_apply_kernel(DevicePlan d) {
+  extern __shared__ int mf_lds[];
+  __shared__ double tcx[kMfRows3], tcy[kMfRows3], tcz[kMfRows3];
+  __shared__ int tbc[kMfRows3];
+  int* run_row0 = mf_lds;
+  int* run_off = run_row0 + d.max_runs;
+  const int lane = threadIdx.x;
+  const int64_t N = d.n;
+  const int nq = d.nq;
+  const double sc = 1. / 2 / d.mu;
+  for (int item = blockIdx.x; item < d.near_nitems; item += gridDim.x) {
+    const int4 it = d.near_items[item];
+    const int t = it.x;
+    const int ncols = d.near_ncols[t], nrows_all = it.z, row0 = d.leaf_row0[t] + it.y;
+    __builtin_amdgcn_wave_barrier();
+    const Runs runs = load_runs(d, t, run_row0, run_off);
+    wave_lds_fence();
+    for (int rb = 0; rb < nrows_all; rb += kMfRows3) {
+      const int nr = nrows_all - rb < kMfRows3 ? nrows_all - rb : kMfRows3;
+      if (lane < nr) {
+        const int64_t i = row0 + rb + lane;
+        tcx[lane] = d.cx[i]; tcy[lane] = d.cy[i]; tcz[lane] = d.cz[i]; tbc[lane] = d.bc[i];
+      }
+      double a0[kMfRows3], a1[kMfRows3], a2[kMfRows3];
+#pragma unroll
+      for (int r = 0; r < kMfRows3; ++r) a0[r] = a1[r] = a2[r] = 0;
+      wave_lds_fence();
+      for (int c0 = 0; c0 < ncols; c0 += kWave) {
+        const int c = c0 + lane;
+        const bool valid = c < ncols;
+        const int j = valid ? column_to_row(runs, c) : 0;
+        const double sx = d.cx[j], sy = d.cy[j], sz = d.cz[j], A = d.area[j];
+        const double near2 = 8.0 * A * (1.0 + 1e-9);
+        const double x0 = valid ? d.xt[3 * (int64_t)j] : 0.0, x1 = valid ? d.xt[3 * (int64_t)j + 1] : 0.0, x2 = valid ? d.xt[3 * (int64_t)j + 2] : 0.0;
+        const double nx = d.nx[j], ny = d.ny[j], nz = d.nz[j];
+        double qx[4], qy[4], qz[4], wA[4];               // the far-regime points in registers: K = 1, 3, 4 (the launcher sends larger
+        const int nqr = nq <= 4 ? nq : 0;                // rules to the literal kernel: a call to stokes_entry in here costs the sweep its registers)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
           const bool have = q < nqr;
           qx[q] = have ? d.quad[(q * 3 + 0) * N + j] : 0.0; qy[q] = have ? d.quad[(q * 3 + 1) * N + j] : 0.0;
           qz[q] = have ? d.quad[(q * 3 + 2) * N + j] : 1.0; wA[q] = have ? d.qw[q] * A : 0.0;
         }
-        const double near2 = 8.0 * A * (1.0 + 1e-9);      // d^2 <= 8 A  <=>  sqrt(2 A) / d >= 0.5; the band goes to the exact test
 #pragma unroll
-        for (int r = 0; r < kMfRows; ++r) {
-          if (r < nr) {                                    // wave-uniform
-            if (qn > kMfQueue - kWave) { mf_flush(d, lane, nr, qn, tcx, tcy, tcz, tbc, qrow, qj, qval, &racc); qn = 0; }
+        for (int r = 0; r < kMfRows3; ++r) {
+          if (r < nr) {
             const double tx = tcx[r], ty = tcy[r], tz = tcz[r];
-            const int dn = __builtin_amdgcn_readfirstlane(tbc[r]);      // the row's operator: a scalar branch, not a select per point
             const double dx = tx - sx, dy = ty - sy, dz = tz - sz;
-            const double d2 = dx * dx + dy * dy + dz * dz;
-            const bool slow = valid && d2 <= near2;
-            double v = 0;
-            if (nqr) {                                     // K <= 3: straight-line, the slow lanes' values are dropped below
+            const bool slow = valid && dx * dx + dy * dy + dz * dz <= near2;      // the expression of mf_sweep_kernel: the same pairs
+            const int trac = __builtin_amdgcn_readfirstlane(tbc[r]);
+            double u0 = 0, u1 = 0, u2 = 0;
+            if (nqr) {
 #pragma unroll
-              for (int q = 0; q < 3; ++q) {
-                const double ex = qx[q] - tx, ey = qy[q] - ty, ez = qz[q] - tz;
+              for (int q = 0; q < 4; ++q) {
+                const double ex = tx - qx[q], ey = ty - qy[q], ez = tz - qz[q];
                 const double ir = rsqrt_pos(fma(ex, ex, fma(ey, ey, ez * ez)));
-                if (dn) v = fma(wA[q] * fma(ex, nx, fma(ey, ny, ez * nz)), ir * ir * ir, v); else v = fma(wA[q], ir, v);
+                const double ir3 = ir * ir * ir, dxq = fma(ex, x0, fma(ey, x1, ez * x2));
+                if (trac) {
+                  const double g = wA[q] * fma(ex, nx, fma(ey, ny, ez * nz)) * dxq * (ir3 * ir * ir);
+                  u0 = fma(g, ex, u0); u1 = fma(g, ey, u1); u2 = fma(g, ez, u2);
+                } else {
+                  const double f1 = wA[q] * ir, g = wA[q] * ir3 * dxq;
+                  u0 = fma(f1, x0, fma(g, ex, u0)); u1 = fma(f1, x1, fma(g, ey, u1)); u2 = fma(f1, x2, fma(g, ez, u2));
+                }
               }
-            } else if (valid && !slow) v = mf_far_general(d, j, tx, ty, tz, dn, A, nx, ny, nz);
-            const unsigned long long m = __ballot(slow);
-            if (m) {
-              if (slow) {
-                const int k = qn + __popcll(m & ((1ull << lane) - 1));
-                qrow[k] = (short)r; qj[k] = j; qval[k] = xj;
-              }
-              qn += __popcll(m);
+              const double f = trac ? -3.0 : sc;
+              u0 *= f; u1 *= f; u2 *= f;
             }
-            // lanes past the last column ran the arithmetic against panel 0: its value may be inf/NaN (K = 1: the only point of
-            // panel 0 IS the centroid of row 0) and NaN * 0 is NaN -- masked by validity, not by xj = 0
-            acc[r] = fma((slow || !valid) ? 0.0 : v, xj, acc[r]);
+            const bool drop = slow || !valid;
+            a0[r] += drop ? 0.0 : u0; a1[r] += drop ? 0.0 : u1; a2[r] += drop ? 0.0 : u2;
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
       }
-      mf_flush(d, lane, nr, qn, tcx, tcy, tcz, tbc, qrow, qj, qval, &racc);
+      double r0 = 0, r1 = 0, r2 = 0;
 #pragma unroll
-      for (int r = 0; r < kMfRows; ++r)
+      for (int r = 0; r < kMfRows3; ++r)
         if (r < nr) {
-          const double srow = wave_sum(acc[r]);
-          if (lane == r) racc += srow;
+          const double s0 = wave_sum(a0[r]), s1 = wave_sum(a1[r]), s2 = wave_sum(a2[r]);
+          if (lane == r) { r0 = s0; r1 = s1; r2 = s2; }
         }
-      if (lane < nr) d.yt[row0 + rb + lane] = racc;
+      if (lane < nr) {
+        const int64_t i = row0 + rb + lane;
+        for (int64_t k = d.side_ptr[i]; k < d.side_ptr[i + 1]; ++k) {
+          const double* m = d.side_val + 9 * k;
+          const int64_t cj = d.side_col[k];
+          const double y0 = d.xt[3 * cj], y1 = d.xt[3 * cj + 1], y2 = d.xt[3 * cj + 2];
+          r0 = fma(m[0], y0, fma(m[1], y1, fma(m[2], y2, r0)));
+          r1 = fma(m[3], y0, fma(m[4], y1, fma(m[5], y2, r1)));
+          r2 = fma(m[6], y0, fma(m[7], y1, fma(m[8], y2, r2)));
+        }
+        d.yt[3 * i] = r0; d.yt[3 * i + 1] = r1; d.yt[3 * i + 2] = r2;
+      }
       wave_lds_fence();
     }
   }
+}
+
+// one thread per listed pair: the entry, by the function the assembled path uses (which repeats the exact regime test)
+__global__ void mf_side_eval_kernel(DevicePlan d, const int* __restrict__ side_row, const int* __restrict__ side_col, double* __restrict__ side_val, int64_t nside) {
+  const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (k >= nside) return;
+  const int64_t i = side_row[k];
+  if (d.dof == 3) stokes_entry(d, V3{d.cx[i], d.cy[i], d.cz[i]}, d.bc[i], side_col[k], side_val + 9 * k);
+  else side_val[k] = laplace_entry(d, V3{d.cx[i], d.cy[i], d.cz[i]}, d.bc[i], side_col[k]);
 }
 
 // The same for StokesSphericalBEM (StokesBEM -disable_sparse): the 3x3 panel integral of every (target, source) pair of the
@@ -1126,19 +1246,36 @@ hipError_t launch_near_assemble_stokes(const DevicePlan& d, hipStream_t s) {
 hipError_t launch_near_matfree(const DevicePlan& d, hipStream_t s) {
   const int nb = d.leaf_end - d.leaf_begin;
   if (nb <= 0) return hipSuccess;
+  const char* v1 = getenv("FMMBEM_MATFREE_V1");                       // the literal form (A/B)
   if (d.dof == 3) {
+    if (!(v1 && atoi(v1) != 0) && d.side_ptr && d.nq <= 4) {
+      hipLaunchKernelGGL(mf_sweep3_apply_kernel, dim3(d.near_nitems < 256 * 16 ? d.near_nitems : 256 * 16), dim3(kWave), 2 * (size_t)d.max_runs * sizeof(int), s, d);
+      return hipGetLastError();
+    }
     const size_t lds3 = (size_t)(kAsmChunk / 2) * (3 * sizeof(double) + sizeof(int)) + 2 * (size_t)d.max_runs * sizeof(int);
     hipLaunchKernelGGL(near_matfree_stokes_kernel, dim3(nb < 256 * 8 ? nb : 256 * 8), dim3(256), lds3, s, d);
     return hipGetLastError();
   }
-  const char* v1 = getenv("FMMBEM_MATFREE_V1");                       // the literal form (A/B)
-  if (!(v1 && atoi(v1) != 0)) {
+  if (!(v1 && atoi(v1) != 0) && d.side_ptr) {
     const size_t lds2 = 2 * (size_t)d.max_runs * sizeof(int);
-    hipLaunchKernelGGL(near_matfree2_kernel, dim3(d.near_nitems < 256 * 16 ? d.near_nitems : 256 * 16), dim3(kWave), lds2, s, d);
+    hipLaunchKernelGGL(mf_sweep_kernel<kMfApply>, dim3(d.near_nitems < 256 * 16 ? d.near_nitems : 256 * 16), dim3(kWave), lds2, s, d, nullptr, nullptr, nullptr);
     return hipGetLastError();
   }
   const size_t lds = (size_t)kAsmChunk * (sizeof(double) + sizeof(int)) + 2 * (size_t)d.max_runs * sizeof(int);
   hipLaunchKernelGGL(near_matfree_kernel, dim3(nb < 256 * 8 ? nb : 256 * 8), dim3(256), lds, s, d);
+  return hipGetLastError();
+}
+
+// matrix-free plans, at creation: the list of near-regime pairs.  phase 0: side_cnt[row] = listed pairs of every owned row;
+// phase 1: side_col filled through side_ptr (the exclusive scan of the counts); phase 2: side_val from (side_row, side_col)
+hipError_t launch_mf_side(const DevicePlan& d, int phase, int* side_cnt, const int64_t* side_ptr, int* side_col, const int* side_row,
+                          double* side_val, int64_t nside, hipStream_t s) {
+  if (d.near_nitems <= 0) return hipSuccess;
+  const size_t lds2 = 2 * (size_t)d.max_runs * sizeof(int);
+  const dim3 g(d.near_nitems < 256 * 16 ? d.near_nitems : 256 * 16), b(kWave);
+  if (phase == 0) hipLaunchKernelGGL(mf_sweep_kernel<kMfCount>, g, b, lds2, s, d, side_cnt, nullptr, nullptr);
+  else if (phase == 1) hipLaunchKernelGGL(mf_sweep_kernel<kMfFill>, g, b, lds2, s, d, nullptr, side_ptr, side_col);
+  else if (nside > 0) hipLaunchKernelGGL(mf_side_eval_kernel, dim3((unsigned)((nside + 255) / 256)), dim3(256), 0, s, d, side_row, side_col, side_val, nside);
   return hipGetLastError();
 }
 

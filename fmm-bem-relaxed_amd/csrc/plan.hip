@@ -4,6 +4,7 @@
 // stream.  There is NO CPU execution path: without a device, execute returns FMMBEM_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <complex>
@@ -15,7 +16,7 @@
 #include <vector>
 
 #include "../../include/fmmbem.h"
-#include "device_plan.hpp"
+#include "device_launch.hpp"
 #include "host_plan.hpp"
 #include "m2l_layout.hpp"
 #include "m2l_rot.hpp"
@@ -165,6 +166,7 @@ struct fmmbem_plan {
   int64_t* d_cut = nullptr;                                    // tree-order row cuts of all shards, on the device
   std::vector<ShiftOpDev> up_ops, down_ops;                    // M2M / L2L operators, index p - 1
   int64_t near_bytes = 0;
+  int64_t near_side_entries = 0;                               // matrix-free plans: listed near-regime pairs (12 bytes each)
   int64_t n_classes = 0;
   double build_host_ms = 0, build_assemble_ms = 0;
   // execute state
@@ -357,9 +359,12 @@ int fmmbem_plan::to_device() {
     constexpr int64_t kItemBytes = 256 << 10;          // two-sphere N = 1M (near ms): 64 KB 0.81, 128 0.72, 192 0.74, 256 0.705, 320 0.735, 384 0.72, 512 0.72
     struct Item { int leaf, r0, nr; int64_t bytes; };
     std::vector<Item> items;
+    // (a matrix-free plan runs the sweeps of kernels_near.hip over the same items, which count PANEL rows and pairs whatever
+    // the number of unknowns per panel)
+    const int idof = opts.sparse_local ? dof : 1;
     for (int l = hp.leaf_begin; l < hp.leaf_end; ++l) {
-      const int nr = dof * leaf_nrows[l];
-      const int64_t row_bytes = (int64_t)near_stride[l] * 8;
+      const int nr = idof * leaf_nrows[l];
+      const int64_t row_bytes = opts.sparse_local ? (int64_t)near_stride[l] * 8 : (int64_t)hp.near_ncols[l] * 8;
       if (nr == 0 || row_bytes == 0) continue;
       int per = (int)std::max<int64_t>(1, kItemBytes / row_bytes);
       if (per >= 8) per &= ~7; else per = std::min(4, nr);
@@ -739,6 +744,37 @@ int fmmbem_plan::to_device() {
     else HIP_TRY(launch_near_assemble(d, own_stream));
     HIP_TRY(hipStreamSynchronize(own_stream));
   }
+  else if (hp.row_end > hp.row_begin) {
+    // matrix-free: nothing is assembled, but the pairs of the near regimes -- the expensive 4.5 %, the same numbers every matvec
+    // -- are listed per target row and evaluated once (kernels_near.hip, near_matfree third form): count, scan, fill, evaluate
+    int* d_cnt = nullptr;
+    TRY(alloc((size_t)hp.n, &d_cnt, true));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(launch_mf_side(d, 0, d_cnt, nullptr, nullptr, nullptr, nullptr, 0, own_stream));
+    HIP_TRY(hipStreamSynchronize(own_stream));
+    std::vector<int> cnt((size_t)hp.n);
+    HIP_TRY(hipMemcpy(cnt.data(), d_cnt, sizeof(int) * cnt.size(), hipMemcpyDeviceToHost));
+    std::vector<int64_t> ptr((size_t)hp.n + 1, 0);
+    for (int64_t i = 0; i < hp.n; ++i) ptr[(size_t)i + 1] = ptr[(size_t)i] + cnt[(size_t)i];
+    const int64_t nside = ptr.back();
+    std::vector<int> row((size_t)nside);
+    for (int64_t i = 0; i < hp.n; ++i)
+      for (int64_t k = ptr[(size_t)i]; k < ptr[(size_t)i + 1]; ++k) row[(size_t)k] = (int)i;
+    const int* d_row = nullptr;
+    int* d_col = nullptr;
+    double* d_val = nullptr;
+    TRY(upload(ptr, &d.side_ptr)); TRY(upload(row, &d_row));
+    TRY(alloc((size_t)nside, &d_col, false)); TRY(alloc((size_t)nside * (dof == 3 ? 9 : 1), &d_val, false));
+    HIP_TRY(launch_mf_side(d, 1, nullptr, d.side_ptr, d_col, nullptr, nullptr, nside, own_stream));
+    HIP_TRY(launch_mf_side(d, 2, nullptr, nullptr, d_col, d_row, d_val, nside, own_stream));
+    HIP_TRY(hipStreamSynchronize(own_stream));
+    d.side_col = d_col; d.side_val = d_val;
+    near_side_entries = nside;
+    for (void* tmp : {(void*)d_cnt, (void*)const_cast<int*>(d_row)}) {        // creation-time scratch
+      (void)hipFree(tmp);
+      allocs.erase(std::find(allocs.begin(), allocs.end(), tmp));
+    }
+  }
   build_assemble_ms = now_ms() - t0;
   mark("near assembly");
   {                                                    // the plan itself, readable from the device
@@ -1106,6 +1142,8 @@ int fmmbem_plan_stats(const fmmbem_plan* plan, fmmbem_stats* o) {
   o->owned_row_begin = h.row_begin; o->owned_row_end = h.row_end;
   o->near_bytes = plan->near_bytes;
   o->m2l_items = (int64_t)h.rot_item_ptr.size() - 1; o->m2l_passes = h.rot_passes;
+  o->near_side_entries = plan->near_side_entries;
+  o->m2l_kernel = plan->last_p > 0 ? (plan->use_rot(plan->last_p) ? 1 : plan->last_p <= 4 ? 3 : 2) : 0;
   o->expansions_active = (h.has_bc[0] ? 1 : 0) | (h.has_bc[1] ? 2 : 0);
   o->last_p = plan->last_p;
   o->build_host_ms = plan->build_host_ms; o->build_assemble_ms = plan->build_assemble_ms;

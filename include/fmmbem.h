@@ -114,6 +114,10 @@ typedef struct {
   int64_t l2l_reference_omitted;/* L2L edges FMMBEM_L2L_REFERENCE leaves out of this tree (0: the rules coincide) */
   int64_t m2l_items, m2l_passes;/* rotation M2L: work items (one wavefront each) and 64-pair passes over them; pairs / (64 passes)
                                  * is the lane fill                                                   */
+  int64_t near_side_entries;    /* matrix-free plans (sparse_local = 0): near-regime pairs evaluated once at creation and kept
+                                 * (12 bytes each: column + value); 0 for assembled plans                */
+  int32_t m2l_kernel;           /* the M2L an execute at last_p took: 1 rotation kernel, 2 double sum, 3 double sum (lanes = sources) */
+  int32_t reserved_;
 } fmmbem_stats;
 
 typedef struct fmmbem_plan fmmbem_plan;

@@ -230,7 +230,7 @@ def test_larger_case_r8_properties(fb, oracle_mod):
 
 
 @pytest.mark.parametrize("bc_val,quad_k", [(0, 3), (1, 3), (0, 1), (1, 1), (0, 4), (1, 13)])
-def test_matrix_free_near_field(fb, oracle_mod, bc_val, quad_k):
+def test_matrix_free_near_field(fb, oracle_mod, monkeypatch, bc_val, quad_k):
     """sparse_local = false: EvalInteractionLazy recomputes the panel integrals every matvec.
     K = 1: the only quadrature point of a panel is its centroid, so a lane past the last column that runs the far-regime
     arithmetic against tree panel 0 meets distance zero in row 0 -- its NaN must not reach the row's sum (round-2 advisory);
@@ -242,13 +242,17 @@ def test_matrix_free_near_field(fb, oracle_mod, bc_val, quad_k):
     opts.sparse_local = False
     K = fb.LaplaceSphericalBEM(10, quad_k)
     pl = fb.FMM_plan(K, v, opts, bc=bc)
-    assert pl.stats()["near_bytes"] == 0
+    st = pl.stats()
+    assert st["near_bytes"] == 0 and 0 < st["near_side_entries"] < 0.2 * st["near_nnz"]     # the near-regime pairs, kept; no matrix
     x = drand48(n, seed=5)
     y = pl.execute(x)
     assert np.isfinite(y).all()
     assert rel_l2(y, oracle_mod.Oracle(v, K=quad_k, bc=bc).matvec(x, 10)) <= TOL_MATVEC
     dense = fb.FMM_plan(K, v, bc=bc).execute(x)
     assert rel_l2(y, dense) <= 1e-14
+    if quad_k == 3:
+        monkeypatch.setenv("FMMBEM_MATFREE_V1", "1")      # the literal form (every entry recomputed by laplace_entry every matvec)
+        assert rel_l2(fb.FMM_plan(K, v, opts, bc=bc).execute(x), dense) <= 1e-14
 
 
 @pytest.mark.gpu

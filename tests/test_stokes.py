@@ -256,7 +256,7 @@ def test_gpu_stokes_traction_entries_and_near_field_operators(fb, oracle_mod):
 
 
 @pytest.mark.gpu
-def test_gpu_stokes_matrix_free_near_field(fb, stokes5):
+def test_gpu_stokes_matrix_free_near_field(fb, stokes5, monkeypatch):
     """StokesBEM -disable_sparse (examples/StokesBEM.cpp:197; EvalInteractionLazy.hpp:239-252): the near field recomputed
     every matvec equals the assembled one."""
     v, o = stokes5
@@ -265,9 +265,14 @@ def test_gpu_stokes_matrix_free_near_field(fb, stokes5):
     fo = fb.FMMOptions()
     fo.sparse_local = False
     pl = fb.FMM_plan(K, v, fo)
-    assert pl.stats()["near_bytes"] == 0
+    st = pl.stats()
+    assert st["near_bytes"] == 0 and 0 < st["near_side_entries"] < 0.2 * st["near_nnz"]     # the near-regime pairs, kept; no matrix
     x = drand48(3 * o.n, seed=11).reshape(o.n, 3)
-    assert rel_l2(pl.execute(x), o.matvec(x, 8)) <= 1e-12
+    y = pl.execute(x)
+    assert rel_l2(y, o.matvec(x, 8)) <= 1e-12
+    assert rel_l2(y, fb.FMM_plan(K, v).execute(x)) <= 1e-14                                  # the assembled operator
+    monkeypatch.setenv("FMMBEM_MATFREE_V1", "1")                                             # the literal form: every block, every matvec
+    assert rel_l2(fb.FMM_plan(K, v, fo).execute(x), y) <= 1e-14
 
 
 @pytest.mark.gpu

@@ -15,6 +15,9 @@ import fmm_bem_relaxed_amd as fb  # noqa: E402
 
 def main():
     args = sys.argv[1:]
+    stage = None
+    if args and args[0].startswith("--stage="):             # also print this stage's time (ms_p2m, ms_m2l, ...) from an instrumented pass
+        stage = args.pop(0).split("=", 1)[1]
     orders = (1, 2, 3, 6, 10, 12)
     if "--" in args:
         k = args.index("--")
@@ -52,7 +55,15 @@ def main():
                 same = "" if torch.equal(y, ref[p]) else " DIFFERS(%.1e)" % float((y - ref[p]).abs().max() / ref[p].abs().max())
             else:
                 ref[p] = y.clone()
-            line.append("p=%d %.3f%s" % (p, e0.elapsed_time(e1) / 20, same))
+            extra = ""
+            if stage:
+                plan.set_timing(1)
+                for _ in range(5):
+                    plan.execute_torch(x, out=y, p=p)
+                torch.cuda.synchronize()
+                extra = " (%s %.3f)" % (stage, plan.stats()["ms_" + stage])
+                plan.set_timing(0)
+            line.append("p=%d %.3f%s%s" % (p, e0.elapsed_time(e1) / 20, extra, same))
         print("%-60s %s" % (setting, "  ".join(line)), flush=True)
         plan.close()
 

@@ -7,5 +7,8 @@ name=$1; shift
 mkdir -p ../variants /tmp/rotvar
 /opt/rocm/bin/hipcc -std=c++17 -O3 -fPIC --offload-arch=gfx950 -mllvm -pragma-unroll-threshold=4000000 -mllvm -unroll-threshold=4000000 \
   "$@" -c -o /tmp/rotvar/kr_$name.o kernels_m2l_rot.hip
+# the same check as the product build: a variant with a DPP hazard or an early touch of a load in flight computes wrong
+# numbers, and its timing means nothing
+python3 ../../tools/check_rot_isa.py /tmp/rotvar/kr_$name.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../variants/libfmmbem_hip_$name.so host_plan.o mesh_io.o kernels_near.o kernels_far.o kernels_m2l.o /tmp/rotvar/kr_$name.o kernels_m2m_rot.o kernels_l2l_rot.o krylov.o plan.o
 echo built ../variants/libfmmbem_hip_$name.so
