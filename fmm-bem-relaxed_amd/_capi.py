@@ -58,7 +58,7 @@ SYMBOLS = (
     "fmmbem_options_default", "fmmbem_plan_create", "fmmbem_plan_destroy", "fmmbem_plan_execute",
     "fmmbem_mgs_column_device", "fmmbem_mgs_scratch_doubles", "fmmbem_plan_execute_device", "fmmbem_plan_exchange_doubles", "fmmbem_plan_exchange_counts", "fmmbem_plan_upward_device",
     "fmmbem_plan_downward_device", "fmmbem_plan_near_split_device", "fmmbem_plan_near_device", "fmmbem_plan_set_result_slices", "fmmbem_plan_shard_rows",
-    "fmmbem_plan_assemble_slices_device", "fmmbem_plan_set_timing", "fmmbem_plan_stats",
+    "fmmbem_plan_assemble_slices_device", "fmmbem_plan_set_timing", "fmmbem_plan_set_graphs", "fmmbem_plan_stats",
     "fmmbem_plan_get_perm", "fmmbem_plan_get_boxes", "fmmbem_plan_get_pairs", "fmmbem_plan_get_near_row",
     "fmmbem_plan_get_expansions", "fmmbem_plan_get_diagonal", "fmmbem_kernel_entries", "fmmbem_mesh_unit_sphere", "fmmbem_mesh_red_blood_cell", "fmmbem_mesh_red_blood_cells", "fmmbem_mesh_read_msh",
     "fmmbem_mesh_read_vert_face", "fmmbem_mesh_write_vert_face", "fmmbem_quadrature", "fmmbem_status_string", "fmmbem_last_error",
@@ -102,6 +102,7 @@ def lib():
     L.fmmbem_plan_shard_rows.argtypes = [vp, vp]
     L.fmmbem_plan_assemble_slices_device.argtypes = [vp, vp, C.c_size_t, vp, vp]
     L.fmmbem_plan_set_timing.argtypes = [vp, i32]
+    L.fmmbem_plan_set_graphs.argtypes = [vp, i32]
     L.fmmbem_plan_stats.argtypes = [vp, C.POINTER(Stats)]
     L.fmmbem_plan_get_perm.argtypes = [vp, vp]
     L.fmmbem_plan_get_boxes.argtypes = [vp] * 8

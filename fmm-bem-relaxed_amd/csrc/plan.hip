@@ -156,6 +156,14 @@ struct fmmbem_plan {
   int shift_stream_off[12] = {};
   int shift_rot_min = 2048;                                    // boxes on a tree level from which the rotation kernels take it
   bool shift_rot = true;
+  // hipGraphs of the launch chain between the gather and the delivery of a matvec (those two take the caller's pointers),
+  // one per (region of the execute, order p, exchange buffer): captured on own_stream the SECOND time a region runs at an
+  // order (the first run goes out launch by launch, so that every one-time initialisation inside the launchers has happened),
+  // then replayed on the caller's stream.  Off unless fmmbem_plan_set_graphs / FMMBEM_GRAPH=1: on this runtime dependent
+  // launches already run back to back on the device (profiles/r03b), what a graph saves is host time per matvec.
+  struct GraphEntry { int region, p; const void* buf; int runs; hipGraphExec_t exec; };
+  std::vector<GraphEntry> graphs;
+  bool use_graphs = false;
   int m2m_pass(int p, bool shared, hipStream_t s);
   int l2l_pass(int p, hipStream_t s);
   const DevicePlan* d_dev = nullptr;                            // copy of d in device memory
@@ -221,6 +229,7 @@ struct fmmbem_plan {
       DeviceGuard guard(opts.device);
       for (void* p : allocs) (void)hipFree(p);
       for (auto& e : ev) (void)hipEventDestroy(e);
+      for (auto& g : graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
       if (own_stream) (void)hipStreamDestroy(own_stream);
       if (near_stream) (void)hipStreamDestroy(near_stream);
       if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -346,6 +355,7 @@ int fmmbem_plan::to_device() {
   if (const char* e = getenv("FMMBEM_M2L_ROT_MAX")) rot_max = atoi(e);
   if (const char* ov = getenv("FMMBEM_OVERLAP_NEAR")) overlap_near = atoi(ov) != 0;
   if (const char* nw = getenv("FMMBEM_NEAR_WGS")) near_wgs = std::max(1, std::min(8, atoi(nw)));
+  if (const char* ge = getenv("FMMBEM_GRAPH")) use_graphs = atoi(ge) != 0;
   d.max_ncols = max_cols;
   near_bytes = total * (int64_t)sizeof(double);
   TRY(upload(leaf_row0, &d.leaf_row0)); TRY(upload(leaf_nrows, &d.leaf_nrows)); TRY(upload(hp.leaf_box, &d.leaf_box));
@@ -846,19 +856,44 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
   // M2L, L2L, L2P.  The near field only meets the far field in y, so it is launched on a second stream next
   // to M2L (an HBM-bound kernel beside an FMA-bound one); the two are joined before L2P adds into y.
   const bool overlap = overlap_near && !near_only && phase == 0 && opts.sparse_local;
+  // a region of the chain, launch by launch or as a graph (see GraphEntry)
+  const bool graph_ok = use_graphs && tm == 0 && !overlap;
+  auto graphed = [&](int region, const void* buf, auto&& body) -> int {
+    if (!graph_ok) return body(s);
+    GraphEntry* ge = nullptr;
+    for (auto& g : graphs) if (g.region == region && g.p == p && g.buf == buf) ge = &g;
+    if (!ge) { graphs.push_back(GraphEntry{region, p, buf, 0, nullptr}); ge = &graphs.back(); }
+    if (++ge->runs == 1) return body(s);
+    if (!ge->exec) {
+      HIP_TRY(hipStreamBeginCapture(own_stream, hipStreamCaptureModeThreadLocal));
+      const int rc = body(own_stream);
+      hipGraph_t g = nullptr;
+      const hipError_t e = hipStreamEndCapture(own_stream, &g);
+      if (rc != FMMBEM_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+      HIP_TRY(e);
+      const hipError_t ei = hipGraphInstantiate(&ge->exec, g, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(g);
+      HIP_TRY(ei);
+    }
+    HIP_TRY(hipGraphLaunch(ge->exec, s));
+    return FMMBEM_OK;
+  };
   if (phase < 2) {
     HIP_TRY(begin(0, s));
     HIP_TRY(launch_gather_x(d, d_x, s));
     HIP_TRY(end(0, s));
   }
   if (phase == 1) {                                    // upward half: my leaves, my boxes, pack what the others need
-    HIP_TRY(begin(3, s));
-    if (d.kernel == FMMBEM_KERNEL_STOKES_BEM) HIP_TRY(launch_p2m_stokes(d, p, s)); else HIP_TRY(launch_p2m(d, p, s));
-    HIP_TRY(end(3, s));
-    HIP_TRY(begin(4, s));
-    TRY(m2m_pass(p, false, s));
-    HIP_TRY(launch_xch_pack(d, p, reinterpret_cast<double2*>(xbuf), s));
-    HIP_TRY(end(4, s));
+    TRY(graphed(1, xbuf, [&](hipStream_t s) -> int {
+      HIP_TRY(begin(3, s));
+      if (d.kernel == FMMBEM_KERNEL_STOKES_BEM) HIP_TRY(launch_p2m_stokes(d, p, s)); else HIP_TRY(launch_p2m(d, p, s));
+      HIP_TRY(end(3, s));
+      HIP_TRY(begin(4, s));
+      TRY(m2m_pass(p, false, s));
+      HIP_TRY(launch_xch_pack(d, p, reinterpret_cast<double2*>(xbuf), s));
+      HIP_TRY(end(4, s));
+      return FMMBEM_OK;
+    }));
     pending_mask = mask;
     pending_near = false;
     return FMMBEM_OK;
@@ -892,7 +927,7 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
     pending_near = true;
     return FMMBEM_OK;
   }
-  if (!overlap && !(phase == 2 && pending_near)) TRY(near_field(s));
+  const bool near_here = !overlap && !(phase == 2 && pending_near);
   pending_near = false;
   if (overlap) {
     HIP_TRY(hipEventRecord(ev_fork, s));
@@ -900,6 +935,8 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
     TRY(near_field(near_stream));
     HIP_TRY(hipEventRecord(ev_join, near_stream));
   }
+  TRY(graphed((phase == 2 ? 2 : 0) + (near_here ? 0 : 4) + (near_only ? 8 : 0), xbuf, [&](hipStream_t s) -> int {
+  if (near_here) TRY(near_field(s));
   if (!near_only) {
     if (phase == 0) {
       HIP_TRY(begin(3, s));
@@ -929,8 +966,10 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
     if (d.kernel == FMMBEM_KERNEL_STOKES_BEM) HIP_TRY(launch_l2p_stokes(d, p, overlap ? d.yfar : d.yt, s, overlap));
     else HIP_TRY(launch_l2p(d, p, overlap ? d.yfar : d.yt, s, overlap));
     HIP_TRY(end(8, s));
-    if (overlap) HIP_TRY(hipStreamWaitEvent(s, ev_join, 0));
   }
+  return FMMBEM_OK;
+  }));
+  if (overlap && !near_only) HIP_TRY(hipStreamWaitEvent(s, ev_join, 0));
   TRY(deliver(s));
   last_p = p;
   if (tm) { ev_mask[ring] = mask; ++ev_count; }
@@ -1117,6 +1156,12 @@ int fmmbem_plan_execute(fmmbem_plan* plan, int p, const double* x, double* y) {
   if (rc != FMMBEM_OK) return rc;
   HIP_TRY(hipMemcpyAsync(y, plan->stage_y, bytes, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
+  return FMMBEM_OK;
+}
+
+int fmmbem_plan_set_graphs(fmmbem_plan* plan, int enabled) {
+  if (!plan) return fail(FMMBEM_ERR_INVALID, "null plan");
+  plan->use_graphs = enabled != 0 && plan->on_device;
   return FMMBEM_OK;
 }
 

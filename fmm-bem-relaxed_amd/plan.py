@@ -317,6 +317,10 @@ class FMM_plan:
         stream time, 85 us per fully instrumented matvec at N = 1M); False / 0: off."""
         _capi.check(_capi.lib().fmmbem_plan_set_timing(self._h, 2 if on == 2 else (1 if on else 0)))
 
+    def set_graphs(self, on=True):
+        """Replay each order's launch chain as a hipGraph from its second execute on (fmmbem_plan_set_graphs)."""
+        _capi.check(_capi.lib().fmmbem_plan_set_graphs(self._h, 1 if on else 0))
+
     def stats(self):
         s = _capi.Stats()
         _capi.check(_capi.lib().fmmbem_plan_stats(self._h, C.byref(s)))

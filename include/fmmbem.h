@@ -154,6 +154,13 @@ int fmmbem_plan_near_device(fmmbem_plan *plan, const double *d_x, double *d_y, v
  * the record.  Default off. */
 int fmmbem_plan_set_timing(fmmbem_plan *plan, int enabled);      /* 0 off; 1 every stage; 2 the near-field kernel only */
 
+/* Replay the launch chain of an execute (everything between the gather of x and the delivery of y) as a hipGraph per order p,
+ * captured the second time the plan runs at that order and launched on the caller's stream from then on: one host call
+ * instead of ~16.  Same kernels, same order, same bits.  Off by default (also FMMBEM_GRAPH=1 at creation); executes with
+ * stage timing on are not graphed.  Environment switches that the launchers read per launch are frozen into a captured
+ * graph. */
+int fmmbem_plan_set_graphs(fmmbem_plan *plan, int enabled);
+
 int fmmbem_plan_stats(const fmmbem_plan *plan, fmmbem_stats *out);
 
 /* ---- introspection (tests, partition checks) --------------------------------------------- */

@@ -289,6 +289,47 @@ def test_alternative_paths_match_oracle(fb, oracle_mod, monkeypatch, env):
 
 
 @pytest.mark.gpu
+def test_graph_replay_is_bitwise_the_launch_chain(fb, oracle_mod):
+    """fmmbem_plan_set_graphs: from its second execute at an order on, the chain between gather and delivery is a captured
+    hipGraph launched on the caller's stream -- the same kernels in the same order, so the same bits as launch by launch, for
+    every order of a relaxed schedule, repeated, for both kernels, and next to the near-field-only entry point."""
+    import torch
+    v = np.concatenate([oracle_mod.unit_sphere(5), oracle_mod.unit_sphere(4, center=(2.5, 0.3, -0.2))])
+    rng = np.random.default_rng(5)
+    bc = (rng.random(len(v)) < 0.3).astype(np.uint8)
+    x = rng.standard_normal(len(v))
+    K0, K1 = fb.LaplaceSphericalBEM(12, 3), fb.LaplaceSphericalBEM(12, 3)
+    plain, graphed = fb.FMM_plan(K0, v, bc=bc), fb.FMM_plan(K1, v, bc=bc)
+    graphed.set_graphs(True)
+    xd = torch.from_numpy(x).cuda()
+    for p in (12, 12, 12, 7, 3, 7, 3, 1, 12, 3, 7):
+        a = plain.execute_torch(xd, p=p)
+        b = graphed.execute_torch(xd, p=p)
+        assert torch.equal(a, b), p
+        yn_a, yn_b = torch.empty_like(xd), torch.empty_like(xd)
+        s = torch.cuda.current_stream().cuda_stream
+        plain.near_device(xd.data_ptr(), yn_a.data_ptr(), s)
+        graphed.near_device(xd.data_ptr(), yn_b.data_ptr(), s)
+        assert torch.equal(yn_a, yn_b)
+    # on a side stream, and with other inputs than the graph was captured with
+    side = torch.cuda.Stream()
+    x2 = torch.from_numpy(rng.standard_normal(len(v))).cuda()
+    with torch.cuda.stream(side):
+        b = graphed.execute_torch(x2, p=7)
+    side.synchronize()
+    assert torch.equal(plain.execute_torch(x2, p=7), b)
+    vs = oracle_mod.unit_sphere(4)
+    KS = fb.StokesSphericalBEM(6, 4, 1e-3)
+    KS.set_Kfine(19)
+    f = rng.standard_normal((len(vs), 3))
+    ref = fb.FMM_plan(KS, vs).execute(f)
+    gs = fb.FMM_plan(KS, vs)
+    gs.set_graphs(True)
+    for _ in range(3):
+        assert np.array_equal(gs.execute(f), ref)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("bc_val", [0, 1])
 def test_p2m_streaming_kernel(fb, oracle_mod, monkeypatch, bc_val):
     """One expansion per box and more than 32 coefficients: the streaming P2M contraction (scalar leaf records and charges,

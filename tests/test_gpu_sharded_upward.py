@@ -87,6 +87,41 @@ def test_mixed_bc_and_stokes_split(fb):
     assert np.array_equal(total.cpu().numpy(), fulls)
 
 
+def test_split_execute_as_graphs(fb, monkeypatch):
+    """The two halves of a split execute replayed as hipGraphs (FMMBEM_GRAPH=1: one graph per half, order and exchange
+    buffer): three matvecs in a row -- launch by launch, captured, replayed -- each summing bitwise to the single plan's."""
+    import torch
+    monkeypatch.setenv("FMMBEM_GRAPH", "1")
+    v = np.concatenate([fb.unit_sphere(5), fb.unit_sphere(4, center=(3.0, 0.0, 0.0))])
+    n, world, p = len(v), 3, 8
+    rng = np.random.default_rng(77)
+    plans = [fb.FMM_plan(fb.LaplaceSphericalBEM(p, 3), v, shard=(r, world), shard_upward=2) for r in range(world)]
+    monkeypatch.delenv("FMMBEM_GRAPH")
+    single = fb.FMM_plan(fb.LaplaceSphericalBEM(p, 3), v)
+    counts = [pl.exchange_counts(p) for pl in plans]
+    s = torch.cuda.current_stream().cuda_stream
+    send = [torch.full((max(int(c[0].sum()), 1),), float("nan"), dtype=torch.float64, device="cuda") for c in counts]
+    recv = [torch.full((max(int(c[1].sum()), 1),), float("nan"), dtype=torch.float64, device="cuda") for c in counts]
+    for it in range(4):
+        x = rng.standard_normal(n)
+        xd = torch.from_numpy(x).cuda()
+        for r, pl in enumerate(plans):
+            pl.upward_device(xd.data_ptr(), send[r].data_ptr(), s, p)
+        torch.cuda.synchronize()
+        for r in range(world):
+            so = np.concatenate([[0], np.cumsum(counts[r][0])])
+            for q in range(world):
+                ro = np.concatenate([[0], np.cumsum(counts[q][1])])
+                recv[q][ro[r]:ro[r + 1]] = send[r][so[q]:so[q + 1]]
+        total = torch.zeros_like(xd)
+        for r, pl in enumerate(plans):
+            y = torch.empty_like(xd)
+            pl.downward_device(recv[r].data_ptr(), y.data_ptr(), s, p)
+            total += y
+        torch.cuda.synchronize()
+        assert np.array_equal(total.cpu().numpy(), single.execute(x)), it
+
+
 @pytest.mark.parametrize("world,p,traction", [(2, 10, False), (3, 8, False), (8, 5, False), (4, 6, True)])
 def test_selective_exchange_sums_bitwise(fb, world, p, traction):
     """shard_upward = 2: every shard sends every other only the multipoles that shard's lists read, in one all-to-all with

@@ -5,6 +5,7 @@ Each setting = comma-separated NAME=VALUE, applied before the plan is created (p
 every setting is compared bit for bit with the first one's."""
 import os
 import sys
+import time
 
 import numpy as np
 import torch
@@ -46,8 +47,10 @@ def main():
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
+            h0 = time.perf_counter()
             for _ in range(20):
                 plan.execute_torch(x, out=y, p=p)
+            host_us = (time.perf_counter() - h0) / 20 * 1e6      # what the host spends enqueueing one matvec
             e1.record()
             torch.cuda.synchronize()
             same = ""
@@ -63,7 +66,7 @@ def main():
                 torch.cuda.synchronize()
                 extra = " (%s %.3f)" % (stage, plan.stats()["ms_" + stage])
                 plan.set_timing(0)
-            line.append("p=%d %.3f%s%s" % (p, e0.elapsed_time(e1) / 20, extra, same))
+            line.append("p=%d %.3f [host %.0f us]%s%s" % (p, e0.elapsed_time(e1) / 20, host_us, extra, same))
         print("%-60s %s" % (setting, "  ".join(line)), flush=True)
         plan.close()
 
