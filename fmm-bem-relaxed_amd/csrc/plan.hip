@@ -952,8 +952,6 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
       TRY(m2m_pass(p, true, s));
     }
     const bool rot = use_rot(p);
-    if (!rot && d.kernel == FMMBEM_KERNEL_STOKES_BEM && d.stokes_traction_targets)
-      return fail(FMMBEM_ERR_UNSUPPORTED, "Stokes TRACTION far field needs the rotation M2L kernel (p <= 12, FMMBEM_M2L_ROT unset)");
     if (!rot) HIP_TRY(launch_mh_prep(d, p, s));      // the rotation kernel reads M itself
     HIP_TRY(end(5, s));
     HIP_TRY(begin(6, s));
@@ -1004,10 +1002,8 @@ int fmmbem_plan_create(const fmmbem_options* opts, size_t n_panels, const double
     // TRACTION panels: the near blocks are eval_traction_integral (kernel/StokesSphericalBEM.hpp:160-258).  Their far field
     // is the double-layer decomposition of kernels_far.hip (seven dipole potentials), checked against the Direct sum -- the
     // reference's own far field for this operator disagrees with its Direct sum by 50-75 %, so there
-    // is nothing of the reference's to be equal to beyond Direct.  It runs through the rotation M2L kernel: p_max <= 12.
-    if (bc && opts->evaluator == FMMBEM_EVAL_FMM && opts->p_max > kRotPmax)
-      for (size_t i = 0; i < n_panels; ++i)
-        if (bc[i]) return fail(FMMBEM_ERR_UNSUPPORTED, "Stokes: the far field of TRACTION targets is built for p_max <= 12");
+    // is nothing of the reference's to be equal to beyond Direct.  Orders up to 12 take the rotation M2L kernel, 13 ... 16 the
+    // double sum over the eleven slots, one slot per pass.
   }
   if (!vertices || n_panels == 0) return fail(FMMBEM_ERR_INVALID, "no panels");
   if (opts->l2l_rule != FMMBEM_L2L_COMPLETE && opts->l2l_rule != FMMBEM_L2L_REFERENCE) return fail(FMMBEM_ERR_INVALID, "unknown l2l_rule");

@@ -116,7 +116,8 @@ def test_adapter_matches_oracle(tmp_path, oracle_mod):
         assert abs(float(st[3 + c]) - u[:, c].sum()) <= 1e-11 * np.abs(u).sum()
     tr = [ln for ln in out if ln[0] == "traction"][0]             # the double layer of the closed sphere on u = (1,0,0): 4 pi u
     assert tr[1] == "accepted" and abs(float(tr[2]) - 1.0) < 2e-2 and float(tr[3]) < 2e-2
-    assert ["traction14", "refused", "6"] in out                # FMMBEM_ERR_UNSUPPORTED above order 12
+    t14 = [ln for ln in out if ln[0] == "traction14"][0]         # orders above 12: the double-sum M2L, slot by slot
+    assert t14[1] == "accepted" and abs(float(t14[2]) - 1.0) < 2e-2 and float(t14[3]) < 2e-2
 
 
 @pytest.mark.gpu

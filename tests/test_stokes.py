@@ -115,11 +115,31 @@ def test_gpu_stokes_traction_far_field_against_direct(fb, oracle_mod):
 
 
 @pytest.mark.gpu
-def test_gpu_stokes_traction_far_field_needs_the_rotation_orders(fb):
-    v = fb.unit_sphere(3)
-    with pytest.raises(fb.FmmBemError) as e:
-        fb.FMM_plan(fb.StokesSphericalBEM(14, 3), v, bc=np.ones(len(v), dtype=np.uint8))
-    assert e.value.status == 6
+def test_gpu_stokes_traction_far_field_above_the_rotation_orders(fb, oracle_mod, monkeypatch):
+    """Orders 13 ... 16 (the reference accepts any p, StokesSphericalBEM.hpp:131-141): the eleven slots of a mixed operator
+    go through the double-sum M2L one slot per pass.  Against Direct the error keeps falling (p = 12: 6.8e-5); at p <= 12 the
+    two M2L kernels give the same operator to rounding (FMMBEM_M2L_ROT=0)."""
+    v = np.concatenate([oracle_mod.unit_sphere(4), oracle_mod.unit_sphere(3, center=(2.6, 0.2, -0.3))])
+    n = len(v)
+    x = drand48(3 * n, seed=23).reshape(n, 3)
+    bc = (np.arange(n) % 3 != 0).astype(np.uint8)
+    o = oracle_mod.StokesOracle(v, K=4, K_fine=19, mu=1e-3, bc=bc)
+    ref = o.direct(x)
+    K = fb.StokesSphericalBEM(16, 4, 1e-3)
+    K.set_Kfine(19)
+    pl = fb.FMM_plan(K, v, bc=bc)
+    errs = {}
+    for p in (10, 12, 13, 14, 16):
+        K.set_p(p)
+        errs[p] = rel_l2(pl.execute(x), ref)
+    assert errs[16] < errs[14] < errs[13] < errs[12] < errs[10] and errs[16] < 0.3 * errs[12], errs
+    K.set_p(12)
+    y_rot = pl.execute(x)
+    monkeypatch.setenv("FMMBEM_M2L_ROT", "0")
+    K2 = fb.StokesSphericalBEM(12, 4, 1e-3)
+    K2.set_Kfine(19)
+    assert rel_l2(fb.FMM_plan(K2, v, bc=bc).execute(x), y_rot) <= 1e-13
+    o.close()
 
 
 @pytest.mark.gpu
