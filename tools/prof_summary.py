@@ -3,7 +3,8 @@
 
   python tools/prof_summary.py kernel-stats <dir> <out.md>        (from --kernel-trace --stats)
   python tools/prof_summary.py pmc <fetch_dir> <write_dir> <out.json> <n_panels> <n_gpus>
-  python tools/prof_summary.py timeline <dir> <out.md> [first kernel]   (from --kernel-trace: one matvec, dispatch by dispatch)
+  python tools/prof_summary.py timeline <dir> <out.md> [first kernel [matvecs to skip at the end]]
+                                                   (from --kernel-trace: one matvec, dispatch by dispatch)
 PMC units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and
 WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming
 read, so the read side of the streaming near_spmv kernel is doubled.
@@ -71,7 +72,7 @@ def pmc(fetch_dir, write_dir, out, n_panels, n_gpus):
     print(json.dumps(res, indent=1))
 
 
-def timeline(d, out, first="gather_x", last_n=8):
+def timeline(d, out, first="gather_x", last_n=8, skip_last=0):
     """One matvec as the GPU saw it (from --kernel-trace): per dispatch its start relative to the matvec's first kernel, its
     duration and the idle gap in front of it, averaged over the last `last_n` matvecs of the trace (a matvec = from one
     `first` kernel to the next; FMMBEM graphs and fused kernels change the dispatch list, not this definition)."""
@@ -81,7 +82,8 @@ def timeline(d, out, first="gather_x", last_n=8):
     starts = [i for i, r in enumerate(rows) if r[2].startswith(first)]
     if len(starts) < last_n + 2:
         raise SystemExit("fewer than %d matvecs in the trace" % (last_n + 2))
-    runs = [rows[starts[k]:starts[k + 1]] for k in range(len(starts) - 1 - last_n, len(starts) - 1)]
+    skip_last = int(skip_last)                   # bench.py: the last 10 matvecs of a run are the fully instrumented pass
+    runs = [rows[starts[k]:starts[k + 1]] for k in range(len(starts) - 1 - last_n - skip_last, len(starts) - 1 - skip_last)]
     n = min(len(r) for r in runs)
     runs = [r for r in runs if len(r) == n]
     with open(out, "w") as o:
@@ -103,6 +105,6 @@ if __name__ == "__main__":
     if sys.argv[1] == "kernel-stats":
         kernel_stats(sys.argv[2], sys.argv[3])
     elif sys.argv[1] == "timeline":
-        timeline(sys.argv[2], sys.argv[3], *sys.argv[4:5])
+        timeline(sys.argv[2], sys.argv[3], *(sys.argv[4:5] or ["gather_x"]), 8, *(sys.argv[5:6] or [0]))
     else:
         pmc(*sys.argv[2:7])
