@@ -28,6 +28,17 @@ def physical_cores():
         return None
 
 
+def mem_cap_bytes():
+    """What the oracle's near matrix may take: 60 % of MemAvailable (16 GB if /proc/meminfo cannot be read)."""
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable:"):
+                return 0.6 * float(ln.split()[1]) * 1024.0
+    except Exception:
+        pass
+    return 16e9
+
+
 def main():
     kind = sys.argv[1]
     args = sys.argv[2:]
@@ -85,7 +96,8 @@ def main():
            "mode": "faithful (serial SpMV/M2M/L2L, OpenMP P2M/M2L/L2P, both expansions)",
            "sample_n": n_s, "sample_s_per_matvec": t_s}
     est_full = t_s * scale
-    if 4 * est_full + build_s * scale <= budget and near_bytes_s * scale <= 16e9:
+    cap = mem_cap_bytes()
+    if 4 * est_full + build_s * scale <= budget and near_bytes_s * scale <= cap:
         o, x = make(r)
         t_f, build_f, reps_f = timed(o, x, p)
         o.close()
@@ -96,8 +108,8 @@ def main():
         res.update(value=1.0 / est_full, extrapolated=True,
                    sample=(what + " N=%d p=%d: %.3f s/matvec (mean of %d after 1 warm-up; near-matrix build %.1f s not counted), "
                            "scaled x%.0f by O(N) to N=%d (the full workload: est. %.0f s for 4 executes + %.0f s build against a budget of %.0f s, "
-                           "%.1f GB of near matrix against a cap of 16)")
-                   % (sample_r, n_s, p, t_s, reps, build_s, scale, n_full, 4 * est_full, build_s * scale, budget, near_bytes_s * scale / 1e9))
+                           "%.1f GB of near matrix against a cap of %.0f)")
+                   % (sample_r, n_s, p, t_s, reps, build_s, scale, n_full, 4 * est_full, build_s * scale, budget, near_bytes_s * scale / 1e9, cap / 1e9))
     print(json.dumps(res))
 
 
