@@ -1061,7 +1061,9 @@ __device__ __forceinline__ void spmv_pipe_run(const DevicePlan& d, double* xs_al
 // that the grid could be any size and a workgroup that shares its CU simply takes fewer -- was built and measured in round 3:
 // inside the pipelined loop it costs the loop its scalar registers (spills, 1.44 ms); with the pipeline restarted per batch
 // every restart is an atomic and three dependent loads at the latency of a saturated memory system, ~60 us: 1.15 ms against
-// 0.70.  profiles/r03d_overlap_near_far.txt.)
+// 0.70.  profiles/r03d_overlap_near_far.txt.  One WAVEFRONT per item, free-running, no barrier at all -- 2.5 % instead of 17 % of
+// the row slots empty on this tree's 19-row leaves -- takes 0.86-0.96 ms whatever it keeps in flight: the set-up of an item is a
+// third of that wavefront's instruction stream.  profiles/r03m_near_spmv_free_running_wavefronts.txt.)
 template <int kRows, int kVecs>
 __global__ __launch_bounds__(kSpmvWaves * kWave, kSpmvOcc) void near_spmv_pipe_kernel(DevicePlan d) {
   extern __shared__ double xs_all[];
