@@ -661,6 +661,42 @@ __global__ __launch_bounds__(kL2LWaves * kWave) void l2l_kernel(DevicePlan d, Sh
 // y_tree[i] += r0 (POTENTIAL target) or -= r1 (NORMAL_DERIV target): the far field joins the near field in TREE order
 // (coalesced; the one scatter to the caller's order comes after, plan.hip).
 // ---------------------------------------------------------------------------------------------
+// The L of a group's leaves into this wavefront's LDS slice, `slots` expansions per leaf ([leaf][slot][S], the flat index of
+// an element IS its LDS index).  Lane k looks up leaf k -- two dependent loads for all leaves at once -- and the copy then has
+// every load of a batch in flight before the first LDS write.  (Leaf by leaf in a loop it was three dependent round trips per
+// leaf, 24 per group, most of the kernel's time: 91 -> see DESIGN.md section 4.)  Returns through the references this lane's leaf
+// within the group, that leaf's first lane, the rows of the group; my_* = what lane k found for leaf k.
+template <class SlotOf>
+__device__ __forceinline__ void l2p_stage_group(const DevicePlan& d, int l0, int nl, int slots, int S, int lane, double2* Lw, SlotOf slot_of,
+                                                int& my_leaf, int& my_box, int& my_nr, int& g, int& first, int& total) {
+  my_leaf = 0; my_box = 0; my_nr = 0;
+  if (lane < nl) { my_leaf = d.l2p_leaf[l0 + lane]; my_box = d.leaf_box[my_leaf]; my_nr = d.leaf_nrows[my_leaf]; }
+  const int per = slots * S, T = nl * per;
+  constexpr int U = 8;
+  for (int e0 = 0; e0 < T; e0 += U * kWave) {
+    double2 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = e0 + u * kWave + lane;
+      const int ee = e < T ? e : T - 1;
+      const int k = ee / per, rem = ee - k * per, a = rem / S, i = rem - a * S;
+      const int box = __shfl(my_box, k, kWave);
+      v[u] = d.L[((size_t)box * d.nslots + slot_of(a)) * d.s_max + i];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = e0 + u * kWave + lane;
+      if (e < T) Lw[e] = v[u];
+    }
+  }
+  g = -1; first = 0; total = 0;
+  for (int k = 0; k < nl; ++k) {
+    const int nr = __shfl(my_nr, k, kWave);
+    if (lane >= total && lane < total + nr) { g = k; first = total; }
+    total += nr;
+  }
+}
+
 constexpr int kL2PLeaves = 8, kL2PWaves = 4;
 // store: y[i] = the far field (the near field runs beside this on another stream and the two meet in the delivery kernel)
 // instead of y[i] += (the near field is already there).
@@ -677,20 +713,13 @@ __global__ __launch_bounds__(kL2PWaves * kWave) void l2p_kernel(DevicePlan d, co
   for (int gi = blockIdx.x * nwaves + wave; gi < d.n_l2p_grp; gi += gridDim.x * nwaves) {
     const int l0 = d.l2p_grp[gi], nl = d.l2p_grp[gi + 1] - l0;
     wave_lds_sync();                                    // the previous group's reads are done
-    int g = -1, first = 0, total = 0;                   // this lane's leaf within the group, its first lane, rows of the group
-    for (int k = 0; k < nl; ++k) {
-      const int leaf = d.l2p_leaf[l0 + k], box = d.leaf_box[leaf], nr = d.leaf_nrows[leaf];
-      for (int a = 0; a < na; ++a) {
-        const double2* src = d.L + ((size_t)box * d.nslots + (a == 0 ? d.act[0] : d.act[1])) * d.s_max;
-        for (int i = lane; i < S; i += kWave) Lw[(size_t)(k * na + a) * S + i] = src[i];
-      }
-      if (lane >= total && lane < total + nr) { g = k; first = total; }
-      total += nr;
-    }
+    int g, first, total, my_leaf, my_box, my_nr;        // this lane's leaf within the group, its first lane, rows of the group
+    const int act0 = d.act[0], act1 = d.act[1];
+    l2p_stage_group(d, l0, nl, na, S, lane, Lw, [&](int a) { return a == 0 ? act0 : act1; }, my_leaf, my_box, my_nr, g, first, total);
     wave_lds_sync();
     if (nl == 1) { g = 0; first = 0; }                  // single leaf: every lane, chunk by chunk
-    const int leaf = d.l2p_leaf[l0 + (g < 0 ? 0 : g)], box = d.leaf_box[leaf];
-    const int row0 = d.leaf_row0[leaf], nrows = d.leaf_nrows[leaf];
+    const int leaf = __shfl(my_leaf, g < 0 ? 0 : g, kWave), box = __shfl(my_box, g < 0 ? 0 : g, kWave);
+    const int row0 = d.leaf_row0[leaf], nrows = __shfl(my_nr, g < 0 ? 0 : g, kWave);
     const double c0 = d.box_center[3 * box], c1 = d.box_center[3 * box + 1], c2 = d.box_center[3 * box + 2];
     for (int chunk = 0; chunk < total; chunk += kWave) {
       const int r_in_leaf = chunk + lane - first;
@@ -751,20 +780,12 @@ __global__ __launch_bounds__(kL2PWaves * kWave) void l2p_stokes_kernel(DevicePla
   for (int gi = blockIdx.x * nwaves + wave; gi < d.n_l2p_grp; gi += gridDim.x * nwaves) {
     const int l0 = d.l2p_grp[gi], nl = d.l2p_grp[gi + 1] - l0;
     wave_lds_sync();
-    int g = -1, first = 0, total = 0;
-    for (int k = 0; k < nl; ++k) {
-      const int leaf = d.l2p_leaf[l0 + k], box = d.leaf_box[leaf], nr = d.leaf_nrows[leaf];
-      for (int e = 0; e < NE; ++e) {
-        const double2* src = d.L + ((size_t)box * d.nslots + SB + e) * d.s_max;
-        for (int i = lane; i < S; i += kWave) Lw[(size_t)(k * NE + e) * S + i] = src[i];
-      }
-      if (lane >= total && lane < total + nr) { g = k; first = total; }
-      total += nr;
-    }
+    int g, first, total, my_leaf, my_box, my_nr;
+    l2p_stage_group(d, l0, nl, NE, S, lane, Lw, [&](int e) { return SB + e; }, my_leaf, my_box, my_nr, g, first, total);
     wave_lds_sync();
     if (nl == 1) { g = 0; first = 0; }
-    const int leaf = d.l2p_leaf[l0 + (g < 0 ? 0 : g)], box = d.leaf_box[leaf];
-    const int row0 = d.leaf_row0[leaf], nrows = d.leaf_nrows[leaf];
+    const int leaf = __shfl(my_leaf, g < 0 ? 0 : g, kWave), box = __shfl(my_box, g < 0 ? 0 : g, kWave);
+    const int row0 = d.leaf_row0[leaf], nrows = __shfl(my_nr, g < 0 ? 0 : g, kWave);
     const double2* Ls = Lw + (size_t)(g < 0 ? 0 : g) * NE * S;
     const double c0 = d.box_center[3 * box], c1 = d.box_center[3 * box + 1], c2 = d.box_center[3 * box + 2];
     for (int chunk = 0; chunk < total; chunk += kWave) {
