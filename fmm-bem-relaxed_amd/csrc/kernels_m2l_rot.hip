@@ -538,9 +538,15 @@ hipError_t launch_rot(const DevicePlan& d, const RotWork& w, int p, hipStream_t 
 #if FMMBEM_ROT_OP == 0
 bool m2l_rot_supported(int p) { return p >= 1 && p <= kRotPmax; }
 
+// L = 0 for the boxes that hold a local expansion but have no M2L source (also in front of the split form, kernels_m2l_rot2.hip)
+hipError_t launch_m2l_rot_zero(const DevicePlan& d, int p, hipStream_t s) {
+  if (d.n_rot_empty > 0) hipLaunchKernelGGL(m2l_rot_zero_kernel, dim3(d.n_rot_empty), dim3(kWave), 0, s, d, p * (p + 1) / 2);
+  return hipGetLastError();
+}
+
 hipError_t launch_m2l_rot(const DevicePlan& d, const DevicePlan* d_dev, int p, hipStream_t s) {
   (void)d_dev;
-  if (d.n_rot_empty > 0) hipLaunchKernelGGL(m2l_rot_zero_kernel, dim3(d.n_rot_empty), dim3(kWave), 0, s, d, p * (p + 1) / 2);
+  if (hipError_t e = launch_m2l_rot_zero(d, p, s); e != hipSuccess) return e;
   RotWork w;
   w.src = d.rot_src; w.cls = d.rot_cls; w.tgt = d.rot_tgt; w.item_ptr = d.rot_item_ptr; w.n_items = d.n_rot_items;
   w.rec = d.rot_cls_rec; w.stream = d.rot_tab + d.rot_tab_off[p - 1];

@@ -100,7 +100,10 @@ inline void build_rot_table(int P, std::vector<double>& out) {
 // k, then j >= k, then n >= k.  The kernel reads the stream sixteen at a time (one 8-byte load per lane, lane & 15) and
 // multiplies by lane k of every 16-lane row (v_fmac_f64_dpp row_newbcast:k).
 constexpr int kRotGroup = 16;
-constexpr int kRotAhead = 8;                        // groups in flight
+#ifndef FMMBEM_ROT_AHEAD
+#define FMMBEM_ROT_AHEAD 8
+#endif
+constexpr int kRotAhead = FMMBEM_ROT_AHEAD;          // groups in flight (kernels_m2l_rot.hip: 8)
 constexpr int rot_kk(int n, int m, int mp) {        // routing phase of entry (m, mp): 0 +Re, 1 +Im, 2 -Re, 3 -Im
   return ((mp == 0 ? m : m + 3 * mp) + ((mp != 0 && ((n + m) & 1)) ? 1 : 0)) & 3;
 }

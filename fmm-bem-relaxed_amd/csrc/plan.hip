@@ -221,6 +221,14 @@ struct fmmbem_plan {
   // FMMBEM_M2L_ROT=0 (A/B runs); FMMBEM_M2L_ROT_MIN / _MAX narrow the range
   int rot_min = 1, rot_max = kRotPmax;
   bool use_rot(int p) const { return p >= rot_min && p <= rot_max && m2l_rot_supported(p); }
+  // the split form of the rotation kernel (kernels_m2l_rot2.hip: a pair on two lanes, two wavefronts per SIMD).  OFF unless
+  // FMMBEM_M2L_ROT2=1: correct (same L to 6e-16) but 0.61-0.66 ms against 0.56 at p = 10 -- the gather of the multipoles,
+  // which the one-pair-per-lane form fetches ahead into AGPRs, has nowhere to go at 256 registers per wavefront
+  // (profiles/r03p_m2l_split_form.txt)
+  bool rot2_on = false;
+  const double* rot2_tab = nullptr;
+  int rot2_off[kRotPmax + 1] = {};
+  bool use_rot2(int p) const { return rot2_on && use_rot(p) && m2l_rot2_supported(p) && rot2_tab != nullptr; }
   int to_device();
   // phase 0: whole matvec; 1: upward half (gather, P2M, M2M of owned boxes, pack -> xbuf); 2: the rest (xbuf = gathered)
   int run(int p, const double* d_x, double* d_y, hipStream_t s, bool near_only, int phase = 0, double* xbuf = nullptr);
@@ -698,6 +706,15 @@ int fmmbem_plan::to_device() {
       all.insert(all.end(), one.begin(), one.end());
     }
     TRY(upload(all, &d.rot_tab));
+    if (const char* e2 = std::getenv("FMMBEM_M2L_ROT2")) rot2_on = std::atoi(e2) != 0;
+    std::vector<double> all2;
+    for (int p = 1; p <= kRotPmax; ++p) {
+      rot2_off[p] = (int)all2.size();
+      if (!m2l_rot2_supported(p)) continue;
+      build_rot2_stream(p, one);
+      all2.insert(all2.end(), one.begin(), one.end());
+    }
+    TRY(upload(all2, &rot2_tab));
   }
 
   mark("m2l class tables");
@@ -955,7 +972,14 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
     if (!rot) HIP_TRY(launch_mh_prep(d, p, s));      // the rotation kernel reads M itself
     HIP_TRY(end(5, s));
     HIP_TRY(begin(6, s));
-    if (rot) HIP_TRY(launch_m2l_rot(d, d_dev, p, s)); else HIP_TRY(launch_m2l(d, d_dev, p, s));
+    if (rot && use_rot2(p)) {
+      HIP_TRY(launch_m2l_rot_zero(d, p, s));
+      RotWork w2;
+      w2.src = d.rot_src; w2.cls = d.rot_cls; w2.tgt = d.rot_tgt; w2.item_ptr = d.rot_item_ptr; w2.n_items = d.n_rot_items;
+      w2.rec = d.rot_cls_rec; w2.stream = rot2_tab + rot2_off[p];
+      HIP_TRY(launch_m2l_rot2(d, w2, p, s));
+    } else if (rot) HIP_TRY(launch_m2l_rot(d, d_dev, p, s));
+    else HIP_TRY(launch_m2l(d, d_dev, p, s));
     HIP_TRY(end(6, s));
     HIP_TRY(begin(7, s));
     TRY(l2l_pass(p, s));

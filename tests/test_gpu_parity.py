@@ -289,6 +289,33 @@ def test_alternative_paths_match_oracle(fb, oracle_mod, monkeypatch, env):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("p", [10, 12])
+def test_split_form_of_the_rotation_m2l(fb, oracle_mod, monkeypatch, p):
+    """FMMBEM_M2L_ROT2=1: the M2L kernel that puts a pair on two lanes (even degrees / odd degrees, kernels_m2l_rot2.hip).  L per
+    box and the result against the oracle, mixed boundary conditions (both expansion slots), two bodies; shards add up bitwise
+    (the reduction is the chain scheme of the one-pair-per-lane kernel in pair space); the two kernels agree to rounding."""
+    v = np.concatenate([oracle_mod.unit_sphere(5), oracle_mod.unit_sphere(4, center=(2.5, 0.3, -0.2))])
+    rng = np.random.default_rng(13)
+    bc = (rng.random(len(v)) < 0.4).astype(np.uint8)
+    x = rng.standard_normal(len(v))
+    o = oracle_mod.Oracle(v, bc=bc)
+    yo = o.matvec(x, p)
+    y_plain = fb.FMM_plan(fb.LaplaceSphericalBEM(p, 3), v, bc=bc).execute(x)
+    monkeypatch.setenv("FMMBEM_M2L_ROT2", "1")
+    pl = fb.FMM_plan(fb.LaplaceSphericalBEM(p, 3), v, bc=bc)
+    y = pl.execute(x)
+    got, ref = pl.expansions("L", p), o.expansions(p, "L")
+    scale = np.abs(ref).max(axis=2, keepdims=True) + 1e-300
+    assert np.max(np.abs(got - ref) / scale) <= TOL_EXPANSION
+    assert rel_l2(y, yo) <= TOL_MATVEC
+    assert rel_l2(y, y_plain) <= 1e-14
+    total = np.zeros_like(y)
+    for r in range(3):
+        total += fb.FMM_plan(fb.LaplaceSphericalBEM(p, 3), v, bc=bc, shard=(r, 3)).execute(x)
+    assert np.array_equal(total, y)
+
+
+@pytest.mark.gpu
 def test_graph_replay_is_bitwise_the_launch_chain(fb, oracle_mod):
     """fmmbem_plan_set_graphs: from its second execute at an order on, the chain between gather and delivery is a captured
     hipGraph launched on the caller's stream -- the same kernels in the same order, so the same bits as launch by launch, for
