@@ -63,3 +63,21 @@ def test_two_shards_sum_bitwise(fb, big):
         assert np.count_nonzero(yp) < plan.n                    # zero outside the owned rows
         total += yp
     assert np.array_equal(total, y)
+
+
+def test_matrix_free_near_field_at_full_size(fb, big):
+    """sparse_local = 0 at N = 1 048 576: no near matrix (4.1 GB), the near-regime pairs -- a few per cent of the near pairs --
+    listed and evaluated once, the far regime recomputed per matvec: the operator of the assembled plan to rounding, linear,
+    repeatable bit for bit."""
+    v, plan = big
+    fo = fb.FMMOptions()
+    fo.sparse_local = False
+    mf = fb.FMM_plan(fb.LaplaceSphericalBEM(10, 3), v, fo, p_max=10)
+    st = mf.stats()
+    assert st["near_bytes"] == 0 and 0.02 * st["near_nnz"] < st["near_side_entries"] < 0.08 * st["near_nnz"]
+    rng = np.random.default_rng(14)
+    x = rng.standard_normal(plan.n)
+    y = mf.execute(x)
+    assert np.linalg.norm(y - plan.execute(x)) <= 1e-13 * np.linalg.norm(y)
+    assert np.array_equal(mf.execute(x), y)
+    mf.close()
