@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Whole-matvec time on the bench input (N = 1 048 576) per order under environment settings -- a tuning aid.
-  python tools/lowp_overlap.py "FMMBEM_OVERLAP_NEAR=0" "FMMBEM_OVERLAP_NEAR=1,FMMBEM_NEAR_WGS=3" ... [-- p p p]
+  python tools/matvec_sweep.py "FMMBEM_OVERLAP_NEAR=0" "FMMBEM_OVERLAP_NEAR=1,FMMBEM_NEAR_WGS=3" ... [-- p p p]
 Each setting = comma-separated NAME=VALUE, applied before the plan is created (plan.hip reads them then); the result of
 every setting is compared bit for bit with the first one's."""
 import os
