@@ -473,7 +473,7 @@ __global__ __launch_bounds__(256) void near_matfree_kernel(DevicePlan d) {
 //   * a row's sum is formed in a fixed order: column groups in order, then the lanes' tree sum, then the list.
 // ---------------------------------------------------------------------------------------------
 #ifndef FMMBEM_MF_ROWS
-#define FMMBEM_MF_ROWS 32
+#define FMMBEM_MF_ROWS 24                             /* N = 1M, K = 3 (near ms): 12 rows 2.04, 16 1.96, 20 1.90, 24 1.85 (122 VGPRs), 28 2.21, 32 2.11, 40 2.19 */
 #endif
 constexpr int kMfRows = FMMBEM_MF_ROWS;               // rows per block: their partial sums live in registers (2 VGPRs each)
 
@@ -501,7 +501,9 @@ __device__ __noinline__ double mf_far_general(const DevicePlan& d, int64_t j, do
 enum MfMode { kMfCount = 0, kMfFill = 1, kMfApply = 2 };
 
 // side_cnt (COUNT): listed pairs per tree-order row; side_ptr / side_col (FILL): the CSR being filled; APPLY: d.side_*
-template <int MODE>
+// GEN: rules of more than three points (the points re-read per row by a called function, whose frame costs the kernel a third
+// of its registers: 209 instead of 139 VGPRs) -- the reference's K = 1, 3 take the kernel without it
+template <int MODE, bool GEN>
 __global__ __launch_bounds__(kWave) void mf_sweep_kernel(DevicePlan d, int* __restrict__ side_cnt, const int64_t* __restrict__ side_ptr,
                                                          int* __restrict__ side_col) {
   extern __shared__ int mf_lds[];
@@ -570,7 +572,9 @@ __global__ __launch_bounds__(kWave) void mf_sweep_kernel(DevicePlan d, int* __re
                   const double ir = rsqrt_pos(fma(ex, ex, fma(ey, ey, ez * ez)));
                   if (dn) v = fma(wA[q] * fma(ex, nx, fma(ey, ny, ez * nz)), ir * ir * ir, v); else v = fma(wA[q], ir, v);
                 }
-              } else if (valid && !slow) v = mf_far_general(d, j, tx, ty, tz, dn, A, nx, ny, nz);
+              } else if constexpr (GEN) {
+                if (valid && !slow) v = mf_far_general(d, j, tx, ty, tz, dn, A, nx, ny, nz);
+              }
               // lanes past the last column ran the arithmetic against panel 0: its value may be inf/NaN (K = 1: the only point of
               // panel 0 IS the centroid of row 0) and NaN * 0 is NaN -- masked by validity, not by xj = 0
               acc[r] = fma((slow || !valid) ? 0.0 : v, xj, acc[r]);
@@ -616,7 +620,7 @@ __global__ __launch_bounds__(kWave) void mf_sweep_kernel(DevicePlan d, int* __re
 // one reciprocal square root per point; listed pairs (near regime: the K_fine rule; self: Fata's closed form / 2 pi I) come
 // from the list with their 3 x 3 blocks.  Rows in blocks of kMfRows3 (three partial sums each in registers).
 #ifndef FMMBEM_MF_ROWS3
-#define FMMBEM_MF_ROWS3 16
+#define FMMBEM_MF_ROWS3 24                            /* red blood cell N = 524 288 (near ms): 8 rows 2.60, 12 2.35, 16 2.21, 20 2.15, 24 2.10 (243 VGPRs) */
 #endif
 constexpr int kMfRows3 = FMMBEM_MF_ROWS3;
 __global__ __launch_bounds__(kWave) void mf_sweep3_apply_kernel(DevicePlan d) {
@@ -1260,7 +1264,9 @@ hipError_t launch_near_matfree(const DevicePlan& d, hipStream_t s) {
   }
   if (!(v1 && atoi(v1) != 0) && d.side_ptr) {
     const size_t lds2 = 2 * (size_t)d.max_runs * sizeof(int);
-    hipLaunchKernelGGL(mf_sweep_kernel<kMfApply>, dim3(d.near_nitems < 256 * 16 ? d.near_nitems : 256 * 16), dim3(kWave), lds2, s, d, nullptr, nullptr, nullptr);
+    const dim3 g(d.near_nitems < 256 * 16 ? d.near_nitems : 256 * 16);
+    if (d.nq <= 3) hipLaunchKernelGGL((mf_sweep_kernel<kMfApply, false>), g, dim3(kWave), lds2, s, d, nullptr, nullptr, nullptr);
+    else hipLaunchKernelGGL((mf_sweep_kernel<kMfApply, true>), g, dim3(kWave), lds2, s, d, nullptr, nullptr, nullptr);
     return hipGetLastError();
   }
   const size_t lds = (size_t)kAsmChunk * (sizeof(double) + sizeof(int)) + 2 * (size_t)d.max_runs * sizeof(int);
@@ -1275,8 +1281,8 @@ hipError_t launch_mf_side(const DevicePlan& d, int phase, int* side_cnt, const i
   if (d.near_nitems <= 0) return hipSuccess;
   const size_t lds2 = 2 * (size_t)d.max_runs * sizeof(int);
   const dim3 g(d.near_nitems < 256 * 16 ? d.near_nitems : 256 * 16), b(kWave);
-  if (phase == 0) hipLaunchKernelGGL(mf_sweep_kernel<kMfCount>, g, b, lds2, s, d, side_cnt, nullptr, nullptr);
-  else if (phase == 1) hipLaunchKernelGGL(mf_sweep_kernel<kMfFill>, g, b, lds2, s, d, nullptr, side_ptr, side_col);
+  if (phase == 0) hipLaunchKernelGGL((mf_sweep_kernel<kMfCount, false>), g, b, lds2, s, d, side_cnt, nullptr, nullptr);
+  else if (phase == 1) hipLaunchKernelGGL((mf_sweep_kernel<kMfFill, false>), g, b, lds2, s, d, nullptr, side_ptr, side_col);
   else if (nside > 0) hipLaunchKernelGGL(mf_side_eval_kernel, dim3((unsigned)((nside + 255) / 256)), dim3(256), 0, s, d, side_row, side_col, side_val, nside);
   return hipGetLastError();
 }
