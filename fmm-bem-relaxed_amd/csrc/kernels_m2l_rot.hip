@@ -272,7 +272,11 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(rot_waves
   constexpr int PF = rot_prefetch(P);
   constexpr bool kAhead = rot_waves(P) == 1 && OP == kRotM2L;   // fetch the next pass's operands ahead (NextPass); with several
                                                       // wavefronts per SIMD the others cover the loads, and registers are scarce
-  for (int q = 0; q < d.n_act; ++q) {
+  // M2L: a wavefront takes the item's pairs through every active expansion slot in turn (tens of passes per SIMD either way).
+  // The shifts: one slot per wavefront (blockIdx.y) -- a level is a single pass on a chip that is not full, and what one waits for
+  // is the length of one wavefront's program
+  const int q_begin = OP == kRotM2L ? 0 : (int)blockIdx.y, q_end = OP == kRotM2L ? d.n_act : q_begin + 1;
+  for (int q = q_begin; q < q_end; ++q) {
     const int slot = d.act[q];
     const double2* Mslot = (OP == kRotL2L ? d.L : d.M) + (size_t)slot * d.s_max;      // the operand: M, or the parent's L
     const size_t box_stride = (size_t)d.nslots * d.s_max;
@@ -516,7 +520,7 @@ hipError_t launch_rot(const DevicePlan& d, const RotWork& w, int p, hipStream_t 
   if (w.n_items <= 0) return hipSuccess;
   constexpr int CH = FMMBEM_ROT_XCD_CHUNK;
   const int grid = (w.n_items + 8 * CH - 1) / (8 * CH) * (8 * CH);
-#define ROT_CASE(PP) case PP: hipLaunchKernelGGL((ROT_KERNEL<PP>), dim3(grid), dim3(kWave), 0, s, d, w); break;
+#define ROT_CASE(PP) case PP: hipLaunchKernelGGL((ROT_KERNEL<PP>), dim3(grid, OP == kRotM2L ? 1 : d.n_act), dim3(kWave), 0, s, d, w); break;
   switch (p) {
 #ifdef FMMBEM_ROT_ONLY                                 // experiment builds (tools/rot_variant.sh): one order, 20 s instead of 3.5 min
     ROT_CASE(FMMBEM_ROT_ONLY)
