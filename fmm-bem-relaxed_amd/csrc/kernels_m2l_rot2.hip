@@ -170,9 +170,6 @@ constexpr int rot2_tile(int P) {                      // coefficients per reduct
   return 1;
 }
 
-// pairs staged in LDS at a time by the gather at the head of a pass (rows of S | 1 double2 beside the carry, in a wavefront's 20 KB)
-constexpr int rot2_stage_pairs(int P) { return P <= 10 ? 16 : 8; }
-
 // first lane (the E lane) of pair j of a pass
 __device__ __forceinline__ int lane_of_pair(int j) { return (j & 15) | ((j >> 4) << 5); }
 
@@ -181,13 +178,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
   constexpr int S = P * (P + 1) / 2, Q = rot2_pairs(P), NS = rot2_nslots(P);
   constexpr int KT = rot2_tile(P);
   constexpr int NT = (S + KT - 1) / KT;
-  // one buffer, two uses that never overlap in a pass: the staging rows of the gather at the head (kStageG pairs x SR) and the
-  // reduction tile [KT][kRow2] at the end
-  constexpr int SR = S | 1;                            // row stride in double2, odd: lanes that read one coefficient of 16 different rows hit 16 x 4 different banks
-  constexpr int kStageG = rot2_stage_pairs(P);
-  constexpr int kBufN = KT * kRow2 > kStageG * SR ? KT * kRow2 : kStageG * SR;
-  __shared__ double2 buf[kBufN];
-  double2 (*tile)[kRow2] = reinterpret_cast<double2 (*)[kRow2]>(buf);
+  __shared__ double2 tile[KT][kRow2];
   __shared__ double2 carry[S][kChains];
   const int lane = threadIdx.x;
   int par = (lane >> 4) & 1;                           // 0: E lane (even degrees), 1: O lane (odd degrees)
@@ -233,10 +224,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
       // (round 3 also tried the multipoles re-laid-out per parity by a preparation kernel -- one base address and immediates per
       // lane, four cache lines of its own: 0.74 ms against 0.66, the preparation pass costs more than the loads gain)
       double a[NS], b[NS];
-#ifdef FMMBEM_ROT2_LANE_GATHER
       {
-        // every lane fetches its own 30 pieces of 16 bytes: 64 cache lines per instruction, ~100 cycles of the CU's one address
-        // path per pair -- 0.35 ms per launch at p = 10, which two wavefronts per SIMD do not hide (profiles/r03p)
         const double2* M = Mslot + (size_t)src * box_stride;
         static_for<0, Q>([&](auto Q_) FMMBEM_INLINE {
           constexpr int q = decltype(Q_)::value;
@@ -251,58 +239,6 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
           });
         });
       }
-#else
-      {
-        // the gather, row by row: one instruction loads one pair's whole multipole (S x 16 bytes in a row: 7 cache lines, lane =
-        // coefficient), kStageG rows go to LDS, and the lanes of those pairs pick their half out of their row
-        constexpr int NR = (S + kWave - 1) / kWave;      // instructions per row (S = 78 at p = 12)
-        // opaque per pass, like the parity: the 16 + 30 LDS addresses derived from them would otherwise be computed once, kept
-        // across the pass loop and spilled (a scratch load and a full wait between every two LDS writes)
-        int lane_ = lane, pj_ = pj;
-        asm volatile("" : "+v"(lane_), "+v"(pj_));
-        static_for<0, kPairs / kStageG>([&](auto G_) FMMBEM_INLINE {
-          constexpr int g = decltype(G_)::value;
-          double2 r[kStageG][NR];
-#pragma unroll
-          for (int j = 0; j < kStageG; ++j) {
-#ifdef FMMBEM_ROT2_EXP_SRC0                            // experiment: every pair reads one of 64 rows (the gather without the memory system)
-            const int sj = __builtin_amdgcn_readlane(src, lane_of_pair(g * kStageG + j)) & 63;
-#else
-            const int sj = __builtin_amdgcn_readlane(src, lane_of_pair(g * kStageG + j));
-#endif
-#pragma unroll
-            for (int k = 0; k < NR; ++k) {
-              int c = lane_ + k * kWave;
-#ifdef FMMBEM_ROT2_EXP_HALFROW                          // experiment: half the bytes of every row
-              c &= 31;
-#endif
-              r[j][k] = (Mslot + (size_t)sj * box_stride)[c < S ? c : S - 1];
-            }
-          }
-#pragma unroll
-          for (int j = 0; j < kStageG; ++j)
-#pragma unroll
-            for (int k = 0; k < NR; ++k) if (lane_ + k * kWave < S) buf[j * SR + lane_ + k * kWave] = r[j][k];
-          wave_sync();
-          if (pj_ / kStageG == g) {
-            const double2* row = buf + (pj_ % kStageG) * SR;
-            static_for<0, Q>([&](auto Q_) FMMBEM_INLINE {
-              constexpr int q = decltype(Q_)::value;
-              static_for<0, 2 * q + 2>([&](auto T_) FMMBEM_INLINE {
-                constexpr int t = decltype(T_)::value;
-                constexpr bool has_o = 2 * q + 1 < P, has_e = t >= 1;
-                constexpr int io = has_o ? idx_of(2 * q + 1, t) : 0, ie_ = has_e ? idx_of(2 * q, t - 1) : 0;
-                const bool has = odd ? has_o : has_e;
-                const double2 v = row[odd ? io : ie_];
-                a[rot2_sidx(q, t)] = has ? v.x : 0.0;
-                b[rot2_sidx(q, t)] = has ? v.y : 0.0;
-              });
-            });
-          }
-          wave_sync();
-        });
-      }
-#endif
       const double* cr = w.rec + (size_t)cls * 8;
       const double inv_rho = cr[0], ca = cr[1], sa = cr[2], cb = cr[3], sb = cr[4];
       const double inv2 = inv_rho * inv_rho;
