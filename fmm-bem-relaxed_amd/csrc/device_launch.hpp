@@ -34,6 +34,7 @@ bool shift_rot_supported(int p);
 hipError_t launch_m2m_rot(const DevicePlan& d, const RotWork& w, int p, hipStream_t s);   // M[tgt = parent] = sum over its children
 hipError_t launch_l2l_rot(const DevicePlan& d, const RotWork& w, int p, hipStream_t s);   // L[tgt = child] += shift of L[src = parent]
 hipError_t launch_m2l_rot(const DevicePlan& d, const DevicePlan* d_dev, int p, hipStream_t s);
+bool m2l_rot_long_items(int p);
 hipError_t launch_m2l_rot_zero(const DevicePlan& d, int p, hipStream_t s);
 // the split form (kernels_m2l_rot2.hip): a pair on two lanes, two wavefronts per SIMD; w.stream = build_rot2_stream(p)
 bool m2l_rot2_supported(int p);

@@ -124,6 +124,7 @@ struct DevicePlan {
   // {1/rho, cos alpha, sin alpha, cos beta, sin beta, 0, 0, 0}; per order p the constants in consumption order
   const int *rot_src = nullptr, *rot_cls = nullptr, *rot_tgt = nullptr, *rot_item_ptr = nullptr;
   int n_rot_items = 0;
+  const int* rot_item_ptr_long = nullptr;  int n_rot_items_long = 0;   // the same pairs in long items, for the orders at one wavefront per SIMD
   const int* rot_empty = nullptr;   int n_rot_empty = 0;      // targets without a source of their own: L = 0
   const double* rot_cls_rec = nullptr;
   const double* rot_tab = nullptr;  int rot_tab_off[12] = {};

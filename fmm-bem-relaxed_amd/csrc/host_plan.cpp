@@ -622,14 +622,23 @@ void partition_leaves(const HostPlan& hp, int world, std::vector<int>& cut) {
 // (the kernel carries its chain sums across, kernels_m2l_rot.hip), so the only idle lanes are those of an item's last pass:
 // each cut goes to the target boundary, among those around the nominal item length, that leaves the fewest.  Items of up to
 // kRotItemPasses passes when there are enough pairs to keep every SIMD of the chip busy several times over with them, shorter
-// ones on small operators.  Lane fill at N = 1M: 0.97 (0.73 for items of whole targets in at most one pass).
+// ones on small operators.  Two cuts of the same list (the reduction does not depend on the cut, so the two give the same bits):
+//   short items (2 passes) for the orders with two or four wavefronts per SIMD, where the neighbours cover an item's first pass:
+//     M2L ms at N = 1M with items of 2 / 4 / 15 passes: p = 2 0.039 / 0.041 / 0.050, p = 4 0.080 / 0.086 / 0.108, p = 8 0.290 / 0.299 / 0.318
+//   long items for the orders with ONE wavefront per SIMD (p >= 9): two even rounds over the chip's 1 024 SIMDs, at most 16 passes:
+//     p = 9 0.451 / 0.447 / 0.437, p = 10 0.571 (4) / 0.538 (15), p = 11 0.809 / 0.803 / 0.785, p = 12 1.042 (4) / 1.017 (15)
+//     (30 passes in 1 030 items, a second round of thirty items: 0.918 at p = 10)
 void HostPlan::build_rot_items() {
-  constexpr int kLanes = 64, kItemsWanted = 4 * 1024;
-  int kRotItemPasses = 4;
+  constexpr int kLanes = 64, kSimds = 1024;
+  int kItemsWanted = 4 * 1024, kRotItemPasses = 2, kRotLongRounds = 2, kRotLongMax = 16;
   if (const char* e = std::getenv("FMMBEM_ROT_ITEM_PASSES")) kRotItemPasses = std::max(1, std::atoi(e));   // tuning runs
+  if (const char* e = std::getenv("FMMBEM_ROT_ITEMS_WANTED")) kItemsWanted = std::max(1, std::atoi(e));
+  if (const char* e = std::getenv("FMMBEM_ROT_LONG_ROUNDS")) kRotLongRounds = std::max(1, std::atoi(e));
+  if (const char* e = std::getenv("FMMBEM_ROT_LONG_MAX")) kRotLongMax = std::max(1, std::atoi(e));
   rot_src.clear(); rot_cls.clear(); rot_tgt.clear(); rot_empty.clear();
   rot_item_ptr.assign(1, 0);
-  rot_passes = 0;
+  rot_item_ptr_long.assign(1, 0);
+  rot_passes = rot_passes_long = 0;
   std::vector<int> tg;                                 // owned targets with sources, box order
   for (int b = 0; b < nboxes; ++b) {
     if (!(has_L[b] && owned_L[b])) continue;
@@ -643,6 +652,17 @@ void HostPlan::build_rot_items() {
   for (size_t i = 0; i < tg.size(); ++i) len[i] = m2l_ptr[tg[i] + 1] - m2l_ptr[tg[i]];
   rot_item_ptr.clear();
   rot_passes = cut_rot_items(len, nominal, 0, rot_item_ptr);
+  const int64_t all_passes = ((int64_t)rot_src.size() + kLanes - 1) / kLanes;
+  const int64_t slots = (int64_t)kSimds * kRotLongRounds;
+  int long_passes = (int)std::max<int64_t>(nominal / kLanes, std::min<int64_t>(kRotLongMax, (all_passes + slots - 1) / slots));
+  for (;;) {
+    rot_item_ptr_long.clear();
+    rot_passes_long = cut_rot_items(len, kLanes * long_passes, 0, rot_item_ptr_long);
+    // a handful of items beyond the last even round would run alone at the end (1 030 items of 30 passes: 0.92 ms against 0.54)
+    const int64_t n = (int64_t)rot_item_ptr_long.size() - 1;
+    if (n <= slots || long_passes >= kRotLongMax + 8 || n < kSimds) break;
+    ++long_passes;
+  }
 }
 
 int64_t HostPlan::cut_rot_items(const std::vector<int>& seg_len, int nominal, int pair_base, std::vector<int>& item_ptr) {

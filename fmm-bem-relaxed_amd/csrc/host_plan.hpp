@@ -106,6 +106,10 @@ struct HostPlan {
   // 64 pairs (one wavefront pass, lane = pair); a target with more than 64 sources is an item of its own (several passes)
   std::vector<int> rot_src, rot_cls, rot_tgt, rot_item_ptr, rot_empty;   // rot_empty: owned targets with no source at all
   int64_t rot_passes = 0;
+  // the same pairs cut into LONG items for the orders that run one wavefront per SIMD (p >= 9): there the chip holds 1 024
+  // wavefronts at a time, the first pass of an item stands in the open, and two even rounds of long items beat seven of short ones
+  std::vector<int> rot_item_ptr_long;
+  int64_t rot_passes_long = 0;
   void build_rot_items();
   // cut a run of targets (pairs per target in seg_len) into items of about `nominal` pairs; appends the boundaries, as
   // positions in the pair list starting at pair_base, to item_ptr (n_items + 1 entries); returns the 64-pair passes

@@ -541,6 +541,8 @@ hipError_t launch_rot(const DevicePlan& d, const RotWork& w, int p, hipStream_t 
 
 #if FMMBEM_ROT_OP == 0
 bool m2l_rot_supported(int p) { return p >= 1 && p <= kRotPmax; }
+// the orders that run one wavefront per SIMD take the long items (host_plan.cpp build_rot_items)
+bool m2l_rot_long_items(int p) { return p >= 1 && p <= kRotPmax && rot_waves(p) == 1; }
 
 // L = 0 for the boxes that hold a local expansion but have no M2L source (also in front of the split form, kernels_m2l_rot2.hip)
 hipError_t launch_m2l_rot_zero(const DevicePlan& d, int p, hipStream_t s) {
@@ -552,7 +554,9 @@ hipError_t launch_m2l_rot(const DevicePlan& d, const DevicePlan* d_dev, int p, h
   (void)d_dev;
   if (hipError_t e = launch_m2l_rot_zero(d, p, s); e != hipSuccess) return e;
   RotWork w;
-  w.src = d.rot_src; w.cls = d.rot_cls; w.tgt = d.rot_tgt; w.item_ptr = d.rot_item_ptr; w.n_items = d.n_rot_items;
+  w.src = d.rot_src; w.cls = d.rot_cls; w.tgt = d.rot_tgt;
+  if (m2l_rot_long_items(p)) { w.item_ptr = d.rot_item_ptr_long; w.n_items = d.n_rot_items_long; }
+  else { w.item_ptr = d.rot_item_ptr; w.n_items = d.n_rot_items; }
   w.rec = d.rot_cls_rec; w.stream = d.rot_tab + d.rot_tab_off[p - 1];
   if (hipError_t e = launch_rot(d, w, p, s); e != hipSuccess) return e;
   return hipGetLastError();

@@ -692,6 +692,8 @@ int fmmbem_plan::to_device() {
     d.n_rot_empty = (int)hp.rot_empty.size();
     TRY(upload(hp.rot_src, &d.rot_src)); TRY(upload(hp.rot_cls, &d.rot_cls)); TRY(upload(hp.rot_tgt, &d.rot_tgt));
     TRY(upload(hp.rot_item_ptr, &d.rot_item_ptr)); TRY(upload(hp.rot_empty, &d.rot_empty));
+    d.n_rot_items_long = (int)hp.rot_item_ptr_long.size() - 1;
+    TRY(upload(hp.rot_item_ptr_long, &d.rot_item_ptr_long));
     std::vector<double> rec((size_t)n_classes * 8, 0.0);
     for (int64_t c = 0; c < n_classes; ++c) {
       double tr[3];
@@ -975,7 +977,7 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
     if (rot && use_rot2(p)) {
       HIP_TRY(launch_m2l_rot_zero(d, p, s));
       RotWork w2;
-      w2.src = d.rot_src; w2.cls = d.rot_cls; w2.tgt = d.rot_tgt; w2.item_ptr = d.rot_item_ptr; w2.n_items = d.n_rot_items;
+      w2.src = d.rot_src; w2.cls = d.rot_cls; w2.tgt = d.rot_tgt; w2.item_ptr = d.rot_item_ptr; w2.n_items = d.n_rot_items;   // two wavefronts per SIMD: short items
       w2.rec = d.rot_cls_rec; w2.stream = rot2_tab + rot2_off[p];
       HIP_TRY(launch_m2l_rot2(d, w2, p, s));
     } else if (rot) HIP_TRY(launch_m2l_rot(d, d_dev, p, s));
@@ -1206,7 +1208,9 @@ int fmmbem_plan_stats(const fmmbem_plan* plan, fmmbem_stats* o) {
   o->owned_leaf_begin = h.leaf_begin; o->owned_leaf_end = h.leaf_end;
   o->owned_row_begin = h.row_begin; o->owned_row_end = h.row_end;
   o->near_bytes = plan->near_bytes;
-  o->m2l_items = (int64_t)h.rot_item_ptr.size() - 1; o->m2l_passes = h.rot_passes;
+  const bool long_items = plan->last_p > 0 && m2l_rot_long_items(plan->last_p) && plan->use_rot(plan->last_p) && !plan->use_rot2(plan->last_p);   // the cut the last execute ran
+  o->m2l_items = (int64_t)(long_items ? h.rot_item_ptr_long : h.rot_item_ptr).size() - 1;
+  o->m2l_passes = long_items ? h.rot_passes_long : h.rot_passes;
   o->near_side_entries = plan->near_side_entries;
   o->m2l_kernel = plan->last_p > 0 ? (plan->use_rot(plan->last_p) ? 1 : plan->last_p <= 4 ? 3 : 2) : 0;
   o->expansions_active = (h.has_bc[0] ? 1 : 0) | (h.has_bc[1] ? 2 : 0);
