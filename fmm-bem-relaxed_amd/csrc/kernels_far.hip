@@ -23,8 +23,10 @@
 // (j,k) outputs, Yh staged in LDS, Mh read through the scalar cache (wave-uniform), L accumulated
 // in registers over the whole source list and written once -- no atomics, fixed summation order.
 #include "device_launch.hpp"
+#define FMMBEM_INLINE __attribute__((always_inline))
 
 #include <mutex>
+#include <type_traits>
 
 namespace fmmbem {
 
@@ -698,10 +700,20 @@ __device__ __forceinline__ void l2p_stage_group(const DevicePlan& d, int l0, int
 }
 
 constexpr int kL2PLeaves = 8, kL2PWaves = 4;
+// Stokes stages 4 or 7 expansions per leaf: with room for 8 leaves a wavefront's LDS slice (18 KB at p = 8) leaves two wavefronts per
+// SIMD; groups of at most 4 leaves (plan.hip asks l2p_group_leaves) halve it
+constexpr int kL2PLeavesStokes = 4;
+constexpr int kL2PUnrollMax = 12;                     // orders with an L2P kernel of their own (the orders of the rotation kernels)
+static bool l2p_generic() { const char* e = std::getenv("FMMBEM_L2P_GENERIC"); return e && std::atoi(e) != 0; }   // A/B runs
 // store: y[i] = the far field (the near field runs beside this on another stream and the two meet in the delivery kernel)
 // instead of y[i] += (the near field is already there).
-__global__ __launch_bounds__(kL2PWaves * kWave) void l2p_kernel(DevicePlan d, const int P, double* __restrict__ y, const int store) {
+// PT > 0: the order at compile time -- both loops unrolled, every table entry and every coefficient at a constant LDS offset,
+// no loop counters or index arithmetic left (the runtime-order loop spends more instructions on those than on the recurrences:
+// L2P at N = 1M, p = 10: 0.089 ms generic, see DESIGN.md section 4 for the unrolled figure).  PT = 0: any order (p > kL2PUnrollMax).
+template <int PT>
+__global__ __launch_bounds__(kL2PWaves * kWave) __attribute__((amdgpu_waves_per_eu(4))) void l2p_kernel(DevicePlan d, const int Prt, double* __restrict__ y, const int store) {
   extern __shared__ double2 l2p_lds[];                  // step tables (3 S doubles), then [wave][leaf][active slot][S]
+  const int P = PT > 0 ? PT : Prt;
   const int S = P * (P + 1) / 2, na = d.n_act;
   double* sPref = reinterpret_cast<double*>(l2p_lds);
   double* sC1 = sPref + S;
@@ -730,26 +742,45 @@ __global__ __launch_bounds__(kL2PWaves * kWave) void l2p_kernel(DevicePlan d, co
       const Sph s = cart2sph(d.cx[i] - c0, d.cy[i] - c1, d.cz[i] - c2);
       double r = 0;
       double pn = 1, rhom = 1, er = 1, ei = 0, fact = 1;
-      int step = 0;
-#pragma nounroll
-      for (int m = 0; m < P; ++m) {
+      auto order = [&](int m, int& step, auto unrolled) FMMBEM_INLINE {
+        // unrolled: an offset the compiler cannot see through, tied to the sum so far -- at constant addresses all 4 S LDS reads of
+        // a row are otherwise issued at its head (or lifted out of the chunk loop): 512 VGPRs and scratch at p = 10
+        int tz = 0;
+        if constexpr (decltype(unrolled)::value) asm volatile("" : "+v"(tz), "+v"(r));
+        const double *tPref = sPref + tz, *tC1 = sC1 + tz, *tC2 = sC2 + tz;
+        const double2* Lm = Lt + tz;
         double p = pn, p1 = p, rhon = rhom;
         const double w = m == 0 ? 1.0 : 2.0;
-#pragma nounroll
-        for (int n = m; n < P; ++n, ++step) {
-          const double mag = rhon * p * sPref[step];
-          const double2 Lc = Lt[n * (n + 1) / 2 + m];
+        auto degree = [&](int n) FMMBEM_INLINE {
+          const double mag = rhon * p * tPref[step];
+          const double2 Lc = Lm[n * (n + 1) / 2 + m];
           r += w * (Lc.x * (mag * er) - Lc.y * (mag * ei));        // Re(L * Ynm), Ynm = mag e^{+i m beta}
           const double pcur = p;
-          p = sC1[step] * s.ca * pcur - sC2[step] * p1;
+          p = tC1[step] * s.ca * pcur - tC2[step] * p1;
           p1 = pcur;
           rhon *= s.rho;
+          ++step;
+        };
+        if constexpr (decltype(unrolled)::value) {
+#pragma unroll
+          for (int n = m; n < PT; ++n) degree(n);
+        } else {
+#pragma nounroll
+          for (int n = m; n < P; ++n) degree(n);
         }
         pn = -pn * fact * s.sa;
         fact += 2;
         rhom *= s.rho;
         const double nr = er * s.cb - ei * s.sb, ni = er * s.sb + ei * s.cb;
         er = nr; ei = ni;
+      };
+      int step = 0;
+      if constexpr (PT > 0) {
+#pragma unroll
+        for (int m = 0; m < PT; ++m) order(m, step, std::true_type{});
+      } else {
+#pragma nounroll
+        for (int m = 0; m < P; ++m) order(m, step, std::false_type{});
       }
       y[i] = (store ? 0.0 : y[i]) + (tb ? -r : r);
     }
@@ -765,16 +796,18 @@ __global__ __launch_bounds__(kL2PWaves * kWave) void l2p_kernel(DevicePlan d, co
 // ---------------------------------------------------------------------------------------------
 // TRAC: the rows of TRACTION targets, from the seven potentials of the double layer (p2m_apply_kernel<3>):
 //   t_i = x_k d_i Psi_k - d_i Psi_0 - Theta_i     (slots 4..6 Psi_k, 7 Psi_0: gradients; 8..10 Theta_i: values; no 1/(2 mu))
-template <bool TRAC>
-__global__ __launch_bounds__(kL2PWaves * kWave) void l2p_stokes_kernel(DevicePlan d, const int P, double* __restrict__ y, const int store) {
+// PT as in l2p_kernel: the order at compile time (both loops unrolled) or 0 for any order.
+template <bool TRAC, int PT>
+__global__ __launch_bounds__(kL2PWaves * kWave) __attribute__((amdgpu_waves_per_eu(PT > 0 ? 2 : 1))) void l2p_stokes_kernel(DevicePlan d, const int Prt, double* __restrict__ y, const int store) {
   constexpr int NE = TRAC ? 7 : 4, SB = TRAC ? 4 : 0;   // potentials staged per leaf, first slot
   extern __shared__ double2 l2p_lds[];                  // as l2p_kernel: step tables, then [wave][leaf][4 potentials][S]
+  const int P = PT > 0 ? PT : Prt;
   const int S = P * (P + 1) / 2;
   double* sPref = reinterpret_cast<double*>(l2p_lds);
   double* sC1 = sPref + S;
   double* sC2 = sC1 + S;
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, nwaves = blockDim.x / kWave;
-  double2* Lw = l2p_lds + (3 * S + 1) / 2 + (size_t)wave * kL2PLeaves * NE * S;
+  double2* Lw = l2p_lds + (3 * S + 1) / 2 + (size_t)wave * kL2PLeavesStokes * NE * S;
   if (wave == 0) fill_step_tables(d, P, lane, sPref, sC1, sC2);
   __syncthreads();
   for (int gi = blockIdx.x * nwaves + wave; gi < d.n_l2p_grp; gi += gridDim.x * nwaves) {
@@ -798,27 +831,33 @@ __global__ __launch_bounds__(kL2PWaves * kWave) void l2p_stokes_kernel(DevicePla
       double val[3] = {0, 0, 0};               // potentials phi_0..2 at the target
       double g[4][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};   // (d/dr, d/dtheta, d/dphi-ish) of phi_0..3
       double pn = 1, rhom = 1, er = 1, ei = 0, fact = 1;
-      int step = 0;
-#pragma nounroll
-      for (int m = 0; m < P; ++m) {
+      const double inv_sa = 1.0 / s.sa, inv_rho = 1.0 / s.rho;     // one division each per row instead of one per coefficient
+      auto order = [&](int m, int& step, auto unrolled) FMMBEM_INLINE {
         double p = pn, p1 = p, rhon = rhom;
         const double w = m == 0 ? 1.0 : 2.0;
-#pragma nounroll
-        for (int n = m; n < P; ++n, ++step) {
-          const double pref = sPref[step];
+        auto degree = [&](int n) FMMBEM_INLINE {
+          // unrolled: the LDS reads of a coefficient (tables + 4 or 7 expansions) stay with that coefficient (see l2p_kernel; an
+          // order at a time is already 280 VGPRs here)
+          int tz = 0;
+          if constexpr (decltype(unrolled)::value)         // every running sum: tied to one alone, the compiler runs that one's chain ahead through all coefficients
+            asm volatile("" : "+v"(tz), "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(g[0][0]), "+v"(g[0][1]), "+v"(g[0][2]), "+v"(g[1][0]), "+v"(g[1][1]),
+                         "+v"(g[1][2]), "+v"(g[2][0]), "+v"(g[2][1]), "+v"(g[2][2]), "+v"(g[3][0]), "+v"(g[3][1]), "+v"(g[3][2]));
+          const double *tPref = sPref + tz, *tC1 = sC1 + tz, *tC2 = sC2 + tz;
+          const double2* Lm = Ls + tz;
+          const double pref = tPref[step];
           const double mag = rhon * p * pref;
           const double yr = mag * er, yi = mag * ei;                 // Ynm = mag e^{+i m beta}
           const double pcur = p;
-          const double pnext = sC1[step] * s.ca * pcur - sC2[step] * p1;
+          const double pnext = tC1[step] * s.ca * pcur - tC2[step] * p1;
           double tmag;                                               // YnmTheta (LaplaceSpherical.hpp:471,482)
-          if (n == m) tmag = rhon * (pnext - (m + 1) * s.ca * pcur) / s.sa * pref;
-          else tmag = rhon * ((n - m + 1) * pnext - (n + 1) * s.ca * pcur) / s.sa * pref;
+          if (n == m) tmag = rhon * (pnext - (m + 1) * s.ca * pcur) * inv_sa * pref;
+          else tmag = rhon * ((n - m + 1) * pnext - (n + 1) * s.ca * pcur) * inv_sa * pref;
           const double tr = tmag * er, ti = tmag * ei;
-          const double factor = 1. / s.rho * n;
+          const double factor = inv_rho * n;
           const int idx = n * (n + 1) / 2 + m;
 #pragma unroll
           for (int e = 0; e < NE; ++e) {
-            const double2 L = Ls[e * S + idx];
+            const double2 L = Lm[e * S + idx];
             const double re = L.x * yr - L.y * yi;                   // Re(L Ynm)
             if (TRAC ? e >= 4 : e < 3) val[TRAC ? e - 4 : e] += w * re;
             if (e < 4) {
@@ -829,12 +868,28 @@ __global__ __launch_bounds__(kL2PWaves * kWave) void l2p_stokes_kernel(DevicePla
           }
           p1 = pcur; p = pnext;
           rhon *= s.rho;
+          ++step;
+        };
+        if constexpr (decltype(unrolled)::value) {
+#pragma unroll
+          for (int n = m; n < PT; ++n) degree(n);
+        } else {
+#pragma nounroll
+          for (int n = m; n < P; ++n) degree(n);
         }
         pn = -pn * fact * s.sa;
         fact += 2;
         rhom *= s.rho;
         const double nr = er * s.cb - ei * s.sb, ni = er * s.sb + ei * s.cb;
         er = nr; ei = ni;
+      };
+      int step = 0;
+      if constexpr (PT > 0) {
+#pragma unroll
+        for (int m = 0; m < PT; ++m) order(m, step, std::true_type{});
+      } else {
+#pragma nounroll
+        for (int m = 0; m < P; ++m) order(m, step, std::false_type{});
       }
       // sph2cart (kernel/LaplaceSpherical.hpp:546-561) of each gradient, then the recombination
       const double r = s.rho, st = s.sa, ct = s.ca, cp = s.cb, sp = s.sb;
@@ -877,9 +932,9 @@ hipError_t upload_constants_once() {
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(m2m_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(l2l_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     // L2P with one wavefront per workgroup at p = 16: 8 leaves x 4 potentials x 136 coefficients = 69.6 KB (Stokes)
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(l2p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(l2p_stokes_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(l2p_stokes_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(l2p_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(l2p_stokes_kernel<false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(l2p_stokes_kernel<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     return e;
   }();
   if (st == hipSuccess) done[dev] = true;
@@ -1024,6 +1079,8 @@ hipError_t launch_l2l_level(const DevicePlan& d, const ShiftOpDev& op, int p, in
   return hipGetLastError();
 }
 
+int l2p_group_leaves(int kernel) { return kernel == 1 ? kL2PLeavesStokes : kL2PLeaves; }   // 1 = FMMBEM_KERNEL_STOKES_BEM
+
 hipError_t launch_l2p(const DevicePlan& d, int p, double* y, hipStream_t s, bool store) {
   if (hipError_t e = upload_constants_once(); e != hipSuccess) return e;
   if (d.n_l2p <= 0) return hipSuccess;
@@ -1034,7 +1091,14 @@ hipError_t launch_l2p(const DevicePlan& d, int p, double* y, hipStream_t s, bool
   nw = nw < 1 ? 1 : nw > kL2PWaves ? kL2PWaves : nw;
   const int nblk = (d.n_l2p_grp + nw - 1) / nw;
   const size_t lds = sizeof(double2) * (size_t)((3 * S + 1) / 2) + nw * per_wave;
-  hipLaunchKernelGGL(l2p_kernel, dim3(nblk < 256 * 8 ? nblk : 256 * 8), dim3(nw * kWave), lds, s, d, p, y, store ? 1 : 0);
+  const dim3 grid(nblk < 256 * 8 ? nblk : 256 * 8), block(nw * kWave);
+#define L2P_CASE(PP) case PP: hipLaunchKernelGGL(l2p_kernel<PP>, grid, block, lds, s, d, p, y, store ? 1 : 0); break;
+  switch (p <= kL2PUnrollMax && !l2p_generic() ? p : 0) {
+    L2P_CASE(1) L2P_CASE(2) L2P_CASE(3) L2P_CASE(4) L2P_CASE(5) L2P_CASE(6) L2P_CASE(7) L2P_CASE(8)
+    L2P_CASE(9) L2P_CASE(10) L2P_CASE(11) L2P_CASE(12)
+    default: hipLaunchKernelGGL(l2p_kernel<0>, grid, block, lds, s, d, p, y, store ? 1 : 0);
+  }
+#undef L2P_CASE
   return hipGetLastError();
 }
 
@@ -1065,13 +1129,20 @@ hipError_t launch_l2p_stokes(const DevicePlan& d, int p, double* y, hipStream_t 
   const int S = p * (p + 1) / 2;
   for (int trac = 0; trac < 2; ++trac) {
     if (!(trac ? d.stokes_traction_targets : d.stokes_velocity_targets)) continue;
-    const size_t per_wave = sizeof(double2) * (size_t)kL2PLeaves * (trac ? 7 : 4) * S;
+    const size_t per_wave = sizeof(double2) * (size_t)kL2PLeavesStokes * (trac ? 7 : 4) * S;
     int nw = (int)((48 * 1024) / per_wave);
     nw = nw < 1 ? 1 : nw > kL2PWaves ? kL2PWaves : nw;
     const int nblk = (d.n_l2p_grp + nw - 1) / nw;
     const size_t lds = sizeof(double2) * (size_t)((3 * S + 1) / 2) + nw * per_wave;
-    if (trac) hipLaunchKernelGGL(l2p_stokes_kernel<true>, dim3(nblk < 256 * 8 ? nblk : 256 * 8), dim3(nw * kWave), lds, s, d, p, y, store ? 1 : 0);
-    else hipLaunchKernelGGL(l2p_stokes_kernel<false>, dim3(nblk < 256 * 8 ? nblk : 256 * 8), dim3(nw * kWave), lds, s, d, p, y, store ? 1 : 0);
+    const dim3 grid(nblk < 256 * 8 ? nblk : 256 * 8), block(nw * kWave);
+#define L2PS_CASE(PP) case PP: if (trac) hipLaunchKernelGGL((l2p_stokes_kernel<true, PP>), grid, block, lds, s, d, p, y, store ? 1 : 0); \
+                               else hipLaunchKernelGGL((l2p_stokes_kernel<false, PP>), grid, block, lds, s, d, p, y, store ? 1 : 0); break;
+    switch (p <= kL2PUnrollMax && !l2p_generic() ? p : 0) {
+      L2PS_CASE(1) L2PS_CASE(2) L2PS_CASE(3) L2PS_CASE(4) L2PS_CASE(5) L2PS_CASE(6) L2PS_CASE(7) L2PS_CASE(8)
+      L2PS_CASE(9) L2PS_CASE(10) L2PS_CASE(11) L2PS_CASE(12)
+      default: L2PS_CASE(0)
+    }
+#undef L2PS_CASE
   }
   return hipGetLastError();
 }

@@ -479,13 +479,14 @@ int fmmbem_plan::to_device() {
   TRY(upload(p2m_leaf, &d.p2m_leaf)); TRY(upload(l2p_leaf, &d.l2p_leaf));
   {
     // L2P work groups: a leaf of this tree holds ~19 panels, a third of a wavefront; consecutive leaves are packed until
-    // 64 rows or 8 leaves (a leaf with more than 64 panels is a group of its own)
+    // 64 rows or 8 leaves (Stokes: 4) (a leaf with more than 64 panels is a group of its own)
     std::vector<int> grp(1, 0);
     int rows = 0;
+    const int max_leaves = l2p_group_leaves(d.kernel);
     for (size_t i = 0; i < l2p_leaf.size(); ++i) {
       const int nr = hp.box_body_end[hp.leaf_box[l2p_leaf[i]]] - hp.box_body_begin[hp.leaf_box[l2p_leaf[i]]];
       const int in_group = (int)i - grp.back();
-      if (in_group > 0 && (rows + nr > 64 || in_group == 8)) { grp.push_back((int)i); rows = 0; }
+      if (in_group > 0 && (rows + nr > 64 || in_group == max_leaves)) { grp.push_back((int)i); rows = 0; }
       rows += nr;
     }
     grp.push_back((int)l2p_leaf.size());
