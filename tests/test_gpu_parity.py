@@ -257,11 +257,13 @@ def test_matrix_free_near_field(fb, oracle_mod, monkeypatch, bc_val, quad_k):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"FMMBEM_P2M_TABLE": "0"}, {"FMMBEM_SPMV_PIPE": "0"},
-                                 {"FMMBEM_OVERLAP_NEAR": "1"}, {"FMMBEM_OVERLAP_NEAR": "1", "FMMBEM_NEAR_WGS": "1"}])
+                                 {"FMMBEM_OVERLAP_NEAR": "1"}, {"FMMBEM_OVERLAP_NEAR": "1", "FMMBEM_NEAR_WGS": "1"},
+                                 {"FMMBEM_L2P_GENERIC": "1"}, {"FMMBEM_ROT_ITEM_PASSES": "1", "FMMBEM_ROT_LONG_MAX": "1"},
+                                 {"FMMBEM_ROT_ITEM_PASSES": "5", "FMMBEM_ROT_LONG_ROUNDS": "1", "FMMBEM_ROT_LONG_MAX": "40"}])
 def test_alternative_paths_match_oracle(fb, oracle_mod, monkeypatch, env):
     """The switches that select the older / optional kernels (recurrence P2M instead of the stored moments, the plain
-    near_spmv kernel, the near field beside the far field on a stream of its own) give the same operator -- the two schedules
-    bit for bit."""
+    near_spmv kernel, the near field beside the far field on a stream of its own, the L2P kernel that takes the order at run
+    time, other cuts of the M2L pair list into items) give the same operator -- schedules, cuts and the two L2P kernels bit for bit."""
     for k, val in env.items():
         monkeypatch.setenv(k, val)
     v = oracle_mod.unit_sphere(5)
@@ -277,7 +279,7 @@ def test_alternative_paths_match_oracle(fb, oracle_mod, monkeypatch, env):
         y, yo = pl.execute(x), o.matvec(x, p)
         assert np.linalg.norm(y - yo) <= 1e-12 * np.linalg.norm(yo)
         res[p] = y
-    if "FMMBEM_OVERLAP_NEAR" in env:                            # a schedule, not other arithmetic: the same bits
+    if "FMMBEM_OVERLAP_NEAR" in env or "FMMBEM_L2P_GENERIC" in env or "FMMBEM_ROT_ITEM_PASSES" in env:   # not other arithmetic: the same bits
         for k in env:
             monkeypatch.delenv(k)
         monkeypatch.setenv("FMMBEM_OVERLAP_NEAR", "0")
