@@ -495,11 +495,13 @@ __global__ __launch_bounds__(4 * kWave) void p2m_stream_kernel(DevicePlan d, con
         tvec2 t[U];
         double x[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {                    // a leaf's last batch is a masked one: the row test is scalar
-          const bool ok = r + u < nrows;
-          const int64_t iu = (int64_t)row0 + (ok ? r + u : r);
-          t[u] = __builtin_nontemporal_load(reinterpret_cast<const tvec2*>(tab + (size_t)iu * TS + idx));
-          x[u] = ok ? xt[iu] : 0.0;
+        for (int u = 0; u < U; ++u) {                    // a leaf's last batch is a short one: the row test is scalar, a branch
+          t[u] = tvec2{0, 0}; x[u] = 0.0;                //  around the load (re-reading row r instead costs L2 requests: 24 for 19 rows)
+          if (r + u < nrows) {
+            const int64_t iu = (int64_t)row0 + r + u;
+            t[u] = __builtin_nontemporal_load(reinterpret_cast<const tvec2*>(tab + (size_t)iu * TS + idx));
+            x[u] = xt[iu];
+          }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) { m.x = fma(x[u], t[u].x, m.x); m.y = fma(x[u], t[u].y, m.y); }   // panel order, as p2m_apply_kernel
