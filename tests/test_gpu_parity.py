@@ -388,6 +388,38 @@ def test_p2m_streaming_kernel(fb, oracle_mod, monkeypatch, bc_val):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("p", [4, 10])
+def test_tree_passes_at_the_default_level_rule(fb, monkeypatch, p):
+    """The rule the product runs with -- rotation kernels on tree levels of 2 048 boxes and more, sparse operators on the
+    levels near the root -- on a mesh big enough to have both kinds of level (UnitSphere(8), 131 072 panels), both
+    expansion slots live.  No oracle at this size: the two families are each held to the oracle level by level on small meshes
+    (test_tree_passes_by_rotation_match_oracle, test_expansions_and_matvec_vs_oracle); here the mixed pass must give the M and L
+    of the all-sparse pass box by box, and the M2L items (long ones at p = 10, short ones at p = 4) the same bits under another cut."""
+    v = fb.unit_sphere(8)
+    rng = np.random.default_rng(5)
+    bc = (rng.random(len(v)) < 0.5).astype(np.uint8)
+    x = rng.standard_normal(len(v))
+    K = fb.LaplaceSphericalBEM(p, 3)
+    pl = fb.FMM_plan(K, v, bc=bc)
+    lev = pl.boxes()["level"]
+    per_level = np.bincount(lev)
+    assert per_level.max() >= 2048 and (per_level[2:] < 2048).any()          # both kernels families run
+    y = pl.execute(x)
+    M, L = pl.expansions("M", p), pl.expansions("L", p)
+    monkeypatch.setenv("FMMBEM_SHIFT_ROT", "0")
+    pl2 = fb.FMM_plan(K, v, bc=bc)
+    y2 = pl2.execute(x)
+    for got, ref, which in ((M, pl2.expansions("M", p), "M"), (L, pl2.expansions("L", p), "L")):
+        scale = np.abs(ref).max(axis=2, keepdims=True) + 1e-300
+        assert np.max(np.abs(got - ref) / scale) <= TOL_EXPANSION, which
+    assert rel_l2(y, y2) <= 1e-13
+    monkeypatch.delenv("FMMBEM_SHIFT_ROT")
+    monkeypatch.setenv("FMMBEM_ROT_ITEM_PASSES", "3")
+    monkeypatch.setenv("FMMBEM_ROT_LONG_ROUNDS", "5")
+    assert np.array_equal(fb.FMM_plan(K, v, bc=bc).execute(x), y)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("p", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
 def test_tree_passes_by_rotation_match_oracle(fb, oracle_mod, monkeypatch, p):
     """M2M and L2L through the rotation kernels (kernels_m2l_rot.hip compiled with FMMBEM_ROT_OP = 1, 2).  By default only
