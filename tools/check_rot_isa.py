@@ -178,7 +178,7 @@ def main():
         m = re.search(r"kernelILi(\d+)E", name)
         print("p=%-3s dpp %5d  dpp hazards %d  early touches of loads in flight %d"
               % (m.group(1) if m else name, ndpp, len(dpp), len(loads)))
-        for i in (dpp + loads)[:6]:
+        for i in (dpp + loads)[:int(os.environ.get("ROT_ISA_SHOW", "6"))]:
             print("      %x: %s" % (i.addr, i.text))
         total += len(dpp) + len(loads)
     sys.exit(1 if total else 0)
