@@ -159,19 +159,26 @@ __device__ __forceinline__ void fixed_rotation(double (&a)[P * (P + 1) / 2], dou
   static_for<1, P>([&](auto N) FMMBEM_INLINE {         // degree 0 is the identity
     constexpr int n = decltype(N)::value;
     double na[P], nb[P];
-    static_for<0, n + 1>([&](auto M_) FMMBEM_INLINE {
-      constexpr int m = decltype(M_)::value;
-      double sa = 0, sb = 0;
+    // two output rows at a time, their terms side by side: consecutive FMAs feed four accumulators in turn (m2l_rot.hpp rot_index)
+    static_for<0, (n + 2) / 2>([&](auto M_) FMMBEM_INLINE {
+      constexpr int m0 = 2 * decltype(M_)::value;
+      double sa[2] = {0, 0}, sb[2] = {0, 0};
       static_for<0, n + 1>([&](auto Q) FMMBEM_INLINE {
         constexpr int mp = decltype(Q)::value;
-        if constexpr (rot_live(n, m, mp)) {
-          constexpr int e = rot_stage_base(P, STAGE, OP) + rot_index(n, m, mp);
-          constexpr bool even = ((n + m) & 1) == 0;
-          const double src = (mp == 0 || even) ? a[idx_of(n, mp)] : b[idx_of(n, mp)];
-          if constexpr ((rot_kk(n, m, mp) & 1) == 0) cf.template fma1<e>(sa, src); else cf.template fma1<e>(sb, src);
-        }
+        static_for<0, 2>([&](auto R_) FMMBEM_INLINE {
+          constexpr int r = decltype(R_)::value, m = m0 + r;
+          if constexpr (m <= n) {
+            if constexpr (rot_live(n, m, mp)) {
+              constexpr int e = rot_stage_base(P, STAGE, OP) + rot_index(n, m, mp);
+              constexpr bool even = ((n + m) & 1) == 0;
+              const double src = (mp == 0 || even) ? a[idx_of(n, mp)] : b[idx_of(n, mp)];
+              if constexpr ((rot_kk(n, m, mp) & 1) == 0) cf.template fma1<e>(sa[r], src); else cf.template fma1<e>(sb[r], src);
+            }
+          }
+        });
       });
-      na[m] = sa; nb[m] = sb;
+      na[m0] = sa[0]; nb[m0] = sb[0];
+      if constexpr (m0 + 1 <= n) { na[m0 + 1] = sa[1]; nb[m0 + 1] = sb[1]; }
     });
 #pragma unroll
     for (int m = 0; m <= n; ++m) { a[idx_of(n, m)] = na[m]; b[idx_of(n, m)] = nb[m]; }
@@ -212,13 +219,15 @@ constexpr int rot_waves(int P) { return FMMBEM_ROT_OCC(P); }
 // the pass at p = 10.  The AGPRs are free once the last fixed rotation is through (the allocator parks values there during
 // the arithmetic only), the VMEM queue is empty behind the last group of constants, and the z rotation and the reduction that
 // follow use neither: the loads go out there, as asm so that they stay there, into AGPRs, and the next pass begins by waiting
-// for them and moving them over.  PF double2 of the multipole are fetched ahead -- all of them at p = 8, 9, 36 of 55 at p = 10,
+// for them and moving them over.  PF double2 of the multipole are fetched ahead -- all of them at p = 8, 9, 32 of 55 at p = 10
+// (36 until the rotation rows were taken two at a time: four accumulators instead of two, and 36 then spills; same box, M2L ms:
+// row by row with 36: 0.547-0.558; two rows with 36: 0.606, 35: 0.522-0.534, 34: 0.561, 32: 0.533-0.536 and no scratch),
 // 16 at p = 11, none at p = 12: what the AGPRs hold beside the allocator's own use of them (more: the prefetched values are
 // spilled to scratch at once, which tools/check_rot_isa.py reports) -- and the rest at the head of the pass.  The tree-pass
 // operators (OP != M2L) take items of one pass and fetch nothing ahead.
 typedef double v2d __attribute__((ext_vector_type(2)));
 #ifndef FMMBEM_ROT_PF
-#define FMMBEM_ROT_PF(P) ((P) <= 9 ? 64 : (P) == 10 ? 36 : (P) == 11 ? 16 : 0)
+#define FMMBEM_ROT_PF(P) ((P) <= 9 ? 64 : (P) == 10 ? 32 : (P) == 11 ? 16 : 0)
 #endif
 constexpr int rot_prefetch(int P) { return (rot_waves(P) > 1 || OP != kRotM2L) ? 0 : (P * (P + 1) / 2 < FMMBEM_ROT_PF(P) ? P * (P + 1) / 2 : FMMBEM_ROT_PF(P)); }
 
@@ -345,16 +354,25 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(rot_waves
       static_for<0, P>([&](auto K_) FMMBEM_INLINE {
         constexpr int k = decltype(K_)::value;
         double la[P], lb[P];
-        static_for<k, P>([&](auto J) FMMBEM_INLINE {
-          constexpr int j = decltype(J)::value;
-          double s1 = 0, s2 = 0;
-          static_for<axial_row_begin(P, OP, k, j), axial_row_end(P, OP, k, j)>([&](auto N) FMMBEM_INLINE {
+        // two output rows j at a time, n ascending with the two rows' terms side by side (m2l_rot.hpp axial_index)
+        static_for<0, (P - k + 1) / 2>([&](auto J) FMMBEM_INLINE {
+          constexpr int j0 = k + 2 * decltype(J)::value;
+          double s1[2] = {0, 0}, s2[2] = {0, 0};
+          static_for<k, P>([&](auto N) FMMBEM_INLINE {
             constexpr int n = decltype(N)::value;
-            constexpr int e = rot_stage_base(P, 2, OP) + axial_index(P, OP, k, j, n);
-            if constexpr (k != 0) cf.template fma2<e>(s1, a[idx_of(n, k)], s2, b[idx_of(n, k)]);
-            else cf.template fma1<e>(s1, a[idx_of(n, k)]);
+            static_for<0, 2>([&](auto R_) FMMBEM_INLINE {
+              constexpr int r = decltype(R_)::value, j = j0 + r;
+              if constexpr (j < P) {
+                if constexpr (n >= axial_row_begin(P, OP, k, j) && n < axial_row_end(P, OP, k, j)) {
+                  constexpr int e = rot_stage_base(P, 2, OP) + axial_index(P, OP, k, j, n);
+                  if constexpr (k != 0) cf.template fma2<e>(s1[r], a[idx_of(n, k)], s2[r], b[idx_of(n, k)]);
+                  else cf.template fma1<e>(s1[r], a[idx_of(n, k)]);
+                }
+              }
+            });
           });
-          la[j] = s1; lb[j] = s2;
+          la[j0] = s1[0]; lb[j0] = s2[0];
+          if constexpr (j0 + 1 < P) { la[j0 + 1] = s1[1]; lb[j0 + 1] = s2[1]; }
         });
 #pragma unroll
         for (int j = k; j < P; ++j) { a[idx_of(j, k)] = la[j]; b[idx_of(j, k)] = lb[j]; }

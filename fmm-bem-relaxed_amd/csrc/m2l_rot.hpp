@@ -107,9 +107,24 @@ constexpr int kRotAhead = FMMBEM_ROT_AHEAD;          // groups in flight (kernel
 constexpr int rot_kk(int n, int m, int mp) {        // routing phase of entry (m, mp): 0 +Re, 1 +Im, 2 -Re, 3 -Im
   return ((mp == 0 ? m : m + 3 * mp) + ((mp != 0 && ((n + m) & 1)) ? 1 : 0)) & 3;
 }
-// position of a constant in the stream: stage 0..4 = rotation, rotation, axial, rotation, rotation
+// position of a constant in the stream: stage 0..4 = rotation, rotation, axial, rotation, rotation.
+// ORDER OF CONSUMPTION, rotation segment: degree by degree; within a degree the output rows m two at a time, and for a pair of
+// rows the input orders mp ascending with the two rows' entries side by side -- (m0, mp), (m0 + 1, mp), (m0, mp + 1), ... --
+// so that consecutive FMAs feed FOUR accumulators (Re and Im of two outputs), not two: a lone wavefront issues an FP64 FMA
+// every 3.7 ns into two alternating accumulators and every 2.95 ns into four (tools/microbench/dpp_chain.hip).  Every output
+// still adds its own terms in ascending mp: the same bits as the row-by-row order.
 constexpr int rot_index(int n, int m, int mp) {     // within one rotation segment (degrees 1..P-1)
   int c = rot_off(n) - 1;
+  for (int m0 = 0; m0 <= n; m0 += 2)
+    for (int q = 0; q <= n; ++q)
+      for (int r = m0; r <= (m0 + 1 <= n ? m0 + 1 : n); ++r) {
+        if (r == m && q == mp) return c;
+        c += rot_live(n, r, q) ? 1 : 0;
+      }
+  return c;
+}
+constexpr int rot_plain_index(int n, int m, int mp) {   // in build_rot_table's table: row by row
+  int c = rot_off(n);
   for (int i = 0; i <= n; ++i)
     for (int q = 0; q <= n; ++q) {
       if (i == m && q == mp) return c;
@@ -140,11 +155,19 @@ constexpr int axial_len(int P, int op) {
   for (int k = 0; k < P; ++k) c += axial_block_len(P, op, k);
   return c;
 }
+// ORDER OF CONSUMPTION, axial block of order k: the output rows j two at a time, n ascending with the two rows' entries side by
+// side (as in the rotation segments: four accumulators in turn; two for k = 0, where the imaginary parts are zero)
 constexpr int axial_index(int P, int op, int k, int j, int n) {
   int c = 0;
   for (int i = 0; i < k; ++i) c += axial_block_len(P, op, i);
-  for (int jj = k; jj < j; ++jj) c += axial_row_end(P, op, k, jj) - axial_row_begin(P, op, k, jj);
-  return c + n - axial_row_begin(P, op, k, j);
+  for (int j0 = k; j0 < P; j0 += 2)
+    for (int nn = k; nn < P; ++nn)
+      for (int r = j0; r <= (j0 + 1 < P ? j0 + 1 : P - 1); ++r) {
+        if (nn < axial_row_begin(P, op, k, r) || nn >= axial_row_end(P, op, k, r)) continue;
+        if (r == j && nn == n) return c;
+        ++c;
+      }
+  return c;
 }
 constexpr int tz_index(int P, int k, int j, int n) { return axial_index(P, kRotM2L, k, j, n); }
 constexpr int rot_stage_base(int P, int stage, int op = kRotM2L) {
@@ -158,27 +181,29 @@ inline void build_rot_stream(int P, std::vector<double>& out, int op = kRotM2L) 
   std::vector<double> plain;
   build_rot_table(P, plain);                        // [rotation coefficients, unsigned][Tz of M2L]
   out.assign((size_t)rot_stream_doubles(P, op), 0.0);
-  size_t at = 0;
+  size_t at = 0;                                    // base of the segment being written; entries go where the index functions say
   auto rotation = [&](bool back) {
-    size_t ci = (size_t)rot_off(1);
     for (int n = 1; n < P; ++n)
       for (int m = 0; m <= n; ++m)
         for (int mp = 0; mp <= n; ++mp) {
           if (!rot_live(n, m, mp)) continue;
           const bool neg = (rot_kk(n, m, mp) >= 2) != (back && ((m + mp) & 1));
-          out[at++] = neg ? -plain[ci] : plain[ci];
-          ++ci;
+          const double c = plain[(size_t)rot_plain_index(n, m, mp)];
+          out[at + (size_t)rot_index(n, m, mp)] = neg ? -c : c;
         }
+    at += (size_t)(rot_off(P) - 1);
   };
   auto fact = [](int k) { long double f = 1; for (int i = 2; i <= k; ++i) f *= i; return f; };
   auto a = [&](int n, int m) { return ((n & 1) ? -1.0L : 1.0L) / std::sqrt(fact(n - m) * fact(n + m)); };
   auto axial = [&]() {
-    if (op == kRotM2L) { for (int i = rot_off(P); i < tz_off(P, P); ++i) out[at++] = plain[(size_t)i]; return; }
     for (int k = 0; k < P; ++k)
       for (int j = k; j < P; ++j)
         for (int n = axial_row_begin(P, op, k, j); n < axial_row_end(P, op, k, j); ++n)
-          out[at++] = op == kRotM2M ? (double)((((j - n) & 1) ? -1.0L : 1.0L) * a(j - n, 0) * a(n, k) / a(j, k))
-                                    : (double)(a(n - j, 0) * a(j, k) / a(n, k));
+          out[at + (size_t)axial_index(P, op, k, j, n)] =
+              op == kRotM2L ? plain[(size_t)tz_off(P, k) + (size_t)(j - k) * (P - k) + (n - k)]      // build_rot_table: [j-k][n-k]
+              : op == kRotM2M ? (double)((((j - n) & 1) ? -1.0L : 1.0L) * a(j - n, 0) * a(n, k) / a(j, k))
+                              : (double)(a(n - j, 0) * a(j, k) / a(n, k));
+    at += (size_t)axial_len(P, op);
   };
   rotation(false); rotation(true); axial(); rotation(false); rotation(true);
 }
@@ -288,7 +313,7 @@ inline void build_rot2_stream(int P, std::vector<double>& out) {
   // Tz[j, n, k] of M2L (build_rot_table's second part: k, then j >= k, then n >= k), zero outside its range
   auto tz = [&](int j, int n, int k) -> double {
     if (k < 0 || j < k || n < k || j >= P || n >= P) return 0.0;
-    return plain[(size_t)rot_off(P) + (size_t)tz_index(P, k, j, n)];
+    return plain[(size_t)tz_off(P, k) + (size_t)(j - k) * (P - k) + (n - k)];
   };
   auto axial = [&]() {
     const int Q = rot2_pairs(P);
