@@ -166,16 +166,26 @@ __global__ __launch_bounds__(kP2MWaves * kWave) void p2m_kernel(DevicePlan d, co
       // wmode 0: Laplace, charge * w * Area for panels whose BC feeds this slot (LaplaceSphericalBEM.hpp:323-344)
       // wmode 1..3: Stokes f_e * w * Area; wmode 4: (f . x_q) * w * Area with the ABSOLUTE quadrature point
       // (kernel/StokesSphericalBEM.hpp:417-431)
+      // wmode 5..11 (slot = 1, the gradient branch): the seven dipole potentials of the Stokes double layer without stored
+      // gradient records -- the moment is  wq (u . grad)(rho^n Ynm)  with
+      //   5..7   Psi_k:    u = g (the panel's density),  wq = n_k w Area      (expansion slots 4..6, p2m_apply_kernel<3>)
+      //   8      Psi_0:    u = g,                         wq = (c . n) w Area  (slot 7; y.n is constant on a flat panel)
+      //   9..11  Theta_i:  u = n,                         wq = g_i w Area      (slots 8..10)
       const bool live = pt < npts && (wmode ? true : d.bc[i] == slot);
       double wq = 0.0;
+      double n0 = live ? d.nx[i] : 0, n1 = live ? d.ny[i] : 0, n2 = live ? d.nz[i] : 0;      // the direction u of the gradient branch
       if (live) {
         const double aw = d.area[i] * d.qw[q];
         if (wmode == 0) wq = d.xt[i] * aw;
         else if (wmode < 4) wq = d.xt[3 * i + (wmode - 1)] * aw;
-        else wq = (d.xt[3 * i] * d.quad[(q * 3 + 0) * N + i] + d.xt[3 * i + 1] * d.quad[(q * 3 + 1) * N + i] +
-                   d.xt[3 * i + 2] * d.quad[(q * 3 + 2) * N + i]) * aw;
+        else if (wmode == 4) wq = (d.xt[3 * i] * d.quad[(q * 3 + 0) * N + i] + d.xt[3 * i + 1] * d.quad[(q * 3 + 1) * N + i] +
+                                   d.xt[3 * i + 2] * d.quad[(q * 3 + 2) * N + i]) * aw;
+        else if (wmode >= 9) wq = d.xt[3 * i + (wmode - 9)] * aw;
+        else {
+          wq = (wmode == 8 ? d.cx[i] * n0 + d.cy[i] * n1 + d.cz[i] * n2 : wmode == 5 ? n0 : wmode == 6 ? n1 : n2) * aw;
+          n0 = d.xt[3 * i]; n1 = d.xt[3 * i + 1]; n2 = d.xt[3 * i + 2];
+        }
       }
-      const double n0 = live ? d.nx[i] : 0, n1 = live ? d.ny[i] : 0, n2 = live ? d.nz[i] : 0;
       const Sph s = cart2sph(live ? d.quad[(q * 3 + 0) * N + i] - c0 : 0.3, live ? d.quad[(q * 3 + 1) * N + i] - c1 : 0.4,
                              live ? d.quad[(q * 3 + 2) * N + i] - c2 : 0.5);
       double pn = 1, rhom = 1, er = 1, ei = 0, fact = 1;
@@ -1112,7 +1122,11 @@ hipError_t launch_p2m_stokes(const DevicePlan& d, int p, hipStream_t s) {
   if (d.n_p2m <= 0) return hipSuccess;
   if (p < 1 || p > kPmaxDev) return hipErrorInvalidValue;
   const int nb = (d.n_p2m + 3) / 4;
+  const int nblk_r = (d.n_p2m + kP2MWaves - 1) / kP2MWaves;
+  const dim3 gr(nblk_r < 256 * 8 ? nblk_r : 256 * 8), br(kP2MWaves * kWave);
   if (d.p2m_tab_g) hipLaunchKernelGGL((p2m_apply_kernel<3>), dim3(nb < 256 * 16 ? nb : 256 * 16), dim3(4 * kWave), 0, s, d, p);
+  else if (d.stokes_traction_targets)                  // no gradient records (FMMBEM_P2M_TABLE=0, or more than 16 GB of them): the recurrences, slot by slot
+    for (int e = 0; e < 7; ++e) hipLaunchKernelGGL((p2m_kernel<1>), gr, br, 0, s, d, p, 5 + e, 4 + e);
   if (!d.stokes_velocity_targets) return hipGetLastError();
   if (d.p2m_tab) {
     hipLaunchKernelGGL((p2m_apply_kernel<4>), dim3(nb < 256 * 16 ? nb : 256 * 16), dim3(4 * kWave), 0, s, d, p);

@@ -746,9 +746,9 @@ int fmmbem_plan::to_device() {
     d.p2m_tab_row0 = r0;
     const size_t count = (size_t)(r1 - r0) * ntab * d.p2m_stride;
     const bool stokes = opts.kernel == FMMBEM_KERNEL_STOKES_BEM;
-    if (stokes && d.stokes_traction_targets && d.n_p2m > 0) {       // the double layer has no recurrence form here: records or nothing
-      const size_t count_g = (size_t)(r1 - r0) * 3 * d.p2m_stride;
-      if (count_g * sizeof(double2) > ((size_t)16 << 30)) return fail(FMMBEM_ERR_UNSUPPORTED, "Stokes TRACTION far field: the gradient records exceed 16 GB");
+    const size_t count_g = (size_t)(r1 - r0) * 3 * d.p2m_stride;
+    if (stokes && d.stokes_traction_targets && d.n_p2m > 0 && !(e && std::atoi(e) == 0) && count_g * sizeof(double2) <= ((size_t)16 << 30)) {
+      // the double layer's gradient records; without them (switch, or more than 16 GB) its P2M runs the recurrences per matvec
       double2* tab = nullptr;
       TRY(alloc(count_g, &tab, true));
       HIP_TRY(hipDeviceSynchronize());
@@ -1213,6 +1213,7 @@ int fmmbem_plan_stats(const fmmbem_plan* plan, fmmbem_stats* o) {
   o->m2l_items = (int64_t)(long_items ? h.rot_item_ptr_long : h.rot_item_ptr).size() - 1;
   o->m2l_passes = long_items ? h.rot_passes_long : h.rot_passes;
   o->near_side_entries = plan->near_side_entries;
+  o->expansion_slots = plan->on_device ? plan->d.nslots : (plan->opts.kernel == FMMBEM_KERNEL_STOKES_BEM ? 8 : 2);
   o->m2l_kernel = plan->last_p > 0 ? (plan->use_rot(plan->last_p) ? 1 : plan->last_p <= 4 ? 3 : 2) : 0;
   o->expansions_active = (h.has_bc[0] ? 1 : 0) | (h.has_bc[1] ? 2 : 0);
   o->last_p = plan->last_p;

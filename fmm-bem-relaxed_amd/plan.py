@@ -367,7 +367,7 @@ class FMM_plan:
     def expansions(self, which, p=None):
         p = self._K.P if p is None else p
         nb = self.stats()["n_boxes"]
-        out = np.empty((nb, 2 if self.dof == 1 else 8, p * (p + 1) // 2), dtype=np.complex128)
+        out = np.empty((nb, self.stats()["expansion_slots"], p * (p + 1) // 2), dtype=np.complex128)   # Stokes: 8, 11 with TRACTION targets
         _capi.check(_capi.lib().fmmbem_plan_get_expansions(self._h, 0 if which == "M" else 1, p,
                                                            out.ctypes.data_as(C.c_void_p)))
         return out

@@ -117,7 +117,7 @@ typedef struct {
   int64_t near_side_entries;    /* matrix-free plans (sparse_local = 0): near-regime pairs evaluated once at creation and kept
                                  * (12 bytes each: column + value); 0 for assembled plans                */
   int32_t m2l_kernel;           /* the M2L an execute at last_p took: 1 rotation kernel, 2 double sum, 3 double sum (lanes = sources) */
-  int32_t reserved_;
+  int32_t expansion_slots;             /* slots per box in M and L (fmmbem_plan_get_expansions): Laplace 2, Stokes 8, 11 with TRACTION targets */
 } fmmbem_stats;
 
 typedef struct fmmbem_plan fmmbem_plan;
@@ -236,7 +236,8 @@ int fmmbem_plan_shard_rows(const fmmbem_plan *plan, int64_t *cut);
 int fmmbem_plan_assemble_slices_device(fmmbem_plan *plan, const double *d_slices, size_t chunk_doubles, double *d_y, void *stream);
 
 /* Multipole (which=0) or local (which=1) coefficients of the last execute for every box:
- * out[box][slot][p(p+1)/2][re,im]; Laplace: 2 slots (G, dG/dn); Stokes: 8 slots (M[2][4]). */
+ * out[box][slot][p(p+1)/2][re,im]; slots = fmmbem_stats.expansion_slots: Laplace 2 (G, dG/dn); Stokes 8 (M[2][4]), or 11 when
+ * the plan has TRACTION targets (slots 4..10: the seven dipole potentials of the double layer). */
 int fmmbem_plan_get_expansions(const fmmbem_plan *plan, int which, int p, double *out);
 
 /* ---- mesh generator of the reference's drivers ------------------------------------------- */

@@ -115,6 +115,30 @@ def test_gpu_stokes_traction_far_field_against_direct(fb, oracle_mod):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("p", [6, 14])
+def test_gpu_stokes_traction_p2m_without_stored_gradient_records(fb, monkeypatch, p):
+    """The double layer's P2M without its gradient records (FMMBEM_P2M_TABLE=0; a plan whose records would pass 16 GB takes
+    the same path instead of being refused): the seven dipole multipoles from the harmonic recurrences, slot by slot
+    (`p2m_kernel<1>` with wmode 5..11).  Every M of every box as with the stored records, and the result; mixed target
+    flags so that the velocity group's recurrence P2M runs beside it."""
+    v = np.concatenate([fb.unit_sphere(5), fb.unit_sphere(4, center=(2.6, 0.2, -0.3))])
+    n = len(v)
+    bc = (np.arange(n) % 3 == 0).astype(np.uint8)
+    x = (drand48(3 * n, seed=5) - 0.5).reshape(n, 3)
+    K = fb.StokesSphericalBEM(p, 4, 1.0)
+    K.set_Kfine(7)
+    ref_plan = fb.FMM_plan(K, v, bc=bc)
+    y_ref, M_ref = ref_plan.execute(x), ref_plan.expansions("M", p)
+    monkeypatch.setenv("FMMBEM_P2M_TABLE", "0")
+    pl = fb.FMM_plan(K, v, bc=bc)
+    y, M = pl.execute(x), pl.expansions("M", p)
+    scale = np.abs(M_ref).max(axis=2, keepdims=True) + 1e-300
+    assert np.abs(M_ref[:, 4:]).max() > 0                      # the dipole slots are live
+    assert np.max(np.abs(M - M_ref) / scale) <= 1e-12
+    assert rel_l2(y, y_ref) <= 1e-12
+
+
+@pytest.mark.gpu
 def test_gpu_stokes_traction_far_field_above_the_rotation_orders(fb, oracle_mod, monkeypatch):
     """Orders 13 ... 16 (the reference accepts any p, StokesSphericalBEM.hpp:131-141): the eleven slots of a mixed operator
     go through the double-sum M2L one slot per pass.  Against Direct the error keeps falling (p = 12: 6.8e-5); at p <= 12 the
