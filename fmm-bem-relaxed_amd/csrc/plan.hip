@@ -188,7 +188,7 @@ struct fmmbem_plan {
   // stores the far field in yfar and the delivery adds the two -- the same bits as the serial schedule.  Measured in rounds
   // 1, 2 and 3 and slower every time (p = 2: 1.01 ms against 0.87): beside the saturated memory system of the near field
   // every dependent access of the latency-bound far kernels takes 10-70x longer (profiles/r03d_overlap_near_far.txt).
-  bool overlap_near = false;
+  int overlap_near = 0;                               // 1: fork behind the gather; 2: fork in front of M2L (near field beside M2L only)
   int near_wgs = 3;
   int64_t ev_count = 0;                                        // executes recorded since timing was enabled
   double *stage_x = nullptr, *stage_y = nullptr;               // device staging for host-pointer execute
@@ -361,7 +361,7 @@ int fmmbem_plan::to_device() {
   if (const char* e = getenv("FMMBEM_M2L_ROT")) { if (atoi(e) == 0) rot_max = 0; }
   if (const char* e = getenv("FMMBEM_M2L_ROT_MIN")) rot_min = atoi(e);
   if (const char* e = getenv("FMMBEM_M2L_ROT_MAX")) rot_max = atoi(e);
-  if (const char* ov = getenv("FMMBEM_OVERLAP_NEAR")) overlap_near = atoi(ov) != 0;
+  if (const char* ov = getenv("FMMBEM_OVERLAP_NEAR")) overlap_near = atoi(ov);
   if (const char* nw = getenv("FMMBEM_NEAR_WGS")) near_wgs = std::max(1, std::min(8, atoi(nw)));
   if (const char* ge = getenv("FMMBEM_GRAPH")) use_graphs = atoi(ge) != 0;
   d.max_ncols = max_cols;
@@ -949,12 +949,14 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
   }
   const bool near_here = !overlap && !(phase == 2 && pending_near);
   pending_near = false;
-  if (overlap) {
-    HIP_TRY(hipEventRecord(ev_fork, s));
+  auto fork_near = [&](hipStream_t from) -> int {
+    HIP_TRY(hipEventRecord(ev_fork, from));
     HIP_TRY(hipStreamWaitEvent(near_stream, ev_fork, 0));
     TRY(near_field(near_stream));
     HIP_TRY(hipEventRecord(ev_join, near_stream));
-  }
+    return FMMBEM_OK;
+  };
+  if (overlap && overlap_near < 2) TRY(fork_near(s));
   TRY(graphed((phase == 2 ? 2 : 0) + (near_here ? 0 : 4) + (near_only ? 8 : 0), xbuf, [&](hipStream_t s) -> int {
   if (near_here) TRY(near_field(s));
   if (!near_only) {
@@ -974,6 +976,7 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
     const bool rot = use_rot(p);
     if (!rot) HIP_TRY(launch_mh_prep(d, p, s));      // the rotation kernel reads M itself
     HIP_TRY(end(5, s));
+    if (overlap && overlap_near >= 2) TRY(fork_near(s));   // the HBM-bound kernel beside the FMA-bound one, and beside nothing else
     HIP_TRY(begin(6, s));
     if (rot && use_rot2(p)) {
       HIP_TRY(launch_m2l_rot_zero(d, p, s));
@@ -984,6 +987,7 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
     } else if (rot) HIP_TRY(launch_m2l_rot(d, d_dev, p, s));
     else HIP_TRY(launch_m2l(d, d_dev, p, s));
     HIP_TRY(end(6, s));
+    if (overlap && overlap_near == 3) HIP_TRY(hipStreamWaitEvent(s, ev_join, 0));   // 3: the latency-bound rest waits for the near field
     HIP_TRY(begin(7, s));
     TRY(l2l_pass(p, s));
     HIP_TRY(end(7, s));

@@ -258,6 +258,7 @@ def test_matrix_free_near_field(fb, oracle_mod, monkeypatch, bc_val, quad_k):
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"FMMBEM_P2M_TABLE": "0"}, {"FMMBEM_SPMV_PIPE": "0"},
                                  {"FMMBEM_OVERLAP_NEAR": "1"}, {"FMMBEM_OVERLAP_NEAR": "1", "FMMBEM_NEAR_WGS": "1"},
+                                 {"FMMBEM_OVERLAP_NEAR": "2", "FMMBEM_NEAR_WGS": "5"}, {"FMMBEM_OVERLAP_NEAR": "3"},
                                  {"FMMBEM_L2P_GENERIC": "1"}, {"FMMBEM_ROT_ITEM_PASSES": "1", "FMMBEM_ROT_LONG_MAX": "1"},
                                  {"FMMBEM_ROT_ITEM_PASSES": "5", "FMMBEM_ROT_LONG_ROUNDS": "1", "FMMBEM_ROT_LONG_MAX": "40"}])
 def test_alternative_paths_match_oracle(fb, oracle_mod, monkeypatch, env):
