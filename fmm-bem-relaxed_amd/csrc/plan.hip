@@ -1295,7 +1295,8 @@ int fmmbem_plan_get_pairs(const fmmbem_plan* plan, int which, int32_t* out, int6
     case 3: for (int c : h.l2l_children) { flat.push_back(h.box_parent[c]); flat.push_back(c); } break;
     case 4: for (size_t i = 0; i < h.rot_src.size(); ++i) { flat.push_back(h.rot_src[i]); flat.push_back(h.rot_tgt[i]); } break;
     case 5: for (size_t i = 0; i + 1 < h.rot_item_ptr.size(); ++i) { flat.push_back(h.rot_item_ptr[i]); flat.push_back(h.rot_item_ptr[i + 1]); } break;
-    default: return fail(FMMBEM_ERR_INVALID, "which must be 0..5");
+    case 6: for (size_t i = 0; i + 1 < h.rot_item_ptr_long.size(); ++i) { flat.push_back(h.rot_item_ptr_long[i]); flat.push_back(h.rot_item_ptr_long[i + 1]); } break;
+    default: return fail(FMMBEM_ERR_INVALID, "which must be 0..6");
   }
   *n = (int64_t)flat.size() / 2;
   if (out) std::memcpy(out, flat.data(), flat.size() * sizeof(int32_t));

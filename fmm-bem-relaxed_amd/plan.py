@@ -341,7 +341,7 @@ class FMM_plan:
         return d
 
     def pairs(self, which):
-        idx = {"p2p": 0, "m2l": 1, "m2m": 2, "l2l": 3, "m2l_work": 4, "m2l_items": 5}[which]
+        idx = {"p2p": 0, "m2l": 1, "m2m": 2, "l2l": 3, "m2l_work": 4, "m2l_items": 5, "m2l_items_long": 6}[which]
         n = C.c_int64(0)
         _capi.check(_capi.lib().fmmbem_plan_get_pairs(self._h, idx, None, C.byref(n)))
         out = np.empty((n.value, 2), dtype=np.int32)

@@ -171,7 +171,8 @@ int fmmbem_plan_get_boxes(const fmmbem_plan *plan, double *center, double *side,
                           int32_t *is_leaf, int32_t *parent, int32_t *body_begin, int32_t *body_end);
 /* Pair lists; which: 0 = P2P (source leaf, target leaf), 1 = M2L (source box, target box),
  * 2 = M2M (child, parent), 3 = L2L (parent, child); the work list of the rotation M2L kernel: 4 = its OWNED pairs (source
- * box, target box) in the order the kernel takes them, 5 = its items as (first, one past last) positions in list 4.
+ * box, target box) in the order the kernel takes them, 5 = its items as (first, one past last) positions in list 4 (the
+ * short cut, orders with several wavefronts per SIMD), 6 = the long cut of the same list (orders p >= 9).
  * out may be NULL; returns the count via *n. */
 int fmmbem_plan_get_pairs(const fmmbem_plan *plan, int which, int32_t *out, int64_t *n);
 /* One assembled near-matrix row (tree-order index of the unknown, i.e. dof*panel + component; must be

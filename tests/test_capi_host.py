@@ -137,7 +137,33 @@ def test_rotation_m2l_work_list_items_are_runs_of_whole_targets():
             passes += (e - b + 63) // 64
         assert passes == st["m2l_passes"]
         assert st["m2l_pairs_owned"] / (64.0 * passes) > 0.8
+        # the long cut (orders at one wavefront per SIMD) is another cut of the same list at target boundaries
+        long_items = plan.pairs("m2l_items_long")
+        assert long_items[0, 0] == 0 and long_items[-1, 1] == len(work) and np.array_equal(long_items[1:, 0], long_items[:-1, 1])
+        for b, e in long_items:
+            assert e > b and (b == 0 or work[b - 1, 1] != work[b, 1])
+        assert len(long_items) <= len(items)
         plan.close()
+
+
+def test_long_m2l_items_fill_the_chip_in_even_rounds():
+    """HostPlan::build_rot_items, the cut for the orders that run one wavefront per SIMD: on an operator with many more passes
+    than the chip has SIMDs the items are long (up to 16 passes) and there are at most two rounds of 1 024 of them -- never a
+    handful beyond a round (measured: thirty items too many cost 0.92 ms against 0.54) -- and the lanes are full."""
+    import fmm_bem_relaxed_amd as fb
+    v = np.concatenate([fb.unit_sphere(8), fb.unit_sphere(8, center=(3.0, 0.0, 0.0))])
+    plan = fb.FMM_plan(fb.LaplaceSphericalBEM(10, 3), v, host_only=True)
+    work, short, long_items = plan.pairs("m2l_work"), plan.pairs("m2l_items"), plan.pairs("m2l_items_long")
+    n_pass = lambda it: int(((it[:, 1] - it[:, 0] + 63) // 64).sum())
+    assert len(work) > 64 * 1024 * 4                            # enough pairs for the rule to matter
+    assert len(long_items) <= 2048                              # two rounds over 1 024 SIMDs, not one item more
+    per_item = (long_items[:, 1] - long_items[:, 0] + 63) // 64
+    want = -(-(len(work) // 64) // 2048)                        # passes per item the rule aims at
+    assert np.median(per_item) in (want, want + 1) and per_item.max() <= 17
+    assert np.mean(per_item >= want) > 0.95                     # the few short ones sit in front of targets longer than an item
+    assert len(work) / (64.0 * n_pass(long_items)) > 0.95 > len(work) / (64.0 * n_pass(short))     # fuller lanes than the short cut
+    assert np.median((short[:, 1] - short[:, 0] + 63) // 64) <= 2
+    plan.close()
 
 
 @pytest.mark.parametrize("world", [2, 3, 8])
