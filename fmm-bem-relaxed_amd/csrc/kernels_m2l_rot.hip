@@ -270,6 +270,10 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(rot_waves
   __shared__ double2 tile[KT][kRow];
   __shared__ double2 carry[S][kChains];               // chain sums of a target that goes on in the next pass
   const int lane = threadIdx.x;
+  if constexpr (OP == kRotM2L) {                      // column kWave of every tile row stays zero: what a chain reads past its segment's end
+    for (int c = lane; c < KT; c += kWave) tile[c][kWave] = double2{0, 0};
+    wave_sync();
+  }
   // workgroups are dealt round-robin to the 8 XCDs: keep runs of consecutive items (neighbouring targets, which share
   // sources) on one XCD's L2.  gridDim.x is a multiple of 8 * CH.
   constexpr int CH = FMMBEM_ROT_XCD_CHUNK;
@@ -484,7 +488,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(rot_waves
 #pragma unroll
               for (int u = 0; u < NU; ++u) {
                 const int l = first + u * kChains;
-                v[k][u] = l < e ? tile[cc[k]][l] : double2{0, 0};     // a lane past the segment's end adds zero
+                v[k][u] = tile[cc[k]][l < e ? l : kWave];            // past the segment's end: the row's zero column (one select on the index, not four on the value)
               }
             }
 #pragma unroll
