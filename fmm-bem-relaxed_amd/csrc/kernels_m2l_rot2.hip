@@ -173,7 +173,11 @@ constexpr int rot2_tile(int P) {                      // coefficients per reduct
 // first lane (the E lane) of pair j of a pass
 __device__ __forceinline__ int lane_of_pair(int j) { return (j & 15) | ((j >> 4) << 5); }
 
-template <int P>
+// OP: kRotM2L, or one of the shifts of the tree passes (kRotM2M: lane pair = (parent, child), the children of a parent added
+// like the pairs of an M2L target; kRotL2L: lane pair = (child, parent), added into the child's L).  The shifts run items of ONE
+// pass of 32 pairs, one expansion slot per wavefront (blockIdx.y): a level of the tree is a single pass on a chip that is not
+// full, and this form's pass is half as long as that of kernels_m2l_rot.hip.
+template <int P, int OP>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) void m2l_rot2_kernel(const DevicePlan d, const RotWork w) {
   constexpr int S = P * (P + 1) / 2, Q = rot2_pairs(P), NS = rot2_nslots(P);
   constexpr int KT = rot2_tile(P);
@@ -194,9 +198,10 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 #endif
   const double mask_o = par ? 1.0 : 0.0, mask_e = par ? 0.0 : 1.0;
 
-  for (int qs = 0; qs < d.n_act; ++qs) {
+  const int qs_begin = OP == kRotM2L ? 0 : (int)blockIdx.y, qs_end = OP == kRotM2L ? d.n_act : qs_begin + 1;
+  for (int qs = qs_begin; qs < qs_end; ++qs) {
     const int slot = d.act[qs];
-    const double2* Mslot = d.M + (size_t)slot * d.s_max;
+    const double2* Mslot = (OP == kRotL2L ? d.L : d.M) + (size_t)slot * d.s_max;       // the operand: M, or the parent's L
     const size_t box_stride = (size_t)d.nslots * d.s_max;
     bool cont_in = false;
     int cont_q = 0;
@@ -241,7 +246,9 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
       }
       const double* cr = w.rec + (size_t)cls * 8;
       const double inv_rho = cr[0], ca = cr[1], sa = cr[2], cb = cr[3], sb = cr[4];
-      const double inv2 = inv_rho * inv_rho;
+      // powers in front of and behind the axial operator (kernels_m2l_rot.hip): M2L rho^-n, rho^-(j+1); M2M rho^-n, rho^j; L2L rho^n, rho^-j
+      const double pre = OP == kRotL2L ? cr[5] : inv_rho, post = OP == kRotM2M ? cr[5] : inv_rho;
+      const double pre2 = pre * pre, post2 = post * post;
       ConstFeed2<(rot2_stream_len(P) + kRotGroup - 1) / kRotGroup> cf;
 #ifndef FMMBEM_ROT2_EXP_NOARITH                          // experiment builds: where does a pass spend its time
       cf.start(w.stream, lane);
@@ -249,7 +256,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
       fixed_rotation2<P, 0>(a, b, cf);
       z_rotation2<P>(a, b, ca, sa, odd ? ca : 1.0, odd ? sa : 0.0);
       fixed_rotation2<P, 1>(a, b, cf);
-      scale2<P>(a, b, odd ? inv_rho : 1.0, inv2);      // M''[n, m] = rho^-n M'[n, m]: E degree 2q, O degree 2q + 1
+      scale2<P>(a, b, odd ? pre : 1.0, pre2);          // pre^n: E degree 2q, O degree 2q + 1
       {
         // axial translation, slot order by slot order (m2l_rot.hpp): own rows in place, the other parity's rows to the partner
         double pa[Q], pb_[Q];                            // E lanes: what the partner sent at the previous step, for slot t
@@ -296,13 +303,14 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
           for (int qo = 0; qo < q0o; ++qo) { pa[qo] = 0; pb_[qo] = 0; }
         });
       }
-      scale2<P>(a, b, odd ? inv2 : inv_rho, inv2);     // L'[j, k] *= rho^-(j+1)
+      if constexpr (OP == kRotM2L) scale2<P>(a, b, odd ? post2 : post, post2);     // L'[j, k] *= rho^-(j+1)
+      else scale2<P>(a, b, odd ? post : 1.0, post2);                                // rho^j (M2M), rho^-j (L2L)
       fixed_rotation2<P, 3>(a, b, cf);
       z_rotation2<P>(a, b, ca, -sa, odd ? ca : 1.0, odd ? -sa : 0.0);
       fixed_rotation2<P, 4>(a, b, cf);
       z_rotation2<P>(a, b, cb, -sb, odd ? cb : 1.0, odd ? -sb : 0.0);
 #else
-      a[0] += inv_rho + ca + sa + cb + sb + inv2 + mask_o + mask_e;
+      a[0] += inv_rho + ca + sa + cb + sb + pre2 + post2 + mask_o + mask_e;
 #endif
 
       // does the last target go on in the next pass?  (pairs past cnt repeat the item's last pair: pair 31 is the last pair)
@@ -318,6 +326,64 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         (void)smask; (void)nseg; (void)live;
       }
 #else
+      if constexpr (OP == kRotL2L) {
+        // every pair is a child of its own: L[child] += the shifted parent, each lane its half, straight from the registers
+        if (live) {
+          double2* own = d.L + ((size_t)tgt * d.nslots + slot) * d.s_max;
+          static_for<0, Q>([&](auto Q_) FMMBEM_INLINE {
+            constexpr int q = decltype(Q_)::value;
+            static_for<0, 2 * q + 2>([&](auto TT) FMMBEM_INLINE {
+              constexpr int t = decltype(TT)::value;
+              constexpr bool has_o = 2 * q + 1 < P, has_e = t >= 1;
+              constexpr int io = has_o ? idx_of(2 * q + 1, t) : 0, ie_ = has_e ? idx_of(2 * q, t - 1) : 0;
+              if (odd ? has_o : has_e) {
+                double2* at = own + (odd ? io : ie_);
+                double2 v = *at;
+                v.x += a[rot2_sidx(q, t)]; v.y += b[rot2_sidx(q, t)];
+                *at = v;
+              }
+            });
+          });
+        }
+      } else if constexpr (OP == kRotM2M) {
+        // a parent has at most eight children and an item holds whole parents in its one pass: lane = (parent, coefficient) adds the
+        // parent's children in the chain order of the general case -- (c0 + c4) + (c1 + c5) and so on (kernels_m2l_rot.hip)
+        __shared__ int seg_first[kPairs + 1], seg_tgt[kPairs];
+        const int segid = __popc(smask & ((2u << pj) - 1u)) - 1;
+        if (live && !odd && (pj == 0 || prev != tgt)) { seg_first[segid] = pj; seg_tgt[segid] = tgt; }
+        if (lane == 0) seg_first[nseg] = cnt;
+        static_for<0, NT>([&](auto T_) FMMBEM_INLINE {
+          constexpr int tr = decltype(T_)::value;
+          constexpr int kt = S - tr * KT < KT ? S - tr * KT : KT;
+          static_for<0, Q>([&](auto Q_) FMMBEM_INLINE {
+            constexpr int q = decltype(Q_)::value;
+            static_for<0, 2 * q + 2>([&](auto TT) FMMBEM_INLINE {
+              constexpr int t = decltype(TT)::value;
+              constexpr bool has_o = 2 * q + 1 < P, has_e = t >= 1;
+              constexpr int io = has_o ? idx_of(2 * q + 1, t) : -1, ie_ = has_e ? idx_of(2 * q, t - 1) : -1;
+              constexpr bool in_o = io >= tr * KT && io < tr * KT + kt, in_e = ie_ >= tr * KT && ie_ < tr * KT + kt;
+              if constexpr (in_o || in_e) {
+                const bool mine = odd ? in_o : in_e;
+                const int row = (odd ? io : ie_) - tr * KT;
+                if (mine) tile[row][pj] = double2{a[rot2_sidx(q, t)], b[rot2_sidx(q, t)]};
+              }
+            });
+          });
+          wave_sync();
+          for (int task = lane; task < nseg * kt; task += kWave) {
+            const int sg = task / kt, c = task - sg * kt;
+            const int f = seg_first[sg], e = seg_first[sg + 1];
+            double2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = f + u < e ? tile[c][f + u] : double2{0, 0};
+            double2 sum;
+            sum.x = ((v[0].x + v[4].x) + (v[1].x + v[5].x)) + ((v[2].x + v[6].x) + (v[3].x + v[7].x));
+            sum.y = ((v[0].y + v[4].y) + (v[1].y + v[5].y)) + ((v[2].y + v[6].y) + (v[3].y + v[7].y));
+            d.M[((size_t)seg_tgt[sg] * d.nslots + slot) * d.s_max + tr * KT + c] = sum;
+          }
+          wave_sync();
+        });
+      } else
       static_for<0, NT>([&](auto T_) FMMBEM_INLINE {
         constexpr int tr = decltype(T_)::value;
         constexpr int kt = S - tr * KT < KT ? S - tr * KT : KT;          // coefficients of this round
@@ -347,7 +413,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
           const bool head = s == 0 && cont_in;
           const bool tail = s == nseg - 1 && cont_out;
           const int q0 = head ? cont_q : 0;
-          double2* Ls = d.L + ((size_t)stgt * d.nslots + slot) * d.s_max + tr * KT;
+          double2* Ls = (OP == kRotM2M ? d.M : d.L) + ((size_t)stgt * d.nslots + slot) * d.s_max + tr * KT;
           auto segment = [&](auto NU_) FMMBEM_INLINE {
             constexpr int NU = decltype(NU_)::value;                    // terms per chain
             double2 sum[NTASK], v[NTASK][NU];
@@ -378,7 +444,10 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
               else {
                 sum[k].x += quad_swap<0xB1>(sum[k].x); sum[k].y += quad_swap<0xB1>(sum[k].y);
                 sum[k].x += quad_swap<0x4E>(sum[k].x); sum[k].y += quad_swap<0x4E>(sum[k].y);
-                if (h == 0 && valid[k]) Ls[cc[k]] = sum[k];
+                if (h == 0 && valid[k]) {
+                  if constexpr (OP == kRotL2L) { const double2 own = Ls[cc[k]]; sum[k].x += own.x; sum[k].y += own.y; }   // L[child] += ...
+                  Ls[cc[k]] = sum[k];
+                }
               }
             }
           };
@@ -406,10 +475,25 @@ hipError_t launch_m2l_rot2(const DevicePlan& d, const RotWork& w, int p, hipStre
   constexpr int CH = FMMBEM_ROT_XCD_CHUNK;
   const int grid = (w.n_items + 8 * CH - 1) / (8 * CH) * (8 * CH);
   switch (p) {
-    case 10: hipLaunchKernelGGL((m2l_rot2_kernel<10>), dim3(grid), dim3(kWave), 0, s, d, w); break;
-    case 12: hipLaunchKernelGGL((m2l_rot2_kernel<12>), dim3(grid), dim3(kWave), 0, s, d, w); break;
+    case 10: hipLaunchKernelGGL((m2l_rot2_kernel<10, kRotM2L>), dim3(grid), dim3(kWave), 0, s, d, w); break;
+    case 12: hipLaunchKernelGGL((m2l_rot2_kernel<12, kRotM2L>), dim3(grid), dim3(kWave), 0, s, d, w); break;
     default: return hipErrorInvalidValue;
   }
+  return hipGetLastError();
+}
+
+// the shifts of the tree passes in the same form: op = kRotM2M or kRotL2L, items of ONE pass (at most 32 pairs of whole targets)
+hipError_t launch_shift_rot2(const DevicePlan& d, const RotWork& w, int p, int op, hipStream_t s) {
+  if (w.n_items <= 0) return hipSuccess;
+  constexpr int CH = FMMBEM_ROT_XCD_CHUNK;
+  const dim3 grid((w.n_items + 8 * CH - 1) / (8 * CH) * (8 * CH), d.n_act);
+#define SHIFT2_CASE(PP) case PP: if (op == kRotM2M) hipLaunchKernelGGL((m2l_rot2_kernel<PP, kRotM2M>), grid, dim3(kWave), 0, s, d, w); \
+                                 else hipLaunchKernelGGL((m2l_rot2_kernel<PP, kRotL2L>), grid, dim3(kWave), 0, s, d, w); break;
+  switch (p) {
+    SHIFT2_CASE(10) SHIFT2_CASE(12)
+    default: return hipErrorInvalidValue;
+  }
+#undef SHIFT2_CASE
   return hipGetLastError();
 }
 

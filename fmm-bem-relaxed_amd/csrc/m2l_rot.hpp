@@ -274,7 +274,9 @@ constexpr int rot2_stream_len(int P) { return 4 * rot2_rot_len(P) + rot2_axial_l
 // layout: groups of sixteen positions; group g holds 16 E constants then 16 O constants: [g][parity][k]
 constexpr int rot2_stream_doubles(int P) { return ((rot2_stream_len(P) + kRotGroup - 1) / kRotGroup + 1) * 2 * kRotGroup; }
 
-inline void build_rot2_stream(int P, std::vector<double>& out) {
+// op: the axial operator in the middle -- M2L, or one of the two shifts of the tree passes (same skeleton, the entries outside
+// the shift's triangle are zeros: the split kernel runs one instruction stream for all three)
+inline void build_rot2_stream(int P, std::vector<double>& out, int op = kRotM2L) {
   std::vector<double> plain;
   build_rot_table(P, plain);                        // [rotation coefficients of degrees 0 .. P-1, unsigned][Tz of M2L]
   out.assign((size_t)rot2_stream_doubles(P), 0.0);
@@ -310,10 +312,16 @@ inline void build_rot2_stream(int P, std::vector<double>& out) {
         }
     }
   };
-  // Tz[j, n, k] of M2L (build_rot_table's second part: k, then j >= k, then n >= k), zero outside its range
+  // Tz[j, n, k] of M2L (build_rot_table's second part: k, then j >= k, then n >= k), zero outside its range; for the shifts
+  // Tm / Tl of build_rot_stream, zero outside the triangle
+  auto fact = [](int k) { long double f = 1; for (int i = 2; i <= k; ++i) f *= i; return f; };
+  auto an = [&](int n, int m) { return ((n & 1) ? -1.0L : 1.0L) / std::sqrt(fact(n - m) * fact(n + m)); };
   auto tz = [&](int j, int n, int k) -> double {
     if (k < 0 || j < k || n < k || j >= P || n >= P) return 0.0;
-    return plain[(size_t)tz_off(P, k) + (size_t)(j - k) * (P - k) + (n - k)];
+    if (op == kRotM2L) return plain[(size_t)tz_off(P, k) + (size_t)(j - k) * (P - k) + (n - k)];
+    if (n < axial_row_begin(P, op, k, j) || n >= axial_row_end(P, op, k, j)) return 0.0;
+    return op == kRotM2M ? (double)((((j - n) & 1) ? -1.0L : 1.0L) * an(j - n, 0) * an(n, k) / an(j, k))
+                         : (double)(an(n - j, 0) * an(j, k) / an(n, k));
   };
   auto axial = [&]() {
     const int Q = rot2_pairs(P);

@@ -148,10 +148,15 @@ struct fmmbem_plan {
   std::vector<std::pair<int, int>> m2m_launch, l2l_launch;     // (first, count) per level
   std::vector<std::pair<int, int>> m2m_shared_launch;          // sharded upward pass: parents spanning shards
   // the same launches for the rotation kernels (kernels_m2l_rot.hip with FMMBEM_ROT_OP = 1, 2): (first item, items, pairs)
-  struct ShiftRot { int item_first = 0, n_items = 0, pairs = 0, level_boxes = 0; };   // level_boxes: boxes of the child level in the WHOLE tree
+  struct ShiftRot { int item_first = 0, n_items = 0, pairs = 0, level_boxes = 0, item_first32 = 0, n_items32 = 0; };   // level_boxes: boxes of the child level in the WHOLE tree; *32: the cut into items of 32 pairs (split form)
   std::vector<ShiftRot> m2m_rot, m2m_shared_rot, l2l_rot;
   const int *up_rsrc = nullptr, *up_rcls = nullptr, *up_rtgt = nullptr, *up_ritem = nullptr;
   const int *dn_rsrc = nullptr, *dn_rcls = nullptr, *dn_rtgt = nullptr, *dn_ritem = nullptr;
+  // the shifts in the split form (kernels_m2l_rot2.hip): the same pairs in items of 32, the split constant streams per order
+  const int *up_ritem32 = nullptr, *dn_ritem32 = nullptr;
+  const double *up_stream2 = nullptr, *dn_stream2 = nullptr;
+  int shift_stream2_off[kRotPmax + 1] = {};
+  bool shift_rot2 = true;                             // FMMBEM_SHIFT_ROT2=0: the one-pair-per-lane shift kernels at every order
   const double *up_rec = nullptr, *dn_rec = nullptr, *up_stream = nullptr, *dn_stream = nullptr;
   int shift_stream_off[12] = {};
   int shift_rot_min = 2048;                                    // boxes on a tree level from which the rotation kernels take it
@@ -562,14 +567,14 @@ int fmmbem_plan::to_device() {
     // ---- M2M / L2L by rotation: pair lists per level launch, items, records, constant streams ----
     {
       TRY(upload(up_rec_h, &up_rec)); TRY(upload(dn_rec_h, &dn_rec));
-      std::vector<int> rs, rc, rt, ri, len;
+      std::vector<int> rs, rc, rt, ri, ri32, len;
       auto level_boxes = [&](int l) { return l >= 0 && l < hp.nlevels ? hp.level_off[l + 1] - hp.level_off[l] : 0; };
       // items of the shifts: whole targets, ONE pass (at most 64 pairs) -- the shift kernels carry nothing between passes
-      auto cut_single_pass = [](const std::vector<int>& seg_len, int pair_base, std::vector<int>& item_ptr) {
+      auto cut_single_pass = [](const std::vector<int>& seg_len, int pair_base, std::vector<int>& item_ptr, int lanes = 64) {
         item_ptr.push_back(pair_base);
         int fill = 0;
         for (int l : seg_len) {
-          if (fill + l > 64) { item_ptr.push_back(item_ptr.back() + fill); fill = 0; }
+          if (fill + l > lanes) { item_ptr.push_back(item_ptr.back() + fill); fill = 0; }
           fill += l;
         }
         if (fill > 0) item_ptr.push_back(item_ptr.back() + fill);
@@ -587,6 +592,9 @@ int fmmbem_plan::to_device() {
           }
           cut_single_pass(len, base, ri);
           sr.n_items = (int)ri.size() - sr.item_first - 1;
+          sr.item_first32 = (int)ri32.size();
+          cut_single_pass(len, base, ri32, 32);
+          sr.n_items32 = (int)ri32.size() - sr.item_first32 - 1;
           sr.pairs = (int)rs.size() - base;
           sr.level_boxes = count > 0 ? level_boxes(hp.box_level[hp.m2m_parents[first]] + 1) : 0;
           out.push_back(sr);
@@ -594,8 +602,8 @@ int fmmbem_plan::to_device() {
       };
       add_m2m(m2m_launch, m2m_rot);
       add_m2m(m2m_shared_launch, m2m_shared_rot);
-      TRY(upload(rs, &up_rsrc)); TRY(upload(rc, &up_rcls)); TRY(upload(rt, &up_rtgt)); TRY(upload(ri, &up_ritem));
-      rs.clear(); rc.clear(); rt.clear(); ri.clear();
+      TRY(upload(rs, &up_rsrc)); TRY(upload(rc, &up_rcls)); TRY(upload(rt, &up_rtgt)); TRY(upload(ri, &up_ritem)); TRY(upload(ri32, &up_ritem32));
+      rs.clear(); rc.clear(); rt.clear(); ri.clear(); ri32.clear();
       for (auto [first, count] : l2l_launch) {
         ShiftRot sr;
         sr.item_first = (int)ri.size();
@@ -607,11 +615,14 @@ int fmmbem_plan::to_device() {
         len.assign((size_t)count, 1);
         cut_single_pass(len, base, ri);
         sr.n_items = (int)ri.size() - sr.item_first - 1;
+        sr.item_first32 = (int)ri32.size();
+        cut_single_pass(len, base, ri32, 32);
+        sr.n_items32 = (int)ri32.size() - sr.item_first32 - 1;
         sr.pairs = count;
         sr.level_boxes = count > 0 ? level_boxes(hp.box_level[hp.l2l_children[first]]) : 0;
         l2l_rot.push_back(sr);
       }
-      TRY(upload(rs, &dn_rsrc)); TRY(upload(rc, &dn_rcls)); TRY(upload(rt, &dn_rtgt)); TRY(upload(ri, &dn_ritem));
+      TRY(upload(rs, &dn_rsrc)); TRY(upload(rc, &dn_rcls)); TRY(upload(rt, &dn_rtgt)); TRY(upload(ri, &dn_ritem)); TRY(upload(ri32, &dn_ritem32));
       std::vector<double> ups, dns, one;
       for (int q = 1; q <= kRotPmax; ++q) {
         shift_stream_off[q - 1] = (int)ups.size();
@@ -620,6 +631,15 @@ int fmmbem_plan::to_device() {
         build_rot_stream(q, one, kRotL2L); dns.insert(dns.end(), one.begin(), one.end());
       }
       TRY(upload(ups, &up_stream)); TRY(upload(dns, &dn_stream));
+      ups.clear(); dns.clear();
+      for (int q = 1; q <= kRotPmax; ++q) {
+        shift_stream2_off[q] = (int)ups.size();
+        if (!m2l_rot2_supported(q) || q > pm) continue;
+        build_rot2_stream(q, one, kRotM2M); ups.insert(ups.end(), one.begin(), one.end());
+        build_rot2_stream(q, one, kRotL2L); dns.insert(dns.end(), one.begin(), one.end());
+      }
+      TRY(upload(ups, &up_stream2)); TRY(upload(dns, &dn_stream2));
+      if (const char* e = std::getenv("FMMBEM_SHIFT_ROT2")) shift_rot2 = std::atoi(e) != 0;
       if (const char* e = std::getenv("FMMBEM_SHIFT_ROT")) shift_rot = std::atoi(e) != 0;
       if (const char* e = std::getenv("FMMBEM_SHIFT_ROT_MIN")) shift_rot_min = std::atoi(e);
     }
@@ -829,8 +849,14 @@ int fmmbem_plan::m2m_pass(int p, bool shared, hipStream_t s) {
     const ShiftRot& sr = rots[i];
     if (shift_rot && shift_rot_supported(p) && sr.level_boxes >= shift_rot_min) {
       RotWork w;
-      w.src = up_rsrc; w.cls = up_rcls; w.tgt = up_rtgt; w.item_ptr = up_ritem + sr.item_first; w.n_items = sr.n_items;
-      w.rec = up_rec; w.stream = up_stream + shift_stream_off[p - 1];
+      w.src = up_rsrc; w.cls = up_rcls; w.tgt = up_rtgt; w.rec = up_rec;
+      if (shift_rot2 && m2l_rot2_supported(p) && up_stream2) {       // the split form: a pass half as long
+        w.item_ptr = up_ritem32 + sr.item_first32; w.n_items = sr.n_items32; w.stream = up_stream2 + shift_stream2_off[p];
+        HIP_TRY(launch_shift_rot2(d, w, p, kRotM2M, s));
+        continue;
+      }
+      w.item_ptr = up_ritem + sr.item_first; w.n_items = sr.n_items;
+      w.stream = up_stream + shift_stream_off[p - 1];
       HIP_TRY(launch_m2m_rot(d, w, p, s));
     } else HIP_TRY(launch_m2m_level(d, up_ops[p - 1], p, first, count, s));
   }
@@ -842,8 +868,14 @@ int fmmbem_plan::l2l_pass(int p, hipStream_t s) {
     const ShiftRot& sr = l2l_rot[i];
     if (shift_rot && shift_rot_supported(p) && sr.level_boxes >= shift_rot_min) {
       RotWork w;
-      w.src = dn_rsrc; w.cls = dn_rcls; w.tgt = dn_rtgt; w.item_ptr = dn_ritem + sr.item_first; w.n_items = sr.n_items;
-      w.rec = dn_rec; w.stream = dn_stream + shift_stream_off[p - 1];
+      w.src = dn_rsrc; w.cls = dn_rcls; w.tgt = dn_rtgt; w.rec = dn_rec;
+      if (shift_rot2 && m2l_rot2_supported(p) && dn_stream2) {
+        w.item_ptr = dn_ritem32 + sr.item_first32; w.n_items = sr.n_items32; w.stream = dn_stream2 + shift_stream2_off[p];
+        HIP_TRY(launch_shift_rot2(d, w, p, kRotL2L, s));
+        continue;
+      }
+      w.item_ptr = dn_ritem + sr.item_first; w.n_items = sr.n_items;
+      w.stream = dn_stream + shift_stream_off[p - 1];
       HIP_TRY(launch_l2l_rot(d, w, p, s));
     } else HIP_TRY(launch_l2l_level(d, down_ops[p - 1], p, first, count, s));
   }

@@ -16,10 +16,10 @@ using namespace fmmbem;
 
 static int idx_of(int n, int m) { return n * (n + 1) / 2 + m; }
 
-struct Geo { double inv_rho, ca, sa, cb, sb; };
+struct Geo { double inv_rho, ca, sa, cb, sb, rho; };
 
 // ---- the form of kernels_m2l_rot.hip ----
-static void plain_program(int P, const std::vector<double>& st, const Geo& g, std::vector<double>& a, std::vector<double>& b) {
+static void plain_program(int P, int op, const std::vector<double>& st, const Geo& g, std::vector<double>& a, std::vector<double>& b) {
   auto zrot = [&](double c1, double s1) {
     double cm = c1, sm = s1;
     for (int m = 1; m < P; ++m) {
@@ -39,7 +39,7 @@ static void plain_program(int P, const std::vector<double>& st, const Geo& g, st
         double sa = 0, sb = 0;
         for (int mp = 0; mp <= n; ++mp) {
           if (!rot_live(n, m, mp)) continue;
-          const double c = st[(size_t)rot_stage_base(P, stage) + rot_index(n, m, mp)];
+          const double c = st[(size_t)rot_stage_base(P, stage, op) + rot_index(n, m, mp)];
           const bool even = ((n + m) & 1) == 0;
           const double src = (mp == 0 || even) ? a[idx_of(n, mp)] : b[idx_of(n, mp)];
           if ((rot_kk(n, m, mp) & 1) == 0) sa = std::fma(c, src, sa); else sb = std::fma(c, src, sb);
@@ -50,13 +50,14 @@ static void plain_program(int P, const std::vector<double>& st, const Geo& g, st
     }
   };
   zrot(g.cb, g.sb); fixed(0); zrot(g.ca, g.sa); fixed(1);
-  { double r = g.inv_rho; for (int n = 1; n < P; ++n) { for (int m = 0; m <= n; ++m) { a[idx_of(n, m)] *= r; if (m) b[idx_of(n, m)] *= r; } r *= g.inv_rho; } }
+  { const double base = op == kRotL2L ? g.rho : g.inv_rho;          // M2L, M2M: rho^-n;  L2L: rho^n  (kernels_m2l_rot.hip)
+    double r = base; for (int n = 1; n < P; ++n) { for (int m = 0; m <= n; ++m) { a[idx_of(n, m)] *= r; if (m) b[idx_of(n, m)] *= r; } r *= base; } }
   for (int k = 0; k < P; ++k) {
     std::vector<double> la(P), lb(P);
     for (int j = k; j < P; ++j) {
       double s1 = 0, s2 = 0;
-      for (int n = k; n < P; ++n) {
-        const double c = st[(size_t)rot_stage_base(P, 2) + tz_index(P, k, j, n)];
+      for (int n = axial_row_begin(P, op, k, j); n < axial_row_end(P, op, k, j); ++n) {
+        const double c = st[(size_t)rot_stage_base(P, 2, op) + axial_index(P, op, k, j, n)];
         s1 = std::fma(c, a[idx_of(n, k)], s1);
         if (k) s2 = std::fma(c, b[idx_of(n, k)], s2);
       }
@@ -64,12 +65,14 @@ static void plain_program(int P, const std::vector<double>& st, const Geo& g, st
     }
     for (int j = k; j < P; ++j) { a[idx_of(j, k)] = la[j]; b[idx_of(j, k)] = lb[j]; }
   }
-  { double r = g.inv_rho; for (int j = 0; j < P; ++j) { for (int k = 0; k <= j; ++k) { a[idx_of(j, k)] *= r; if (k) b[idx_of(j, k)] *= r; } r *= g.inv_rho; } }
+  { const double base = op == kRotM2M ? g.rho : g.inv_rho;          // M2L: rho^-(j+1);  M2M: rho^j;  L2L: rho^-j
+    double r = op == kRotM2L ? base : 1.0;
+    for (int j = 0; j < P; ++j) { for (int k = 0; k <= j; ++k) { a[idx_of(j, k)] *= r; if (k) b[idx_of(j, k)] *= r; } r *= base; } }
   fixed(3); zrot(g.ca, -g.sa); fixed(4); zrot(g.cb, -g.sb);
 }
 
 // ---- the split form: lane[0] = E (even degrees), lane[1] = O (odd degrees); slots (q, t) ----
-static void split_program(int P, const std::vector<double>& st2, const Geo& g, std::vector<double>& a, std::vector<double>& b) {
+static void split_program(int P, int op, const std::vector<double>& st2, const Geo& g, std::vector<double>& a, std::vector<double>& b) {
   const int Q = rot2_pairs(P), NS = rot2_nslots(P);
   std::vector<double> A[2] = {std::vector<double>(NS, 0.0), std::vector<double>(NS, 0.0)}, B[2] = {std::vector<double>(NS, 0.0), std::vector<double>(NS, 0.0)};
   auto cst = [&](int e, int par) { return st2[(size_t)(e / kRotGroup) * 2 * kRotGroup + (size_t)par * kRotGroup + e % kRotGroup]; };
@@ -114,17 +117,18 @@ static void split_program(int P, const std::vector<double>& st2, const Geo& g, s
         for (int m = 0; m <= n; ++m) { A[par][rot2_sidx(q, m)] = na[m]; B[par][rot2_sidx(q, m)] = nb[m]; }
       }
   };
-  auto scale = [&](double first_e, double first_o) {                  // per degree pair times inv_rho^2
+  auto scale = [&](double first_e, double first_o, double step) {     // per degree pair times step
     for (int par = 0; par < 2; ++par) {
       double r = par ? first_o : first_e;
       for (int q = 0; q < Q; ++q) {
         for (int t = 0; t <= 2 * q + 1; ++t) { A[par][rot2_sidx(q, t)] *= r; B[par][rot2_sidx(q, t)] *= r; }
-        r *= g.inv_rho * g.inv_rho;
+        r *= step;
       }
     }
   };
+  const double pre = op == kRotL2L ? g.rho : g.inv_rho, post = op == kRotM2M ? g.rho : g.inv_rho;
   zrot(g.cb, g.sb); fixed(0); zrot(g.ca, g.sa); fixed(1);
-  scale(1.0, g.inv_rho);                                              // rho^-n: E degree 2q, O degree 2q+1
+  scale(1.0, pre, pre * pre);                                         // pre^n: E degree 2q, O degree 2q+1
   {
     std::vector<double> pendA(Q, 0.0), pendB(Q, 0.0);                 // E lane: what O sent at the previous step, for slot t
     for (int t = 0; t < 2 * Q; ++t) {
@@ -154,7 +158,8 @@ static void split_program(int P, const std::vector<double>& st2, const Geo& g, s
       for (int qo = q0; qo < Q; ++qo) if (t + 1 > 2 * qo + 1) { pendA[qo] = 0; pendB[qo] = 0; }
     }
   }
-  scale(g.inv_rho, g.inv_rho * g.inv_rho);                            // rho^-(j+1)
+  if (op == kRotM2L) scale(post, post * post, post * post);           // rho^-(j+1)
+  else scale(1.0, post, post * post);                                 // M2M rho^j, L2L rho^-j
   fixed(3); zrot(g.ca, -g.sa); fixed(4); zrot(g.cb, -g.sb);
   for (int par = 0; par < 2; ++par)
     for (int q = 0; q < Q; ++q)
@@ -169,10 +174,12 @@ int main(int argc, char** argv) {
   std::mt19937_64 rng(12345);
   std::uniform_real_distribution<double> U(-1.0, 1.0);
   double worst_all = 0;
+  const char* names[3] = {"M2L", "M2M", "L2L"};
+  for (int op = 0; op < 3; ++op)
   for (int P = 1; P <= kRotPmax; ++P) {
     std::vector<double> st, st2;
-    build_rot_stream(P, st);
-    build_rot2_stream(P, st2);
+    build_rot_stream(P, st, op);
+    build_rot2_stream(P, st2, op);
     const int S = P * (P + 1) / 2;
     double worst = 0;
     for (int it = 0; it < trials; ++it) {
@@ -183,16 +190,17 @@ int main(int argc, char** argv) {
       if (it == 0) { v[0] = 0; v[1] = 0; v[2] = 2.5; }                  // along the axis
       const double rho = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]) + 1e-12, h = std::hypot(v[0], v[1]);
       Geo g;
+      g.rho = rho;
       g.inv_rho = 1.0 / rho; g.ca = v[2] / rho; g.sa = std::sqrt((1 - g.ca) * (1 + g.ca));
       g.cb = h > 0 ? v[0] / h : 1.0; g.sb = h > 0 ? v[1] / h : 0.0;
       std::vector<double> a1 = a, b1 = b, a2 = a, b2 = b;
-      plain_program(P, st, g, a1, b1);
-      split_program(P, st2, g, a2, b2);
+      plain_program(P, op, st, g, a1, b1);
+      split_program(P, op, st2, g, a2, b2);
       double num = 0, den = 0;
       for (int i = 0; i < S; ++i) { num = std::max(num, std::max(std::fabs(a1[i] - a2[i]), std::fabs(b1[i] - b2[i]))); den = std::max(den, std::max(std::fabs(a1[i]), std::fabs(b1[i]))); }
       worst = std::max(worst, num / den);
     }
-    std::printf("p=%d stream %d / %d constants  max rel diff %.3e\n", P, rot_stream_len(P), rot2_stream_len(P), worst);
+    std::printf("%s p=%d stream %d / %d constants  max rel diff %.3e\n", names[op], P, rot_stream_len(P, op), rot2_stream_len(P), worst);
     worst_all = std::max(worst_all, worst);
   }
   return worst_all < 1e-12 ? 0 : 1;

@@ -444,3 +444,13 @@ def test_tree_passes_by_rotation_match_oracle(fb, oracle_mod, monkeypatch, p):
     monkeypatch.setenv("FMMBEM_SHIFT_ROT", "0")
     y2 = fb.FMM_plan(K, v, bc=bc).execute(x)
     assert rel_l2(y, y2) <= 1e-14
+    # p = 10, 12 took the split form of the shift kernels (kernels_m2l_rot2.hip, a pair on two lanes): the one-pair form too
+    monkeypatch.setenv("FMMBEM_SHIFT_ROT", "1")
+    monkeypatch.setenv("FMMBEM_SHIFT_ROT2", "0")
+    pl3 = fb.FMM_plan(K, v, bc=bc)
+    y3 = pl3.execute(x)
+    for which in ("M", "L"):
+        got, ref = pl3.expansions(which, p), o.expansions(p, which)
+        scale = np.abs(ref).max(axis=2, keepdims=True) + 1e-300
+        assert np.max(np.abs(got - ref) / scale) <= TOL_EXPANSION, which
+    assert rel_l2(y, y3) <= 1e-14 and (p in (10, 12) or np.array_equal(y, y3))
