@@ -157,6 +157,11 @@ struct fmmbem_plan {
   const double *up_stream2 = nullptr, *dn_stream2 = nullptr;
   int shift_stream2_off[kRotPmax + 1] = {};
   bool shift_rot2 = true;                             // FMMBEM_SHIFT_ROT2=0: the one-pair-per-lane shift kernels at every order
+  // ... on levels of at most this many boxes (WHOLE tree, like shift_rot_min: shards must pick alike).  Every level by default: in a
+  // trace the biggest level is slower in the split form (39 062 boxes, two wavefronts share a SIMD: 25.7 us against 23.6) and the
+  // others faster (21 348: 17.3 against 19.5; 5 786: 12.3 against 16.3), but with the cut at 32 768 boxes the passes take 0.086 +
+  // 0.118 ms against 0.081 + 0.103 for all levels split (0.087 + 0.117 one-pair): two big kernels in turn cost more than they save
+  int shift_rot2_max = 1 << 30;
   const double *up_rec = nullptr, *dn_rec = nullptr, *up_stream = nullptr, *dn_stream = nullptr;
   int shift_stream_off[12] = {};
   int shift_rot_min = 2048;                                    // boxes on a tree level from which the rotation kernels take it
@@ -640,6 +645,7 @@ int fmmbem_plan::to_device() {
       }
       TRY(upload(ups, &up_stream2)); TRY(upload(dns, &dn_stream2));
       if (const char* e = std::getenv("FMMBEM_SHIFT_ROT2")) shift_rot2 = std::atoi(e) != 0;
+      if (const char* e = std::getenv("FMMBEM_SHIFT_ROT2_MAX")) shift_rot2_max = std::atoi(e);
       if (const char* e = std::getenv("FMMBEM_SHIFT_ROT")) shift_rot = std::atoi(e) != 0;
       if (const char* e = std::getenv("FMMBEM_SHIFT_ROT_MIN")) shift_rot_min = std::atoi(e);
     }
@@ -850,7 +856,7 @@ int fmmbem_plan::m2m_pass(int p, bool shared, hipStream_t s) {
     if (shift_rot && shift_rot_supported(p) && sr.level_boxes >= shift_rot_min) {
       RotWork w;
       w.src = up_rsrc; w.cls = up_rcls; w.tgt = up_rtgt; w.rec = up_rec;
-      if (shift_rot2 && m2l_rot2_supported(p) && up_stream2) {       // the split form: a pass half as long
+      if (shift_rot2 && m2l_rot2_supported(p) && up_stream2 && sr.level_boxes <= shift_rot2_max) {       // the split form: a shorter pass
         w.item_ptr = up_ritem32 + sr.item_first32; w.n_items = sr.n_items32; w.stream = up_stream2 + shift_stream2_off[p];
         HIP_TRY(launch_shift_rot2(d, w, p, kRotM2M, s));
         continue;
@@ -869,7 +875,7 @@ int fmmbem_plan::l2l_pass(int p, hipStream_t s) {
     if (shift_rot && shift_rot_supported(p) && sr.level_boxes >= shift_rot_min) {
       RotWork w;
       w.src = dn_rsrc; w.cls = dn_rcls; w.tgt = dn_rtgt; w.rec = dn_rec;
-      if (shift_rot2 && m2l_rot2_supported(p) && dn_stream2) {
+      if (shift_rot2 && m2l_rot2_supported(p) && dn_stream2 && sr.level_boxes <= shift_rot2_max) {
         w.item_ptr = dn_ritem32 + sr.item_first32; w.n_items = sr.n_items32; w.stream = dn_stream2 + shift_stream2_off[p];
         HIP_TRY(launch_shift_rot2(d, w, p, kRotL2L, s));
         continue;
