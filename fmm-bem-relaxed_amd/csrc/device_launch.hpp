@@ -35,6 +35,7 @@ hipError_t launch_m2m_rot(const DevicePlan& d, const RotWork& w, int p, hipStrea
 hipError_t launch_l2l_rot(const DevicePlan& d, const RotWork& w, int p, hipStream_t s);   // L[tgt = child] += shift of L[src = parent]
 hipError_t launch_m2l_rot(const DevicePlan& d, const DevicePlan* d_dev, int p, hipStream_t s);
 bool m2l_rot_long_items(int p);
+bool shift_rot2_supported(int p);
 hipError_t launch_shift_rot2(const DevicePlan& d, const RotWork& w, int p, int op, hipStream_t s);   // kernels_m2l_rot2.hip: M2M / L2L in the split form
 int l2p_group_leaves(int kernel);                      // most leaves an L2P work group may hold (the kernels' LDS slice per wavefront)
 hipError_t launch_m2l_rot_zero(const DevicePlan& d, int p, hipStream_t s);

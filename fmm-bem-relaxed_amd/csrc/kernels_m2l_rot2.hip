@@ -482,6 +482,8 @@ hipError_t launch_m2l_rot2(const DevicePlan& d, const RotWork& w, int p, hipStre
   return hipGetLastError();
 }
 
+bool shift_rot2_supported(int p) { return p >= 8 && p <= 12; }
+
 // the shifts of the tree passes in the same form: op = kRotM2M or kRotL2L, items of ONE pass (at most 32 pairs of whole targets)
 hipError_t launch_shift_rot2(const DevicePlan& d, const RotWork& w, int p, int op, hipStream_t s) {
   if (w.n_items <= 0) return hipSuccess;
@@ -490,7 +492,7 @@ hipError_t launch_shift_rot2(const DevicePlan& d, const RotWork& w, int p, int o
 #define SHIFT2_CASE(PP) case PP: if (op == kRotM2M) hipLaunchKernelGGL((m2l_rot2_kernel<PP, kRotM2M>), grid, dim3(kWave), 0, s, d, w); \
                                  else hipLaunchKernelGGL((m2l_rot2_kernel<PP, kRotL2L>), grid, dim3(kWave), 0, s, d, w); break;
   switch (p) {
-    SHIFT2_CASE(10) SHIFT2_CASE(12)
+    SHIFT2_CASE(8) SHIFT2_CASE(9) SHIFT2_CASE(10) SHIFT2_CASE(11) SHIFT2_CASE(12)
     default: return hipErrorInvalidValue;
   }
 #undef SHIFT2_CASE

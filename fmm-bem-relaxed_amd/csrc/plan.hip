@@ -162,6 +162,11 @@ struct fmmbem_plan {
   // others faster (21 348: 17.3 against 19.5; 5 786: 12.3 against 16.3), but with the cut at 32 768 boxes the passes take 0.086 +
   // 0.118 ms against 0.081 + 0.103 for all levels split (0.087 + 0.117 one-pair): two big kernels in turn cost more than they save
   int shift_rot2_max = 1 << 30;
+  // bit p: the orders that take the split form (FMMBEM_SHIFT_ROT2_ORDERS, a mask).  M2M / L2L ms at N = 1M, one-pair / split:
+  // p = 8 0.063 / 0.064, 0.073 / 0.075 (Stokes, four slots: 0.090 / 0.087, 0.108 / 0.091); 9 0.073 / 0.074, 0.093 / 0.088;
+  // 10 0.087 / 0.081, 0.116 / 0.103; 11 0.108 / 0.120, 0.149 / 0.158 (not taken); 12 0.135 / 0.127, 0.183 / 0.178
+  unsigned shift_rot2_orders = (1u << 8) | (1u << 9) | (1u << 10) | (1u << 12);
+  bool shift_rot2_order(int p) const { return (shift_rot2_orders >> p) & 1u; }
   const double *up_rec = nullptr, *dn_rec = nullptr, *up_stream = nullptr, *dn_stream = nullptr;
   int shift_stream_off[12] = {};
   int shift_rot_min = 2048;                                    // boxes on a tree level from which the rotation kernels take it
@@ -639,13 +644,14 @@ int fmmbem_plan::to_device() {
       ups.clear(); dns.clear();
       for (int q = 1; q <= kRotPmax; ++q) {
         shift_stream2_off[q] = (int)ups.size();
-        if (!m2l_rot2_supported(q) || q > pm) continue;
+        if (!shift_rot2_supported(q) || q > pm) continue;
         build_rot2_stream(q, one, kRotM2M); ups.insert(ups.end(), one.begin(), one.end());
         build_rot2_stream(q, one, kRotL2L); dns.insert(dns.end(), one.begin(), one.end());
       }
       TRY(upload(ups, &up_stream2)); TRY(upload(dns, &dn_stream2));
       if (const char* e = std::getenv("FMMBEM_SHIFT_ROT2")) shift_rot2 = std::atoi(e) != 0;
       if (const char* e = std::getenv("FMMBEM_SHIFT_ROT2_MAX")) shift_rot2_max = std::atoi(e);
+      if (const char* e = std::getenv("FMMBEM_SHIFT_ROT2_ORDERS")) shift_rot2_orders = (unsigned)std::strtoul(e, nullptr, 0);
       if (const char* e = std::getenv("FMMBEM_SHIFT_ROT")) shift_rot = std::atoi(e) != 0;
       if (const char* e = std::getenv("FMMBEM_SHIFT_ROT_MIN")) shift_rot_min = std::atoi(e);
     }
@@ -856,7 +862,7 @@ int fmmbem_plan::m2m_pass(int p, bool shared, hipStream_t s) {
     if (shift_rot && shift_rot_supported(p) && sr.level_boxes >= shift_rot_min) {
       RotWork w;
       w.src = up_rsrc; w.cls = up_rcls; w.tgt = up_rtgt; w.rec = up_rec;
-      if (shift_rot2 && m2l_rot2_supported(p) && up_stream2 && sr.level_boxes <= shift_rot2_max) {       // the split form: a shorter pass
+      if (shift_rot2 && shift_rot2_supported(p) && shift_rot2_order(p) && up_stream2 && sr.level_boxes <= shift_rot2_max) {       // the split form: a shorter pass
         w.item_ptr = up_ritem32 + sr.item_first32; w.n_items = sr.n_items32; w.stream = up_stream2 + shift_stream2_off[p];
         HIP_TRY(launch_shift_rot2(d, w, p, kRotM2M, s));
         continue;
@@ -875,7 +881,7 @@ int fmmbem_plan::l2l_pass(int p, hipStream_t s) {
     if (shift_rot && shift_rot_supported(p) && sr.level_boxes >= shift_rot_min) {
       RotWork w;
       w.src = dn_rsrc; w.cls = dn_rcls; w.tgt = dn_rtgt; w.rec = dn_rec;
-      if (shift_rot2 && m2l_rot2_supported(p) && dn_stream2 && sr.level_boxes <= shift_rot2_max) {
+      if (shift_rot2 && shift_rot2_supported(p) && shift_rot2_order(p) && dn_stream2 && sr.level_boxes <= shift_rot2_max) {
         w.item_ptr = dn_ritem32 + sr.item_first32; w.n_items = sr.n_items32; w.stream = dn_stream2 + shift_stream2_off[p];
         HIP_TRY(launch_shift_rot2(d, w, p, kRotL2L, s));
         continue;
