@@ -145,6 +145,7 @@ int  orc_build_near(orc_ctx *c);
 int  orc_build_near_pattern(orc_ctx *c);    /* row_ptr/col only */
 int  orc_matvec(orc_ctx *c, int P, const double *x, double *y, int flags, double stage_s[8]);
 void orc_direct(const orc_ctx *c, const double *x, double *y, int row_begin, int row_end);
+void orc_direct_rows(const orc_ctx *c, const double *x, double *y_out, int nrows, const int32_t *rows);
 void orc_near_only(const orc_ctx *c, const double *x, double *y);
 
 /* ---- stokes.c ---- */
@@ -153,6 +154,7 @@ void orc_stokes_entry(const orc_ctx *c, const orc_panel *t, const orc_panel *s, 
 int  orc_stokes_build_near(orc_ctx *c);
 int  orc_stokes_matvec(orc_ctx *c, int P, const double *x, double *y, int flags, double stage_s[8]);
 void orc_stokes_direct(const orc_ctx *c, const double *x, double *y, int row_begin, int row_end);
+void orc_stokes_direct_rows(const orc_ctx *c, const double *x, double *y_out, int nrows, const int32_t *rows);
 void orc_red_blood_cell_map(long n, double *verts);
 
 #define ORC_FLAG_FAITHFUL 1   /* both expansions, serial SpMV/M2M/L2L like the reference */

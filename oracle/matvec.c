@@ -200,3 +200,15 @@ void orc_direct(const orc_ctx *c, const double *x, double *y, int row_begin, int
     y[i] = r;
   }
 }
+
+/* The same sum (include/Direct.hpp:99-125, error over chosen bodies as tests/scaling.cpp:56-74 forms it) on a LIST of
+ * target rows, original panel order: y_out[k] = row rows[k].  Test tooling: lets a seeded sample cover the whole vector. */
+void orc_direct_rows(const orc_ctx *c, const double *x, double *y_out, int nrows, const int32_t *rows) {
+  #pragma omp parallel for schedule(dynamic, 4)
+  for (int k = 0; k < nrows; ++k) {
+    const int i = rows[k];
+    double r = 0;
+    for (int j = 0; j < c->n; ++j) r += orc_kernel(c, &c->panels[i], &c->panels[j]) * x[j];
+    y_out[k] = r;
+  }
+}

@@ -49,6 +49,8 @@ def lib():
         L.orc_matvec.argtypes = [vp, i32, vp, vp, i32, vp]
         L.orc_matvec.restype = i32
         L.orc_direct.argtypes = [vp, vp, vp, i32, i32]
+        L.orc_direct_rows.argtypes = [vp, vp, vp, i32, vp]
+        L.orc_stokes_direct_rows.argtypes = [vp, vp, vp, i32, vp]
         L.orc_near_only.argtypes = [vp, vp, vp]
         L.orc_get_perm.argtypes = [vp, vp]
         L.orc_get_boxes.argtypes = [vp] * 10
@@ -188,6 +190,14 @@ class Oracle:
         b, e = (0, self.n) if rows is None else rows
         lib().orc_direct(self._h, _p(x), _p(y), b, e)
         return y if rows is None else y[b:e]
+
+    def direct_rows(self, x, rows):
+        """Direct sum on a list of target rows (original panel order): the seeded whole-vector sample of the accuracy gate."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        y = np.zeros(len(rows))
+        lib().orc_direct_rows(self._h, _p(x), _p(y), len(rows), _p(rows))
+        return y
 
     def near_only(self, x):
         self.build_near()
@@ -346,6 +356,13 @@ class StokesOracle(Oracle):
         b, e = (0, self.n) if rows is None else rows
         lib().orc_stokes_direct(self._h, _p(x), _p(y), b, e)
         return y if rows is None else y[b:e]
+
+    def direct_rows(self, x, rows):
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(self.n, 3)
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        y = np.zeros((len(rows), 3))
+        lib().orc_stokes_direct_rows(self._h, _p(x), _p(y), len(rows), _p(rows))
+        return y
 
     def near_csr(self):
         if lib().orc_stokes_build_near(self._h):

@@ -345,6 +345,23 @@ void orc_stokes_direct(const orc_ctx *c, const double *x, double *y, int row_beg
   }
 }
 
+/* the same on a list of target panels (original order): y_out[3k..3k+2] = rows of panel rows[k] */
+void orc_stokes_direct_rows(const orc_ctx *c, const double *x, double *y_out, int nrows, const int32_t *rows) {
+  #pragma omp parallel for schedule(dynamic, 4)
+  for (int k = 0; k < nrows; ++k) {
+    const int i = rows[k];
+    double r[3] = {0, 0, 0}, A[9];
+    for (int j = 0; j < c->n; ++j) {
+      orc_stokes_entry(c, &c->panels[i], &c->panels[j], A);
+      const double *xs = x + 3*(size_t)j;
+      r[0] += A[0]*xs[0] + A[1]*xs[1] + A[2]*xs[2];
+      r[1] += A[3]*xs[0] + A[4]*xs[1] + A[5]*xs[2];
+      r[2] += A[6]*xs[0] + A[7]*xs[1] + A[8]*xs[2];
+    }
+    y_out[3*k] = r[0]; y_out[3*k+1] = r[1]; y_out[3*k+2] = r[2];
+  }
+}
+
 void orc_stokes_get_near(const orc_ctx *c, double *val9) { memcpy(val9, c->val9, sizeof(double)*9*(size_t)c->nnz); }
 void orc_stokes_get_expansions(const orc_ctx *c, int P, int which, double *out) {
   memcpy(out, which == 0 ? c->MS : c->LS, sizeof(cplx)*(size_t)c->nboxes*8*(size_t)(P*(P+1)/2));

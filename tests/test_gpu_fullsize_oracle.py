@@ -1,0 +1,117 @@
+"""Full-VECTOR oracle parity at BASELINE.json's full sizes: every element of the GPU result against the oracle's FMM result
+on the same workload -- the far field at N = 1 048 576 (8 tree levels, the long-item M2L cut, the >= 2 048-box level rule of
+the tree passes, multi-chunk near leaves) compared with the CPU restatement, not only through size-independent properties.
+
+  config 3   two disjoint UnitSphere(9), N = 1 048 576, p = 10
+  config 5   the same operator at the two extreme orders of the relaxed solve, p = 12 and p = 1
+  config 4   StokesSphericalBEM on RedBloodCell(9), N = 524 288 panels, p = 8 (when the host can hold the oracle's 21 GB CSR)
+
+and the north-star accuracy gate the way the reference forms its error (tests/scaling.cpp:56-74: over the bodies; here a
+seeded sample of 4 096 rows drawn over the WHOLE vector, include/Direct.hpp:99-125 for the sum): GPU-vs-Direct and
+oracle-vs-Direct on the SAME rows, so that a figure above 1e-6 is attributed -- the reference algorithm's truncation error
+at that order on that mesh, or the device path."""
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+GATE_ROWS, GATE_SEED = 4096, 4096
+
+
+def gate_rows(n, nrows=GATE_ROWS):
+    return np.sort(np.random.default_rng(GATE_SEED).choice(n, size=nrows, replace=False)).astype(np.int32)
+
+
+def mem_available_gb():
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable:"):
+                return float(ln.split()[1]) / 1048576.0
+    except Exception:
+        pass
+    return 0.0
+
+
+@pytest.fixture(scope="module")
+def cfg3(fb, oracle_mod):
+    v = np.concatenate([fb.unit_sphere(9, center=(3.0 * i, 0.0, 0.0)) for i in range(2)])
+    K = fb.LaplaceSphericalBEM(12, 3)
+    plan = fb.FMM_plan(K, v, p_max=12)
+    o = oracle_mod.Oracle(v)
+    o.build_near()                                             # 513 M entries, 6.2 GB of CSR on the host
+    x = np.random.default_rng(1234).random(len(v))             # bench.py's charge vector
+    yield v, K, plan, o, x
+    o.close()
+    plan.close()
+
+
+@pytest.mark.parametrize("p", [10, 12, 1])
+def test_config3_and_config5_orders_full_vector_vs_oracle(fb, cfg3, p):
+    v, K, plan, o, x = cfg3
+    K.set_p(p)
+    y = plan.execute(x)
+    yo = o.matvec(x, p)                                        # `tuned` mode: every stage threaded, one expansion
+    assert rel_l2(y, yo) <= 1e-12, (p, rel_l2(y, yo))
+    assert np.max(np.abs(y - yo)) <= 1e-11 * np.max(np.abs(yo))          # no single row off either
+
+
+def test_config3_accuracy_gate_4096_seeded_rows(fb, cfg3):
+    """GPU and oracle against the Direct sum on the same 4 096 rows drawn over the whole vector.  Two disjoint spheres at
+    p = 10: below the 1e-6 north-star gate; and the GPU's error IS the oracle's (the reference algorithm's) error."""
+    v, K, plan, o, x = cfg3
+    rows = gate_rows(len(v))
+    d = o.direct_rows(x, rows)
+    K.set_p(10)
+    y = plan.execute(x)
+    yo = o.matvec(x, 10)
+    g, r = rel_l2(y[rows], d), rel_l2(yo[rows], d)
+    assert abs(g - r) <= 1e-3 * r, (g, r)                      # the same error to three digits
+    assert g < 1e-6, g
+    K.set_p(12)
+    assert rel_l2(plan.execute(x)[rows], d) < 1e-7             # and it falls with p as the reference's does (5.0e-8 at r = 6)
+
+
+def test_single_sphere_error_level_is_the_reference_algorithm_s(fb, oracle_mod):
+    """One UnitSphere(9) (N = 524 288) at p = 10 sits at 2.5e-6 of Direct on a sample -- above 1e-6.  Same rows, oracle
+    and GPU: the two agree to 1e-12 with each other and to three digits in their distance from Direct, i.e. the figure is
+    the truncation error of p = 10, theta = 0.5 on this mesh (all sources on ONE smooth closed surface: the multipole
+    bound's worst case, every cell's far field comes from the same side), not the device path.  The two-sphere headline
+    workload measures lower because the second body's contribution is a well-separated, rapidly converging far field."""
+    v = fb.unit_sphere(9)
+    plan = fb.FMM_plan(fb.LaplaceSphericalBEM(10, 3), v, p_max=10)
+    o = oracle_mod.Oracle(v)
+    x = np.random.default_rng(1234).random(len(v))
+    y = plan.execute(x)
+    yo = o.matvec(x, 10)
+    rows = gate_rows(len(v))
+    d = o.direct_rows(x, rows)
+    o.close()
+    plan.close()
+    assert rel_l2(y, yo) <= 1e-12
+    g, r = rel_l2(y[rows], d), rel_l2(yo[rows], d)
+    assert abs(g - r) <= 1e-3 * r, (g, r)
+    assert g < 5e-6, g                                         # the reference's level on this mesh (2.5e-6), not the 1e-6 gate
+
+
+def test_config4_stokes_full_vector_vs_oracle(fb, oracle_mod):
+    need = 40.0                                                # the oracle's Mat3 CSR: 265 M x 76 B = 20 GB, plus the plan's host copy
+    if mem_available_gb() < need:
+        pytest.skip("host has %.0f GB available; the Stokes oracle at N = 524 288 needs %.0f" % (mem_available_gb(), need))
+    v = fb.red_blood_cell(9)
+    K = fb.StokesSphericalBEM(8, 4, 1e-3)
+    K.set_Kfine(19)
+    plan = fb.FMM_plan(K, v, p_max=8)
+    o = oracle_mod.StokesOracle(v, K=4, K_fine=19, mu=1e-3)
+    x = np.random.default_rng(1234).random(3 * len(v)).reshape(-1, 3)
+    y = plan.execute(x)
+    yo = o.matvec(x, 8)
+    rows = gate_rows(len(v), 512)
+    d = o.direct_rows(x, rows)
+    o.close()
+    plan.close()
+    assert rel_l2(y, yo) <= 1e-12, rel_l2(y, yo)
+    g, r = rel_l2(y[rows], d), rel_l2(yo[rows], d)
+    assert abs(g - r) <= 1e-3 * r, (g, r)
+    assert g < 5e-5, g                                         # the reference's level at p = 8 is 1.4e-5
