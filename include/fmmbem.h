@@ -205,6 +205,68 @@ int fmmbem_mgs_column_device(int64_t n, double *d_w, const double *d_V, int64_t 
                              double *d_scratch, void *stream);
 int fmmbem_mgs_scratch_doubles(int max_cols);
 
+/* ---- the caller of the hot path, resident on the device: restarted GMRES / flexible GMRES with the per-iteration relaxation
+ * of the expansion order p (examples/BEM/GMRES.hpp:143-252 GMRES, :276-380 FGMRES; examples/BEM/GMRES_Stokes.hpp:173-320 the
+ * same loops on Vec<3,double> values with the Stokes order rule; examples/BEM/SolverOptions.hpp:11-39).  The Krylov basis V
+ * (and Z of FGMRES) lives in HBM, every matvec is fmmbem_plan_execute_device, every Arnoldi column one
+ * fmmbem_mgs_column_device; the Hessenberg column comes to the host once per iteration (its only synchronisation) for the
+ * Givens rotations, the residual estimate and predict_p; restart, back substitution and the solution update as the reference.
+ * The same steps in the same order as the reference's loop -- order schedule, iteration counts and printed residuals are
+ * the reference's (tests/golden/gmres_ref_r*.json) -- only the association inside a dot product differs. */
+typedef enum { FMMBEM_RELAX_SIMONCINI = 0, FMMBEM_RELAX_BOURAS = 1 } fmmbem_relaxation;   /* SolverOptions::relaxation_type */
+typedef enum {
+  FMMBEM_ORDER_GMRES = 0,          /* GMRES.hpp:195         p = max(1, predict_p(|r|))                                    */
+  FMMBEM_ORDER_GMRES_STOKES = 1,   /* GMRES_Stokes.hpp:229  p = max(p_min, predict_p(|r|) - 1)                            */
+  FMMBEM_ORDER_FGMRES = 2,         /* GMRES.hpp:324         p = predict_p(|r|)  (raised to 1: the library has no order 0)   */
+  FMMBEM_ORDER_FGMRES_STOKES = 3   /* GMRES_Stokes.hpp:373  p = max(5, predict_p(|r|))                                     */
+} fmmbem_order_rule;
+
+typedef struct {
+  double  residual;        /* SolverOptions::residual: stop when |r| / |b| falls below it                               */
+  int32_t max_iters;       /* SolverOptions::max_iters                                                                 */
+  int32_t restart;         /* SolverOptions::restart (the drivers set it to max_iters, LaplaceBEM.cpp:162-163)          */
+  int32_t max_p, p_min;    /* SolverOptions::max_p, p_min                                                              */
+  int32_t variable_p;      /* SolverOptions::variable_p: 0 = every matvec at max_p                                     */
+  int32_t relax_type;      /* fmmbem_relaxation                                                                        */
+  int32_t order_rule;      /* fmmbem_order_rule: which call site's floor is applied to predict_p                       */
+  int32_t flexible;        /* 0 GMRES (x += y_j M(V_j), the preconditioner applied again in the update, GMRES.hpp:237-241);
+                            * 1 FGMRES (Z_j = M(V_j) kept, x += y_j Z_j, :318-320, :368-371)                           */
+  int32_t initial_p;       /* the order of the FIRST matvec r0 = A x0 - b, run before any predict_p: the reference uses whatever
+                            * the kernel object holds (its construction order); 0 = max_p                               */
+} fmmbem_solver_options;
+void fmmbem_solver_options_default(fmmbem_solver_options *opts);   /* SolverOptions(): 1e-5, 500, 500, 16, 5, true, BOURAS */
+
+typedef enum {
+  FMMBEM_PC_IDENTITY = 0,    /* Preconditioners::Identity (Preconditioner.hpp:8-17)                                       */
+  FMMBEM_PC_DIAGONAL = 1,    /* Preconditioners::Diagonal (:19-42): z = reciprocals .* v, in whatever order the caller built them */
+  FMMBEM_PC_INNER_PLAN = 2   /* Preconditioners::LocalInnerSolver / BlockDiagonal (LocalPC.hpp:26-59, BlockDiagonalPC.hpp:16-60):
+                              * z = GMRES(inner_plan, 0, v, inner) on a plan created with evaluator LOCAL or BLOCK_DIAGONAL */
+} fmmbem_preconditioner_kind;
+typedef struct {
+  int32_t kind;                      /* fmmbem_preconditioner_kind                                                     */
+  const double *reciprocals;         /* DIAGONAL: n_panels * dof values; a DEVICE pointer for fmmbem_gmres_device, a host
+                                      * pointer for fmmbem_gmres                                                       */
+  fmmbem_plan *inner_plan;           /* INNER_PLAN: same panels, same device                                           */
+  fmmbem_solver_options inner;       /* INNER_PLAN: LocalPC.hpp:52-54 uses residual 1e-1, variable_p 0, max_iters 1     */
+} fmmbem_preconditioner;
+
+typedef struct {
+  int32_t iterations;                /* out: matvecs of the inner loops (the reference's `iter`)                        */
+  double  residual;                  /* out: last |r| / |b| estimate                                                  */
+  double  seconds;                   /* out: wall time of the call, the final synchronisation included                 */
+  int32_t capacity;                  /* in: entries p[] / resid[] can take (0 or NULL arrays: no history)              */
+  int32_t *p;                        /* out: order of iteration k (what the reference prints as fmm_req_p)             */
+  double  *resid;                    /* out: |r| / |b| after iteration k                                               */
+} fmmbem_solver_log;
+
+/* x: initial guess in, solution out; b: right-hand side; n_panels * dof doubles each, ORIGINAL panel order, DEVICE pointers.
+ * M == NULL: identity.  log may be NULL.  Synchronises `stream` once per iteration and before returning. */
+int fmmbem_gmres_device(fmmbem_plan *plan, const fmmbem_solver_options *opts, double *d_x, const double *d_b,
+                        const fmmbem_preconditioner *M, fmmbem_solver_log *log, void *stream);
+/* The same with HOST pointers (x, b, M->reciprocals): the vectors cross PCIe once each way per solve, not per matvec. */
+int fmmbem_gmres(fmmbem_plan *plan, const fmmbem_solver_options *opts, double *x, const double *b,
+                 const fmmbem_preconditioner *M, fmmbem_solver_log *log);
+
 /* ---- split execute of a plan created with shard_upward = 1 and shard_world > 1 (no reference counterpart:
  * the reference is single-node) ----------------------------------------------------------
  *   upward:   x -> P2M and M2M of the boxes this shard owns -> d_send (exchange_doubles(p) doubles)
