@@ -13,7 +13,7 @@ def __getattr__(name):
     if name == "ShardedFMM":
         from .distributed import ShardedFMM
         return ShardedFMM
-    if name in ("SolverOptions", "gmres", "fgmres", "LocalInnerSolver", "BlockDiagonal", "Diagonal", "laplace_bem_first_kind"):
+    if name in ("SolverOptions", "gmres", "gmres_capi", "fgmres", "LocalInnerSolver", "BlockDiagonal", "Diagonal", "laplace_bem_first_kind"):
         from . import solver
         return getattr(solver, name)
     raise AttributeError(name)

@@ -45,6 +45,28 @@ class Stats(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class SolverOpts(C.Structure):
+    """fmmbem_solver_options"""
+    _fields_ = [("residual", C.c_double), ("max_iters", C.c_int32), ("restart", C.c_int32), ("max_p", C.c_int32),
+                ("p_min", C.c_int32), ("variable_p", C.c_int32), ("relax_type", C.c_int32), ("order_rule", C.c_int32),
+                ("flexible", C.c_int32), ("initial_p", C.c_int32)]
+
+
+class Preconditioner(C.Structure):
+    """fmmbem_preconditioner"""
+    _fields_ = [("kind", C.c_int32), ("reciprocals", C.c_void_p), ("inner_plan", C.c_void_p), ("inner", SolverOpts)]
+
+
+class SolverLog(C.Structure):
+    """fmmbem_solver_log"""
+    _fields_ = [("iterations", C.c_int32), ("residual", C.c_double), ("seconds", C.c_double), ("capacity", C.c_int32),
+                ("p", C.POINTER(C.c_int32)), ("resid", C.POINTER(C.c_double))]
+
+
+PC_IDENTITY, PC_DIAGONAL, PC_INNER_PLAN = 0, 1, 2
+ORDER_GMRES, ORDER_GMRES_STOKES, ORDER_FGMRES, ORDER_FGMRES_STOKES = 0, 1, 2, 3
+
+
 class FmmBemError(RuntimeError):
     def __init__(self, status, text):
         super().__init__("fmmbem status %d (%s): %s" % (status, _status_string(status), text))
@@ -62,7 +84,7 @@ SYMBOLS = (
     "fmmbem_plan_get_perm", "fmmbem_plan_get_boxes", "fmmbem_plan_get_pairs", "fmmbem_plan_get_near_row",
     "fmmbem_plan_get_expansions", "fmmbem_plan_get_diagonal", "fmmbem_kernel_entries", "fmmbem_mesh_unit_sphere", "fmmbem_mesh_red_blood_cell", "fmmbem_mesh_red_blood_cells", "fmmbem_mesh_read_msh",
     "fmmbem_mesh_read_vert_face", "fmmbem_mesh_write_vert_face", "fmmbem_quadrature", "fmmbem_status_string", "fmmbem_last_error",
-    "fmmbem_version",
+    "fmmbem_version", "fmmbem_solver_options_default", "fmmbem_gmres_device", "fmmbem_gmres",
 )
 
 
@@ -122,6 +144,10 @@ def lib():
     L.fmmbem_status_string.restype = C.c_char_p
     L.fmmbem_last_error.restype = C.c_char_p
     L.fmmbem_version.restype = i32
+    L.fmmbem_solver_options_default.argtypes = [C.POINTER(SolverOpts)]
+    L.fmmbem_solver_options_default.restype = None
+    L.fmmbem_gmres_device.argtypes = [vp, C.POINTER(SolverOpts), vp, vp, C.POINTER(Preconditioner), C.POINTER(SolverLog), vp]
+    L.fmmbem_gmres.argtypes = [vp, C.POINTER(SolverOpts), vp, vp, C.POINTER(Preconditioner), C.POINTER(SolverLog)]
     _lib = L
     return L
 

@@ -32,6 +32,9 @@ int fail(int code, const std::string& msg) {          // also used by mesh_io.cp
   g_last_error = msg;
   return code;
 }
+struct SolverWs;                                      // krylov.hip
+void solver_ws_destroy(SolverWs* ws);
+int plan_solver_info(fmmbem_plan* plan, int* device, int64_t* unknowns, int* p_max, SolverWs*** slot);
 }  // namespace fmmbem
 
 namespace {
@@ -207,6 +210,7 @@ struct fmmbem_plan {
   int near_wgs = 3;
   int64_t ev_count = 0;                                        // executes recorded since timing was enabled
   double *stage_x = nullptr, *stage_y = nullptr;               // device staging for host-pointer execute
+  fmmbem::SolverWs* solver_ws = nullptr;                       // workspace of fmmbem_gmres* on this plan (krylov.hip), kept between solves
   hipStream_t own_stream = nullptr;
   hipStream_t near_stream = nullptr;                          // the HBM-bound near field runs beside the far field
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -248,6 +252,7 @@ struct fmmbem_plan {
   // phase 0: whole matvec; 1: upward half (gather, P2M, M2M of owned boxes, pack -> xbuf); 2: the rest (xbuf = gathered)
   int run(int p, const double* d_x, double* d_y, hipStream_t s, bool near_only, int phase = 0, double* xbuf = nullptr);
   ~fmmbem_plan() {
+    if (solver_ws) fmmbem::solver_ws_destroy(solver_ws);
     if (on_device) {
       DeviceGuard guard(opts.device);
       for (void* p : allocs) (void)hipFree(p);
@@ -1545,3 +1550,17 @@ const char* fmmbem_last_error(void) { return g_last_error.c_str(); }
 int fmmbem_version(void) { return FMMBEM_VERSION; }
 
 }  // extern "C"
+
+// what the solver of krylov.hip needs to know about a plan; it reaches the matvec through the public entry point
+int fmmbem::plan_solver_info(fmmbem_plan* plan, int* device, int64_t* unknowns, int* p_max, fmmbem::SolverWs*** slot) {
+  if (!plan) return fail(FMMBEM_ERR_INVALID, "null plan");
+  if (!plan->on_device) return fail(FMMBEM_ERR_NO_DEVICE, "plan was built host-only; there is no CPU execution path");
+  if (plan->result_slices || plan->hp.opt.shard_world > 1)
+    return fail(FMMBEM_ERR_UNSUPPORTED, "fmmbem_gmres runs on a whole operator; shards are driven by the caller's collectives (distributed.py)");
+  *device = plan->opts.device;
+  *unknowns = (int64_t)plan->hp.n * (plan->opts.kernel == FMMBEM_KERNEL_STOKES_BEM ? 3 : 1);
+  *p_max = plan->hp.opt.p_max;
+  *slot = &plan->solver_ws;
+  return FMMBEM_OK;
+}
+

@@ -227,6 +227,45 @@ def fgmres(MV, x, b, opts, M, log=None, stokes=False):
     return x, it, abs(resid)
 
 
+def _c_options(opts, stokes, flexible, initial_p):
+    from . import _capi
+    o = _capi.SolverOpts()
+    o.residual, o.max_iters, o.restart, o.max_p, o.p_min = opts.residual, opts.max_iters, opts.restart, opts.max_p, opts.p_min
+    o.variable_p, o.relax_type = int(bool(opts.variable_p)), opts.relax_type
+    o.order_rule = ((_capi.ORDER_FGMRES_STOKES if stokes else _capi.ORDER_FGMRES) if flexible else
+                    (_capi.ORDER_GMRES_STOKES if stokes else _capi.ORDER_GMRES))
+    o.flexible, o.initial_p = int(bool(flexible)), int(initial_p)
+    return o
+
+
+def gmres_capi(MV, x, b, opts, M=None, log=None, stokes=False, flexible=False):
+    """The same solve through the C ABI's device-resident solver (include/fmmbem.h fmmbem_gmres_device; csrc/krylov.hip):
+    what a C or C++ caller of the library gets.  MV: an FMM_plan; x, b: float64 CUDA tensors (x updated in place);
+    M: None, a Diagonal, or a LocalInnerSolver / BlockDiagonal.  Returns (x, iterations, |residual|, seconds)."""
+    import ctypes as C
+    from . import _capi
+    o = _c_options(opts, stokes, flexible, MV.kernel().P)
+    pc = None
+    if M is not None:
+        pc = _capi.Preconditioner()
+        if isinstance(M, Diagonal):
+            pc.kind, pc.reciprocals = _capi.PC_DIAGONAL, M.recip.data_ptr()
+        elif isinstance(M, _InnerSolver):
+            pc.kind, pc.inner_plan = _capi.PC_INNER_PLAN, M.plan._h
+            pc.inner = _c_options(M.options, False, False, M.options.max_p)
+        else:
+            raise TypeError("gmres_capi: M must be None, Diagonal, LocalInnerSolver or BlockDiagonal")
+    cap = max(1, opts.max_iters + opts.restart + 2)
+    ps, rs = (C.c_int32 * cap)(), (C.c_double * cap)()
+    lg = _capi.SolverLog()
+    lg.capacity, lg.p, lg.resid = cap, ps, rs
+    _capi.check(_capi.lib().fmmbem_gmres_device(MV._h, C.byref(o), x.data_ptr(), b.data_ptr(), C.byref(pc) if pc is not None else None,
+                                                C.byref(lg), torch.cuda.current_stream(x.device).cuda_stream))
+    if log is not None:
+        log.extend((k + 1, int(ps[k]), float(rs[k])) for k in range(min(lg.iterations, cap)))
+    return x, lg.iterations, lg.residual, lg.seconds
+
+
 class Diagonal:
     """Preconditioners::Diagonal (examples/BEM/Preconditioner.hpp:19-42): y = x / K(s,s), panel by panel."""
 

@@ -306,6 +306,8 @@ class PlanAdapter {
 
   fmmbem_plan* handle() { return plan_; }
   int p_max() const { return p_max_; }
+  // size the plan for orders up to p now (what execute() does lazily when set_p asks for more)
+  void reserve_order(int p) { if (p > p_max_) create(p); }
 
  private:
   void create(int p_max) {
@@ -374,3 +376,185 @@ class FMM_plan<StokesSphericalBEM> : public fmmbem::PlanAdapter<StokesSphericalB
  public:
   using fmmbem::PlanAdapter<StokesSphericalBEM>::PlanAdapter;
 };
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The relaxed solvers with the reference's argument lists, resident on the device (fmmbem_gmres, include/fmmbem.h):
+//
+//     fmmbem::GMRES(plan, x, b, solver_options);          // examples/BEM/GMRES.hpp:119-128;  GMRES_Stokes.hpp the same on Vec<3,double>
+//     fmmbem::GMRES(plan, x, b, solver_options, M);       // :131-141, M = Preconditioners::Identity / Diagonal<T>, fmmbem::InnerSolverPC
+//     fmmbem::FGMRES(plan, x, b, solver_options[, M]);    // :254-274
+//
+// The reference's own GMRES.hpp keeps working against this header (every matvec then moves x and y across PCIe and the
+// Arnoldi vectors live on the host: INTEGRATION.md gives the cost); these functions are what replaces it when the solve
+// should run where the matvec runs: x and b cross once.  `SolverOptions` is whatever struct the caller uses -- the
+// reference's (examples/BEM/SolverOptions.hpp:11-39) or one with the same members: residual, max_iters, restart, max_p,
+// variable_p, and, where present, p_min and relax_type.  The order rule follows the kernel as the reference's two headers
+// do: LaplaceSphericalBEM p = max(1, predict_p) (GMRES.hpp:195), StokesSphericalBEM p = max(p_min, predict_p - 1)
+// (GMRES_Stokes.hpp:229), FGMRES :324 / GMRES_Stokes.hpp:373.  With fmmbem::solver_output() (default on, as
+// GMRESContext::output) the lines the reference prints -- "it: 003, res: 1.234e-05, fmm_req_p: 4", "Final residual: ..." --
+// are printed once the solve returns.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace fmmbem {
+
+inline bool& solver_output() { static bool on = true; return on; }
+
+struct SolveReport {
+  int iterations = 0;
+  double residual = 0, seconds = 0;
+  std::vector<int> p;               // order of every inner iteration
+  std::vector<double> resid;        // |r| / |b| after it
+};
+
+namespace detail {
+template <class O> auto relax_of(const O& o, int) -> decltype((int)o.relax_type) { return (int)o.relax_type; }
+template <class O> int relax_of(const O&, long) { return FMMBEM_RELAX_BOURAS; }
+template <class O> auto pmin_of(const O& o, int) -> decltype((int)o.p_min) { return (int)o.p_min; }
+template <class O> int pmin_of(const O&, long) { return 5; }
+
+template <class Kernel> struct OrderRules;
+template <> struct OrderRules<LaplaceSphericalBEM> { static constexpr int gmres = FMMBEM_ORDER_GMRES, fgmres = FMMBEM_ORDER_FGMRES; };
+template <> struct OrderRules<StokesSphericalBEM> { static constexpr int gmres = FMMBEM_ORDER_GMRES_STOKES, fgmres = FMMBEM_ORDER_FGMRES_STOKES; };
+
+template <class Kernel, class Options>
+fmmbem_solver_options c_solver_options(const Options& o, bool flexible, int initial_p) {
+  fmmbem_solver_options c;
+  fmmbem_solver_options_default(&c);
+  c.residual = o.residual; c.max_iters = o.max_iters; c.restart = o.restart; c.max_p = (int)o.max_p;
+  c.p_min = pmin_of(o, 0); c.variable_p = o.variable_p ? 1 : 0; c.relax_type = relax_of(o, 0);
+  c.order_rule = flexible ? OrderRules<Kernel>::fgmres : OrderRules<Kernel>::gmres;
+  c.flexible = flexible ? 1 : 0;
+  c.initial_p = initial_p;
+  return c;
+}
+}  // namespace detail
+
+// Preconditioners::LocalInnerSolver (examples/BEM/LocalPC.hpp:26-59) and Preconditioners::BlockDiagonal
+// (BlockDiagonalPC.hpp:16-60): a few GMRES steps on the near-field-only / leaf-diagonal operator of the same panels.  As a
+// functor (x, y) it works with any solver, the reference's FGMRES included; fmmbem::GMRES / FGMRES recognise it and run the
+// inner solves on the device as well.
+template <class Kernel>
+class InnerSolverPC {
+ public:
+  typedef typename Kernel::charge_type value_type;
+  enum Kind { LOCAL, BLOCK_DIAGONAL };
+  InnerSolverPC(const Kernel& k, const std::vector<typename Kernel::source_type>& sources, Kind kind = LOCAL, int device = 0)
+      : opts_(make_options(kind)), plan_(k, sources, opts_, 0, device) {
+    fmmbem_solver_options_default(&inner_);       // LocalPC.hpp:52-54 on top of SolverOptions()
+    inner_.residual = 1e-1; inner_.variable_p = 0; inner_.max_iters = 1;
+    inner_.max_p = plan_.p_max();
+  }
+  void operator()(const std::vector<value_type>& x, std::vector<value_type>& y) {
+    y.assign(x.size(), value_type(0.));
+    check(fmmbem_gmres(plan_.handle(), &inner_, KernelBinding<Kernel>::out(y), KernelBinding<Kernel>::in(x), nullptr, nullptr));
+  }
+  fmmbem_plan* handle() { return plan_.handle(); }
+  const fmmbem_solver_options& inner_options() const { return inner_; }
+
+ private:
+  static FMMOptions make_options(Kind kind) {     // LocalPC.hpp:7-16, BlockDiagonalPC.hpp:53-63
+    FMMOptions o;
+    o.lazy_evaluation = false;
+    o.local_evaluation = kind == LOCAL;
+    o.block_diagonal = kind == BLOCK_DIAGONAL;
+    o.sparse_local = true;
+    o.set_mac_theta(0.5);
+    return o;
+  }
+  FMMOptions opts_;
+  PlanAdapter<Kernel> plan_;
+  fmmbem_solver_options inner_;
+};
+
+namespace detail {
+
+// A preconditioner functor of the reference's shape, M(x, y), reduced to what the device solver takes.  Identity and
+// Preconditioners::Diagonal are linear and diagonal: two probes recover the reciprocals and prove the shape; anything else
+// is refused (an inner-solver preconditioner goes in as fmmbem::InnerSolverPC).
+template <class Kernel, class PC>
+void describe(PC& M, size_t n, fmmbem_preconditioner& pc, std::vector<double>& recip) {
+  typedef typename Kernel::charge_type value_type;
+  const size_t dof = sizeof(value_type) / sizeof(double);
+  std::vector<value_type> one(n), u(n), y1(n), y2(n);
+  double* pu = KernelBinding<Kernel>::out(u);
+  double* p1 = KernelBinding<Kernel>::out(one);
+  for (size_t i = 0; i < n * dof; ++i) { p1[i] = 1.0; pu[i] = 1.0 + 0.25 * double((i * 2654435761u >> 7) & 3u); }
+  M(one, y1);
+  M(u, y2);
+  const double* r = KernelBinding<Kernel>::in(y1);
+  const double* q = KernelBinding<Kernel>::in(y2);
+  bool identity = true;
+  for (size_t i = 0; i < n * dof; ++i) {
+    if (!(std::fabs(q[i] - r[i] * pu[i]) <= 1e-12 * std::fabs(r[i] * pu[i])))
+      throw Error(FMMBEM_ERR_UNSUPPORTED, "fmmbem::GMRES: the preconditioner is not diagonal (use fmmbem::InnerSolverPC for inner-solver preconditioners)");
+    identity = identity && r[i] == 1.0;
+  }
+  pc.kind = identity ? FMMBEM_PC_IDENTITY : FMMBEM_PC_DIAGONAL;
+  if (!identity) { recip.assign(r, r + n * dof); pc.reciprocals = recip.data(); }
+}
+template <class Kernel>
+void describe(InnerSolverPC<Kernel>& M, size_t, fmmbem_preconditioner& pc, std::vector<double>&) {
+  pc.kind = FMMBEM_PC_INNER_PLAN;
+  pc.inner_plan = M.handle();
+  pc.inner = M.inner_options();
+}
+
+template <class Kernel, class Options>
+SolveReport solve(PlanAdapter<Kernel>& MV, std::vector<typename Kernel::charge_type>& x, std::vector<typename Kernel::result_type>& b,
+                  const Options& opts, const fmmbem_preconditioner* pc, bool flexible) {
+  if (x.size() != b.size()) throw Error(FMMBEM_ERR_INVALID, "x.size() != b.size()");
+  MV.reserve_order((int)opts.max_p);                       // set_p above the plan's size grows it once, as execute() does
+  fmmbem_solver_options c = c_solver_options<Kernel>(opts, flexible, MV.kernel().p());
+  SolveReport rep;
+  const int cap = opts.max_iters + opts.restart + 2;
+  rep.p.assign((size_t)cap, 0);
+  rep.resid.assign((size_t)cap, 0.0);
+  fmmbem_solver_log log;
+  log.capacity = cap; log.p = rep.p.data(); log.resid = rep.resid.data();
+  check(fmmbem_gmres(MV.handle(), &c, KernelBinding<Kernel>::out(x), KernelBinding<Kernel>::in(b), pc, &log));
+  rep.iterations = log.iterations; rep.residual = log.residual; rep.seconds = log.seconds;
+  rep.p.resize((size_t)std::min(log.iterations, cap));
+  rep.resid.resize(rep.p.size());
+  if (!rep.p.empty()) MV.kernel().set_p(rep.p.back());     // the kernel object ends at the last order set (GMRES.hpp:196)
+  if (solver_output()) {
+    for (size_t k = 0; k < rep.p.size(); ++k)
+      if (!(rep.resid[k] < opts.residual)) std::printf("it: %03d, res: %.3e, fmm_req_p: %01d\n", (int)k + 1, rep.resid[k], rep.p[k]);
+    std::printf("Final residual: %.4e, after %d iterations\n", rep.residual, rep.iterations);
+  }
+  return rep;
+}
+}  // namespace detail
+
+// In a nested namespace reached through a using-directive: `fmmbem::GMRES(...)` finds the functions, argument-dependent
+// lookup does not (using-directives of an associated namespace are ignored) -- so an unqualified `GMRES(plan, ...)` in code
+// that also includes the reference's GMRES.hpp keeps meaning the reference's.
+namespace device_solvers {
+template <class Kernel, class Options>
+SolveReport GMRES(PlanAdapter<Kernel>& MV, std::vector<typename Kernel::charge_type>& x, std::vector<typename Kernel::result_type>& b,
+                  const Options& opts) {
+  return detail::solve(MV, x, b, opts, nullptr, false);
+}
+template <class Kernel, class Options, class PC>
+SolveReport GMRES(PlanAdapter<Kernel>& MV, std::vector<typename Kernel::charge_type>& x, std::vector<typename Kernel::result_type>& b,
+                  const Options& opts, PC&& M) {
+  fmmbem_preconditioner pc = {};
+  std::vector<double> recip;
+  detail::describe<Kernel>(M, x.size(), pc, recip);
+  return detail::solve(MV, x, b, opts, &pc, false);
+}
+template <class Kernel, class Options>
+SolveReport FGMRES(PlanAdapter<Kernel>& MV, std::vector<typename Kernel::charge_type>& x, std::vector<typename Kernel::result_type>& b,
+                   const Options& opts) {
+  return detail::solve(MV, x, b, opts, nullptr, true);
+}
+template <class Kernel, class Options, class PC>
+SolveReport FGMRES(PlanAdapter<Kernel>& MV, std::vector<typename Kernel::charge_type>& x, std::vector<typename Kernel::result_type>& b,
+                   const Options& opts, PC&& M) {
+  fmmbem_preconditioner pc = {};
+  std::vector<double> recip;
+  detail::describe<Kernel>(M, x.size(), pc, recip);
+  return detail::solve(MV, x, b, opts, &pc, true);
+}
+}  // namespace device_solvers
+using namespace device_solvers;
+
+}  // namespace fmmbem

@@ -13,7 +13,7 @@ REF_BEM = "/root/reference/examples/BEM"          # present in the build contain
 
 
 def _build(tmp_path, src="adapter_example", extra=()):
-    exe = str(tmp_path / (src + ("_ref" if extra else "")))
+    exe = str(tmp_path / (src + ("_%08x" % (hash(tuple(extra)) & 0xffffffff) if extra else "")))
     libdir = os.path.join(ROOT, "fmm-bem-relaxed_amd")
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"),
                            "-I" + os.path.join(ROOT, "tests", "cpp"), *extra,
@@ -39,6 +39,20 @@ def test_driver_sequence_compiles_with_the_references_own_solver_headers(tmp_pat
     source_begin/source_end, K(s, s), Vec<3,double> arithmetic) exists with the reference's meaning."""
     for src in ("laplace_bem_sequence", "stokes_bem_sequence"):
         exe = _build(tmp_path, src, extra=("-DUSE_REFERENCE_SOLVER", "-I" + REF_BEM))
+        if not gpu_available:
+            r = subprocess.run([exe, "3", "8", "1e-5", "1"], capture_output=True, text=True)
+            assert r.returncode == 2 and "no HIP device" in r.stdout
+
+
+def test_device_solver_call_sites_compile(tmp_path, gpu_available):
+    """`#define GMRES fmmbem::GMRES` (-DUSE_DEVICE_SOLVER) turns the driver sequence's call sites into the device-resident
+    solve, beside the test-side solver's names and -- in the build container -- beside the REFERENCE's GMRES.hpp, whose
+    unqualified GMRES(plan, ...) stays the reference's (no ADL capture); FGMRES / InnerSolverPC / the Stokes order rule compile."""
+    variants = [("laplace_bem_sequence", ("-DUSE_DEVICE_SOLVER",)), ("device_solver_sequence", ("-DX",))]
+    if os.path.isdir(REF_BEM):
+        variants.append(("laplace_bem_sequence", ("-DUSE_DEVICE_SOLVER", "-DUSE_REFERENCE_SOLVER", "-I" + REF_BEM)))
+    for src, extra in variants:
+        exe = _build(tmp_path, src, extra=extra)
         if not gpu_available:
             r = subprocess.run([exe, "3", "8", "1e-5", "1"], capture_output=True, text=True)
             assert r.returncode == 2 and "no HIP device" in r.stdout
@@ -121,12 +135,68 @@ def test_adapter_matches_oracle(tmp_path, oracle_mod):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("pc", [0, 1])
-def test_driver_sequence_matches_python_solver(tmp_path, fb, oracle_mod, pc):
-    """The C++ driver sequence on the GPU against the same solve through solver.py: identical order schedule,
-    iteration count, solution to rounding; K(s, s) and K(t, s) of the kernel object against the oracle's entries."""
+def test_device_solver_sequences_match_python_solver(tmp_path, fb):
+    """fmmbem::GMRES on the Stokes plan and fmmbem::FGMRES with InnerSolverPC, from C++, against solver.py on the same
+    problems: schedule, iterations, solution sums."""
     import torch
-    exe = _build(tmp_path, "laplace_bem_sequence")
+    exe = _build(tmp_path, "device_solver_sequence", extra=("-DX",))
+    r = subprocess.run([exe, "4", "8", "1e-5"], capture_output=True, text=True, check=True)
+    out = r.stdout.splitlines()
+
+    def block(tag):
+        i = out.index(tag + " begin")
+        ps = []
+        for ln in out[i + 1:]:
+            if ln.startswith("it:"):
+                ps.append(int(ln.split("fmm_req_p:")[1]))
+            elif ln.startswith("Final residual"):
+                return ps, int(ln.split()[4])
+    v = fb.unit_sphere(4)
+    n = len(v)
+    # Stokes
+    K = fb.StokesSphericalBEM(8, 4, 1e-3)
+    K.set_Kfine(19)
+    plan = fb.FMM_plan(K, v, p_max=8)
+    b = torch.zeros(3 * n, dtype=torch.float64, device="cuda")
+    b[0::3] = 1.0
+    so = fb.SolverOptions(residual=1e-5, max_iters=100, max_p=8, restart=100)
+    log = []
+    x, it, res = fb.gmres(plan, torch.zeros_like(b), b, so, log=log, stokes=True)
+    ps, its = block("stokes")
+    assert its == it and ps == [p for _, p, _ in log][:len(ps)]
+    st = [ln for ln in out if ln.startswith("stokes sum:")][0].split()
+    sums = x.view(n, 3).sum(0).cpu().numpy()
+    assert np.allclose([float(t) for t in st[2:5]], sums, rtol=1e-8, atol=1e-8 * abs(sums).max())
+    assert int(st[8]) == log[-1][1]                              # the kernel object ends at the last order set
+    plan.close()
+    # Laplace FGMRES with the two inner-solver preconditioners
+    K = fb.LaplaceSphericalBEM(8, 3)
+    plan = fb.FMM_plan(K, v, p_max=8)
+    rhs = fb.FMM_plan(fb.LaplaceSphericalBEM(8, 3), v, bc=np.ones(n, dtype=np.uint8), p_max=8)
+    b = rhs.execute_torch(torch.ones(n, dtype=torch.float64, device="cuda"))
+    for kind, cls in enumerate((fb.LocalInnerSolver, fb.BlockDiagonal)):
+        M = cls(fb, fb.LaplaceSphericalBEM(8, 3), v)
+        K.set_p(8)
+        log = []
+        x, it, res = fb.fgmres(plan, torch.zeros_like(b), b, so, M, log=log)
+        ps, its = block("fgmres %d" % kind)
+        assert its == it and ps == [p for _, p, _ in log][:len(ps)]
+        s_cpp = float([ln for ln in out if ln.startswith("fgmres %d sum:" % kind)][0].split()[3])
+        assert abs(s_cpp - float(x.sum())) <= 1e-8 * abs(s_cpp)
+        z_cpp = float([ln for ln in out if ln.startswith("functor %d sum:" % kind)][0].split()[3])
+        assert abs(z_cpp - float(M(b).sum())) <= 1e-8 * abs(z_cpp)
+    assert "shift refused %d" % 6 in out                       # FMMBEM_ERR_UNSUPPORTED
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pc", [0, 1])
+@pytest.mark.parametrize("device_solver", [False, True])
+def test_driver_sequence_matches_python_solver(tmp_path, fb, oracle_mod, pc, device_solver):
+    """The C++ driver sequence on the GPU against the same solve through solver.py: identical order schedule,
+    iteration count, solution to rounding; K(s, s) and K(t, s) of the kernel object against the oracle's entries.
+    device_solver: the same source with -DUSE_DEVICE_SOLVER (GMRES -> fmmbem::GMRES, the Arnoldi process in HBM)."""
+    import torch
+    exe = _build(tmp_path, "laplace_bem_sequence", extra=("-DUSE_DEVICE_SOLVER",) if device_solver else ())
     r = subprocess.run([exe, "5", "12", "1e-5", str(pc)], capture_output=True, text=True, check=True)
     out = r.stdout.splitlines()
     ps_cpp = [int(ln.split("fmm_req_p:")[1]) for ln in out if ln.startswith("it:")]
