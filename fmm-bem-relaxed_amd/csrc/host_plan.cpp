@@ -134,11 +134,13 @@ int64_t unit_sphere(int recursions, double* vertices) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Morton helpers (10 bits per dimension, x lowest)
+// Morton helpers (x lowest).  Two coders: the reference's -- 10 bits per dimension in a 32-bit key, 10 tree levels
+// (include/tree/Octree.hpp:82-92) -- and a 64-bit one with 21 bits per dimension that HostPlan::build falls back to ONLY
+// when a box on level 10 still holds more than ncrit bodies (the reference cannot build such a tree at all: its shift
+// 3*(levels - level - 1) wraps, Octree.hpp:649).  Cells are (extent / 2^L): the first ten levels of the deep tree are the
+// boxes the 10-level coder would have made, bit for bit.
 // ------------------------------------------------------------------------------------------
 namespace {
-constexpr unsigned kLevels = 10;
-
 inline uint32_t spread3(uint32_t x) {
   x = (x | (x << 16)) & 0x030000FFu;
   x = (x | (x << 8)) & 0x0300F00Fu;
@@ -154,9 +156,116 @@ inline uint32_t compact3(uint32_t x) {
   x = (x | (x >> 16)) & 0x000003FFu;
   return x;
 }
+inline uint64_t spread3(uint64_t x) {              // 21 bits -> every third bit
+  x &= 0x1FFFFFull;
+  x = (x | (x << 32)) & 0x1F00000000FFFFull;
+  x = (x | (x << 16)) & 0x1F0000FF0000FFull;
+  x = (x | (x << 8)) & 0x100F00F00F00F00Full;
+  x = (x | (x << 4)) & 0x10C30C30C30C30C3ull;
+  x = (x | (x << 2)) & 0x1249249249249249ull;
+  return x;
+}
+inline uint64_t compact3(uint64_t x) {
+  x &= 0x1249249249249249ull;
+  x = (x | (x >> 2)) & 0x10C30C30C30C30C3ull;
+  x = (x | (x >> 4)) & 0x100F00F00F00F00Full;
+  x = (x | (x >> 8)) & 0x1F0000FF0000FFull;
+  x = (x | (x >> 16)) & 0x1F00000000FFFFull;
+  x = (x | (x >> 32)) & 0x1FFFFFull;
+  return x;
+}
 inline int level_of_key(uint32_t key) { return (31 - __builtin_clz(key)) / 3; }
+inline int level_of_key(uint64_t key) { return (63 - __builtin_clzll(key)) / 3; }
 
-struct Coded { uint32_t code, idx; };
+template <class Code> struct CodedT { Code code; uint32_t idx; };
+
+// Octree.hpp:617-692 on codes of L bits per dimension: BFS construction with stable 8-way bucketing per box, then the box
+// geometry (:334-355 through :109-113, :243-248).  Returns false when a box on level L still holds more than ncrit bodies.
+template <class Code>
+bool build_tree(HostPlan& hp, unsigned L, const std::vector<double>& cen, double ext_hi[3], unsigned ncrit) {
+  typedef CodedT<Code> Coded;
+  const int64_t n = hp.n;
+  for (int k = 0; k < 3; ++k) hp.cell[k] = (ext_hi[k] - hp.pmin[k]) / std::ldexp(1.0, (int)L);
+  // ---- Morton codes (Octree.hpp:118-129) ----
+  std::vector<Coded> codes(n), scratch(n);
+  for (int64_t i = 0; i < n; ++i) {
+    Code s[3];
+    for (int k = 0; k < 3; ++k) {
+      double v = cen[3 * i + k];
+      v -= hp.pmin[k];
+      v /= hp.cell[k];
+      s[k] = (Code)(uint32_t)v;
+    }
+    codes[i] = {(Code)(spread3(s[0]) | (spread3(s[1]) << 1) | (spread3(s[2]) << 2)), (uint32_t)i};
+  }
+  std::vector<Code> key(1, (Code)1);
+  hp.box_parent.assign(1, 0);
+  hp.box_body_begin.assign(1, 0);
+  hp.box_body_end.assign(1, (int)n);
+  hp.box_child_begin.assign(1, 0);
+  hp.box_child_end.assign(1, 0);
+  hp.box_leaf.assign(1, 0);
+  hp.box_level.assign(1, 0);
+  hp.level_off.assign(1, 0);
+  int deepest = 0;
+  for (size_t k = 0; k < key.size(); ++k) {
+    const int b0 = hp.box_body_begin[k], b1 = hp.box_body_end[k];
+    if ((unsigned)(b1 - b0) <= ncrit) { hp.box_leaf[k] = 1; continue; }
+    const int lev = hp.box_level[k];
+    if (lev >= (int)L) return false;
+    const unsigned shift = 3 * (L - lev - 1);
+    int count[9] = {0};
+    for (int i = b0; i < b1; ++i) ++count[((codes[i].code >> shift) & 7) + 1];
+    for (int c = 0; c < 8; ++c) count[c + 1] += count[c];
+    int cursor[8];
+    std::copy(count, count + 8, cursor);
+    for (int i = b0; i < b1; ++i) scratch[b0 + cursor[(codes[i].code >> shift) & 7]++] = codes[i];
+    std::copy(scratch.begin() + b0, scratch.begin() + b1, codes.begin() + b0);
+    hp.box_child_begin[k] = (int)key.size();
+    for (int c = 0; c < 8; ++c) {
+      if (count[c + 1] == count[c]) continue;        // empty octants get no box (:666)
+      const Code kc = (Code)((key[k] << 3) | (Code)c);
+      const int l = level_of_key(kc);
+      if (l > deepest) { deepest = l; hp.level_off.push_back((int)key.size()); }
+      key.push_back(kc);
+      hp.box_parent.push_back((int)k);
+      hp.box_body_begin.push_back(b0 + count[c]);
+      hp.box_body_end.push_back(b0 + count[c + 1]);
+      hp.box_child_begin.push_back(0);
+      hp.box_child_end.push_back(0);
+      hp.box_leaf.push_back(0);
+      hp.box_level.push_back(l);
+    }
+    hp.box_child_end[k] = (int)key.size();
+  }
+  hp.nboxes = (int)key.size();
+  hp.level_off.push_back(hp.nboxes);
+  hp.nlevels = (int)hp.level_off.size() - 1;
+  hp.perm.resize(n);
+  for (int64_t i = 0; i < n; ++i) hp.perm[i] = codes[i].idx;
+  hp.box_key.assign(key.begin(), key.end());
+  // ---- box geometry ----
+  hp.box_center.resize(3 * (size_t)hp.nboxes);
+  hp.box_side.resize(hp.nboxes);
+  hp.box_icoord.resize(3 * (size_t)hp.nboxes);
+  const double root_side = (hp.pmin[0] + std::ldexp(1.0, (int)L) * hp.cell[0]) - hp.pmin[0];
+  const Code top = (Code)1 << (3 * L);
+  for (int b = 0; b < hp.nboxes; ++b) {
+    Code m = key[b];
+    while (!(m & top)) m <<= 3;
+    const Code lower = m & ~top;
+    const Code ix[3] = {compact3(lower), compact3((Code)(lower >> 1)), compact3((Code)(lower >> 2))};
+    const int lev = hp.box_level[b];
+    for (int k = 0; k < 3; ++k) {
+      const double a = hp.pmin[k] + hp.cell[k] * double(ix[k]);
+      const double w = (a + hp.cell[k]) - a;
+      hp.box_center[3 * b + k] = a + w * std::ldexp(1.0, (int)L - 1 - lev);
+      hp.box_icoord[3 * b + k] = 2 * (int32_t)ix[k] + (int32_t)(1 << (L - lev));   // exact, in half-cells of the finest level
+    }
+    hp.box_side[b] = root_side / std::ldexp(1.0, lev);
+  }
+  return true;
+}
 }  // namespace
 
 void alloc_panels(PanelSoA& P, int64_t n, int nq) {
@@ -223,95 +332,17 @@ std::string HostPlan::build(const HostOptions& o, int64_t n_panels, const double
   for (int k = 0; k < 3; ++k) {
     hi[k] = std::max(hi[k], lo[k] + ext * (1 + 1e-6));
     pmin[k] = lo[k];
-    cell[k] = (hi[k] - lo[k]) / double(1u << kLevels);
   }
-
   mark("setup+bounds");
-  // ---- Morton codes (Octree.hpp:118-129) ----
-  std::vector<Coded> codes(n), scratch(n);
-  for (int64_t i = 0; i < n; ++i) {
-    uint32_t s[3];
-    for (int k = 0; k < 3; ++k) {
-      double v = cen[3 * i + k];
-      v -= pmin[k];
-      v /= cell[k];
-      s[k] = (uint32_t)v;
-    }
-    codes[i] = {spread3(s[0]) | (spread3(s[1]) << 1) | (spread3(s[2]) << 2), (uint32_t)i};
+  // The reference's coder first: 32-bit keys, 10 levels -- every tree it can build comes out bit for bit.  Deeper than that
+  // (many small bodies in a large box, MultipleRedBloodCell's use case, Triangulation.hpp:260-321) only the 64-bit coder
+  // resolves: 21 levels.
+  tree_levels_max = 10;
+  if (!build_tree<uint32_t>(*this, 10, cen, hi, o.ncrit)) {
+    tree_levels_max = 21;
+    if (!build_tree<uint64_t>(*this, 21, cen, hi, o.ncrit)) return "octree deeper than 21 levels (coincident panel centroids?)";
   }
-
-  mark("morton codes");
-  // ---- BFS construction with stable 8-way bucketing per box (Octree.hpp:617-692) ----
-  box_key.assign(1, 1u);
-  box_parent.assign(1, 0);
-  box_body_begin.assign(1, 0);
-  box_body_end.assign(1, (int)n);
-  box_child_begin.assign(1, 0);
-  box_child_end.assign(1, 0);
-  box_leaf.assign(1, 0);
-  box_level.assign(1, 0);
-  level_off.assign(1, 0);
-  int deepest = 0;
-  for (size_t k = 0; k < box_key.size(); ++k) {
-    const int b0 = box_body_begin[k], b1 = box_body_end[k];
-    if ((unsigned)(b1 - b0) <= o.ncrit) { box_leaf[k] = 1; continue; }
-    const int lev = box_level[k];
-    if (lev >= (int)kLevels) return "octree deeper than 10 levels (reference 32-bit Morton keys, Octree.hpp:85-92)";
-    const unsigned shift = 3 * (kLevels - lev - 1);
-    int count[9] = {0};
-    for (int i = b0; i < b1; ++i) ++count[((codes[i].code >> shift) & 7) + 1];
-    for (int c = 0; c < 8; ++c) count[c + 1] += count[c];
-    int cursor[8];
-    std::copy(count, count + 8, cursor);
-    for (int i = b0; i < b1; ++i) scratch[b0 + cursor[(codes[i].code >> shift) & 7]++] = codes[i];
-    std::copy(scratch.begin() + b0, scratch.begin() + b1, codes.begin() + b0);
-    box_child_begin[k] = (int)box_key.size();
-    for (int c = 0; c < 8; ++c) {
-      if (count[c + 1] == count[c]) continue;        // empty octants get no box (:666)
-      const uint32_t key = (box_key[k] << 3) | (uint32_t)c;
-      const int l = level_of_key(key);
-      if (l > deepest) { deepest = l; level_off.push_back((int)box_key.size()); }
-      box_key.push_back(key);
-      box_parent.push_back((int)k);
-      box_body_begin.push_back(b0 + count[c]);
-      box_body_end.push_back(b0 + count[c + 1]);
-      box_child_begin.push_back(0);
-      box_child_end.push_back(0);
-      box_leaf.push_back(0);
-      box_level.push_back(l);
-    }
-    box_child_end[k] = (int)box_key.size();
-  }
-  nboxes = (int)box_key.size();
-  level_off.push_back(nboxes);
-  nlevels = (int)level_off.size() - 1;
-  perm.resize(n);
-  for (int64_t i = 0; i < n; ++i) perm[i] = codes[i].idx;
-  codes.clear(); codes.shrink_to_fit();
-  scratch.clear(); scratch.shrink_to_fit();
-
-  mark("tree");
-  // ---- box geometry (Octree.hpp:334-355 through :109-113, :243-248) ----
-  box_center.resize(3 * (size_t)nboxes);
-  box_side.resize(nboxes);
-  box_icoord.resize(3 * (size_t)nboxes);
-  const double root_side = (pmin[0] + double(1u << kLevels) * cell[0]) - pmin[0];
-  for (int b = 0; b < nboxes; ++b) {
-    uint32_t m = box_key[b];
-    while (!(m & (1u << 30))) m <<= 3;
-    const uint32_t lower = m & ~(1u << 30);
-    const uint32_t ix[3] = {compact3(lower), compact3(lower >> 1), compact3(lower >> 2)};
-    const int lev = box_level[b];
-    for (int k = 0; k < 3; ++k) {
-      const double a = pmin[k] + cell[k] * double(ix[k]);
-      const double w = (a + cell[k]) - a;
-      box_center[3 * b + k] = a + w * std::ldexp(1.0, 9 - lev);
-      box_icoord[3 * b + k] = 2 * (int32_t)ix[k] + (1 << (10 - lev));   // exact, in half-cells
-    }
-    box_side[b] = root_side / double(1 << lev);
-  }
-
-  mark("box geometry");
+  mark("tree + box geometry");
   // ---- dual tree traversal (EvalInteractionLazySparse.hpp:68-110, :239-252) ----
   auto accept = [&](int s, int t) {     // DefaultMAC, radius = side/2
     const double dx = box_center[3 * s] - box_center[3 * t], dy = box_center[3 * s + 1] - box_center[3 * t + 1],
@@ -532,14 +563,13 @@ std::string HostPlan::build(const HostOptions& o, int64_t n_panels, const double
   m2l_cls.resize(m2l_pairs_owned);
   {
     std::vector<int> at(m2l_ptr.begin(), m2l_ptr.end() - 1);
-    std::unordered_map<uint64_t, int> cls_of;
+    std::unordered_map<IVec3, int, IVec3Hash> cls_of;
     for (size_t i = 0; i < lr_tgt.size(); ++i) {
       const int s = lr_src[i], t = lr_tgt[i];
       if (!owned_L[t]) continue;
       const int32_t d[3] = {box_icoord[3 * t] - box_icoord[3 * s], box_icoord[3 * t + 1] - box_icoord[3 * s + 1],
                             box_icoord[3 * t + 2] - box_icoord[3 * s + 2]};
-      const uint64_t key = (uint64_t)(uint32_t)(d[0] + 4096) | ((uint64_t)(uint32_t)(d[1] + 4096) << 16) |
-                           ((uint64_t)(uint32_t)(d[2] + 4096) << 32);
+      const IVec3 key = {d[0], d[1], d[2]};                 // exact: half-cells of the finest level (up to 2^22 on a deep tree)
       auto [it, fresh] = cls_of.try_emplace(key, (int)m2l_class_rep.size() / 2);
       if (fresh) {
         m2l_class_vec.insert(m2l_class_vec.end(), {d[0], d[1], d[2]});

@@ -29,6 +29,20 @@ struct QuadRule {            // triangle Gauss rule: barycentric points + weight
 // examples/BEM/GaussQuadrature.hpp:19-185; false for an unknown key (the reference exits, :279-284)
 bool quad_rule(int key, QuadRule& out);
 
+// an exact integer translation vector (half-cells of the finest tree level) as the key of a translation class
+struct IVec3 {
+  int32_t x, y, z;
+  bool operator==(const IVec3& o) const { return x == o.x && y == o.y && z == o.z; }
+};
+struct IVec3Hash {
+  size_t operator()(const IVec3& v) const {
+    uint64_t h = (uint64_t)(uint32_t)v.x * 0x9E3779B97F4A7C15ull;
+    h ^= ((uint64_t)(uint32_t)v.y + 0x7F4A7C15ull) * 0xC2B2AE3D27D4EB4Full + (h << 6) + (h >> 2);
+    h ^= ((uint64_t)(uint32_t)v.z + 0x165667B1ull) * 0xD6E8FEB86659FD93ull + (h << 6) + (h >> 2);
+    return (size_t)(h ^ (h >> 29));
+  }
+};
+
 struct HostOptions {
   int p_max = 10;
   int quad_k = 3;
@@ -74,7 +88,8 @@ struct HostPlan {
   std::vector<uint32_t> perm;             // tree index -> original index
   int nboxes = 0, nlevels = 0;
   std::vector<int> level_off;             // nlevels+1, boxes of one level are contiguous (BFS order)
-  std::vector<uint32_t> box_key;          // marker-bit Morton key
+  std::vector<uint64_t> box_key;          // marker-bit Morton key
+  int tree_levels_max = 10;               // 10: the reference's 32-bit coder built the tree; 21: the 64-bit coder had to
   std::vector<int> box_level, box_parent, box_child_begin, box_child_end;   // children empty for leaves
   std::vector<uint8_t> box_leaf;
   std::vector<int> box_body_begin, box_body_end;

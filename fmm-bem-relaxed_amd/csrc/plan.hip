@@ -544,15 +544,14 @@ int fmmbem_plan::to_device() {
   // parent<->child translation classes and their regular-harmonic tables
   {
     std::vector<int> up_cls(nb, 0), down_cls(nb, 0);
-    std::unordered_map<uint64_t, int> seen;
+    std::unordered_map<IVec3, int, IVec3Hash> seen;
     std::vector<cplx> up_tab, down_tab, h;
     std::vector<double> up_rec_h, dn_rec_h;              // records of the same classes for the rotation kernels
     for (int b = 1; b < nb; ++b) {
       const int par = hp.box_parent[b];
       const int32_t v[3] = {hp.box_icoord[3 * par] - hp.box_icoord[3 * b], hp.box_icoord[3 * par + 1] - hp.box_icoord[3 * b + 1],
                             hp.box_icoord[3 * par + 2] - hp.box_icoord[3 * b + 2]};
-      const uint64_t key = (uint64_t)(uint32_t)(v[0] + 4096) | ((uint64_t)(uint32_t)(v[1] + 4096) << 16) |
-                           ((uint64_t)(uint32_t)(v[2] + 4096) << 32);
+      const IVec3 key = {v[0], v[1], v[2]};
       auto [it, fresh] = seen.try_emplace(key, (int)seen.size());
       if (fresh) {
         double up[3], down[3];

@@ -30,7 +30,8 @@ typedef enum {
   FMMBEM_ERR_NO_DEVICE = 2,     /* no usable HIP device, or the plan was built host-only            */
   FMMBEM_ERR_HIP = 3,           /* a HIP runtime call or kernel launch failed                         */
   FMMBEM_ERR_ALLOC = 4,         /* host or device allocation failed                                   */
-  FMMBEM_ERR_TREE = 5,          /* octree deeper than the 10 levels of the reference's 32-bit keys    */
+  FMMBEM_ERR_TREE = 5,          /* octree deeper than 21 levels (64-bit Morton keys; the reference's 32-bit keys stop at 10:
+                                 * trees that fit 10 levels are built by its rule, bit for bit, deeper ones by the wide coder) */
   FMMBEM_ERR_UNSUPPORTED = 6,   /* option combination not implemented                                 */
   FMMBEM_ERR_IO = 7             /* a mesh file could not be opened or parsed                          */
 } fmmbem_status;

@@ -47,7 +47,7 @@ typedef struct {
 
 /* include/tree/Octree.hpp:201-269 (box_data), plus derived geometry */
 typedef struct {
-  uint32_t key;            /* marker-bit Morton key, leaf bit stripped         */
+  uint64_t key;            /* marker-bit Morton key, leaf bit stripped         */
   uint32_t parent;
   uint32_t cb, ce;         /* children (box ids) or bodies (tree ids) if leaf  */
   int leaf;
@@ -74,7 +74,8 @@ typedef struct orc_ctx {
   int nboxes, nlevels;     /* nlevels = Octree::levels()                       */
   orc_box *boxes;
   uint32_t *perm;          /* tree index -> original index (Body::number())    */
-  uint32_t *code;          /* Morton code per tree index                       */
+  uint64_t *code;          /* Morton code per tree index                       */
+  unsigned levels;         /* bits per dimension of the coder: 10 (reference) or 21 (tree.c DEEP_LEVELS) */
   int *level_offset;       /* nlevels+1 entries                                */
   /* lists: executor/EvalInteractionLazySparse.hpp:37-47 */
   orc_pair *p2p; int n_p2p;        /* (source leaf, target leaf)               */

@@ -7,34 +7,43 @@
 #include <string.h>
 
 #define LEVELS 10u   /* include/tree/Octree.hpp:88 (MortonCoder::levels) */
+/* NOT A REFERENCE RULE: when a box on level 10 still holds more than ncrit bodies the reference's coder is out of bits (its
+ * shift 3*(levels - level - 1) wraps, Octree.hpp:649) and no tree exists.  The product then codes with 21 bits per dimension
+ * in a 64-bit key; the oracle follows with the same switch so that the two can be compared on such meshes.  Every tree the
+ * reference CAN build takes the 10-level path below unchanged. */
+#define DEEP_LEVELS 21u
 
-/* include/tree/Octree.hpp:143-159 (spread_bits, interleave) */
-static uint32_t spread_bits(uint32_t x) {
-  x = (x | (x << 16)) & 0x030000FFu;
-  x = (x | (x <<  8)) & 0x0300F00Fu;
-  x = (x | (x <<  4)) & 0x030C30C3u;
-  x = (x | (x <<  2)) & 0x09249249u;
+/* include/tree/Octree.hpp:143-159 (spread_bits, interleave), widened to 64 bits: on 10-bit inputs the values are the
+ * reference's 32-bit ones */
+static uint64_t spread_bits(uint64_t x) {
+  x &= 0x1FFFFFull;
+  x = (x | (x << 32)) & 0x1F00000000FFFFull;
+  x = (x | (x << 16)) & 0x1F0000FF0000FFull;
+  x = (x | (x <<  8)) & 0x100F00F00F00F00Full;
+  x = (x | (x <<  4)) & 0x10C30C30C30C30C3ull;
+  x = (x | (x <<  2)) & 0x1249249249249249ull;
   return x;
 }
-static uint32_t interleave(uint32_t x, uint32_t y, uint32_t z) {
+static uint64_t interleave(uint64_t x, uint64_t y, uint64_t z) {
   return spread_bits(x) | (spread_bits(y) << 1) | (spread_bits(z) << 2);
 }
 /* include/tree/Octree.hpp:167-174 (compact_bits) */
-static uint32_t compact_bits(uint32_t x) {
-  x &= 0x09249249u;
-  x = (x | (x >>  2)) & 0x030C30C3u;
-  x = (x | (x >>  4)) & 0x0300F00Fu;
-  x = (x | (x >>  8)) & 0x030000FFu;
-  x = (x | (x >> 16)) & 0x000003FFu;
+static uint64_t compact_bits(uint64_t x) {
+  x &= 0x1249249249249249ull;
+  x = (x | (x >>  2)) & 0x10C30C30C30C30C3ull;
+  x = (x | (x >>  4)) & 0x100F00F00F00F00Full;
+  x = (x | (x >>  8)) & 0x1F0000FF0000FFull;
+  x = (x | (x >> 16)) & 0x1F00000000FFFFull;
+  x = (x | (x >> 32)) & 0x1FFFFFull;
   return x;
 }
 
-static int key_level(uint32_t key) {          /* box_data::level(), Octree.hpp:226-238 */
-  int hb = 31 - __builtin_clz(key);
+static int key_level(uint64_t key) {          /* box_data::level(), Octree.hpp:226-238 */
+  int hb = 63 - __builtin_clzll(key);
   return hb / 3;
 }
 
-typedef struct { uint32_t code, idx; } code_pair;
+typedef struct { uint64_t code; uint32_t idx; } code_pair;
 
 #define VEC(T) struct { T *d; size_t n, cap; }
 #define PUSH(v, x) do { if ((v).n == (v).cap) { (v).cap = (v).cap ? 2*(v).cap : 1024; \
@@ -43,17 +52,18 @@ typedef struct { uint32_t code, idx; } code_pair;
 static void box_geometry(orc_ctx *c, orc_box *b) {
   /* Box::center(), Octree.hpp:350-355, through MortonCoder::cell (:109-113) and
      box_data::get_mc_lower_bound (:243-248); Box::side_length (:334-336) */
-  uint32_t m = b->key;
-  while (!(m & (1u << 30))) m <<= 3;
-  uint32_t lower = m & ~(1u << 30);
+  const unsigned L = c->levels;
+  uint64_t m = b->key, top = (uint64_t)1 << (3*L);
+  while (!(m & top)) m <<= 3;
+  uint64_t lower = m & ~top;
   double ix[3] = { (double)compact_bits(lower), (double)compact_bits(lower >> 1), (double)compact_bits(lower >> 2) };
   for (int k = 0; k < 3; ++k) {
     double lo = c->pmin[k] + c->cell[k]*ix[k];
     double hi = lo + c->cell[k];
     double dim = hi - lo;
-    b->center[k] = lo + dim * ldexp(1.0, 9 - b->level);   /* = 1 << (10-level-1) for level <= 9 */
+    b->center[k] = lo + dim * ldexp(1.0, (int)L - 1 - b->level);   /* = 1 << (10-level-1) for level <= 9 */
   }
-  double bbmax0 = c->pmin[0] + (double)(1u << LEVELS) * c->cell[0];   /* MortonCoder::bounding_box, :102-105 */
+  double bbmax0 = c->pmin[0] + ldexp(1.0, (int)L) * c->cell[0];   /* MortonCoder::bounding_box, :102-105 */
   b->side = (bbmax0 - c->pmin[0]) / (double)(1 << b->level);
 }
 
@@ -133,24 +143,28 @@ orc_ctx *orc_create_eval(int n, const double *verts, const uint8_t *bc, int K, d
     double a = mn[k] + ext*(1 + 1e-6);
     mx[k] = fmax(mx[k], a);
     c->pmin[k] = mn[k];
-    c->cell[k] = (mx[k] - mn[k]) / (double)(1u << LEVELS);     /* MortonCoder ctor, :95-99 */
   }
+  c->levels = LEVELS;
+  code_pair *codes = malloc(sizeof(code_pair)*(size_t)n), *tmp = malloc(sizeof(code_pair)*(size_t)n);
+  VEC(orc_box) boxes = {0};
+  int_vec level_offset = {0};
+rebuild:;
+  const unsigned L = c->levels;
+  for (int k = 0; k < 3; ++k) c->cell[k] = (mx[k] - mn[k]) / ldexp(1.0, (int)L);     /* MortonCoder ctor, :95-99 */
 
   /* ---- codes: MortonCoder::code, :118-129 ---- */
-  code_pair *codes = malloc(sizeof(code_pair)*(size_t)n), *tmp = malloc(sizeof(code_pair)*(size_t)n);
   for (int i = 0; i < n; ++i) {
-    uint32_t s[3];
+    uint64_t s[3];
     for (int k = 0; k < 3; ++k) {
       double v = c->panels[i].c[k];
       v -= c->pmin[k]; v /= c->cell[k];
-      s[k] = (uint32_t)v;
+      s[k] = (uint64_t)(uint32_t)v;
     }
     codes[i].code = interleave(s[0], s[1], s[2]); codes[i].idx = (uint32_t)i;
   }
 
   /* ---- construct_tree: Octree.hpp:617-692 (incremental stable bucket sort, BFS box order) ---- */
-  VEC(orc_box) boxes = {0};
-  int_vec level_offset = {0};
+  boxes.n = 0; level_offset.n = 0;
   orc_box root; memset(&root, 0, sizeof root);
   root.key = 1; root.parent = 0; root.cb = 0; root.ce = (uint32_t)n; root.level = 0; root.bb = 0; root.be = (uint32_t)n;
   PUSH(boxes, root);
@@ -159,11 +173,12 @@ orc_ctx *orc_create_eval(int n, const double *verts, const uint8_t *bc, int K, d
   for (size_t k = 0; k != boxes.n; ++k) {
     orc_box bk = boxes.d[k];
     if (bk.ce - bk.cb <= ncrit) { boxes.d[k].leaf = 1; continue; }       /* :641-644 */
-    if (bk.level >= (int)LEVELS) {                                       /* 32-bit key limit, :85-92 */
-      fprintf(stderr, "oracle: octree deeper than %u levels\n", LEVELS);
+    if (bk.level >= (int)L) {                                            /* 32-bit key limit, :85-92 */
+      if (L == LEVELS) { c->levels = DEEP_LEVELS; goto rebuild; }        /* not a reference rule: see DEEP_LEVELS */
+      fprintf(stderr, "oracle: octree deeper than %u levels\n", L);
       boxes.d[k].leaf = 1; continue;
     }
-    unsigned shift = 3*(LEVELS - (unsigned)bk.level - 1);               /* :649 */
+    unsigned shift = 3*(L - (unsigned)bk.level - 1);                    /* :649 */
     size_t cnt[9] = {0};
     for (uint32_t i = bk.cb; i < bk.ce; ++i) cnt[((codes[i].code >> shift) & 7) + 1]++;
     for (int b = 0; b < 8; ++b) cnt[b+1] += cnt[b];
@@ -175,7 +190,7 @@ orc_ctx *orc_create_eval(int n, const double *verts, const uint8_t *bc, int K, d
       uint32_t bch = bk.cb + (uint32_t)cnt[ch], ech = bk.cb + (uint32_t)cnt[ch+1];
       if (ech - bch > 0) {
         orc_box nb; memset(&nb, 0, sizeof nb);
-        nb.key = (bk.key << 3) | (uint32_t)ch; nb.parent = (uint32_t)k;
+        nb.key = (bk.key << 3) | (uint64_t)ch; nb.parent = (uint32_t)k;
         nb.cb = bch; nb.ce = ech; nb.bb = bch; nb.be = ech;
         nb.level = key_level(nb.key);
         if (nb.level > maxlevel) { maxlevel = nb.level; PUSH(level_offset, (int)boxes.n); }
@@ -188,7 +203,7 @@ orc_ctx *orc_create_eval(int n, const double *verts, const uint8_t *bc, int K, d
   PUSH(level_offset, (int)boxes.n);                                       /* :684 */
   c->nboxes = (int)boxes.n; c->boxes = boxes.d;
   c->nlevels = (int)level_offset.n - 1; c->level_offset = level_offset.d;
-  c->perm = malloc(sizeof(uint32_t)*(size_t)n); c->code = malloc(sizeof(uint32_t)*(size_t)n);
+  c->perm = malloc(sizeof(uint32_t)*(size_t)n); c->code = malloc(sizeof(uint64_t)*(size_t)n);
   for (int i = 0; i < n; ++i) { c->perm[i] = codes[i].idx; c->code[i] = codes[i].code; }    /* :687-691 */
   free(codes); free(tmp);
   for (int b = 0; b < c->nboxes; ++b) box_geometry(c, &c->boxes[b]);
