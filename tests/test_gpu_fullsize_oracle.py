@@ -97,12 +97,11 @@ def test_config3_accuracy_gate_4096_seeded_rows(fb, cfg3):
     assert g12 < 0.6 * g, (g12, g)                             # and it falls with p
 
 
-def test_single_sphere_error_level_is_the_reference_algorithm_s(fb, oracle_mod):
-    """One UnitSphere(9) (N = 524 288) at p = 10 sits at 2.5e-6 of Direct on a sample -- above 1e-6.  Same rows, oracle
-    and GPU: the two agree to 1e-12 with each other and to three digits in their distance from Direct, i.e. the figure is
-    the truncation error of p = 10, theta = 0.5 on this mesh (all sources on ONE smooth closed surface: the multipole
-    bound's worst case, every cell's far field comes from the same side), not the device path.  The two-sphere headline
-    workload measures lower because the second body's contribution is a well-separated, rapidly converging far field."""
+def test_single_sphere_whole_vector_meets_the_gate(fb, oracle_mod):
+    """One UnitSphere(9) (N = 524 288) at p = 10 over the seeded whole-vector sample: 5.7e-7 of Direct, GPU and oracle alike
+    (profiles/r04b_accuracy_table.jsonl; r = 8 over ALL rows 5.8e-7, r = 10 6.8e-7) -- below the 1e-6 north-star figure.  The
+    2.5e-6 that rounds 2 and 3 recorded for these meshes was the 256 contiguous rows at n/3, which happen to sit in a coarse
+    leaf; the two-sphere headline workload has such leaves on level 3 and is dominated by them (8.97e-6, see the test above)."""
     v = fb.unit_sphere(9)
     plan = fb.FMM_plan(fb.LaplaceSphericalBEM(10, 3), v, p_max=10)
     o = oracle_mod.Oracle(v)
@@ -116,7 +115,7 @@ def test_single_sphere_error_level_is_the_reference_algorithm_s(fb, oracle_mod):
     assert rel_l2(y, yo) <= 1e-12
     g, r = rel_l2(y[rows], d), rel_l2(yo[rows], d)
     assert abs(g - r) <= 1e-3 * r, (g, r)
-    assert g < 5e-6, g                                         # the reference's level on this mesh (2.5e-6), not the 1e-6 gate
+    assert g < 1e-6, g
 
 
 def test_config4_stokes_full_vector_vs_oracle(fb, oracle_mod):
