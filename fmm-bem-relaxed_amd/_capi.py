@@ -39,7 +39,8 @@ class Stats(C.Structure):
         [(n, C.c_double) for n in ("build_host_ms", "build_assemble_ms", "ms_total", "ms_gather", "ms_near",
                                    "ms_scatter", "ms_p2m", "ms_m2m", "ms_mh", "ms_m2l", "ms_l2l", "ms_l2p")] +
         [("timed_executes", C.c_int64), ("l2l_reference_omitted", C.c_int64), ("m2l_items", C.c_int64),
-         ("m2l_passes", C.c_int64), ("near_side_entries", C.c_int64), ("m2l_kernel", C.c_int32), ("expansion_slots", C.c_int32)])
+         ("m2l_passes", C.c_int64), ("near_side_entries", C.c_int64), ("m2l_kernel", C.c_int32), ("expansion_slots", C.c_int32),
+         ("rot_nop_orders", C.c_int64), ("tree_coder_levels", C.c_int32)])
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

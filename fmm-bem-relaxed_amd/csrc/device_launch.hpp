@@ -35,6 +35,11 @@ hipError_t launch_m2m_rot(const DevicePlan& d, const RotWork& w, int p, hipStrea
 hipError_t launch_l2l_rot(const DevicePlan& d, const RotWork& w, int p, hipStream_t s);   // L[tgt = child] += shift of L[src = parent]
 hipError_t launch_m2l_rot(const DevicePlan& d, const DevicePlan* d_dev, int p, hipStream_t s);
 bool m2l_rot_long_items(int p);
+// bit p - 1: orders of the four rotation objects that carry "s_nop 1" in front of their DPP FMAs (csrc/Makefile ROTBUILD)
+unsigned rot_nop_orders_m2l();
+unsigned rot_nop_orders_m2m();
+unsigned rot_nop_orders_l2l();
+unsigned rot_nop_orders_rot2();
 bool shift_rot2_supported(int p);
 hipError_t launch_shift_rot2(const DevicePlan& d, const RotWork& w, int p, int op, hipStream_t s);   // kernels_m2l_rot2.hip: M2M / L2L in the split form
 int l2p_group_leaves(int kernel);                      // most leaves an L2P work group may hold (the kernels' LDS slice per wavefront)

@@ -49,7 +49,12 @@ struct DevicePlan {
   int nq = 0;
   int nboxes = 0, nleaves = 0;
   int p_max = 0, s_max = 0, p2_max = 0, y2_max = 0;   // S, P^2, (2P)^2 at p_max
-  int p2m_stride = 0;                                 // complex per record of p2m_tab: s_max rounded up to a cache line
+  int p2m_stride = 0;                                 // double2 per record of p2m_tab: s_max rounded up to a cache line (classic), or the packed length
+  // Laplace records are PACKED: the moments of order m = 0 are real (e^{i m beta} = 1; also their normal-derivative form), so a
+  // record is [complex (n, m >= 1): n = 1 .., m = 1 .. n][real (n, 0): n = 0 ..] -- 16 p(p-1)/2 + 8 p bytes instead of 16 p(p+1)/2,
+  // 800 instead of 880 (896 with the line padding) at p_max = 10; order p still reads a prefix of either segment.
+  // p2m_real_off: double2 slot at which the reals begin (= p_max (p_max - 1) / 2); the Stokes tables keep the classic layout
+  int p2m_packed = 0, p2m_real_off = 0;
   int leaf_begin = 0, leaf_end = 0;                   // owned target leaves
   int64_t row_begin = 0, row_end = 0;
   int max_ncols = 0;                                  // widest near row block (columns, padded even)

@@ -255,6 +255,14 @@ __global__ __launch_bounds__(kP2MWaves * kWave) void p2m_kernel(DevicePlan d, co
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void wave_lds_sync();     // below
 
+// Packed Laplace records (DevicePlan::p2m_packed): where coefficient (n, m) of a record lives
+__device__ __forceinline__ void coef_nm(int idx, int& n, int& m) {      // idx = n (n + 1) / 2 + m
+  n = 0;
+  while ((n + 1) * (n + 2) / 2 <= idx) ++n;
+  m = idx - n * (n + 1) / 2;
+}
+__device__ __forceinline__ int packed_cpos(int n, int m) { return n * (n - 1) / 2 + m - 1; }      // m >= 1
+
 template <int NT>
 __global__ __launch_bounds__(kWave) void p2m_table_kernel(DevicePlan d, double2* __restrict__ tab) {
   const int P = d.p_max, SM = d.p2m_stride;          // record stride of the table
@@ -317,7 +325,23 @@ __global__ __launch_bounds__(kWave) void p2m_table_kernel(DevicePlan d, double2*
             }
             const int idx = n * (n + 1) / 2 + m;
             const double wt[4] = {aw, aw * qx, aw * qy, aw * qz};      // Stokes: moments of 1 and of the ABSOLUTE point (StokesSphericalBEM.hpp:417-431)
-            if constexpr (NT != 3) {
+            if constexpr (NT == 1) {
+              if (d.p2m_packed) {                      // packed record: complex (n, m >= 1), then the reals (n, 0) -- vi is identically zero there
+                if (m) {
+                  double2* at = out + packed_cpos(n, m);
+                  double2 acc = q ? *at : double2{0, 0};
+                  acc.x += aw * vr; acc.y += aw * vi;
+                  *at = acc;
+                } else {
+                  double* at = reinterpret_cast<double*>(out + d.p2m_real_off) + n;
+                  *at = (q ? *at : 0.0) + aw * vr;
+                }
+              } else {
+                double2 acc = q ? out[idx] : double2{0, 0};
+                acc.x += aw * vr; acc.y += aw * vi;
+                out[idx] = acc;
+              }
+            } else if constexpr (NT != 3) {
 #pragma unroll
               for (int e = 0; e < NT; ++e) {
                 double2 acc = q ? out[(size_t)e * SM + idx] : double2{0, 0};
@@ -357,11 +381,15 @@ __global__ __launch_bounds__(4 * kWave) void p2m_apply_kernel(DevicePlan d, cons
       // low order (where the relaxed solver spends most iterations): S <= 32 coefficients would leave most lanes idle, so
       // G = 64 / S groups of lanes take every G-th panel and the groups are added in order through the LDS
       const int G = kWave / S, g = lane / S, idx = lane - g * S;
+      int cn, cm;
+      coef_nm(idx, cn, cm);
+      const int tslot = !d.p2m_packed ? idx : cm ? packed_cpos(cn, cm) : 0;
       double2 m0 = {0, 0}, m1 = {0, 0};
       if (g < G)
         for (int r = g; r < nrows; r += G) {
           const int64_t i = row0 + r;
-          const double2 t = tab[(size_t)i * TS + idx];
+          const double2* rec = tab + (size_t)i * TS;
+          const double2 t = (d.p2m_packed && !cm) ? double2{reinterpret_cast<const double*>(rec + d.p2m_real_off)[cn], 0.0} : rec[tslot];
           const double x = d.xt[i];
           if (d.bc[i]) { m1.x = fma(x, t.x, m1.x); m1.y = fma(x, t.y, m1.y); }
           else { m0.x = fma(x, t.x, m0.x); m0.y = fma(x, t.y, m0.y); }
@@ -385,6 +413,10 @@ __global__ __launch_bounds__(4 * kWave) void p2m_apply_kernel(DevicePlan d, cons
     }
     for (int idx = lane; idx < S; idx += kWave) {
       if (NT == 1) {
+        int cn, cm;
+        coef_nm(idx, cn, cm);
+        const bool real_only = d.p2m_packed && !cm;    // a packed record holds the m = 0 moments as bare reals
+        const int tslot = !d.p2m_packed ? idx : cm ? packed_cpos(cn, cm) : 0;
         double2 m0 = {0, 0}, m1 = {0, 0};              // G moments (POTENTIAL panels) / dG/dn moments (NORMAL_DERIV panels)
         constexpr int U = FMMBEM_P2M_INFLIGHT;         // panels' records in flight, added in panel order; the last batch of a leaf is
                                                        // a masked one (one latency, not one per leftover panel).  The table is read
@@ -398,7 +430,8 @@ __global__ __launch_bounds__(4 * kWave) void p2m_apply_kernel(DevicePlan d, cons
           for (int u = 0; u < U; ++u) {
             const bool ok = r + u < nrows;
             const int64_t iu = ok ? i + u : i;
-            t[u] = ok ? __builtin_nontemporal_load(reinterpret_cast<const tvec2*>(tab + (size_t)iu * TS + idx)) : tvec2{0, 0};
+            if (real_only) t[u] = ok ? tvec2{__builtin_nontemporal_load(reinterpret_cast<const double*>(tab + (size_t)iu * TS + d.p2m_real_off) + cn), 0.0} : tvec2{0, 0};
+            else t[u] = ok ? __builtin_nontemporal_load(reinterpret_cast<const tvec2*>(tab + (size_t)iu * TS + tslot)) : tvec2{0, 0};
             x[u] = d.xt[iu]; dn[u] = d.bc[iu] != 0;
           }
 #pragma unroll
@@ -490,6 +523,28 @@ __global__ __launch_bounds__(4 * kWave) void p2m_stream_kernel(DevicePlan d, con
   const ConstInt* nrows_of = as_const_space<ConstInt>(d.leaf_nrows);
   const ConstDouble* xt = as_const_space<ConstDouble>(d.xt);
   const int slot = d.act[0], stride = gridDim.x * 4, n = d.n_p2m;
+  // what this lane streams (at most two items: 128 >= the 120 + 8 of p = 16): the table slot it loads and where the sums go.
+  // Classic records: item = coefficient.  Packed records: the complex (n, m >= 1) in order, then the m = 0 reals two to a slot.
+  int tslot[2], st0[2], st1[2];
+  {
+    const int nb = d.p2m_packed ? P * (P - 1) / 2 : S, items = d.p2m_packed ? nb + (P + 1) / 2 : S;
+    for (int it = 0; it < 2; ++it) {
+      const int item = lane + it * kWave;
+      tslot[it] = -1; st0[it] = 0; st1[it] = -2;
+      if (item >= items) continue;
+      if (!d.p2m_packed) { tslot[it] = item; st0[it] = item; }
+      else if (item < nb) {
+        int cn = 1;
+        while (cn * (cn + 1) / 2 <= item) ++cn;          // degree of packed position `item`
+        tslot[it] = item; st0[it] = item + cn + 1;       // n (n + 1) / 2 + m  =  cpos + n + 1
+      } else {
+        const int k = item - nb;
+        tslot[it] = d.p2m_real_off + k;
+        st0[it] = (2 * k) * (2 * k + 1) / 2;
+        st1[it] = 2 * k + 1 < P ? (2 * k + 1) * (2 * k + 2) / 2 : -1;
+      }
+    }
+  }
   int li = blockIdx.x * 4 + wv;
   if (li >= n) return;
   int leaf = leaf_of[li];
@@ -499,7 +554,8 @@ __global__ __launch_bounds__(4 * kWave) void p2m_stream_kernel(DevicePlan d, con
     const int nl = li + stride < n ? li + stride : li;
     const int nleaf = leaf_of[nl];
     const int nbox = box_of[nleaf], nrow0 = row0_of[nleaf], nnrows = nrows_of[nleaf];
-    for (int idx = lane; idx < S; idx += kWave) {
+    for (int it = 0; it < 2; ++it) {
+      if (tslot[it] < 0) break;
       double2 m = {0, 0};
       for (int r = 0; r < nrows; r += U) {
         tvec2 t[U];
@@ -509,14 +565,19 @@ __global__ __launch_bounds__(4 * kWave) void p2m_stream_kernel(DevicePlan d, con
           t[u] = tvec2{0, 0}; x[u] = 0.0;                //  around the load (re-reading row r instead costs L2 requests: 24 for 19 rows)
           if (r + u < nrows) {
             const int64_t iu = (int64_t)row0 + r + u;
-            t[u] = __builtin_nontemporal_load(reinterpret_cast<const tvec2*>(tab + (size_t)iu * TS + idx));
+            t[u] = __builtin_nontemporal_load(reinterpret_cast<const tvec2*>(tab + (size_t)iu * TS + tslot[it]));
             x[u] = xt[iu];
           }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) { m.x = fma(x[u], t[u].x, m.x); m.y = fma(x[u], t[u].y, m.y); }   // panel order, as p2m_apply_kernel
       }
-      d.M[((size_t)box * d.nslots + slot) * SM + idx] = m;
+      double2* Mb = d.M + ((size_t)box * d.nslots + slot) * SM;
+      if (st1[it] == -2) Mb[st0[it]] = m;                // a complex coefficient (classic layout, or packed m >= 1)
+      else {                                             // a packed pair of m = 0 moments: two real coefficients
+        Mb[st0[it]] = double2{m.x, 0.0};
+        if (st1[it] >= 0) Mb[st1[it]] = double2{m.y, 0.0};
+      }
     }
     leaf = nleaf; box = nbox; row0 = nrow0; nrows = nnrows;
   }

@@ -561,6 +561,15 @@ hipError_t launch_rot(const DevicePlan& d, const RotWork& w, int p, hipStream_t 
 
 }  // namespace
 
+// the orders of this object that were built with "s_nop 1" in front of their DPP FMAs (fmmbem_stats.rot_nop_orders)
+#if FMMBEM_ROT_OP == 0
+unsigned rot_nop_orders_m2l() { return (unsigned)(FMMBEM_ROT_NOP_ORDERS); }
+#elif FMMBEM_ROT_OP == 1
+unsigned rot_nop_orders_m2m() { return (unsigned)(FMMBEM_ROT_NOP_ORDERS); }
+#else
+unsigned rot_nop_orders_l2l() { return (unsigned)(FMMBEM_ROT_NOP_ORDERS); }
+#endif
+
 #if FMMBEM_ROT_OP == 0
 bool m2l_rot_supported(int p) { return p >= 1 && p <= kRotPmax; }
 // the orders that run one wavefront per SIMD take the long items (host_plan.cpp build_rot_items)

@@ -65,7 +65,14 @@ __device__ __forceinline__ void static_for(F&& f) {
 // The constant stream of the split form: groups of sixteen positions, per group 16 E constants then 16 O constants
 // (m2l_rot.hpp build_rot2_stream).  A lane loads the constant of its parity at lane & 15; everything else as ConstFeed of
 // kernels_m2l_rot.hip: loads issued by hand kRotAhead groups ahead, in-order vmcnt waits, the FMA takes lane k of its row.
-template <int NG>
+// the DPP hazard remedy of kernels_m2l_rot.hip: orders listed in FMMBEM_ROT_NOP_ORDERS (bit p - 1; set by csrc/Makefile when
+// tools/check_rot_isa.py finds the hazard in the generated code) get "s_nop 1" in front of every DPP FMA
+#ifndef FMMBEM_ROT_NOP_ORDERS
+#define FMMBEM_ROT_NOP_ORDERS 0u
+#endif
+constexpr bool rot2_needs_nop(int P) { return ((FMMBEM_ROT_NOP_ORDERS) >> (P - 1)) & 1u; }
+
+template <int NG, bool kNop = false>
 struct ConstFeed2 {
   static constexpr int NB = kRotAhead + 1;
   static constexpr int kGroupBytes = 2 * kRotGroup * 8;
@@ -88,7 +95,8 @@ struct ConstFeed2 {
   }
   template <int K>
   static __device__ __forceinline__ void dpp_fma(double& acc, double c, double src) {
-    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(c), "v"(src), "n"(K));
+    if constexpr (kNop) asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(c), "v"(src), "n"(K));
+    else asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(c), "v"(src), "n"(K));
   }
   template <int E>
   __device__ __forceinline__ void fma1(double& acc, double src) {
@@ -249,7 +257,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
       // powers in front of and behind the axial operator (kernels_m2l_rot.hip): M2L rho^-n, rho^-(j+1); M2M rho^-n, rho^j; L2L rho^n, rho^-j
       const double pre = OP == kRotL2L ? cr[5] : inv_rho, post = OP == kRotM2M ? cr[5] : inv_rho;
       const double pre2 = pre * pre, post2 = post * post;
-      ConstFeed2<(rot2_stream_len(P) + kRotGroup - 1) / kRotGroup> cf;
+      ConstFeed2<(rot2_stream_len(P) + kRotGroup - 1) / kRotGroup, rot2_needs_nop(P)> cf;
 #ifndef FMMBEM_ROT2_EXP_NOARITH                          // experiment builds: where does a pass spend its time
       cf.start(w.stream, lane);
       z_rotation2<P>(a, b, cb, sb, odd ? cb : 1.0, odd ? sb : 0.0);
@@ -468,6 +476,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 }  // namespace
 
 bool m2l_rot2_supported(int p) { return p == 10 || p == 12; }
+unsigned rot_nop_orders_rot2() { return (unsigned)(FMMBEM_ROT_NOP_ORDERS); }      // fmmbem_stats.rot_nop_orders
 
 // stream: the split-form constants of order p (m2l_rot.hpp build_rot2_stream); pairs, items and class records as for launch_m2l_rot
 hipError_t launch_m2l_rot2(const DevicePlan& d, const RotWork& w, int p, hipStream_t s) {

@@ -314,6 +314,14 @@ int fmmbem_plan::to_device() {
   // lane and is 9 % SLOWER with line-aligned boxes (0.56 -> 0.61 ms at p = 10)
   d.p2m_stride = (d.s_max + 7) & ~7;
   if ((d.p2m_stride - d.s_max) * 32 > d.s_max) d.p2m_stride = d.s_max;      // more than 3 % of padding (36 -> 40 at p_max = 8) costs more than it saves
+  if (opts.kernel != FMMBEM_KERNEL_STOKES_BEM) {
+    // Laplace: packed records (device_plan.hpp p2m_packed) -- the zero imaginary parts of the m = 0 moments are not stored
+    d.p2m_packed = 1;
+    d.p2m_real_off = pm * (pm - 1) / 2;
+    const int len = d.p2m_real_off + (pm + 1) / 2;                          // the reals two to a double2 slot
+    d.p2m_stride = (len + 7) & ~7;
+    if ((d.p2m_stride - len) * 32 > len) d.p2m_stride = len;                // the same 3 % rule: 50 slots = 800 bytes at p_max = 10, 72 = 1 152 at 12
+  }
   d.leaf_begin = hp.leaf_begin; d.leaf_end = hp.leaf_end; d.row_begin = hp.row_begin; d.row_end = hp.row_end;
   for (int q = 0; q < hp.rule.n; ++q) d.qw[q] = hp.rule.w[q];
   d.kernel = opts.kernel;
@@ -1267,6 +1275,9 @@ int fmmbem_plan_stats(const fmmbem_plan* plan, fmmbem_stats* o) {
   o->near_side_entries = plan->near_side_entries;
   o->expansion_slots = plan->on_device ? plan->d.nslots : (plan->opts.kernel == FMMBEM_KERNEL_STOKES_BEM ? 8 : 2);
   o->m2l_kernel = plan->last_p > 0 ? (plan->use_rot(plan->last_p) ? 1 : plan->last_p <= 4 ? 3 : 2) : 0;
+  o->rot_nop_orders = (int64_t)rot_nop_orders_m2l() | ((int64_t)rot_nop_orders_m2m() << 16) | ((int64_t)rot_nop_orders_l2l() << 32) |
+                      ((int64_t)rot_nop_orders_rot2() << 48);
+  o->tree_coder_levels = h.tree_levels_max;
   o->expansions_active = (h.has_bc[0] ? 1 : 0) | (h.has_bc[1] ? 2 : 0);
   o->last_p = plan->last_p;
   o->build_host_ms = plan->build_host_ms; o->build_assemble_ms = plan->build_assemble_ms;

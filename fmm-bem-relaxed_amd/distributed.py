@@ -47,6 +47,13 @@ class ShardedFMM:
                              shard=(self.rank, self.world), host_only=host_only,
                              shard_upward=(2 if self.xch == "alltoall" and local_split is None else True) if (self.split and self.world > 1) else False)
         self.n = self.plan.n
+        # The launch chains of a shard's matvec are replayed as hipGraphs (one per half of a split execute and order): a rank of
+        # eight has 0.45 ms of kernels per matvec at p = 10 and the host must stay ahead of it with two collectives to issue as
+        # well -- one graph launch instead of ~16 kernel launches per half (57 -> 18-27 us of host time per matvec on one GPU,
+        # profiles/r03i_graph.txt; the same kernels, the same bits: tests/test_gpu_sharded_upward.py).  FMMBEM_GRAPH=0: off.
+        if (self.world > 1 and not host_only and local_execute is None and local_split is None
+                and os.environ.get("FMMBEM_GRAPH", "1") != "0"):
+            self.plan.set_graphs(True)
         self._local = local_execute if local_execute is not None else self.plan.execute_torch
         self._xbuf = {}                                   # p -> (send, recv) exchange buffers
         # overlap of the all-gather with the near field: RCCL only (an asynchronous gloo collective on device tensors

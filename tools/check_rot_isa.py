@@ -8,7 +8,12 @@
    from its issue to the s_waitcnt that covers it, along every path of the kernel's control flow, and reports any instruction
    in between that touches its destination registers.
 
-usage: tools/check_rot_isa.py kernels_m2l_rot.o   -> a line per kernel; exit 1 on any finding"""
+usage: tools/check_rot_isa.py kernels_m2l_rot.o    -> a line per kernel; exit 1 on any finding
+       tools/check_rot_isa.py --text listing.s      the same on a disassembly listing (llvm-objdump -d text; tests feed doctored ones)
+       tools/check_rot_isa.py --nop-mask report     reads a report printed by this script and prints the FMMBEM_ROT_NOP_ORDERS mask
+                                                    (bit p - 1) that cures it: the orders with DPP hazards -- or 0 when the report
+                                                    also holds early touches of loads in flight, which no wait state cures.
+The build (csrc/Makefile ROTBUILD) rebuilds an object ONCE with that mask and fails only if the second object is red too."""
 import os
 import re
 import subprocess
@@ -167,8 +172,25 @@ def check_loads(ins):
     return list(uniq.values())
 
 
+def nop_mask(report):
+    mask, incurable = 0, False
+    for ln in open(report):
+        m = re.match(r"p=(\d+)\s+dpp\s+\d+\s+dpp hazards (\d+)\s+early touches of loads in flight (\d+)", ln)
+        if not m:
+            continue
+        if int(m.group(3)):
+            incurable = True
+        if int(m.group(2)):
+            mask |= 1 << (int(m.group(1)) - 1)
+    return 0 if incurable else mask
+
+
 def main():
-    kernels = parse(disassemble(sys.argv[1]))
+    if len(sys.argv) >= 3 and sys.argv[1] == "--nop-mask":
+        print("0x%x" % nop_mask(sys.argv[2]))
+        return
+    text = open(sys.argv[2]).read() if len(sys.argv) >= 3 and sys.argv[1] == "--text" else disassemble(sys.argv[1])
+    kernels = parse(text)
     total = 0
     for name, ins in kernels.items():
         ndpp = sum(1 for i in ins if i.op.endswith("_dpp"))

@@ -42,8 +42,16 @@ def main():
             def run():
                 plan.upward_device(x.data_ptr(), send.data_ptr(), s, a.p)
                 plan.downward_device(recv.data_ptr(), y.data_ptr(), s, a.p)
+        if world > 1 and os.environ.get("FMMBEM_GRAPH", "1") != "0":
+            plan.set_graphs(True)                         # what ShardedFMM does for world > 1
         for _ in range(3):
             run()
+        torch.cuda.synchronize()
+        import time
+        t0 = time.perf_counter()                          # host time to ISSUE a matvec (the GPU is idle at the start: nothing to wait for)
+        for _ in range(a.steps):
+            run()
+        host_us = (time.perf_counter() - t0) / a.steps * 1e6
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -57,9 +65,9 @@ def main():
             run()
         torch.cuda.synchronize()
         st = plan.stats()
-        print("world %d rank %d: %.3f ms back to back | near %.3f p2m %.3f m2m %.3f m2l %.3f l2l %.3f l2p %.3f gather+deliver %.3f | "
+        print("world %d rank %d: %.3f ms back to back (host issue %.0f us per matvec) | near %.3f p2m %.3f m2m %.3f m2l %.3f l2l %.3f l2p %.3f gather+deliver %.3f | "
               "multipoles in %.2f MB, near nnz %.0fM, m2l pairs %d" % (
-                  world, r, wall, st["ms_near"], st["ms_p2m"], st["ms_m2m"], st["ms_m2l"], st["ms_l2l"], st["ms_l2p"],
+                  world, r, wall, host_us, st["ms_near"], st["ms_p2m"], st["ms_m2m"], st["ms_m2l"], st["ms_l2l"], st["ms_l2p"],
                   st["ms_gather"] + st["ms_scatter"], nbytes / 1e6, st["near_nnz"] / 1e6, st["m2l_pairs_owned"]), flush=True)
         plan.close()
 
