@@ -9,13 +9,13 @@ namespace fmmbem {
 // ---- launchers (kernels_near.hip / kernels_far.hip); all asynchronous on `s` ----
 hipError_t launch_near_assemble(const DevicePlan& d, hipStream_t s);
 hipError_t launch_gather_x(const DevicePlan& d, const double* x, hipStream_t s);
-hipError_t launch_near_spmv(const DevicePlan& d, hipStream_t s, int wgs_per_cu = 0);
+hipError_t launch_near_spmv(const DevicePlan& d, hipStream_t s);
 hipError_t launch_kernel_entries(const DevicePlan& d, int m, double* out, hipStream_t s);   // panels [0,m) targets, [m,2m) sources
 hipError_t launch_near_diag(const DevicePlan& d, const int* selfcol, double* out, hipStream_t s);
 hipError_t launch_near_matfree(const DevicePlan& d, hipStream_t s);
 hipError_t launch_mf_side(const DevicePlan& d, int phase, int* side_cnt, const int64_t* side_ptr, int* side_col, const int* side_row,
                           double* side_val, int64_t nside, hipStream_t s);
-hipError_t launch_scatter_y(const DevicePlan& d, double* y, hipStream_t s, const double* add = nullptr, bool slices = false);
+hipError_t launch_scatter_y(const DevicePlan& d, double* y, hipStream_t s);
 hipError_t launch_assemble_slices(const DevicePlan& d, const double* slices, double* y, int world, const int64_t* d_cut, int64_t chunk,
                                   hipStream_t s);
 hipError_t launch_p2m(const DevicePlan& d, int p, hipStream_t s);
@@ -44,14 +44,11 @@ bool shift_rot2_supported(int p);
 hipError_t launch_shift_rot2(const DevicePlan& d, const RotWork& w, int p, int op, hipStream_t s);   // kernels_m2l_rot2.hip: M2M / L2L in the split form
 int l2p_group_leaves(int kernel);                      // most leaves an L2P work group may hold (the kernels' LDS slice per wavefront)
 hipError_t launch_m2l_rot_zero(const DevicePlan& d, int p, hipStream_t s);
-// the split form (kernels_m2l_rot2.hip): a pair on two lanes, two wavefronts per SIMD; w.stream = build_rot2_stream(p)
-bool m2l_rot2_supported(int p);
-hipError_t launch_m2l_rot2(const DevicePlan& d, const RotWork& w, int p, hipStream_t s);
 hipError_t launch_l2l_level(const DevicePlan& d, const ShiftOpDev& op, int p, int first, int count, hipStream_t s);
-hipError_t launch_l2p(const DevicePlan& d, int p, double* y, hipStream_t s, bool store = false);
+hipError_t launch_l2p(const DevicePlan& d, int p, double* y, hipStream_t s);
 hipError_t launch_near_assemble_stokes(const DevicePlan& d, hipStream_t s);
 hipError_t launch_p2m_stokes(const DevicePlan& d, int p, hipStream_t s);
-hipError_t launch_l2p_stokes(const DevicePlan& d, int p, double* y, hipStream_t s, bool store = false);
+hipError_t launch_l2p_stokes(const DevicePlan& d, int p, double* y, hipStream_t s);
 
 
 }  // namespace fmmbem

@@ -145,8 +145,6 @@ struct DevicePlan {
                                                       // its own leaves only keeps only their records)
   // scratch
   double *xt, *yt;                                    // tree-order x and near result
-  double* yfar = nullptr;                             // tree-order far-field result when the near field runs beside the far field (rows L2P never
-                                                      // writes stay zero from the plan's creation on)
 };
 
 // One launch of the rotation kernel (kernels_m2l_rot.hip, compiled per operator): pairs (source box, class, target box) sorted by

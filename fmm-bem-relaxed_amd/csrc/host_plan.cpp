@@ -660,10 +660,10 @@ void partition_leaves(const HostPlan& hp, int world, std::vector<int>& cut) {
 //     (30 passes in 1 030 items, a second round of thirty items: 0.918 at p = 10)
 void HostPlan::build_rot_items() {
   constexpr int kLanes = 64, kSimds = 1024;
-  int kItemsWanted = 4 * 1024, kRotItemPasses = 2, kRotLongRounds = 2, kRotLongMax = 16;
-  if (const char* e = std::getenv("FMMBEM_ROT_ITEM_PASSES")) kRotItemPasses = std::max(1, std::atoi(e));   // tuning runs
-  if (const char* e = std::getenv("FMMBEM_ROT_ITEMS_WANTED")) kItemsWanted = std::max(1, std::atoi(e));
-  if (const char* e = std::getenv("FMMBEM_ROT_LONG_ROUNDS")) kRotLongRounds = std::max(1, std::atoi(e));
+  constexpr int kItemsWanted = 4 * 1024, kRotLongRounds = 2;
+  int kRotItemPasses = 2, kRotLongMax = 16;
+  // the two knobs of the cut, for the test that ANY cut of the list gives the same bits (tests/test_gpu_parity.py)
+  if (const char* e = std::getenv("FMMBEM_ROT_ITEM_PASSES")) kRotItemPasses = std::max(1, std::atoi(e));
   if (const char* e = std::getenv("FMMBEM_ROT_LONG_MAX")) kRotLongMax = std::max(1, std::atoi(e));
   rot_src.clear(); rot_cls.clear(); rot_tgt.clear(); rot_empty.clear();
   rot_item_ptr.assign(1, 0);

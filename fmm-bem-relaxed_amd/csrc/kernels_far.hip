@@ -1154,7 +1154,8 @@ hipError_t launch_l2l_level(const DevicePlan& d, const ShiftOpDev& op, int p, in
 
 int l2p_group_leaves(int kernel) { return kernel == 1 ? kL2PLeavesStokes : kL2PLeaves; }   // 1 = FMMBEM_KERNEL_STOKES_BEM
 
-hipError_t launch_l2p(const DevicePlan& d, int p, double* y, hipStream_t s, bool store) {
+hipError_t launch_l2p(const DevicePlan& d, int p, double* y, hipStream_t s) {
+  constexpr bool store = false;                         // the kernels can also overwrite y (a far field on its own); no caller does
   if (hipError_t e = upload_constants_once(); e != hipSuccess) return e;
   if (d.n_l2p <= 0) return hipSuccess;
   if (p < 1 || p > kPmaxDev) return hipErrorInvalidValue;
@@ -1199,7 +1200,8 @@ hipError_t launch_p2m_stokes(const DevicePlan& d, int p, hipStream_t s) {
   return hipGetLastError();
 }
 
-hipError_t launch_l2p_stokes(const DevicePlan& d, int p, double* y, hipStream_t s, bool store) {
+hipError_t launch_l2p_stokes(const DevicePlan& d, int p, double* y, hipStream_t s) {
+  constexpr bool store = false;
   if (hipError_t e = upload_constants_once(); e != hipSuccess) return e;
   if (d.n_l2p <= 0) return hipSuccess;
   if (p < 1 || p > kPmaxDev) return hipErrorInvalidValue;

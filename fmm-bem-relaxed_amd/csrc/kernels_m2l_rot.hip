@@ -338,7 +338,6 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(rot_waves
         inv_rho = cr[0]; ca = cr[1]; sa = cr[2]; cb = cr[3]; sb = cr[4]; rho = cr[5];
       }
       ConstFeed<(rot_stream_len(P, OP) + kRotGroup - 1) / kRotGroup, rot_needs_nop(P)> cf;
-#ifndef FMMBEM_ROT_EXP_NOARITH
       cf.start(w.stream, lane);
       z_rotation<P>(a, b, cb, sb);
       fixed_rotation<P, 0>(a, b, cf);
@@ -400,25 +399,10 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(rot_waves
         if (more) nx.issue(Mslot + (size_t)nsrc * box_stride, w.rec + (size_t)ncls * 8);
       }
       z_rotation<P>(a, b, cb, -sb);
-#else
-      a[0] += inv_rho + ca + sa + cb + sb + rho;
-      if constexpr (kAhead) {
-        asm volatile("s_waitcnt vmcnt(0)" : "+a"(nsrc), "+a"(ncls), "+a"(ntgt));
-        if (more) nx.issue(Mslot + (size_t)nsrc * box_stride, w.rec + (size_t)ncls * 8);
-      }
-#endif
       // does the last target go on in the next pass?  (lanes past cnt repeat the item's last pair: lane 63 is the last pair)
       const bool cont_out = more && __builtin_amdgcn_readfirstlane(ntgt) == __shfl(tgt, kWave - 1, kWave);
 
       // ---- add the lanes of each target: chain h of a target = its pairs h, h + 4, ... in order ----
-#ifdef FMMBEM_ROT_EXP_NOREDUCE
-      {
-        double sx = 0, sy = 0;
-#pragma unroll
-        for (int i = 0; i < S; ++i) { sx += a[i]; sy += b[i]; }
-        if (sx == 1.2345 && sy == 5.4321) d.L[(size_t)tgt * d.nslots * d.s_max] = double2{sx, sy};
-      }
-#else
       if constexpr (OP == kRotL2L) {
         // every lane is a child of its own: L[child] += the shifted parent, straight from the registers (an item of the
         // shifts is ONE pass -- plan.hip cuts them so -- and nothing is carried)
@@ -519,7 +503,6 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(rot_waves
         }
         wave_sync();
       });
-#endif
       cont_q = cont_out ? (nseg == 1 && cont_in ? cont_q : 0) + (cnt - flast) : 0;
       cont_in = cont_out;
       pi = npi; src = nsrc; cls = ncls; tgt = ntgt;

@@ -475,21 +475,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 
 }  // namespace
 
-bool m2l_rot2_supported(int p) { return p == 10 || p == 12; }
 unsigned rot_nop_orders_rot2() { return (unsigned)(FMMBEM_ROT_NOP_ORDERS); }      // fmmbem_stats.rot_nop_orders
-
-// stream: the split-form constants of order p (m2l_rot.hpp build_rot2_stream); pairs, items and class records as for launch_m2l_rot
-hipError_t launch_m2l_rot2(const DevicePlan& d, const RotWork& w, int p, hipStream_t s) {
-  if (w.n_items <= 0) return hipSuccess;
-  constexpr int CH = FMMBEM_ROT_XCD_CHUNK;
-  const int grid = (w.n_items + 8 * CH - 1) / (8 * CH) * (8 * CH);
-  switch (p) {
-    case 10: hipLaunchKernelGGL((m2l_rot2_kernel<10, kRotM2L>), dim3(grid), dim3(kWave), 0, s, d, w); break;
-    case 12: hipLaunchKernelGGL((m2l_rot2_kernel<12, kRotM2L>), dim3(grid), dim3(kWave), 0, s, d, w); break;
-    default: return hipErrorInvalidValue;
-  }
-  return hipGetLastError();
-}
 
 bool shift_rot2_supported(int p) { return p >= 8 && p <= 12; }
 

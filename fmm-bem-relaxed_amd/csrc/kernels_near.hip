@@ -413,49 +413,10 @@ __global__ __launch_bounds__(256) void near_assemble_stokes_kernel(DevicePlan d)
 }
 
 // ---------------------------------------------------------------------------------------------
-// near_matfree: the matrix-free near field of EvalInteractionLazy (sparse_local = false):
-//   r_i += sum_j K(t_i, s_j) c_j  recomputed every matvec (executor/EvalInteractionLazy.hpp:239-252 ->
-//   executor/P2P.hpp:20-36 -> Direct::eval asymmetric, include/Direct.hpp:99-125).
-// Same decomposition as near_spmv (persistent workgroups over target leaves, source columns staged in LDS
-// chunks, one wavefront per row, shuffle reduction) with the panel integral evaluated in place of a load.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void near_matfree_kernel(DevicePlan d) {
-  extern __shared__ double lds_d[];
-  double* xs = lds_d;                                          // [kAsmChunk]
-  int* colmap = reinterpret_cast<int*>(xs + kAsmChunk);        // [kAsmChunk]
-  int* run_row0 = colmap + kAsmChunk;
-  int* run_off = run_row0 + d.max_runs;
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, nwaves = blockDim.x / kWave;
-  for (int t = d.leaf_begin + blockIdx.x; t < d.leaf_end; t += gridDim.x) {
-    const int ncols = d.near_ncols[t], nrows = d.leaf_nrows[t];
-    const int row0 = d.leaf_row0[t];
-    const Runs runs = load_runs(d, t, run_row0, run_off);
-    for (int c0 = 0; c0 < ncols; c0 += kAsmChunk) {
-      const int cw = ncols - c0 < kAsmChunk ? ncols - c0 : kAsmChunk;
-      if (c0) __syncthreads();
-      for (int c = threadIdx.x; c < cw; c += blockDim.x) {
-        const int j = column_to_row(runs, c0 + c);
-        colmap[c] = j;
-        xs[c] = d.xt[j];
-      }
-      __syncthreads();
-      for (int r = wave; r < nrows; r += nwaves) {
-        const int64_t i = row0 + r;
-        const V3 tc = {d.cx[i], d.cy[i], d.cz[i]};
-        const int tbc = d.bc[i];
-        double acc = 0;
-        for (int c = lane; c < cw; c += kWave) acc = fma(laplace_entry(d, tc, tbc, colmap[c]), xs[c], acc);
-        acc = wave_sum(acc);
-        if (lane == 0) d.yt[i] = c0 ? d.yt[i] + acc : acc;
-      }
-    }
-    __syncthreads();
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// near_matfree, third form (one unknown per panel; the default).  The first form above repeats the reference's arithmetic
-// entry by entry: every entry re-reads its source panel (14 doubles from L2), takes a square root and a division per
+// near_matfree -- the matrix-free near field of EvalInteractionLazy (sparse_local = false): r_i += sum_j K(t_i, s_j) c_j
+// recomputed every matvec (executor/EvalInteractionLazy.hpp:239-252 -> executor/P2P.hpp:20-36 -> Direct::eval asymmetric,
+// include/Direct.hpp:99-125).  Third form (one unknown per panel).  The literal first form (round 1; git history) repeated the
+// reference's arithmetic entry by entry: every entry re-reads its source panel (14 doubles from L2), takes a square root and a division per
 // quadrature point, and a wavefront that meets ONE near-regime pair walks the whole semi-analytic integral (three edges,
 // atan2, cos, five-point rules) with the other lanes idle: 45 ms at N = 1M against 0.7 ms for the assembled matrix.  The
 // second form (round 2: lane = source panel applied to 64 rows out of registers, near-regime pairs queued in LDS and worked
@@ -784,16 +745,13 @@ __global__ void gather_x_kernel(const uint32_t* __restrict__ perm, const double*
   if (u < n * dof) { const int64_t i = u / dof; const int a = (int)(u - i * dof); xt[u] = x[(int64_t)perm[i] * dof + a]; }
 }
 
-// add: a second tree-order vector summed in (the far field, when it was computed beside the near field); slices: the owned
-// rows stay in tree order at the head of y (a shard's contribution to the all-gather) instead of going to panel order
-__global__ void scatter_y_kernel(const uint32_t* __restrict__ perm, const double* __restrict__ yt, const double* __restrict__ add,
-                                 double* __restrict__ y, int64_t row_begin, int64_t row_end, int dof, int slices) {
+__global__ void scatter_y_kernel(const uint32_t* __restrict__ perm, const double* __restrict__ yt, double* __restrict__ y,
+                                 int64_t row_begin, int64_t row_end, int dof) {
   const int64_t u = row_begin * dof + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (u < row_end * dof) {
     const int64_t i = u / dof;
     const int a = (int)(u - i * dof);
-    const double v = add ? yt[u] + add[u] : yt[u];
-    y[slices ? u - row_begin * dof : (int64_t)perm[i] * dof + a] = v;
+    y[(int64_t)perm[i] * dof + a] = yt[u];
   }
 }
 
@@ -1252,9 +1210,8 @@ hipError_t launch_near_assemble_stokes(const DevicePlan& d, hipStream_t s) {
 hipError_t launch_near_matfree(const DevicePlan& d, hipStream_t s) {
   const int nb = d.leaf_end - d.leaf_begin;
   if (nb <= 0) return hipSuccess;
-  const char* v1 = getenv("FMMBEM_MATFREE_V1");                       // the literal form (A/B)
   if (d.dof == 3) {
-    if (!(v1 && atoi(v1) != 0) && d.side_ptr && d.nq <= 4) {
+    if (d.side_ptr && d.nq <= 4) {
       hipLaunchKernelGGL(mf_sweep3_apply_kernel, dim3(d.near_nitems < 256 * 16 ? d.near_nitems : 256 * 16), dim3(kWave), 2 * (size_t)d.max_runs * sizeof(int), s, d);
       return hipGetLastError();
     }
@@ -1262,15 +1219,11 @@ hipError_t launch_near_matfree(const DevicePlan& d, hipStream_t s) {
     hipLaunchKernelGGL(near_matfree_stokes_kernel, dim3(nb < 256 * 8 ? nb : 256 * 8), dim3(256), lds3, s, d);
     return hipGetLastError();
   }
-  if (!(v1 && atoi(v1) != 0) && d.side_ptr) {
-    const size_t lds2 = 2 * (size_t)d.max_runs * sizeof(int);
-    const dim3 g(d.near_nitems < 256 * 16 ? d.near_nitems : 256 * 16);
-    if (d.nq <= 3) hipLaunchKernelGGL((mf_sweep_kernel<kMfApply, false>), g, dim3(kWave), lds2, s, d, nullptr, nullptr, nullptr);
-    else hipLaunchKernelGGL((mf_sweep_kernel<kMfApply, true>), g, dim3(kWave), lds2, s, d, nullptr, nullptr, nullptr);
-    return hipGetLastError();
-  }
-  const size_t lds = (size_t)kAsmChunk * (sizeof(double) + sizeof(int)) + 2 * (size_t)d.max_runs * sizeof(int);
-  hipLaunchKernelGGL(near_matfree_kernel, dim3(nb < 256 * 8 ? nb : 256 * 8), dim3(256), lds, s, d);
+  if (!d.side_ptr) return hipErrorInvalidValue;                       // a matrix-free plan always lists its near-regime pairs (plan.hip)
+  const size_t lds2 = 2 * (size_t)d.max_runs * sizeof(int);
+  const dim3 g(d.near_nitems < 256 * 16 ? d.near_nitems : 256 * 16);
+  if (d.nq <= 3) hipLaunchKernelGGL((mf_sweep_kernel<kMfApply, false>), g, dim3(kWave), lds2, s, d, nullptr, nullptr, nullptr);
+  else hipLaunchKernelGGL((mf_sweep_kernel<kMfApply, true>), g, dim3(kWave), lds2, s, d, nullptr, nullptr, nullptr);
   return hipGetLastError();
 }
 
@@ -1293,7 +1246,7 @@ hipError_t launch_gather_x(const DevicePlan& d, const double* x, hipStream_t s) 
   return hipGetLastError();
 }
 
-hipError_t launch_near_spmv(const DevicePlan& d, hipStream_t s, int wgs_per_cu) {
+hipError_t launch_near_spmv(const DevicePlan& d, hipStream_t s) {
   if (d.near_nitems <= 0) return hipSuccess;
   if (d.dof == 3 && d.near_sym) {
     const size_t lds3 = 3 * (size_t)kSymChunk * sizeof(double) + 2 * (size_t)d.max_runs * sizeof(int);
@@ -1309,13 +1262,9 @@ hipError_t launch_near_spmv(const DevicePlan& d, hipStream_t s, int wgs_per_cu) 
   // start when the others finish (0.98 ms instead of 0.79 at N = 1M); occupancy 6 (80 VGPRs) and 2x2 loads at
   // occupancy 8 measure within 3 % of this.
   const dim3 g(std::min(d.near_nitems, 256 * kSpmvOcc)), b(kSpmvWaves * kWave);
-  const char* pe = getenv("FMMBEM_SPMV_PIPE");                       // read per launch: tests switch it per plan
-  const bool pipe = !(pe && atoi(pe) == 0);
-  if (d.dof == 1 && d.max_runs <= kSpmvWaves * kWave && pipe) {
+  if (d.dof == 1 && d.max_runs <= kSpmvWaves * kWave) {               // the pipelined form; a leaf with more runs than threads (never seen) takes the plain one
     const size_t lds2 = 2 * (size_t)kSpmvPipeChunk * sizeof(double) + 4 * (size_t)d.max_runs * sizeof(int);
-    // wgs_per_cu: fewer resident workgroups when the far field runs beside this kernel (plan.hip, FMMBEM_OVERLAP_NEAR)
-    const dim3 gp(wgs_per_cu > 0 ? std::min(d.near_nitems, 256 * std::min(wgs_per_cu, kSpmvOcc)) : g.x);
-    hipLaunchKernelGGL((near_spmv_pipe_kernel<2, 4>), gp, b, lds2, s, d);
+    hipLaunchKernelGGL((near_spmv_pipe_kernel<2, 4>), g, b, lds2, s, d);
   } else {
     hipLaunchKernelGGL((near_spmv_kernel<2, 4>), g, b, lds, s, d);
   }
@@ -1343,12 +1292,11 @@ hipError_t launch_assemble_slices(const DevicePlan& d, const double* slices, dou
   return hipGetLastError();
 }
 
-hipError_t launch_scatter_y(const DevicePlan& d, double* y, hipStream_t s, const double* add, bool slices) {
+hipError_t launch_scatter_y(const DevicePlan& d, double* y, hipStream_t s) {
   const int64_t rows = (d.row_end - d.row_begin) * d.dof;
   if (rows <= 0) return hipSuccess;
   const int bs = 256;
-  hipLaunchKernelGGL(scatter_y_kernel, dim3((unsigned)((rows + bs - 1) / bs)), dim3(bs), 0, s, d.perm, d.yt, add, y,
-                     d.row_begin, d.row_end, d.dof, slices ? 1 : 0);
+  hipLaunchKernelGGL(scatter_y_kernel, dim3((unsigned)((rows + bs - 1) / bs)), dim3(bs), 0, s, d.perm, d.yt, y, d.row_begin, d.row_end, d.dof);
   return hipGetLastError();
 }
 

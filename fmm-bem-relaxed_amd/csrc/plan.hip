@@ -201,19 +201,10 @@ struct fmmbem_plan {
   static constexpr int kStages = 9, kRing = 64;                // gather spmv scatter p2m m2m mh m2l l2l l2p
   std::vector<hipEvent_t> ev;                                  // kRing sets of 2*kStages events (begin, end)
   unsigned ev_mask[kRing] = {};                                // stages actually recorded in each set
-  // The near field beside the far field (FMMBEM_OVERLAP_NEAR=1; OFF): forked right after the gather onto a stream of its own
-  // with fewer resident workgroups (near_wgs per CU, FMMBEM_NEAR_WGS) so that the far field's kernels find registers; L2P
-  // stores the far field in yfar and the delivery adds the two -- the same bits as the serial schedule.  Measured in rounds
-  // 1, 2 and 3 and slower every time (p = 2: 1.01 ms against 0.87): beside the saturated memory system of the near field
-  // every dependent access of the latency-bound far kernels takes 10-70x longer (profiles/r03d_overlap_near_far.txt).
-  int overlap_near = 0;                               // 1: fork behind the gather; 2: fork in front of M2L (near field beside M2L only)
-  int near_wgs = 3;
   int64_t ev_count = 0;                                        // executes recorded since timing was enabled
   double *stage_x = nullptr, *stage_y = nullptr;               // device staging for host-pointer execute
   fmmbem::SolverWs* solver_ws = nullptr;                       // workspace of fmmbem_gmres* on this plan (krylov.hip), kept between solves
   hipStream_t own_stream = nullptr;
-  hipStream_t near_stream = nullptr;                          // the HBM-bound near field runs beside the far field
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
   template <class T, class A>
   int upload(const std::vector<T, A>& v, const T** out) {
@@ -236,18 +227,10 @@ struct fmmbem_plan {
     *out = static_cast<T*>(p);
     return FMMBEM_OK;
   }
-  // which M2L an execute at order p takes: the rotation kernel for the orders it is instantiated for unless
-  // FMMBEM_M2L_ROT=0 (A/B runs); FMMBEM_M2L_ROT_MIN / _MAX narrow the range
-  int rot_min = 1, rot_max = kRotPmax;
-  bool use_rot(int p) const { return p >= rot_min && p <= rot_max && m2l_rot_supported(p); }
-  // the split form of the rotation kernel (kernels_m2l_rot2.hip: a pair on two lanes, two wavefronts per SIMD).  OFF unless
-  // FMMBEM_M2L_ROT2=1: correct (same L to 6e-16) but 0.61-0.66 ms against 0.56 at p = 10 -- the gather of the multipoles,
-  // which the one-pair-per-lane form fetches ahead into AGPRs, has nowhere to go at 256 registers per wavefront
-  // (profiles/r03p_m2l_split_form.txt)
-  bool rot2_on = false;
-  const double* rot2_tab = nullptr;
-  int rot2_off[kRotPmax + 1] = {};
-  bool use_rot2(int p) const { return rot2_on && use_rot(p) && m2l_rot2_supported(p) && rot2_tab != nullptr; }
+  // which M2L an execute at order p takes: the rotation kernel for the orders it is instantiated for (p <= 12), the double-sum
+  // kernels above; FMMBEM_M2L_ROT=0: the double sum at every order (A/B runs, tools/m2l_ab.py)
+  int rot_max = kRotPmax;
+  bool use_rot(int p) const { return p <= rot_max && m2l_rot_supported(p); }
   int to_device();
   // phase 0: whole matvec; 1: upward half (gather, P2M, M2M of owned boxes, pack -> xbuf); 2: the rest (xbuf = gathered)
   int run(int p, const double* d_x, double* d_y, hipStream_t s, bool near_only, int phase = 0, double* xbuf = nullptr);
@@ -259,9 +242,6 @@ struct fmmbem_plan {
       for (auto& e : ev) (void)hipEventDestroy(e);
       for (auto& g : graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
       if (own_stream) (void)hipStreamDestroy(own_stream);
-      if (near_stream) (void)hipStreamDestroy(near_stream);
-      if (ev_fork) (void)hipEventDestroy(ev_fork);
-      if (ev_join) (void)hipEventDestroy(ev_join);
     }
   }
 };
@@ -288,9 +268,6 @@ int fmmbem_plan::to_device() {
   DEVICE_SCOPE(opts.device);
   on_device = true;
   HIP_TRY(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
-  HIP_TRY(hipStreamCreateWithFlags(&near_stream, hipStreamNonBlocking));
-  HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-  HIP_TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
   ev.assign((size_t)kRing * 2 * kStages, nullptr);
   for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
 
@@ -387,10 +364,6 @@ int fmmbem_plan::to_device() {
   }
   d.max_runs = max_runs;
   if (const char* e = getenv("FMMBEM_M2L_ROT")) { if (atoi(e) == 0) rot_max = 0; }
-  if (const char* e = getenv("FMMBEM_M2L_ROT_MIN")) rot_min = atoi(e);
-  if (const char* e = getenv("FMMBEM_M2L_ROT_MAX")) rot_max = atoi(e);
-  if (const char* ov = getenv("FMMBEM_OVERLAP_NEAR")) overlap_near = atoi(ov);
-  if (const char* nw = getenv("FMMBEM_NEAR_WGS")) near_wgs = std::max(1, std::min(8, atoi(nw)));
   if (const char* ge = getenv("FMMBEM_GRAPH")) use_graphs = atoi(ge) != 0;
   d.max_ncols = max_cols;
   near_bytes = total * (int64_t)sizeof(double);
@@ -662,8 +635,6 @@ int fmmbem_plan::to_device() {
       }
       TRY(upload(ups, &up_stream2)); TRY(upload(dns, &dn_stream2));
       if (const char* e = std::getenv("FMMBEM_SHIFT_ROT2")) shift_rot2 = std::atoi(e) != 0;
-      if (const char* e = std::getenv("FMMBEM_SHIFT_ROT2_MAX")) shift_rot2_max = std::atoi(e);
-      if (const char* e = std::getenv("FMMBEM_SHIFT_ROT2_ORDERS")) shift_rot2_orders = (unsigned)std::strtoul(e, nullptr, 0);
       if (const char* e = std::getenv("FMMBEM_SHIFT_ROT")) shift_rot = std::atoi(e) != 0;
       if (const char* e = std::getenv("FMMBEM_SHIFT_ROT_MIN")) shift_rot_min = std::atoi(e);
     }
@@ -753,21 +724,11 @@ int fmmbem_plan::to_device() {
       all.insert(all.end(), one.begin(), one.end());
     }
     TRY(upload(all, &d.rot_tab));
-    if (const char* e2 = std::getenv("FMMBEM_M2L_ROT2")) rot2_on = std::atoi(e2) != 0;
-    std::vector<double> all2;
-    for (int p = 1; p <= kRotPmax; ++p) {
-      rot2_off[p] = (int)all2.size();
-      if (!m2l_rot2_supported(p)) continue;
-      build_rot2_stream(p, one);
-      all2.insert(all2.end(), one.begin(), one.end());
-    }
-    TRY(upload(all2, &rot2_tab));
   }
 
   mark("m2l class tables");
   TRY(alloc((size_t)hp.n * dof, &d.xt, true));
   TRY(alloc((size_t)hp.n * dof, &d.yt, true));
-  TRY(alloc((size_t)hp.n * dof, &d.yfar, true));
   TRY(alloc((size_t)hp.n * dof, &stage_x, true));
   TRY(alloc((size_t)hp.n * dof, &stage_y, true));
 
@@ -928,12 +889,12 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
     mask |= 1u << i;
     return hipEventRecord(set[2 * i + 1], st);
   };
-  // Stage order of the reference (EvalInteractionLazySparse.hpp:120-168): near-field SpMV, then P2M, M2M,
-  // M2L, L2L, L2P.  The near field only meets the far field in y, so it is launched on a second stream next
-  // to M2L (an HBM-bound kernel beside an FMA-bound one); the two are joined before L2P adds into y.
-  const bool overlap = overlap_near && !near_only && phase == 0 && opts.sparse_local;
+  // Stage order of the reference (EvalInteractionLazySparse.hpp:120-168): near-field SpMV, then P2M, M2M, M2L, L2L, L2P, all on
+  // the caller's stream.  (The near field on a second stream beside the far field was measured in rounds 1, 2 and 3 in five
+  // variants and is slower every time -- beside the saturated memory system of the near field every dependent access of the
+  // latency-bound far kernels takes 10-70x longer; profiles/r03d_overlap_near_far.txt, DESIGN.md section 9 -- and is gone.)
   // a region of the chain, launch by launch or as a graph (see GraphEntry)
-  const bool graph_ok = use_graphs && tm == 0 && !overlap;
+  const bool graph_ok = use_graphs && tm == 0;
   auto graphed = [&](int region, const void* buf, auto&& body) -> int {
     if (!graph_ok) return body(s);
     GraphEntry* ge = nullptr;
@@ -976,7 +937,7 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
   }
   auto near_field = [&](hipStream_t ns) -> int {
     HIP_TRY(begin(1, ns));
-    if (opts.sparse_local) HIP_TRY(launch_near_spmv(d, ns, overlap ? near_wgs : 0)); else HIP_TRY(launch_near_matfree(d, ns));
+    if (opts.sparse_local) HIP_TRY(launch_near_spmv(d, ns)); else HIP_TRY(launch_near_matfree(d, ns));
     HIP_TRY(end(1, ns));
     return FMMBEM_OK;
   };
@@ -985,14 +946,12 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
   // head of d_y, for the caller's all-gather (fmmbem_plan_assemble_slices_device puts the gathered slices in panel order)
   auto deliver = [&](hipStream_t ns) -> int {
     HIP_TRY(begin(2, ns));
-    const double* far = overlap ? d.yfar : nullptr;   // computed beside the near field: the two meet here
     if (result_slices) {
-      if (far) HIP_TRY(launch_scatter_y(d, d_y, ns, far, true));
-      else HIP_TRY(hipMemcpyAsync(d_y, d.yt + d.row_begin * d.dof, sizeof(double) * (size_t)(d.row_end - d.row_begin) * d.dof,
-                                  hipMemcpyDeviceToDevice, ns));
+      HIP_TRY(hipMemcpyAsync(d_y, d.yt + d.row_begin * d.dof, sizeof(double) * (size_t)(d.row_end - d.row_begin) * d.dof,
+                             hipMemcpyDeviceToDevice, ns));
     } else {
       if (hp.opt.shard_world > 1) HIP_TRY(hipMemsetAsync(d_y, 0, sizeof(double) * (size_t)hp.n * d.dof, ns));
-      HIP_TRY(launch_scatter_y(d, d_y, ns, far));
+      HIP_TRY(launch_scatter_y(d, d_y, ns));
     }
     HIP_TRY(end(2, ns));
     return FMMBEM_OK;
@@ -1003,16 +962,8 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
     pending_near = true;
     return FMMBEM_OK;
   }
-  const bool near_here = !overlap && !(phase == 2 && pending_near);
+  const bool near_here = !(phase == 2 && pending_near);
   pending_near = false;
-  auto fork_near = [&](hipStream_t from) -> int {
-    HIP_TRY(hipEventRecord(ev_fork, from));
-    HIP_TRY(hipStreamWaitEvent(near_stream, ev_fork, 0));
-    TRY(near_field(near_stream));
-    HIP_TRY(hipEventRecord(ev_join, near_stream));
-    return FMMBEM_OK;
-  };
-  if (overlap && overlap_near < 2) TRY(fork_near(s));
   TRY(graphed((phase == 2 ? 2 : 0) + (near_here ? 0 : 4) + (near_only ? 8 : 0), xbuf, [&](hipStream_t s) -> int {
   if (near_here) TRY(near_field(s));
   if (!near_only) {
@@ -1032,29 +983,20 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
     const bool rot = use_rot(p);
     if (!rot) HIP_TRY(launch_mh_prep(d, p, s));      // the rotation kernel reads M itself
     HIP_TRY(end(5, s));
-    if (overlap && overlap_near >= 2) TRY(fork_near(s));   // the HBM-bound kernel beside the FMA-bound one, and beside nothing else
     HIP_TRY(begin(6, s));
-    if (rot && use_rot2(p)) {
-      HIP_TRY(launch_m2l_rot_zero(d, p, s));
-      RotWork w2;
-      w2.src = d.rot_src; w2.cls = d.rot_cls; w2.tgt = d.rot_tgt; w2.item_ptr = d.rot_item_ptr; w2.n_items = d.n_rot_items;   // two wavefronts per SIMD: short items
-      w2.rec = d.rot_cls_rec; w2.stream = rot2_tab + rot2_off[p];
-      HIP_TRY(launch_m2l_rot2(d, w2, p, s));
-    } else if (rot) HIP_TRY(launch_m2l_rot(d, d_dev, p, s));
+    if (rot) HIP_TRY(launch_m2l_rot(d, d_dev, p, s));
     else HIP_TRY(launch_m2l(d, d_dev, p, s));
     HIP_TRY(end(6, s));
-    if (overlap && overlap_near == 3) HIP_TRY(hipStreamWaitEvent(s, ev_join, 0));   // 3: the latency-bound rest waits for the near field
     HIP_TRY(begin(7, s));
     TRY(l2l_pass(p, s));
     HIP_TRY(end(7, s));
     HIP_TRY(begin(8, s));
-    if (d.kernel == FMMBEM_KERNEL_STOKES_BEM) HIP_TRY(launch_l2p_stokes(d, p, overlap ? d.yfar : d.yt, s, overlap));
-    else HIP_TRY(launch_l2p(d, p, overlap ? d.yfar : d.yt, s, overlap));
+    if (d.kernel == FMMBEM_KERNEL_STOKES_BEM) HIP_TRY(launch_l2p_stokes(d, p, d.yt, s));
+    else HIP_TRY(launch_l2p(d, p, d.yt, s));
     HIP_TRY(end(8, s));
   }
   return FMMBEM_OK;
   }));
-  if (overlap && !near_only) HIP_TRY(hipStreamWaitEvent(s, ev_join, 0));
   TRY(deliver(s));
   last_p = p;
   if (tm) { ev_mask[ring] = mask; ++ev_count; }
@@ -1269,7 +1211,7 @@ int fmmbem_plan_stats(const fmmbem_plan* plan, fmmbem_stats* o) {
   o->owned_leaf_begin = h.leaf_begin; o->owned_leaf_end = h.leaf_end;
   o->owned_row_begin = h.row_begin; o->owned_row_end = h.row_end;
   o->near_bytes = plan->near_bytes;
-  const bool long_items = plan->last_p > 0 && m2l_rot_long_items(plan->last_p) && plan->use_rot(plan->last_p) && !plan->use_rot2(plan->last_p);   // the cut the last execute ran
+  const bool long_items = plan->last_p > 0 && m2l_rot_long_items(plan->last_p) && plan->use_rot(plan->last_p);   // the cut the last execute ran
   o->m2l_items = (int64_t)(long_items ? h.rot_item_ptr_long : h.rot_item_ptr).size() - 1;
   o->m2l_passes = long_items ? h.rot_passes_long : h.rot_passes;
   o->near_side_entries = plan->near_side_entries;

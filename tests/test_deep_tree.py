@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 
-def cells_in_a_big_box(fb, recursions=3, cells=8, spread=2.0e4):
+def cells_in_a_big_box(fb, recursions=4, cells=8, spread=2.0e4):
     """`cells` red blood cells (radius ~4) with fixed orientations, centres spread over a cube of side `spread`."""
     rng = np.random.default_rng(5)
     placement = np.concatenate([rng.random((cells, 3)) * np.pi, rng.random((cells, 3)) * spread], axis=1)
@@ -18,9 +18,9 @@ def cells_in_a_big_box(fb, recursions=3, cells=8, spread=2.0e4):
 def test_deep_tree_lists_equal_oracle(fb, oracle_mod):
     v = cells_in_a_big_box(fb)
     opts = fb.FMMOptions()
-    opts.set_max_per_box(16)
+    opts.set_max_per_box(32)
     pl = fb.FMM_plan(fb.LaplaceSphericalBEM(8, 3), v, opts, host_only=True)
-    o = oracle_mod.Oracle(v, ncrit=16)
+    o = oracle_mod.Oracle(v, ncrit=32)
     s, so = pl.stats(), o.stats()
     assert s["n_levels"] > 11 and so["levels"] == s["n_levels"]             # deeper than the reference's coder resolves
     assert (s["n_boxes"], s["n_leaves"], s["near_nnz_total"], s["m2l_pairs"], s["m2m_ops"], s["l2l_ops"], s["p2p_pairs"]) == \
@@ -48,14 +48,16 @@ def test_ten_levels_still_take_the_reference_coder(fb, oracle_mod):
 def test_deep_tree_matvec_matches_oracle_and_direct(fb, oracle_mod, p):
     v = cells_in_a_big_box(fb)
     opts = fb.FMMOptions()
-    opts.set_max_per_box(16)
+    opts.set_max_per_box(32)
     plan = fb.FMM_plan(fb.LaplaceSphericalBEM(p, 3), v, opts, p_max=p)
-    o = oracle_mod.Oracle(v, ncrit=16, complete_l2l=True)                    # the product's default L2L list
+    o = oracle_mod.Oracle(v, ncrit=32, complete_l2l=True)                    # the product's default L2L list
     assert plan.stats()["n_levels"] > 11
     x = np.random.default_rng(6).random(len(v))
     y, yo, d = plan.execute(x), o.matvec(x, p), o.direct(x)
     assert np.linalg.norm(y - yo) <= 1e-12 * np.linalg.norm(yo)
-    # far cells are 1e3 radii apart: their contribution converges at once; the error is the within-cell one
+    # far cells are 1e3 radii apart: their contribution converges at once; the error is the within-cell one (7.8e-4 / 6.8e-6 here;
+    # with leaves of 16 coarse panels it would stall at 2e-5 for every p: MAC-accepted boxes then hold panel pairs of the kernel's
+    # NEAR regime, where Direct integrates semi-analytically and P2M uses the K-point rule -- the reference's own floor)
     assert np.linalg.norm(y - d) <= {4: 2e-3, 10: 2e-5}[p] * np.linalg.norm(d)
     plan.close()
 
@@ -67,10 +69,10 @@ def test_deep_tree_stokes_and_shards(fb, oracle_mod):
     K = fb.StokesSphericalBEM(6, 4, 1e-3)
     K.set_Kfine(19)
     opts = fb.FMMOptions()
-    opts.set_max_per_box(16)
+    opts.set_max_per_box(32)
     plan = fb.FMM_plan(K, v, opts, p_max=6)
     assert plan.stats()["n_levels"] > 11
-    o = oracle_mod.StokesOracle(v, K=4, K_fine=19, mu=1e-3, ncrit=16, complete_l2l=True)
+    o = oracle_mod.StokesOracle(v, K=4, K_fine=19, mu=1e-3, ncrit=32, complete_l2l=True)
     x = np.random.default_rng(7).random((len(v), 3))
     y = plan.execute(x)
     yo = o.matvec(x, 6)

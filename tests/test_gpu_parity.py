@@ -250,21 +250,16 @@ def test_matrix_free_near_field(fb, oracle_mod, monkeypatch, bc_val, quad_k):
     assert rel_l2(y, oracle_mod.Oracle(v, K=quad_k, bc=bc).matvec(x, 10)) <= TOL_MATVEC
     dense = fb.FMM_plan(K, v, bc=bc).execute(x)
     assert rel_l2(y, dense) <= 1e-14
-    if quad_k == 3:
-        monkeypatch.setenv("FMMBEM_MATFREE_V1", "1")      # the literal form (every entry recomputed by laplace_entry every matvec)
-        assert rel_l2(fb.FMM_plan(K, v, opts, bc=bc).execute(x), dense) <= 1e-14
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{"FMMBEM_P2M_TABLE": "0"}, {"FMMBEM_SPMV_PIPE": "0"},
-                                 {"FMMBEM_OVERLAP_NEAR": "1"}, {"FMMBEM_OVERLAP_NEAR": "1", "FMMBEM_NEAR_WGS": "1"},
-                                 {"FMMBEM_OVERLAP_NEAR": "2", "FMMBEM_NEAR_WGS": "5"}, {"FMMBEM_OVERLAP_NEAR": "3"},
-                                 {"FMMBEM_L2P_GENERIC": "1"}, {"FMMBEM_ROT_ITEM_PASSES": "1", "FMMBEM_ROT_LONG_MAX": "1"},
-                                 {"FMMBEM_ROT_ITEM_PASSES": "5", "FMMBEM_ROT_LONG_ROUNDS": "1", "FMMBEM_ROT_LONG_MAX": "40"}])
+@pytest.mark.parametrize("env", [{"FMMBEM_P2M_TABLE": "0"}, {"FMMBEM_L2P_GENERIC": "1"},
+                                 {"FMMBEM_ROT_ITEM_PASSES": "1", "FMMBEM_ROT_LONG_MAX": "1"},
+                                 {"FMMBEM_ROT_ITEM_PASSES": "5", "FMMBEM_ROT_LONG_MAX": "40"}])
 def test_alternative_paths_match_oracle(fb, oracle_mod, monkeypatch, env):
-    """The switches that select the older / optional kernels (recurrence P2M instead of the stored moments, the plain
-    near_spmv kernel, the near field beside the far field on a stream of its own, the L2P kernel that takes the order at run
-    time, other cuts of the M2L pair list into items) give the same operator -- schedules, cuts and the two L2P kernels bit for bit."""
+    """The switches that select the fallback kernels (recurrence P2M instead of the stored moments -- what a plan whose records
+    would pass 16 GB runs --, the L2P kernel that takes the order at run time -- p > 12 --) and other cuts of the M2L pair list
+    into items give the same operator -- cuts and the two L2P kernels bit for bit."""
     for k, val in env.items():
         monkeypatch.setenv(k, val)
     v = oracle_mod.unit_sphere(5)
@@ -280,42 +275,14 @@ def test_alternative_paths_match_oracle(fb, oracle_mod, monkeypatch, env):
         y, yo = pl.execute(x), o.matvec(x, p)
         assert np.linalg.norm(y - yo) <= 1e-12 * np.linalg.norm(yo)
         res[p] = y
-    if "FMMBEM_OVERLAP_NEAR" in env or "FMMBEM_L2P_GENERIC" in env or "FMMBEM_ROT_ITEM_PASSES" in env:   # not other arithmetic: the same bits
+    if "FMMBEM_L2P_GENERIC" in env or "FMMBEM_ROT_ITEM_PASSES" in env:   # not other arithmetic: the same bits
         for k in env:
             monkeypatch.delenv(k)
-        monkeypatch.setenv("FMMBEM_OVERLAP_NEAR", "0")
         K2 = fb.LaplaceSphericalBEM(10, 3)
         pl2 = fb.FMM_plan(K2, v, bc=bc)
         for p in (10, 3):
             K2.set_p(p)
             assert np.array_equal(pl2.execute(x), res[p])
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("p", [10, 12])
-def test_split_form_of_the_rotation_m2l(fb, oracle_mod, monkeypatch, p):
-    """FMMBEM_M2L_ROT2=1: the M2L kernel that puts a pair on two lanes (even degrees / odd degrees, kernels_m2l_rot2.hip).  L per
-    box and the result against the oracle, mixed boundary conditions (both expansion slots), two bodies; shards add up bitwise
-    (the reduction is the chain scheme of the one-pair-per-lane kernel in pair space); the two kernels agree to rounding."""
-    v = np.concatenate([oracle_mod.unit_sphere(5), oracle_mod.unit_sphere(4, center=(2.5, 0.3, -0.2))])
-    rng = np.random.default_rng(13)
-    bc = (rng.random(len(v)) < 0.4).astype(np.uint8)
-    x = rng.standard_normal(len(v))
-    o = oracle_mod.Oracle(v, bc=bc)
-    yo = o.matvec(x, p)
-    y_plain = fb.FMM_plan(fb.LaplaceSphericalBEM(p, 3), v, bc=bc).execute(x)
-    monkeypatch.setenv("FMMBEM_M2L_ROT2", "1")
-    pl = fb.FMM_plan(fb.LaplaceSphericalBEM(p, 3), v, bc=bc)
-    y = pl.execute(x)
-    got, ref = pl.expansions("L", p), o.expansions(p, "L")
-    scale = np.abs(ref).max(axis=2, keepdims=True) + 1e-300
-    assert np.max(np.abs(got - ref) / scale) <= TOL_EXPANSION
-    assert rel_l2(y, yo) <= TOL_MATVEC
-    assert rel_l2(y, y_plain) <= 1e-14
-    total = np.zeros_like(y)
-    for r in range(3):
-        total += fb.FMM_plan(fb.LaplaceSphericalBEM(p, 3), v, bc=bc, shard=(r, 3)).execute(x)
-    assert np.array_equal(total, y)
 
 
 @pytest.mark.gpu
@@ -416,7 +383,7 @@ def test_tree_passes_at_the_default_level_rule(fb, monkeypatch, p):
     assert rel_l2(y, y2) <= 1e-13
     monkeypatch.delenv("FMMBEM_SHIFT_ROT")
     monkeypatch.setenv("FMMBEM_ROT_ITEM_PASSES", "3")
-    monkeypatch.setenv("FMMBEM_ROT_LONG_ROUNDS", "5")
+    monkeypatch.setenv("FMMBEM_ROT_LONG_MAX", "5")
     assert np.array_equal(fb.FMM_plan(K, v, bc=bc).execute(x), y)
 
 

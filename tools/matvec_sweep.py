@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Whole-matvec time on the bench input (N = 1 048 576) per order under environment settings -- a tuning aid.
-  python tools/matvec_sweep.py "FMMBEM_OVERLAP_NEAR=0" "FMMBEM_OVERLAP_NEAR=1,FMMBEM_NEAR_WGS=3" ... [-- p p p]
+  python tools/matvec_sweep.py "FMMBEM_GRAPH=0" "FMMBEM_GRAPH=1" "FMMBEM_SHIFT_ROT2=0" ... [-- p p p]
 Each setting = comma-separated NAME=VALUE, applied before the plan is created (plan.hip reads them then); the result of
 every setting is compared bit for bit with the first one's."""
 import os
@@ -24,7 +24,7 @@ def main():
         k = args.index("--")
         orders = tuple(int(a) for a in args[k + 1:])
         args = args[:k]
-    settings = args or ["FMMBEM_OVERLAP_NEAR=0"]
+    settings = args or ["FMMBEM_STOKES_SYM=1"]
     v = np.concatenate([fb.unit_sphere(9, center=(3.0 * i, 0.0, 0.0)) for i in range(2)])
     x = torch.rand(len(v), dtype=torch.float64, generator=torch.Generator().manual_seed(1)).cuda()
     y = torch.empty_like(x)

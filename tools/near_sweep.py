@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Times the assembled near-field operator alone (fmmbem_plan_near_device: gather + near_spmv + scatter) on the bench
 input -- a tuning aid, not part of the product or the bench.  Environment variables named on the command line as
-NAME=VALUE are set before each timing, e.g.  python tools/near_sweep.py FMMBEM_OVERLAP_NEAR=0"""
+NAME=VALUE are set before each timing, e.g.  python tools/near_sweep.py FMMBEM_STOKES_SYM=1"""
 import os
 import sys
 
