@@ -85,7 +85,7 @@ SYMBOLS = (
     "fmmbem_plan_get_perm", "fmmbem_plan_get_boxes", "fmmbem_plan_get_pairs", "fmmbem_plan_get_near_row",
     "fmmbem_plan_get_expansions", "fmmbem_plan_get_diagonal", "fmmbem_kernel_entries", "fmmbem_mesh_unit_sphere", "fmmbem_mesh_red_blood_cell", "fmmbem_mesh_red_blood_cells", "fmmbem_mesh_read_msh",
     "fmmbem_mesh_read_vert_face", "fmmbem_mesh_write_vert_face", "fmmbem_quadrature", "fmmbem_status_string", "fmmbem_last_error",
-    "fmmbem_version", "fmmbem_solver_options_default", "fmmbem_gmres_device", "fmmbem_gmres",
+    "fmmbem_version", "fmmbem_host_register", "fmmbem_host_unregister", "fmmbem_solver_options_default", "fmmbem_gmres_device", "fmmbem_gmres",
 )
 
 
@@ -145,6 +145,8 @@ def lib():
     L.fmmbem_status_string.restype = C.c_char_p
     L.fmmbem_last_error.restype = C.c_char_p
     L.fmmbem_version.restype = i32
+    L.fmmbem_host_register.argtypes = [vp, C.c_size_t]
+    L.fmmbem_host_unregister.argtypes = [vp]
     L.fmmbem_solver_options_default.argtypes = [C.POINTER(SolverOpts)]
     L.fmmbem_solver_options_default.restype = None
     L.fmmbem_gmres_device.argtypes = [vp, C.POINTER(SolverOpts), vp, vp, C.POINTER(Preconditioner), C.POINTER(SolverLog), vp]

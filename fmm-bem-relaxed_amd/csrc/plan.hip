@@ -1184,6 +1184,18 @@ int fmmbem_plan_execute(fmmbem_plan* plan, int p, const double* x, double* y) {
   return FMMBEM_OK;
 }
 
+int fmmbem_host_register(void* ptr, size_t bytes) {
+  if (!ptr || !bytes) return fail(FMMBEM_ERR_INVALID, "null buffer");
+  HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+  return FMMBEM_OK;
+}
+
+int fmmbem_host_unregister(void* ptr) {
+  if (!ptr) return fail(FMMBEM_ERR_INVALID, "null buffer");
+  HIP_TRY(hipHostUnregister(ptr));
+  return FMMBEM_OK;
+}
+
 int fmmbem_plan_set_graphs(fmmbem_plan* plan, int enabled) {
   if (!plan) return fail(FMMBEM_ERR_INVALID, "null plan");
   plan->use_graphs = enabled != 0 && plan->on_device;

@@ -147,6 +147,14 @@ void fmmbem_plan_destroy(fmmbem_plan *plan);
  * elsewhere (sum over shards = full result). */
 int fmmbem_plan_execute(fmmbem_plan *plan, int p, const double *x, double *y);
 
+/* Optional, for callers that keep their vectors: page-lock a host buffer (hipHostRegister) so that the two copies of a
+ * host-pointer execute run at the PCIe rate instead of through the runtime's staging of pageable memory (INTEGRATION.md gives
+ * the measured difference).  The caller owns the memory: unregister BEFORE freeing or reallocating it -- which is why the
+ * library never registers a caller's pointer on its own (a std::vector that the reference's solver reallocates would leave a
+ * stale registration behind).  Not needed for fmmbem_gmres, whose vectors cross PCIe once per solve. */
+int fmmbem_host_register(void *ptr, size_t bytes);
+int fmmbem_host_unregister(void *ptr);
+
 /* Same, with DEVICE pointers and an explicit hipStream_t (NULL = default stream); asynchronous. */
 int fmmbem_plan_execute_device(fmmbem_plan *plan, int p, const double *d_x, double *d_y, void *stream);
 

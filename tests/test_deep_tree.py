@@ -54,7 +54,10 @@ def test_deep_tree_matvec_matches_oracle_and_direct(fb, oracle_mod, p):
     assert plan.stats()["n_levels"] > 11
     x = np.random.default_rng(6).random(len(v))
     y, yo, d = plan.execute(x), o.matvec(x, p), o.direct(x)
-    assert np.linalg.norm(y - yo) <= 1e-12 * np.linalg.norm(yo)
+    # 2e-11, not the 1e-12 of the compact meshes: in a box 2e4 leaf sizes wide a box centre is known to 2e4 x 1e-16 of a leaf
+    # (the oracle subtracts rounded centres, Octree.hpp:350-355; the product takes translations from exact integer grid
+    # vectors): measured 1.6e-12
+    assert np.linalg.norm(y - yo) <= 2e-11 * np.linalg.norm(yo)
     # far cells are 1e3 radii apart: their contribution converges at once; the error is the within-cell one (7.8e-4 / 6.8e-6 here;
     # with leaves of 16 coarse panels it would stall at 2e-5 for every p: MAC-accepted boxes then hold panel pairs of the kernel's
     # NEAR regime, where Direct integrates semi-analytically and P2M uses the K-point rule -- the reference's own floor)
@@ -76,7 +79,7 @@ def test_deep_tree_stokes_and_shards(fb, oracle_mod):
     x = np.random.default_rng(7).random((len(v), 3))
     y = plan.execute(x)
     yo = o.matvec(x, 6)
-    assert np.linalg.norm(y - yo) <= 1e-12 * np.linalg.norm(yo)
+    assert np.linalg.norm(y - yo) <= 2e-11 * np.linalg.norm(yo)          # see above: measured 1.4e-12
     total = np.zeros_like(y)
     for rank in range(2):
         part = fb.FMM_plan(K, v, opts, p_max=6, shard=(rank, 2))
