@@ -3,6 +3,7 @@
 // launcher does not rebuild the rotation kernels, four minutes each.
 #pragma once
 #include "device_plan.hpp"
+#include "shift_lanes.hpp"
 
 namespace fmmbem {
 
@@ -35,6 +36,10 @@ hipError_t launch_m2m_rot(const DevicePlan& d, const RotWork& w, int p, hipStrea
 hipError_t launch_l2l_rot(const DevicePlan& d, const RotWork& w, int p, hipStream_t s);   // L[tgt = child] += shift of L[src = parent]
 hipError_t launch_m2l_rot(const DevicePlan& d, const DevicePlan* d_dev, int p, hipStream_t s);
 bool m2l_rot_long_items(int p);
+// kernels_shift.hip: the tree passes with one pair per wavefront (lane = coefficient); bit for bit the one-pair-per-lane kernels' results
+bool shift_lanes_supported(int p);
+hipError_t launch_m2m_lanes(const DevicePlan& d, const ShiftLaneWork& w, int p, hipStream_t s);
+hipError_t launch_l2l_lanes(const DevicePlan& d, const ShiftLaneWork& w, int p, hipStream_t s);
 // bit p - 1: orders of the four rotation objects that carry "s_nop 1" in front of their DPP FMAs (csrc/Makefile ROTBUILD)
 unsigned rot_nop_orders_m2l();
 unsigned rot_nop_orders_m2m();

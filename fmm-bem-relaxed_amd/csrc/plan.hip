@@ -151,7 +151,7 @@ struct fmmbem_plan {
   std::vector<std::pair<int, int>> m2m_launch, l2l_launch;     // (first, count) per level
   std::vector<std::pair<int, int>> m2m_shared_launch;          // sharded upward pass: parents spanning shards
   // the same launches for the rotation kernels (kernels_m2l_rot.hip with FMMBEM_ROT_OP = 1, 2): (first item, items, pairs)
-  struct ShiftRot { int item_first = 0, n_items = 0, pairs = 0, level_boxes = 0, item_first32 = 0, n_items32 = 0; };   // level_boxes: boxes of the child level in the WHOLE tree; *32: the cut into items of 32 pairs (split form)
+  struct ShiftRot { int item_first = 0, n_items = 0, pairs = 0, level_boxes = 0, item_first32 = 0, n_items32 = 0, pair_first = 0, unit_first = 0, n_units = 0; };   // level_boxes: boxes of the child level in the WHOLE tree; *32: the cut into items of 32 pairs (split form)
   std::vector<ShiftRot> m2m_rot, m2m_shared_rot, l2l_rot;
   const int *up_rsrc = nullptr, *up_rcls = nullptr, *up_rtgt = nullptr, *up_ritem = nullptr;
   const int *dn_rsrc = nullptr, *dn_rcls = nullptr, *dn_rtgt = nullptr, *dn_ritem = nullptr;
@@ -159,6 +159,14 @@ struct fmmbem_plan {
   const int *up_ritem32 = nullptr, *dn_ritem32 = nullptr;
   const double *up_stream2 = nullptr, *dn_stream2 = nullptr;
   int shift_stream2_off[kRotPmax + 1] = {};
+  // one pair per WAVEFRONT (kernels_shift.hip, shift_lanes.hpp): the same bits as the one-pair-per-lane kernels at a fraction of
+  // their latency; levels of up to shift_lanes_max pairs take it (FMMBEM_SHIFT_LANES=0: never; FMMBEM_SHIFT_LANES_MAX)
+  bool shift_lanes = true;
+  int shift_lanes_max = 1 << 30;
+  const int* up_unit_ptr = nullptr;
+  const double *sl_up_class = nullptr, *sl_dn_class = nullptr, *sl_up_rc = nullptr, *sl_up_xc = nullptr, *sl_dn_rc = nullptr, *sl_dn_xc = nullptr;
+  const int32_t *sl_up_rs = nullptr, *sl_up_xs = nullptr, *sl_dn_rs = nullptr, *sl_dn_xs = nullptr;
+  size_t sl_rot_off[kShiftLanesPmax + 1] = {}, sl_ax_off[kShiftLanesPmax + 1] = {};
   bool shift_rot2 = true;                             // FMMBEM_SHIFT_ROT2=0: the one-pair-per-lane shift kernels at every order
   // ... on levels of at most this many boxes (WHOLE tree, like shift_rot_min: shards must pick alike).  Every level by default: in a
   // trace the biggest level is slower in the split form (39 062 boxes, two wavefronts share a SIMD: 25.7 us against 23.6) and the
@@ -562,7 +570,7 @@ int fmmbem_plan::to_device() {
     // ---- M2M / L2L by rotation: pair lists per level launch, items, records, constant streams ----
     {
       TRY(upload(up_rec_h, &up_rec)); TRY(upload(dn_rec_h, &dn_rec));
-      std::vector<int> rs, rc, rt, ri, ri32, len;
+      std::vector<int> rs, rc, rt, ri, ri32, len, uptr;
       auto level_boxes = [&](int l) { return l >= 0 && l < hp.nlevels ? hp.level_off[l + 1] - hp.level_off[l] : 0; };
       // items of the shifts: whole targets, ONE pass (at most 64 pairs) -- the shift kernels carry nothing between passes
       auto cut_single_pass = [](const std::vector<int>& seg_len, int pair_base, std::vector<int>& item_ptr, int lanes = 64) {
@@ -579,12 +587,17 @@ int fmmbem_plan::to_device() {
           ShiftRot sr;
           sr.item_first = (int)ri.size();
           const int base = (int)rs.size();
+          sr.pair_first = base;
+          sr.unit_first = (int)uptr.size();
+          sr.n_units = count;
           len.clear();
           for (int i = first; i < first + count; ++i) {
             const int par = hp.m2m_parents[i];
+            uptr.push_back((int)rs.size());
             for (int c = hp.box_child_begin[par]; c < hp.box_child_end[par]; ++c) { rs.push_back(c); rc.push_back(up_cls[c]); rt.push_back(par); }
             len.push_back(hp.box_child_end[par] - hp.box_child_begin[par]);
           }
+          uptr.push_back((int)rs.size());               // one past the level's last parent
           cut_single_pass(len, base, ri);
           sr.n_items = (int)ri.size() - sr.item_first - 1;
           sr.item_first32 = (int)ri32.size();
@@ -598,11 +611,14 @@ int fmmbem_plan::to_device() {
       add_m2m(m2m_launch, m2m_rot);
       add_m2m(m2m_shared_launch, m2m_shared_rot);
       TRY(upload(rs, &up_rsrc)); TRY(upload(rc, &up_rcls)); TRY(upload(rt, &up_rtgt)); TRY(upload(ri, &up_ritem)); TRY(upload(ri32, &up_ritem32));
+      TRY(upload(uptr, &up_unit_ptr));
       rs.clear(); rc.clear(); rt.clear(); ri.clear(); ri32.clear();
       for (auto [first, count] : l2l_launch) {
         ShiftRot sr;
         sr.item_first = (int)ri.size();
         const int base = (int)rs.size();
+        sr.pair_first = base;
+        sr.n_units = count;
         for (int i = first; i < first + count; ++i) {
           const int c = hp.l2l_children[i];
           rs.push_back(hp.box_parent[c]); rc.push_back(down_cls[c]); rt.push_back(c);
@@ -634,6 +650,31 @@ int fmmbem_plan::to_device() {
         build_rot2_stream(q, one, kRotL2L); dns.insert(dns.end(), one.begin(), one.end());
       }
       TRY(upload(ups, &up_stream2)); TRY(upload(dns, &dn_stream2));
+      {                                                // one pair per wavefront: class tables and the lanes' tables per order
+        const int nclass = (int)up_rec_h.size() / 8, cs = sl_class_doubles(pm);
+        std::vector<double> cu((size_t)nclass * cs), cd((size_t)nclass * cs);
+        for (int c = 0; c < nclass; ++c) {
+          sl_class_table(up_rec_h.data() + (size_t)c * 8, pm, kRotM2M, cu.data() + (size_t)c * cs);
+          sl_class_table(dn_rec_h.data() + (size_t)c * 8, pm, kRotL2L, cd.data() + (size_t)c * cs);
+        }
+        TRY(upload(cu, &sl_up_class)); TRY(upload(cd, &sl_dn_class));
+        std::vector<double> urc, uxc, drc, dxc;
+        std::vector<int32_t> urs, uxs, drs, dxs;
+        ShiftLaneTables t;
+        for (int q = 1; q <= kShiftLanesPmax && q <= pm; ++q) {
+          sl_rot_off[q] = urc.size(); sl_ax_off[q] = uxc.size();
+          build_shift_lane_tables(q, kRotM2M, t);
+          urc.insert(urc.end(), t.rot_c.begin(), t.rot_c.end()); urs.insert(urs.end(), t.rot_s.begin(), t.rot_s.end());
+          uxc.insert(uxc.end(), t.ax_c.begin(), t.ax_c.end()); uxs.insert(uxs.end(), t.ax_s.begin(), t.ax_s.end());
+          build_shift_lane_tables(q, kRotL2L, t);
+          drc.insert(drc.end(), t.rot_c.begin(), t.rot_c.end()); drs.insert(drs.end(), t.rot_s.begin(), t.rot_s.end());
+          dxc.insert(dxc.end(), t.ax_c.begin(), t.ax_c.end()); dxs.insert(dxs.end(), t.ax_s.begin(), t.ax_s.end());
+        }
+        TRY(upload(urc, &sl_up_rc)); TRY(upload(urs, &sl_up_rs)); TRY(upload(uxc, &sl_up_xc)); TRY(upload(uxs, &sl_up_xs));
+        TRY(upload(drc, &sl_dn_rc)); TRY(upload(drs, &sl_dn_rs)); TRY(upload(dxc, &sl_dn_xc)); TRY(upload(dxs, &sl_dn_xs));
+        if (const char* e = std::getenv("FMMBEM_SHIFT_LANES")) shift_lanes = std::atoi(e) != 0;
+        if (const char* e = std::getenv("FMMBEM_SHIFT_LANES_MAX")) shift_lanes_max = std::atoi(e);
+      }
       if (const char* e = std::getenv("FMMBEM_SHIFT_ROT2")) shift_rot2 = std::atoi(e) != 0;
       if (const char* e = std::getenv("FMMBEM_SHIFT_ROT")) shift_rot = std::atoi(e) != 0;
       if (const char* e = std::getenv("FMMBEM_SHIFT_ROT_MIN")) shift_rot_min = std::atoi(e);
@@ -832,7 +873,13 @@ int fmmbem_plan::m2m_pass(int p, bool shared, hipStream_t s) {
   for (size_t i = 0; i < launches.size(); ++i) {
     const auto [first, count] = launches[i];
     const ShiftRot& sr = rots[i];
-    if (shift_rot && shift_rot_supported(p) && sr.level_boxes >= shift_rot_min) {
+    if (shift_rot && shift_lanes && shift_lanes_supported(p) && sr.pairs <= shift_lanes_max) {
+      ShiftLaneWork lw;
+      lw.src = up_rsrc; lw.cls = up_rcls; lw.tgt = up_rtgt; lw.unit_ptr = up_unit_ptr + sr.unit_first; lw.n_units = sr.n_units;
+      lw.class_tab = sl_up_class; lw.class_stride = sl_class_doubles(hp.opt.p_max); lw.p_max = hp.opt.p_max;
+      lw.rot_c = sl_up_rc + sl_rot_off[p]; lw.rot_s = sl_up_rs + sl_rot_off[p]; lw.ax_c = sl_up_xc + sl_ax_off[p]; lw.ax_s = sl_up_xs + sl_ax_off[p];
+      HIP_TRY(launch_m2m_lanes(d, lw, p, s));
+    } else if (shift_rot && shift_rot_supported(p) && sr.level_boxes >= shift_rot_min) {
       RotWork w;
       w.src = up_rsrc; w.cls = up_rcls; w.tgt = up_rtgt; w.rec = up_rec;
       if (shift_rot2 && shift_rot2_supported(p) && shift_rot2_order(p) && up_stream2 && sr.level_boxes <= shift_rot2_max) {       // the split form: a shorter pass
@@ -851,7 +898,13 @@ int fmmbem_plan::l2l_pass(int p, hipStream_t s) {
   for (size_t i = 0; i < l2l_launch.size(); ++i) {
     const auto [first, count] = l2l_launch[i];
     const ShiftRot& sr = l2l_rot[i];
-    if (shift_rot && shift_rot_supported(p) && sr.level_boxes >= shift_rot_min) {
+    if (shift_rot && shift_lanes && shift_lanes_supported(p) && sr.pairs <= shift_lanes_max) {
+      ShiftLaneWork lw;
+      lw.src = dn_rsrc + sr.pair_first; lw.cls = dn_rcls + sr.pair_first; lw.tgt = dn_rtgt + sr.pair_first; lw.n_units = sr.n_units;
+      lw.class_tab = sl_dn_class; lw.class_stride = sl_class_doubles(hp.opt.p_max); lw.p_max = hp.opt.p_max;
+      lw.rot_c = sl_dn_rc + sl_rot_off[p]; lw.rot_s = sl_dn_rs + sl_rot_off[p]; lw.ax_c = sl_dn_xc + sl_ax_off[p]; lw.ax_s = sl_dn_xs + sl_ax_off[p];
+      HIP_TRY(launch_l2l_lanes(d, lw, p, s));
+    } else if (shift_rot && shift_rot_supported(p) && sr.level_boxes >= shift_rot_min) {
       RotWork w;
       w.src = dn_rsrc; w.cls = dn_rcls; w.tgt = dn_rtgt; w.rec = dn_rec;
       if (shift_rot2 && shift_rot2_supported(p) && shift_rot2_order(p) && dn_stream2 && sr.level_boxes <= shift_rot2_max) {

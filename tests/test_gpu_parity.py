@@ -421,3 +421,34 @@ def test_tree_passes_by_rotation_match_oracle(fb, oracle_mod, monkeypatch, p):
         scale = np.abs(ref).max(axis=2, keepdims=True) + 1e-300
         assert np.max(np.abs(got - ref) / scale) <= TOL_EXPANSION, which
     assert rel_l2(y, y3) <= 1e-14 and (p in (8, 9, 10, 12) or np.array_equal(y, y3))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("p", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
+def test_shift_lanes_equal_the_one_pair_kernels_bit_for_bit(fb, oracle_mod, monkeypatch, p):
+    """The tree passes with one pair per wavefront (kernels_shift.hip: lane = coefficient, the pair's coefficients through LDS)
+    against the one-pair-per-lane rotation kernels (kernels_m2l_rot.hip, FMMBEM_ROT_OP = 1, 2): M and L of every box and the
+    result, BIT FOR BIT -- every output is the same sequence of floating-point operations -- and against the oracle."""
+    v = np.concatenate([oracle_mod.unit_sphere(5), oracle_mod.unit_sphere(4, center=(2.5, 0.3, -0.2))])
+    rng = np.random.default_rng(17)
+    bc = (rng.random(len(v)) < 0.4).astype(np.uint8)
+    x = rng.standard_normal(len(v))
+    K = fb.LaplaceSphericalBEM(p, 3)
+    monkeypatch.setenv("FMMBEM_SHIFT_LANES", "1")
+    pl = fb.FMM_plan(K, v, bc=bc)
+    y = pl.execute(x)
+    M, L = pl.expansions("M", p), pl.expansions("L", p)
+    monkeypatch.setenv("FMMBEM_SHIFT_LANES", "0")
+    monkeypatch.setenv("FMMBEM_SHIFT_ROT_MIN", "0")          # every level through the rotation kernels ...
+    monkeypatch.setenv("FMMBEM_SHIFT_ROT2", "0")             # ... in the one-pair form
+    pl1 = fb.FMM_plan(K, v, bc=bc)
+    y1 = pl1.execute(x)
+    assert np.array_equal(pl1.expansions("M", p), M)
+    assert np.array_equal(pl1.expansions("L", p), L)
+    assert np.array_equal(y1, y)
+    o = oracle_mod.Oracle(v, bc=bc)
+    assert rel_l2(y, o.matvec(x, p)) <= TOL_MATVEC
+    for which, got in (("M", M), ("L", L)):
+        ref = o.expansions(p, which)
+        scale = np.abs(ref).max(axis=2, keepdims=True) + 1e-300
+        assert np.max(np.abs(got - ref) / scale) <= TOL_EXPANSION, which
