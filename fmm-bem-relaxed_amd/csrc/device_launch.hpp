@@ -44,9 +44,6 @@ hipError_t launch_l2l_lanes(const DevicePlan& d, const ShiftLaneWork& w, int p, 
 unsigned rot_nop_orders_m2l();
 unsigned rot_nop_orders_m2m();
 unsigned rot_nop_orders_l2l();
-unsigned rot_nop_orders_rot2();
-bool shift_rot2_supported(int p);
-hipError_t launch_shift_rot2(const DevicePlan& d, const RotWork& w, int p, int op, hipStream_t s);   // kernels_m2l_rot2.hip: M2M / L2L in the split form
 int l2p_group_leaves(int kernel);                      // most leaves an L2P work group may hold (the kernels' LDS slice per wavefront)
 hipError_t launch_m2l_rot_zero(const DevicePlan& d, int p, hipStream_t s);
 hipError_t launch_l2l_level(const DevicePlan& d, const ShiftOpDev& op, int p, int first, int count, hipStream_t s);

@@ -558,7 +558,7 @@ bool m2l_rot_supported(int p) { return p >= 1 && p <= kRotPmax; }
 // the orders that run one wavefront per SIMD take the long items (host_plan.cpp build_rot_items)
 bool m2l_rot_long_items(int p) { return p >= 1 && p <= kRotPmax && rot_waves(p) == 1; }
 
-// L = 0 for the boxes that hold a local expansion but have no M2L source (also in front of the split form, kernels_m2l_rot2.hip)
+// L = 0 for the boxes that hold a local expansion but have no M2L source
 hipError_t launch_m2l_rot_zero(const DevicePlan& d, int p, hipStream_t s) {
   if (d.n_rot_empty > 0) hipLaunchKernelGGL(m2l_rot_zero_kernel, dim3(d.n_rot_empty), dim3(kWave), 0, s, d, p * (p + 1) / 2);
   return hipGetLastError();

@@ -209,134 +209,4 @@ inline void build_rot_stream(int P, std::vector<double>& out, int op = kRotM2L) 
 }
 
 
-// ====================================================================================================================
-// Split form (csrc/kernels_m2l_rot2.hip; M2L only): one (target, source) pair on TWO lanes of a wavefront, the even degrees
-// on one ("E"), the odd degrees on the other ("O"), so that a lane holds half the coefficients and two wavefronts fit a SIMD
-// at p = 9 ... 12.  Degrees are taken in pairs q = (2q, 2q+1); a lane's data are SLOTS (q, t), t = 0 .. 2q+1:
-//     O lane:  slot (q, t) = coefficient (n = 2q+1, m = t)
-//     E lane:  slot (q, t) = coefficient (n = 2q,   m = t-1)        (t = 0: padding, zero)
-// With that shift by one in the order, the real rotation block of the EVEN degree 2q is a sub-pattern of the block of the ODD
-// degree 2q+1: for mp >= 2 the routing phase rot_kk(2q, m-1, mp-1) = rot_kk(2q+1, m, mp), the a / b choice of the source
-// depends on n + m only, and the column mp_E = 0 is live exactly where the skeleton reads a.  So BOTH lanes run the program
-// of the odd degrees only -- the same instruction reads the same slots -- and differ in the constants, which come from two
-// streams through the DPP row broadcast (rows 0, 2 of a wavefront are E lanes, rows 1, 3 O lanes; the partner is lane ^ 16).
-// The z rotations are local (slot t turns by e^{i t g} on O lanes, e^{i (t-1) g} on E lanes); only the axial translation
-// couples the degrees: every lane sums over ITS degrees for the outputs of both parities and the partners swap the halves
-// that belong to the other -- one exchange per pass.
-// ====================================================================================================================
-constexpr int rot2_pairs(int P) { return (P + 1) / 2; }                  // degree pairs; an odd P leaves the last O degree empty
-constexpr int rot2_sidx(int q, int t) { return q * (q + 1) + t; }        // slot index: sum_{q' < q} (2 q' + 2) + t
-constexpr int rot2_nslots(int P) { return rot2_pairs(P) * (rot2_pairs(P) + 1); }
-constexpr int rot2_qmin(int t) { return t / 2; }                          // first degree pair that has slot order t
-// one rotation segment of the skeleton: the live entries of the odd degrees 1, 3, ..., in the order of fixed_rotation
-constexpr int rot2_rot_len(int P) {
-  int c = 0;
-  for (int q = 0; q < rot2_pairs(P); ++q) c += rot_nnz(2 * q + 1);
-  return c;
-}
-constexpr int rot2_rot_index(int q, int m, int mp) {
-  int c = 0;
-  for (int i = 0; i < q; ++i) c += rot_nnz(2 * i + 1);
-  const int n = 2 * q + 1;
-  for (int i = 0; i <= n; ++i)
-    for (int j = 0; j <= n; ++j) {
-      if (i == m && j == mp) return c;
-      c += rot_live(n, i, j) ? 1 : 0;
-    }
-  return c;
-}
-// axial segment.  At slot order t the O lanes translate order k = t, the E lanes order k = t - 1, each from ITS degrees (input
-// pairs qi >= qmin(t)).  OWN rows: the output degrees of the lane's parity, pairs qo >= qmin(t).  OTHER rows: the output degrees of
-// the partner's parity -- on an E lane the odd degrees 2 qo + 1 >= t - 1, i.e. qo >= qmin_other(t) = (t - 1) / 2, one pair more
-// than the own rows when t is even (the O lanes' constants of that row are zero).  Per t: for qo from qmin_other(t): the own
-// row (if qo >= qmin(t)), then the other row; a row = the inputs qi = qmin(t) .. Q - 1.
-constexpr int rot2_qmin_other(int t) { return t ? (t - 1) / 2 : 0; }
-constexpr int rot2_axial_rows(int P, int t) { return (rot2_pairs(P) - rot2_qmin(t)) + (rot2_pairs(P) - rot2_qmin_other(t)); }
-constexpr int rot2_axial_len(int P) {
-  int c = 0;
-  for (int t = 0; t < 2 * rot2_pairs(P); ++t) c += rot2_axial_rows(P, t) * (rot2_pairs(P) - rot2_qmin(t));
-  return c;
-}
-constexpr int rot2_axial_index(int P, int t, int qo, int other, int qi) {
-  int c = 0;
-  for (int i = 0; i < t; ++i) c += rot2_axial_rows(P, i) * (rot2_pairs(P) - rot2_qmin(i));
-  const int w = rot2_pairs(P) - rot2_qmin(t);
-  int row = 0;
-  for (int q = rot2_qmin_other(t); q < qo; ++q) row += (q >= rot2_qmin(t) ? 1 : 0) + 1;
-  if (other && qo >= rot2_qmin(t)) row += 1;
-  return c + row * w + (qi - rot2_qmin(t));
-}
-constexpr int rot2_stage_base(int P, int stage) {
-  const int R = rot2_rot_len(P), T = rot2_axial_len(P);
-  return stage == 0 ? 0 : stage == 1 ? R : stage == 2 ? 2 * R : stage == 3 ? 2 * R + T : 3 * R + T;
-}
-constexpr int rot2_stream_len(int P) { return 4 * rot2_rot_len(P) + rot2_axial_len(P); }
-// layout: groups of sixteen positions; group g holds 16 E constants then 16 O constants: [g][parity][k]
-constexpr int rot2_stream_doubles(int P) { return ((rot2_stream_len(P) + kRotGroup - 1) / kRotGroup + 1) * 2 * kRotGroup; }
-
-// op: the axial operator in the middle -- M2L, or one of the two shifts of the tree passes (same skeleton, the entries outside
-// the shift's triangle are zeros: the split kernel runs one instruction stream for all three)
-inline void build_rot2_stream(int P, std::vector<double>& out, int op = kRotM2L) {
-  std::vector<double> plain;
-  build_rot_table(P, plain);                        // [rotation coefficients of degrees 0 .. P-1, unsigned][Tz of M2L]
-  out.assign((size_t)rot2_stream_doubles(P), 0.0);
-  size_t at = 0;
-  auto put = [&](double e, double o) {
-    const size_t g = at / kRotGroup, k = at % kRotGroup;
-    out[g * 2 * kRotGroup + k] = e;
-    out[g * 2 * kRotGroup + kRotGroup + k] = o;
-    ++at;
-  };
-  // coefficient of the real rotation block of degree n at (m, mp), with the sign the kernel's "acc += c * src" wants
-  auto coef = [&](int n, int m, int mp, bool back) -> double {
-    if (n < 0 || n >= P || m < 0 || mp < 0 || m > n || mp > n || !rot_live(n, m, mp)) return 0.0;
-    if (n == 0) return 1.0;
-    size_t ci = (size_t)rot_off(n);
-    for (int i = 0; i <= n; ++i)
-      for (int j = 0; j <= n; ++j) {
-        if (i == m && j == mp) {
-          const bool neg = (rot_kk(n, m, mp) >= 2) != (back && ((m + mp) & 1));
-          return neg ? -plain[ci] : plain[ci];
-        }
-        ci += rot_live(n, i, j) ? 1 : 0;
-      }
-    return 0.0;
-  };
-  auto rotation = [&](bool back) {
-    for (int q = 0; q < rot2_pairs(P); ++q) {
-      const int n = 2 * q + 1;                       // the skeleton: the odd degree of the pair (present or not)
-      for (int m = 0; m <= n; ++m)
-        for (int mp = 0; mp <= n; ++mp) {
-          if (!rot_live(n, m, mp)) continue;
-          put(coef(2 * q, m - 1, mp - 1, back), coef(n, m, mp, back));
-        }
-    }
-  };
-  // Tz[j, n, k] of M2L (build_rot_table's second part: k, then j >= k, then n >= k), zero outside its range; for the shifts
-  // Tm / Tl of build_rot_stream, zero outside the triangle
-  auto fact = [](int k) { long double f = 1; for (int i = 2; i <= k; ++i) f *= i; return f; };
-  auto an = [&](int n, int m) { return ((n & 1) ? -1.0L : 1.0L) / std::sqrt(fact(n - m) * fact(n + m)); };
-  auto tz = [&](int j, int n, int k) -> double {
-    if (k < 0 || j < k || n < k || j >= P || n >= P) return 0.0;
-    if (op == kRotM2L) return plain[(size_t)tz_off(P, k) + (size_t)(j - k) * (P - k) + (n - k)];
-    if (n < axial_row_begin(P, op, k, j) || n >= axial_row_end(P, op, k, j)) return 0.0;
-    return op == kRotM2M ? (double)((((j - n) & 1) ? -1.0L : 1.0L) * an(j - n, 0) * an(n, k) / an(j, k))
-                         : (double)(an(n - j, 0) * an(j, k) / an(n, k));
-  };
-  auto axial = [&]() {
-    const int Q = rot2_pairs(P);
-    for (int t = 0; t < 2 * Q; ++t)
-      for (int qo = rot2_qmin_other(t); qo < Q; ++qo)
-        for (int other = qo >= rot2_qmin(t) ? 0 : 1; other < 2; ++other)
-          for (int qi = rot2_qmin(t); qi < Q; ++qi) {
-            // O lane: inputs n = 2 qi + 1 at order k = t; E lane: inputs n = 2 qi at order k = t - 1.
-            // own: the output degree of the lane's parity; other: of the partner's parity
-            const double o = other ? tz(2 * qo, 2 * qi + 1, t) : tz(2 * qo + 1, 2 * qi + 1, t);
-            const double e = other ? tz(2 * qo + 1, 2 * qi, t - 1) : tz(2 * qo, 2 * qi, t - 1);
-            put(e, o);
-          }
-  };
-  rotation(false); rotation(true); axial(); rotation(false); rotation(true);
-}
-
 }  // namespace fmmbem

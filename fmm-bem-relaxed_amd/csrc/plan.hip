@@ -151,33 +151,21 @@ struct fmmbem_plan {
   std::vector<std::pair<int, int>> m2m_launch, l2l_launch;     // (first, count) per level
   std::vector<std::pair<int, int>> m2m_shared_launch;          // sharded upward pass: parents spanning shards
   // the same launches for the rotation kernels (kernels_m2l_rot.hip with FMMBEM_ROT_OP = 1, 2): (first item, items, pairs)
-  struct ShiftRot { int item_first = 0, n_items = 0, pairs = 0, level_boxes = 0, item_first32 = 0, n_items32 = 0, pair_first = 0, unit_first = 0, n_units = 0; };   // level_boxes: boxes of the child level in the WHOLE tree; *32: the cut into items of 32 pairs (split form)
+  struct ShiftRot { int item_first = 0, n_items = 0, pairs = 0, level_boxes = 0, pair_first = 0, unit_first = 0, n_units = 0; };   // level_boxes: boxes of the child level in the WHOLE tree; units: parents (M2M) / pairs (L2L) of the one-pair-per-wavefront kernel
   std::vector<ShiftRot> m2m_rot, m2m_shared_rot, l2l_rot;
   const int *up_rsrc = nullptr, *up_rcls = nullptr, *up_rtgt = nullptr, *up_ritem = nullptr;
   const int *dn_rsrc = nullptr, *dn_rcls = nullptr, *dn_rtgt = nullptr, *dn_ritem = nullptr;
-  // the shifts in the split form (kernels_m2l_rot2.hip): the same pairs in items of 32, the split constant streams per order
-  const int *up_ritem32 = nullptr, *dn_ritem32 = nullptr;
-  const double *up_stream2 = nullptr, *dn_stream2 = nullptr;
-  int shift_stream2_off[kRotPmax + 1] = {};
-  // one pair per WAVEFRONT (kernels_shift.hip, shift_lanes.hpp): the same bits as the one-pair-per-lane kernels at a fraction of
-  // their latency; levels of up to shift_lanes_max pairs take it (FMMBEM_SHIFT_LANES=0: never; FMMBEM_SHIFT_LANES_MAX)
+  // one pair per WAVEFRONT (kernels_shift.hip, shift_lanes.hpp): the same bits as the one-pair-per-lane kernels, ~5 us for a
+  // level of a few thousand pairs where a pass of those takes ~20 whatever it holds; LDS-bound above (N = 1M, p = 10, L2L: 5 800
+  // pairs 10.6 us against 16-20, 21 000 pairs 26 against 19.5, 39 000 pairs 42 against 23.6).  A launch of up to shift_lanes_max
+  // pairs takes it -- counted on THIS plan's share of the level: the two kernels give the same bits, so a shard may choose for
+  // itself (FMMBEM_SHIFT_LANES=0: never; FMMBEM_SHIFT_LANES_MAX)
   bool shift_lanes = true;
-  int shift_lanes_max = 1 << 30;
+  int shift_lanes_max = 16384;
   const int* up_unit_ptr = nullptr;
   const double *sl_up_class = nullptr, *sl_dn_class = nullptr, *sl_up_rc = nullptr, *sl_up_xc = nullptr, *sl_dn_rc = nullptr, *sl_dn_xc = nullptr;
   const int32_t *sl_up_rs = nullptr, *sl_up_xs = nullptr, *sl_dn_rs = nullptr, *sl_dn_xs = nullptr;
   size_t sl_rot_off[kShiftLanesPmax + 1] = {}, sl_ax_off[kShiftLanesPmax + 1] = {};
-  bool shift_rot2 = true;                             // FMMBEM_SHIFT_ROT2=0: the one-pair-per-lane shift kernels at every order
-  // ... on levels of at most this many boxes (WHOLE tree, like shift_rot_min: shards must pick alike).  Every level by default: in a
-  // trace the biggest level is slower in the split form (39 062 boxes, two wavefronts share a SIMD: 25.7 us against 23.6) and the
-  // others faster (21 348: 17.3 against 19.5; 5 786: 12.3 against 16.3), but with the cut at 32 768 boxes the passes take 0.086 +
-  // 0.118 ms against 0.081 + 0.103 for all levels split (0.087 + 0.117 one-pair): two big kernels in turn cost more than they save
-  int shift_rot2_max = 1 << 30;
-  // bit p: the orders that take the split form (FMMBEM_SHIFT_ROT2_ORDERS, a mask).  M2M / L2L ms at N = 1M, one-pair / split:
-  // p = 8 0.063 / 0.064, 0.073 / 0.075 (Stokes, four slots: 0.090 / 0.087, 0.108 / 0.091); 9 0.073 / 0.074, 0.093 / 0.088;
-  // 10 0.087 / 0.081, 0.116 / 0.103; 11 0.108 / 0.120, 0.149 / 0.158 (not taken); 12 0.135 / 0.127, 0.183 / 0.178
-  unsigned shift_rot2_orders = (1u << 8) | (1u << 9) | (1u << 10) | (1u << 12);
-  bool shift_rot2_order(int p) const { return (shift_rot2_orders >> p) & 1u; }
   const double *up_rec = nullptr, *dn_rec = nullptr, *up_stream = nullptr, *dn_stream = nullptr;
   int shift_stream_off[12] = {};
   int shift_rot_min = 2048;                                    // boxes on a tree level from which the rotation kernels take it
@@ -570,7 +558,7 @@ int fmmbem_plan::to_device() {
     // ---- M2M / L2L by rotation: pair lists per level launch, items, records, constant streams ----
     {
       TRY(upload(up_rec_h, &up_rec)); TRY(upload(dn_rec_h, &dn_rec));
-      std::vector<int> rs, rc, rt, ri, ri32, len, uptr;
+      std::vector<int> rs, rc, rt, ri, len, uptr;
       auto level_boxes = [&](int l) { return l >= 0 && l < hp.nlevels ? hp.level_off[l + 1] - hp.level_off[l] : 0; };
       // items of the shifts: whole targets, ONE pass (at most 64 pairs) -- the shift kernels carry nothing between passes
       auto cut_single_pass = [](const std::vector<int>& seg_len, int pair_base, std::vector<int>& item_ptr, int lanes = 64) {
@@ -600,9 +588,6 @@ int fmmbem_plan::to_device() {
           uptr.push_back((int)rs.size());               // one past the level's last parent
           cut_single_pass(len, base, ri);
           sr.n_items = (int)ri.size() - sr.item_first - 1;
-          sr.item_first32 = (int)ri32.size();
-          cut_single_pass(len, base, ri32, 32);
-          sr.n_items32 = (int)ri32.size() - sr.item_first32 - 1;
           sr.pairs = (int)rs.size() - base;
           sr.level_boxes = count > 0 ? level_boxes(hp.box_level[hp.m2m_parents[first]] + 1) : 0;
           out.push_back(sr);
@@ -610,9 +595,9 @@ int fmmbem_plan::to_device() {
       };
       add_m2m(m2m_launch, m2m_rot);
       add_m2m(m2m_shared_launch, m2m_shared_rot);
-      TRY(upload(rs, &up_rsrc)); TRY(upload(rc, &up_rcls)); TRY(upload(rt, &up_rtgt)); TRY(upload(ri, &up_ritem)); TRY(upload(ri32, &up_ritem32));
+      TRY(upload(rs, &up_rsrc)); TRY(upload(rc, &up_rcls)); TRY(upload(rt, &up_rtgt)); TRY(upload(ri, &up_ritem));
       TRY(upload(uptr, &up_unit_ptr));
-      rs.clear(); rc.clear(); rt.clear(); ri.clear(); ri32.clear();
+      rs.clear(); rc.clear(); rt.clear(); ri.clear();
       for (auto [first, count] : l2l_launch) {
         ShiftRot sr;
         sr.item_first = (int)ri.size();
@@ -626,14 +611,11 @@ int fmmbem_plan::to_device() {
         len.assign((size_t)count, 1);
         cut_single_pass(len, base, ri);
         sr.n_items = (int)ri.size() - sr.item_first - 1;
-        sr.item_first32 = (int)ri32.size();
-        cut_single_pass(len, base, ri32, 32);
-        sr.n_items32 = (int)ri32.size() - sr.item_first32 - 1;
         sr.pairs = count;
         sr.level_boxes = count > 0 ? level_boxes(hp.box_level[hp.l2l_children[first]]) : 0;
         l2l_rot.push_back(sr);
       }
-      TRY(upload(rs, &dn_rsrc)); TRY(upload(rc, &dn_rcls)); TRY(upload(rt, &dn_rtgt)); TRY(upload(ri, &dn_ritem)); TRY(upload(ri32, &dn_ritem32));
+      TRY(upload(rs, &dn_rsrc)); TRY(upload(rc, &dn_rcls)); TRY(upload(rt, &dn_rtgt)); TRY(upload(ri, &dn_ritem));
       std::vector<double> ups, dns, one;
       for (int q = 1; q <= kRotPmax; ++q) {
         shift_stream_off[q - 1] = (int)ups.size();
@@ -642,14 +624,6 @@ int fmmbem_plan::to_device() {
         build_rot_stream(q, one, kRotL2L); dns.insert(dns.end(), one.begin(), one.end());
       }
       TRY(upload(ups, &up_stream)); TRY(upload(dns, &dn_stream));
-      ups.clear(); dns.clear();
-      for (int q = 1; q <= kRotPmax; ++q) {
-        shift_stream2_off[q] = (int)ups.size();
-        if (!shift_rot2_supported(q) || q > pm) continue;
-        build_rot2_stream(q, one, kRotM2M); ups.insert(ups.end(), one.begin(), one.end());
-        build_rot2_stream(q, one, kRotL2L); dns.insert(dns.end(), one.begin(), one.end());
-      }
-      TRY(upload(ups, &up_stream2)); TRY(upload(dns, &dn_stream2));
       {                                                // one pair per wavefront: class tables and the lanes' tables per order
         const int nclass = (int)up_rec_h.size() / 8, cs = sl_class_doubles(pm);
         std::vector<double> cu((size_t)nclass * cs), cd((size_t)nclass * cs);
@@ -675,7 +649,6 @@ int fmmbem_plan::to_device() {
         if (const char* e = std::getenv("FMMBEM_SHIFT_LANES")) shift_lanes = std::atoi(e) != 0;
         if (const char* e = std::getenv("FMMBEM_SHIFT_LANES_MAX")) shift_lanes_max = std::atoi(e);
       }
-      if (const char* e = std::getenv("FMMBEM_SHIFT_ROT2")) shift_rot2 = std::atoi(e) != 0;
       if (const char* e = std::getenv("FMMBEM_SHIFT_ROT")) shift_rot = std::atoi(e) != 0;
       if (const char* e = std::getenv("FMMBEM_SHIFT_ROT_MIN")) shift_rot_min = std::atoi(e);
     }
@@ -863,10 +836,10 @@ int fmmbem_plan::to_device() {
   return FMMBEM_OK;
 }
 
-// One level of the upward / downward pass: the rotation kernel where the level is big enough to fill the chip with lanes
-// (a pass of that kernel takes ~20 us at p = 10 whatever the number of lanes), the sparse-operator kernel of kernels_far.hip
-// for the few boxes near the root.  The rule looks at the number of boxes on the level in the WHOLE tree, not at what this
-// plan owns of it: the two kernels round differently, and shards of one operator must produce the bits of the whole.
+// One level of the upward / downward pass, p <= 12: the one-pair-per-WAVEFRONT kernel (kernels_shift.hip) for up to
+// shift_lanes_max pairs of this plan, the one-pair-per-LANE rotation kernel (kernels_m2l_rot.hip, ~20 us a pass whatever it holds)
+// above -- the two give the same bits, so every plan and every shard chooses by its own share.  p > 12 (and FMMBEM_SHIFT_ROT=0):
+// the sparse-operator kernels of kernels_far.hip, which round differently -- there the choice is the same for all shards.
 int fmmbem_plan::m2m_pass(int p, bool shared, hipStream_t s) {
   const auto& launches = shared ? m2m_shared_launch : m2m_launch;
   const auto& rots = shared ? m2m_shared_rot : m2m_rot;
@@ -882,11 +855,6 @@ int fmmbem_plan::m2m_pass(int p, bool shared, hipStream_t s) {
     } else if (shift_rot && shift_rot_supported(p) && sr.level_boxes >= shift_rot_min) {
       RotWork w;
       w.src = up_rsrc; w.cls = up_rcls; w.tgt = up_rtgt; w.rec = up_rec;
-      if (shift_rot2 && shift_rot2_supported(p) && shift_rot2_order(p) && up_stream2 && sr.level_boxes <= shift_rot2_max) {       // the split form: a shorter pass
-        w.item_ptr = up_ritem32 + sr.item_first32; w.n_items = sr.n_items32; w.stream = up_stream2 + shift_stream2_off[p];
-        HIP_TRY(launch_shift_rot2(d, w, p, kRotM2M, s));
-        continue;
-      }
       w.item_ptr = up_ritem + sr.item_first; w.n_items = sr.n_items;
       w.stream = up_stream + shift_stream_off[p - 1];
       HIP_TRY(launch_m2m_rot(d, w, p, s));
@@ -907,11 +875,6 @@ int fmmbem_plan::l2l_pass(int p, hipStream_t s) {
     } else if (shift_rot && shift_rot_supported(p) && sr.level_boxes >= shift_rot_min) {
       RotWork w;
       w.src = dn_rsrc; w.cls = dn_rcls; w.tgt = dn_rtgt; w.rec = dn_rec;
-      if (shift_rot2 && shift_rot2_supported(p) && shift_rot2_order(p) && dn_stream2 && sr.level_boxes <= shift_rot2_max) {
-        w.item_ptr = dn_ritem32 + sr.item_first32; w.n_items = sr.n_items32; w.stream = dn_stream2 + shift_stream2_off[p];
-        HIP_TRY(launch_shift_rot2(d, w, p, kRotL2L, s));
-        continue;
-      }
       w.item_ptr = dn_ritem + sr.item_first; w.n_items = sr.n_items;
       w.stream = dn_stream + shift_stream_off[p - 1];
       HIP_TRY(launch_l2l_rot(d, w, p, s));
@@ -1282,8 +1245,7 @@ int fmmbem_plan_stats(const fmmbem_plan* plan, fmmbem_stats* o) {
   o->near_side_entries = plan->near_side_entries;
   o->expansion_slots = plan->on_device ? plan->d.nslots : (plan->opts.kernel == FMMBEM_KERNEL_STOKES_BEM ? 8 : 2);
   o->m2l_kernel = plan->last_p > 0 ? (plan->use_rot(plan->last_p) ? 1 : plan->last_p <= 4 ? 3 : 2) : 0;
-  o->rot_nop_orders = (int64_t)rot_nop_orders_m2l() | ((int64_t)rot_nop_orders_m2m() << 16) | ((int64_t)rot_nop_orders_l2l() << 32) |
-                      ((int64_t)rot_nop_orders_rot2() << 48);
+  o->rot_nop_orders = (int64_t)rot_nop_orders_m2l() | ((int64_t)rot_nop_orders_m2m() << 16) | ((int64_t)rot_nop_orders_l2l() << 32);
   o->tree_coder_levels = h.tree_levels_max;
   o->expansions_active = (h.has_bc[0] ? 1 : 0) | (h.has_bc[1] ? 2 : 0);
   o->last_p = plan->last_p;

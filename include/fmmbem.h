@@ -121,7 +121,7 @@ typedef struct {
   int32_t expansion_slots;             /* slots per box in M and L (fmmbem_plan_get_expansions): Laplace 2, Stokes 8, 11 with TRACTION targets */
   int64_t rot_nop_orders;       /* build record: orders p of the rotation kernels that were compiled with a wait state in front of
                                  * every DPP FMA because the build's ISA check found the DPP hazard in their code (csrc/Makefile,
-                                 * tools/check_rot_isa.py): bit p-1 M2L, bit 16+p-1 M2M, bit 32+p-1 L2L, bit 48+p-1 the split form.
+                                 * tools/check_rot_isa.py): bit p-1 M2L, bit 16+p-1 M2M, bit 32+p-1 L2L.
                                  * 0 on the toolchain this was developed with; such an order runs ~30 % slower, not wrong */
   int32_t tree_coder_levels;    /* 10: the reference's 32-bit Morton coder built the tree; 21: the 64-bit coder had to (deeper tree) */
 } fmmbem_stats;

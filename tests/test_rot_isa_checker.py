@@ -64,7 +64,7 @@ def test_makefile_rebuilds_once_with_the_mask(tmp_path):
     (tmp_path / "pkg" / "tools").mkdir()
     shutil.copy(os.path.join(ROOT, "fmm-bem-relaxed_amd", "csrc", "Makefile"), csrc / "Makefile")
     shutil.copy(CHECK, tmp_path / "pkg" / "tools" / "check_rot_isa.py")
-    for f in ("kernels_m2l_rot2.hip", "device_plan.hpp", "device_launch.hpp", "m2l_rot.hpp"):
+    for f in ("kernels_m2l_rot.hip", "device_plan.hpp", "device_launch.hpp", "m2l_rot.hpp"):
         (csrc / f).write_text("")
     cc, chk, log, cnt = tmp_path / "cc.sh", tmp_path / "chk.sh", tmp_path / "cc.log", tmp_path / "count"
     cc.write_text('#!/bin/sh\nout=""; prev=""\nfor a in "$@"; do [ "$prev" = "-o" ] && out="$a"; prev="$a"; done\necho "$@" >> %s\necho obj > "$out"\n' % log)
@@ -73,12 +73,13 @@ def test_makefile_rebuilds_once_with_the_mask(tmp_path):
                    'echo "p=10  dpp  1741  dpp hazards 0  early touches of loads in flight 0"; exit 0\n' % (cnt, cnt))
     os.chmod(cc, 0o755)
     os.chmod(chk, 0o755)
-    r = subprocess.run(["make", "kernels_m2l_rot2.o", "ROTCC=%s" % cc, "ROTCHECK=%s" % chk], cwd=csrc, capture_output=True, text=True)
+    r = subprocess.run(["make", "kernels_m2m_rot.o", "ROTCC=%s" % cc, "ROTCHECK=%s" % chk], cwd=csrc, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     calls = log.read_text().splitlines()
     assert len(calls) == 2 and "FMMBEM_ROT_NOP_ORDERS" not in calls[0] and "-DFMMBEM_ROT_NOP_ORDERS=0x200u" in calls[1]
-    assert (csrc / "kernels_m2l_rot2.o").exists()
-    os.remove(csrc / "kernels_m2l_rot2.o")
+    assert all("-DFMMBEM_ROT_OP=1" in c for c in calls)
+    assert (csrc / "kernels_m2m_rot.o").exists()
+    os.remove(csrc / "kernels_m2m_rot.o")
     chk.write_text('#!/bin/sh\necho "p=9  dpp  1277  dpp hazards 0  early touches of loads in flight 2"; exit 1\n')
-    r = subprocess.run(["make", "kernels_m2l_rot2.o", "ROTCC=%s" % cc, "ROTCHECK=%s" % chk], cwd=csrc, capture_output=True, text=True)
-    assert r.returncode != 0 and "no wait state cures" in r.stdout and not (csrc / "kernels_m2l_rot2.o").exists()
+    r = subprocess.run(["make", "kernels_m2m_rot.o", "ROTCC=%s" % cc, "ROTCHECK=%s" % chk], cwd=csrc, capture_output=True, text=True)
+    assert r.returncode != 0 and "no wait state cures" in r.stdout and not (csrc / "kernels_m2m_rot.o").exists()

@@ -108,21 +108,3 @@ def test_rotation_factorisation_matches_the_reference_operator(oracle_mod, P, op
         ref = getattr(T, op)(v, tr)
         got = fr.back(axial(op, fr.forward(v, alpha, beta), rho, P), alpha, beta)
         assert np.linalg.norm(got - ref) <= 2e-13 * np.linalg.norm(ref), (op, P, tr)
-
-
-def test_split_form_of_the_rotation_program_on_the_cpu(tmp_path):
-    """csrc/m2l_rot.hpp build_rot2_stream: a pair on two lanes, the even degrees on one and the odd on the other, both running the
-    program of the ODD degrees with their own constants (the even block embeds with the order shifted by one), one exchange in
-    the axial translation.  tests/cpp/rot2_emulate.cpp executes that program and the one-pair-per-lane program constant by
-    constant on the CPU -- for M2L and for the two shifts of the tree passes, M2M and L2L (the same skeleton with zeros outside
-    the shift's triangle): equal to rounding for every order the kernels are built for."""
-    import os
-    import subprocess
-    from conftest import ROOT
-    exe = str(tmp_path / "rot2_emulate")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tests", "cpp", "rot2_emulate.cpp"), "-o", exe])
-    r = subprocess.run([exe, "10"], capture_output=True, text=True)
-    assert r.returncode == 0, r.stdout
-    lines = r.stdout.strip().splitlines()
-    assert len(lines) == 36 and [ln.split()[0] for ln in lines[::12]] == ["M2L", "M2M", "L2L"], r.stdout
-    assert all(float(ln.split()[-1]) < 5e-15 for ln in lines), r.stdout

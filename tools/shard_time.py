@@ -18,11 +18,12 @@ def main():
     ap.add_argument("--p", type=int, default=10)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--rank", type=int, default=0)
+    ap.add_argument("--worlds", type=str, default="1,2,4,8")
     a = ap.parse_args()
     v = np.concatenate([fb.unit_sphere(9, center=(3.0 * i, 0.0, 0.0)) for i in range(2)])
     x = torch.rand(len(v), dtype=torch.float64, generator=torch.Generator().manual_seed(7)).cuda()
     s = torch.cuda.current_stream().cuda_stream
-    for world in (1, 2, 4, 8):
+    for world in [int(t) for t in a.worlds.split(",")]:
         K = fb.LaplaceSphericalBEM(a.p, 3)
         r = min(a.rank, world - 1)
         if world == 1:
