@@ -159,9 +159,14 @@ struct fmmbem_plan {
   // level of a few thousand pairs where a pass of those takes ~20 whatever it holds; LDS-bound above (N = 1M, p = 10, L2L: 5 800
   // pairs 10.6 us against 16-20, 21 000 pairs 26 against 19.5, 39 000 pairs 42 against 23.6).  A launch of up to shift_lanes_max
   // pairs takes it -- counted on THIS plan's share of the level: the two kernels give the same bits, so a shard may choose for
-  // itself (FMMBEM_SHIFT_LANES=0: never; FMMBEM_SHIFT_LANES_MAX)
+  // itself (FMMBEM_SHIFT_LANES=0: never; FMMBEM_SHIFT_LANES_MAX).  Pairs are counted per live expansion slot
+  // (Stokes: four, config 4 at p = 8 with the slots uncounted: M2M 0.09 -> 0.18 ms)
+  // Thresholds from tools/shift_lanes_sweep.sh (profiles/r04k_shift_lanes_sweep.txt; M2M / L2L ms for one GPU and one rank of eight):
+  // L2L gains at every order up to 16 384 pair-slots; M2M -- whose wavefronts also walk or share a parent's children -- only at
+  // p = 9, 10, elsewhere the rotation kernel's pass is short enough and only launches of <= 2 048 pair-slots go over.
   bool shift_lanes = true;
-  int shift_lanes_max = 16384;
+  int shift_lanes_max = -1;                           // FMMBEM_SHIFT_LANES_MAX: one threshold for both passes and all orders (sweeps)
+  int lanes_max(int p, bool m2m) const { return shift_lanes_max >= 0 ? shift_lanes_max : !m2m ? 16384 : p == 10 ? 16384 : p == 9 ? 8192 : 2048; }
   const int* up_unit_ptr = nullptr;
   const double *sl_up_class = nullptr, *sl_dn_class = nullptr, *sl_up_rc = nullptr, *sl_up_xc = nullptr, *sl_dn_rc = nullptr, *sl_dn_xc = nullptr;
   const int32_t *sl_up_rs = nullptr, *sl_up_xs = nullptr, *sl_dn_rs = nullptr, *sl_dn_xs = nullptr;
@@ -846,13 +851,13 @@ int fmmbem_plan::m2m_pass(int p, bool shared, hipStream_t s) {
   for (size_t i = 0; i < launches.size(); ++i) {
     const auto [first, count] = launches[i];
     const ShiftRot& sr = rots[i];
-    if (shift_rot && shift_lanes && shift_lanes_supported(p) && sr.pairs <= shift_lanes_max) {
+    if (shift_rot && shift_lanes && shift_lanes_supported(p) && (int64_t)sr.pairs * d.n_act <= lanes_max(p, true)) {
       ShiftLaneWork lw;
       lw.src = up_rsrc; lw.cls = up_rcls; lw.tgt = up_rtgt; lw.unit_ptr = up_unit_ptr + sr.unit_first; lw.n_units = sr.n_units;
       lw.class_tab = sl_up_class; lw.class_stride = sl_class_doubles(hp.opt.p_max); lw.p_max = hp.opt.p_max;
       lw.rot_c = sl_up_rc + sl_rot_off[p]; lw.rot_s = sl_up_rs + sl_rot_off[p]; lw.ax_c = sl_up_xc + sl_ax_off[p]; lw.ax_s = sl_up_xs + sl_ax_off[p];
       HIP_TRY(launch_m2m_lanes(d, lw, p, s));
-    } else if (shift_rot && shift_rot_supported(p) && sr.level_boxes >= shift_rot_min) {
+    } else if (shift_rot && shift_rot_supported(p) && (shift_lanes || sr.level_boxes >= shift_rot_min)) {   // beside the wavefront kernel never the sparse operators: they round differently
       RotWork w;
       w.src = up_rsrc; w.cls = up_rcls; w.tgt = up_rtgt; w.rec = up_rec;
       w.item_ptr = up_ritem + sr.item_first; w.n_items = sr.n_items;
@@ -866,13 +871,13 @@ int fmmbem_plan::l2l_pass(int p, hipStream_t s) {
   for (size_t i = 0; i < l2l_launch.size(); ++i) {
     const auto [first, count] = l2l_launch[i];
     const ShiftRot& sr = l2l_rot[i];
-    if (shift_rot && shift_lanes && shift_lanes_supported(p) && sr.pairs <= shift_lanes_max) {
+    if (shift_rot && shift_lanes && shift_lanes_supported(p) && (int64_t)sr.pairs * d.n_act <= lanes_max(p, false)) {
       ShiftLaneWork lw;
       lw.src = dn_rsrc + sr.pair_first; lw.cls = dn_rcls + sr.pair_first; lw.tgt = dn_rtgt + sr.pair_first; lw.n_units = sr.n_units;
       lw.class_tab = sl_dn_class; lw.class_stride = sl_class_doubles(hp.opt.p_max); lw.p_max = hp.opt.p_max;
       lw.rot_c = sl_dn_rc + sl_rot_off[p]; lw.rot_s = sl_dn_rs + sl_rot_off[p]; lw.ax_c = sl_dn_xc + sl_ax_off[p]; lw.ax_s = sl_dn_xs + sl_ax_off[p];
       HIP_TRY(launch_l2l_lanes(d, lw, p, s));
-    } else if (shift_rot && shift_rot_supported(p) && sr.level_boxes >= shift_rot_min) {
+    } else if (shift_rot && shift_rot_supported(p) && (shift_lanes || sr.level_boxes >= shift_rot_min)) {   // beside the wavefront kernel never the sparse operators: they round differently
       RotWork w;
       w.src = dn_rsrc; w.cls = dn_rcls; w.tgt = dn_rtgt; w.rec = dn_rec;
       w.item_ptr = dn_ritem + sr.item_first; w.n_items = sr.n_items;
