@@ -394,9 +394,19 @@ def main():
         # (3 rsqrt + 20 flop) * K per far panel pair (Laplace; the few near-regime pairs cost more and are not counted)
         kq = 4 if stokes else 3
         mf_flops = st["near_nnz"] * kq * 23.0 * (4 if stokes else 1)
-        mf = {"kernel": "near_matfree (P2P recomputed)", "bound": "fp64 vector + rsqrt", "achieved": mf_flops / (near_ms * 1e-3) / 1e12,
-              "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": mf_flops / (near_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
-              "traffic": None, "algorithmic_flops_per_launch": mf_flops, "launch_ms": near_ms, "panel_pairs": st["near_nnz"]}
+        # What bounds it is FP64 instruction issue, and of that the reciprocal square roots cost most per instruction: measured on
+        # this part (tools/microbench/rsq64.hip, profiles/r04m_rsq64_issue_rate.txt) v_rsq_f64 issues 9.09e12 lane-operations/s
+        # against 33.4e12 for v_fma_f64.  Ceiling = per quadrature point one v_rsq_f64 and ~16 other FP64 instructions (the
+        # difference vector, r^2, the Newton step, the accumulation; kernels_near.hip mf_far) at those rates; `frac` = ceiling time
+        # / launch time.  The FMA-peak view of SURVEY 8(d) is kept beside it, labelled: it is not the bound.
+        RSQ_RATE, FMA_RATE, OTHER = 9.09e12, 33.4e12, 16
+        points = st["near_nnz"] * kq
+        ceil_ms = points * (1.0 / RSQ_RATE + OTHER / FMA_RATE) * 1e3
+        mf = {"kernel": "mf_sweep (P2P recomputed)", "bound": "fp64 instruction issue (v_rsq_f64 at 0.27 of the FMA rate, measured)",
+              "achieved": points / (near_ms * 1e-3) / 1e12, "peak": points / (ceil_ms * 1e-3) / 1e12, "unit": "T quadrature points/s",
+              "frac": ceil_ms / near_ms, "traffic": None, "panel_pairs": st["near_nnz"], "launch_ms": near_ms, "ceiling_ms": ceil_ms,
+              "fma_peak_view": {"algorithmic_flops_per_launch": mf_flops, "tflops": mf_flops / (near_ms * 1e-3) / 1e12,
+                                "frac_of_fma_peak_not_the_bound": mf_flops / (near_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}}
     out = {
         "metric": (("FMM matvecs/s (StokesBEM red blood cell, %s) + achieved HBM GB/s on P2P" % ("TRACTION targets: double layer" if traction else "velocity BC")) if stokes else
                    "FMM matvecs/s (LaplaceBEM sphere N=1e6 p=10) + achieved HBM GB/s on P2P"),
