@@ -7,10 +7,14 @@
 for all three operators, with the closed forms of the M2M and L2L axial coefficients that csrc/m2l_rot.hpp tabulates
 (build_rot_stream).  Plain numpy on complex coefficient vectors; the device kernels use the same maps in real coordinates and
 are checked against the oracle end to end by the -m gpu tests."""
+import os
+import subprocess
 from math import comb, factorial, sqrt
 
 import numpy as np
 import pytest
+
+from conftest import ROOT
 
 
 def idx(n, m):
@@ -107,4 +111,28 @@ def test_rotation_factorisation_matches_the_reference_operator(oracle_mod, P, op
         rho, alpha, beta = oracle_mod.cart2sph(tr)
         ref = getattr(T, op)(v, tr)
         got = fr.back(axial(op, fr.forward(v, alpha, beta), rho, P), alpha, beta)
+        assert np.linalg.norm(got - ref) <= 2e-13 * np.linalg.norm(ref), (op, P, tr)
+
+
+@pytest.mark.parametrize("P", [1, 2, 5, 10, 12])
+@pytest.mark.parametrize("op", ["m2m", "l2l"])
+def test_shift_lane_tables_emulated_on_the_host_match_the_reference_operator(oracle_mod, tmp_path, P, op):
+    """csrc/shift_lanes.hpp -- the tables of the one-pair-per-wavefront shift kernel (rows' constants and operand offsets, class
+    tables of the z rotations and powers of rho) -- run stage by stage by tests/cpp/shift_lanes_emulate.cpp the way the kernel
+    runs them, against the oracle's M2M / L2L (kernel/LaplaceSpherical.hpp:245-285, 378-411)."""
+    exe = str(tmp_path / "sle")
+    if not os.path.exists(exe):
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "fmm-bem-relaxed_amd", "csrc"),
+                               os.path.join(ROOT, "tests", "cpp", "shift_lanes_emulate.cpp"), "-o", exe])
+    T = oracle_mod.Tables(P)
+    S = P * (P + 1) // 2
+    rng = np.random.default_rng(7 + P)
+    v = rng.standard_normal(S) + 1j * rng.standard_normal(S)
+    for n in range(P):
+        v[idx(n, 0)] = v[idx(n, 0)].real
+    for tr in ([0.25, -0.25, 0.25], [-0.5, 0.5, -0.5], [0.125, 0.125, -0.125], [0.0, 0.0, 0.3], [0.0, 0.2, 0.1]):
+        ref = getattr(T, op)(v, np.array(tr))
+        inp = "\n".join("%.17g %.17g" % (z.real, z.imag) for z in v)
+        out = subprocess.run([exe, str(P), "1" if op == "m2m" else "2"] + ["%.17g" % t for t in tr], input=inp, capture_output=True, text=True, check=True).stdout
+        got = np.array([complex(*map(float, ln.split())) for ln in out.strip().splitlines()])
         assert np.linalg.norm(got - ref) <= 2e-13 * np.linalg.norm(ref), (op, P, tr)
