@@ -470,11 +470,11 @@ def main():
     else:
         out["parity_vs_oracle_full"] = None
     if not args.no_accuracy:                                  # rank 0, any N (the result is replicated); independent of the baseline switch
-        g_d, o_d, nr, dist = direct_check(args, np, v, x, y, stokes, bc, y_oracle=y_oracle)
+        g_d, o_d, nr, rowdist = direct_check(args, np, v, x, y, stokes, bc, y_oracle=y_oracle)
         gate = 1e-6
         out["rel_l2_vs_direct_sample"] = g_d
         out["accuracy_gate"] = {"rows": nr, "rows_seed": GATE_SEED, "drawn_over": "the whole vector (numpy default_rng choice without replacement)",
-                                "gpu_vs_direct": g_d, "oracle_vs_direct": o_d, "gate": gate, "pass": bool(g_d < gate), **dist,
+                                "gpu_vs_direct": g_d, "oracle_vs_direct": o_d, "gate": gate, "pass": bool(g_d < gate), **rowdist,
                                 "note": ("below the north-star gate" if g_d < gate else
                                          "reference level: %.3e -- above 1e-6; the oracle's FMM (the reference's algorithm on the CPU) "
                                          "sits at %s on the same rows: the truncation error of p = %d, theta = %g on this tree (rows in "
