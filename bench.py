@@ -116,6 +116,9 @@ def direct_check(args, np, v, x, y, stokes, bc, nrows=GATE_ROWS, y_oracle=None):
     """north_star gate: relative L2 of the result against the O(N^2) Direct sum (include/Direct.hpp:99-125; the oracle as
     checker) on the seeded row sample.  Returns (gpu_vs_direct, oracle_vs_direct or None, rows used)."""
     from oracle import oracle as O
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:                                            # torchrun exports OMP_NUM_THREADS=1: the Direct sum runs on rank 0 only
+        O.set_num_threads(max(1, len(os.sched_getaffinity(0)) // 2))
     n = len(v)
     rows = gate_rows(np, n, nrows // 4 if stokes else nrows)          # a Stokes row costs ~10x a Laplace row on the host
     if stokes:

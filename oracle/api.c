@@ -73,6 +73,9 @@ void orc_get_tables(const orc_tables *t, double *prefactor, double *Anm, double 
 #ifdef _OPENMP
 #include <omp.h>
 int orc_num_threads(void) { return omp_get_max_threads(); }
+/* torchrun exports OMP_NUM_THREADS=1 to every rank: the checker's Direct sum on rank 0 may still use the cores it has */
+void orc_set_num_threads(int n) { if (n > 0) omp_set_num_threads(n); }
 #else
 int orc_num_threads(void) { return 1; }
+void orc_set_num_threads(int n) { (void)n; }
 #endif

@@ -78,6 +78,7 @@ def lib():
         L.orc_quadrature.argtypes = [i32, vp, vp]
         L.orc_quadrature.restype = i32
         L.orc_num_threads.restype = i32
+        L.orc_set_num_threads.argtypes = [i32]
         L.orc_stokes_config.argtypes = [vp, dbl, i32]
         L.orc_stokes_config.restype = i32
         L.orc_stokes_build_near.argtypes = [vp]
@@ -100,6 +101,11 @@ def _p(a):
 def num_threads():
     """OpenMP threads the oracle's parallel stages use."""
     return lib().orc_num_threads()
+
+
+def set_num_threads(n):
+    """OpenMP threads of the oracle's parallel stages from now on (torchrun hands every rank OMP_NUM_THREADS=1)."""
+    lib().orc_set_num_threads(int(n))
 
 
 def unit_sphere(recursions, center=(0.0, 0.0, 0.0)):
