@@ -36,8 +36,12 @@ __device__ __forceinline__ void sl_sync() {
 // h + 4, i.e. chain h of the sum -- for the levels near the root and for a shard's levels, where there are fewer parents than
 // wavefronts on the chip and a wavefront that walks a parent's children one after the other is what one waits for (12 us per
 // launch for eight children against 5 for the L2L of the same level).  Same operations, same order, same bits.
+#ifndef FMMBEM_SL_OCC
+#define FMMBEM_SL_OCC(P) 0                            // wavefronts per SIMD asked of the compiler; 0 = its own choice (2 at p = 7 ... 10)
+#endif
 template <int P, int OP, bool GROUP>
-__global__ __launch_bounds__(kSlWaves * kWave) void shift_lanes_kernel(const DevicePlan d, const ShiftLaneWork w) {
+__global__ __launch_bounds__(kSlWaves * kWave) __attribute__((amdgpu_waves_per_eu(FMMBEM_SL_OCC(P) ? FMMBEM_SL_OCC(P) : 1, FMMBEM_SL_OCC(P) ? FMMBEM_SL_OCC(P) : 8)))
+void shift_lanes_kernel(const DevicePlan d, const ShiftLaneWork w) {
   constexpr int S = sl_S(P), R = sl_rounds(P), LR = sl_rot_len(P), LX = sl_axial_len(P);
   constexpr int XS = 2 * S + 2;                       // a[S] then b[S]
   __shared__ double xbuf[kSlWaves][2][XS];
