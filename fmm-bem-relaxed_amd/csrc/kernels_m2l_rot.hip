@@ -159,26 +159,31 @@ __device__ __forceinline__ void fixed_rotation(double (&a)[P * (P + 1) / 2], dou
   static_for<1, P>([&](auto N) FMMBEM_INLINE {         // degree 0 is the identity
     constexpr int n = decltype(N)::value;
     double na[P], nb[P];
-    // two output rows at a time, their terms side by side: consecutive FMAs feed four accumulators in turn (m2l_rot.hpp rot_index)
-    static_for<0, (n + 2) / 2>([&](auto M_) FMMBEM_INLINE {
-      constexpr int m0 = 2 * decltype(M_)::value;
-      double sa[2] = {0, 0}, sb[2] = {0, 0};
-      static_for<0, n + 1>([&](auto Q) FMMBEM_INLINE {
-        constexpr int mp = decltype(Q)::value;
-        static_for<0, 2>([&](auto R_) FMMBEM_INLINE {
-          constexpr int r = decltype(R_)::value, m = m0 + r;
-          if constexpr (m <= n) {
-            if constexpr (rot_live(n, m, mp)) {
-              constexpr int e = rot_stage_base(P, STAGE, OP) + rot_index(n, m, mp);
-              constexpr bool even = ((n + m) & 1) == 0;
-              const double src = (mp == 0 || even) ? a[idx_of(n, mp)] : b[idx_of(n, mp)];
-              if constexpr ((rot_kk(n, m, mp) & 1) == 0) cf.template fma1<e>(sa[r], src); else cf.template fma1<e>(sb[r], src);
+    // first the rows that read a[n, .] (n + m even), then the rows that read b[n, .] (m2l_rot.hpp rot_index: the a[] of the degree
+    // are dead before the second class's outputs need registers); within a class two output rows at a time, their terms side by
+    // side: consecutive FMAs feed four accumulators in turn
+    static_for<0, 2>([&](auto C_) FMMBEM_INLINE {
+      constexpr int cls = decltype(C_)::value, cnt = rot_class_count(n, cls);
+      static_for<0, (cnt + 1) / 2>([&](auto I_) FMMBEM_INLINE {
+        constexpr int i0 = 2 * decltype(I_)::value;
+        double sa[2] = {0, 0}, sb[2] = {0, 0};
+        static_for<0, n + 1>([&](auto Q) FMMBEM_INLINE {
+          constexpr int mp = decltype(Q)::value;
+          static_for<0, 2>([&](auto R_) FMMBEM_INLINE {
+            constexpr int r = decltype(R_)::value;
+            if constexpr (i0 + r < cnt) {
+              constexpr int m = rot_class_row(n, cls, i0 + r);
+              if constexpr (rot_live(n, m, mp)) {
+                constexpr int e = rot_stage_base(P, STAGE, OP) + rot_index(n, m, mp);
+                const double src = cls == 0 ? a[idx_of(n, mp)] : b[idx_of(n, mp)];       // class 1 has no live mp = 0
+                if constexpr ((rot_kk(n, m, mp) & 1) == 0) cf.template fma1<e>(sa[r], src); else cf.template fma1<e>(sb[r], src);
+              }
             }
-          }
+          });
         });
+        na[rot_class_row(n, cls, i0)] = sa[0]; nb[rot_class_row(n, cls, i0)] = sb[0];
+        if constexpr (i0 + 1 < cnt) { na[rot_class_row(n, cls, i0 + 1)] = sa[1]; nb[rot_class_row(n, cls, i0 + 1)] = sb[1]; }
       });
-      na[m0] = sa[0]; nb[m0] = sb[0];
-      if constexpr (m0 + 1 <= n) { na[m0 + 1] = sa[1]; nb[m0 + 1] = sb[1]; }
     });
 #pragma unroll
     for (int m = 0; m <= n; ++m) { a[idx_of(n, m)] = na[m]; b[idx_of(n, m)] = nb[m]; }

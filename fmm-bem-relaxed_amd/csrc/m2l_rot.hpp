@@ -108,19 +108,29 @@ constexpr int rot_kk(int n, int m, int mp) {        // routing phase of entry (m
   return ((mp == 0 ? m : m + 3 * mp) + ((mp != 0 && ((n + m) & 1)) ? 1 : 0)) & 3;
 }
 // position of a constant in the stream: stage 0..4 = rotation, rotation, axial, rotation, rotation.
-// ORDER OF CONSUMPTION, rotation segment: degree by degree; within a degree the output rows m two at a time, and for a pair of
-// rows the input orders mp ascending with the two rows' entries side by side -- (m0, mp), (m0 + 1, mp), (m0, mp + 1), ... --
-// so that consecutive FMAs feed FOUR accumulators (Re and Im of two outputs), not two: a lone wavefront issues an FP64 FMA
-// every 3.7 ns into two alternating accumulators and every 2.95 ns into four (tools/microbench/dpp_chain.hip).  Every output
-// still adds its own terms in ascending mp: the same bits as the row-by-row order.
+// ORDER OF CONSUMPTION, rotation segment: degree by degree; within a degree FIRST the output rows m with n + m even -- they read
+// the real parts a[n, .] only -- THEN the rows with n + m odd, which read the imaginary parts b[n, .] only: once the first class
+// is through, the degree's a[] are dead and their registers take the second class's outputs (peak of a degree 3n + 2 doubles
+// instead of 4n + 3: 20 VGPRs at n = 9, where the kernel sat 30-odd registers over the 256 it has and moved the excess through
+// AGPRs).  Within a class the rows two at a time, and for a pair of rows the input orders mp ascending with the two rows' entries
+// side by side -- (r0, mp), (r1, mp), (r0, mp + 1), ... -- so that consecutive FMAs feed FOUR accumulators (Re and Im of two
+// outputs), not two: a lone wavefront issues an FP64 FMA every 3.7 ns into two alternating accumulators and every 2.95 ns into
+// four (tools/microbench/dpp_chain.hip).  Every output still adds its own terms in ascending mp: the same bits in any order of rows.
+constexpr int rot_class_count(int n, int cls) {      // rows of class cls (0: n + m even, 1: n + m odd) of degree n
+  const int first = (n + cls) & 1;                  // smallest m of the class
+  return first > n ? 0 : (n - first) / 2 + 1;
+}
+constexpr int rot_class_row(int n, int cls, int i) { return ((n + cls) & 1) + 2 * i; }
 constexpr int rot_index(int n, int m, int mp) {     // within one rotation segment (degrees 1..P-1)
   int c = rot_off(n) - 1;
-  for (int m0 = 0; m0 <= n; m0 += 2)
-    for (int q = 0; q <= n; ++q)
-      for (int r = m0; r <= (m0 + 1 <= n ? m0 + 1 : n); ++r) {
-        if (r == m && q == mp) return c;
-        c += rot_live(n, r, q) ? 1 : 0;
-      }
+  for (int cls = 0; cls < 2; ++cls)
+    for (int i0 = 0; i0 < rot_class_count(n, cls); i0 += 2)
+      for (int q = 0; q <= n; ++q)
+        for (int i = i0; i < i0 + 2 && i < rot_class_count(n, cls); ++i) {
+          const int r = rot_class_row(n, cls, i);
+          if (r == m && q == mp) return c;
+          c += rot_live(n, r, q) ? 1 : 0;
+        }
   return c;
 }
 constexpr int rot_plain_index(int n, int m, int mp) {   // in build_rot_table's table: row by row
