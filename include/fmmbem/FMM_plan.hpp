@@ -203,6 +203,11 @@ class StokesSphericalBEM {
   typedef std::vector<std::vector<std::vector<complex>>> local_type;
   unsigned K, K_fine = 25;
   double Mu;
+  // kernel/StokesSphericalBEM.hpp:12, 420-464: running totals of the strengths every P2M call has seen, summed without
+  // synchronisation across OpenMP threads and over all matvecs of a run; examples/StokesBEM.cpp:370-373 prints them as
+  // "Totals".  A diagnostic of the reference's host loop with no counterpart on the device: present so that the driver
+  // compiles, left at zero.
+  mutable complex stokeslet_str[4] = {0., 0., 0., 0.}, stresslet_str[4] = {0., 0., 0., 0.};
   StokesSphericalBEM() : StokesSphericalBEM(5, 3, 1e-3) {}
   StokesSphericalBEM(int p, unsigned k) : StokesSphericalBEM(p, k, 1e-3) {}
   StokesSphericalBEM(int p, unsigned k, double mu) : K(k), Mu(mu), P(p) { fmmbem::config_K() = k; }
