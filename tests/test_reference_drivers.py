@@ -68,14 +68,24 @@ def test_reference_laplace_driver_reproduces_its_recorded_output():
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "StokesBEM_ref")), reason="oracle/_ref/StokesBEM_ref not built (make -C oracle ref)")
 def test_reference_stokes_driver_runs_on_the_adapter():
-    """`StokesBEM -recursions 4 -p 10`: flow past the unit sphere through the reference's own GMRES_Stokes.hpp; the drag against
-    6 pi mu and the order schedule (first iteration at p - 1, never below p_min) as examples/StokesBEM.py gives them."""
+    """`StokesBEM -recursions 4 -p 10`: flow past the unit sphere through the reference's own GMRES_Stokes.hpp above the GPU plan,
+    beside examples/StokesBEM.py on the same problem: the same right-hand-side check, the same order schedule (first iteration at
+    p - 1, never below p_min) and the same residual history to the printed digits while the two Arnoldi processes agree (ten
+    iterations; then summation order shows), the same area error.  The reference's drag line is NOT compared: its loop
+    (StokesBEM.cpp:343-352) never advances `i`, so its Fx is the first panel's traction times the total area."""
     exe = os.path.join(REFDIR, "StokesBEM_ref")
-    r = subprocess.run([exe, "-recursions", "4", "-p", "10"], capture_output=True, text=True, check=True)
-    out = r.stdout
-    err = float(_lines(out, "error on a sphere")[0].split(":")[1])
-    assert err < 2e-2, out[-800:]
+    out = subprocess.run([exe, "-recursions", "4", "-p", "10"], capture_output=True, text=True, check=True).stdout
     py = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "StokesBEM.py"), "-recursions", "4", "-p", "10"],
                         capture_output=True, text=True, check=True).stdout
-    perr = float(_lines(py, "error on a sphere")[0].split(":")[1])
-    assert abs(perr - err) <= 2e-2 * max(err, 1e-6) + 1e-6, (err, perr)
+
+    def history(text):
+        its = [ln.split() for ln in _lines(text, "it: ")]
+        return [int(t[-1]) for t in its], [float(t[3].rstrip(",")) for t in its]
+    (pc, rc), (pp, rp) = history(out), history(py)
+    assert pc[0] == 9 and min(pc) >= 5 and pc[:12] == pp[:12]
+    assert all(abs(a - b) <= 2e-3 * b for a, b in zip(rc[:10], rp[:10]))
+    assert abs(len(pc) - len(pp)) <= 2
+    for tag in ("rhs error", "Area error"):
+        a = float(_lines(out, tag)[0].split(":")[1]); b = float(_lines(py, tag)[0].split(":")[1])
+        assert abs(a - b) <= 1e-4 * abs(b), tag
+    assert float(_lines(py, "error on a sphere")[0].split(":")[1]) < 2e-2        # the drag, summed over the panels
