@@ -660,8 +660,9 @@ void partition_leaves(const HostPlan& hp, int world, std::vector<int>& cut) {
 //     (30 passes in 1 030 items, a second round of thirty items: 0.918 at p = 10)
 void HostPlan::build_rot_items() {
   constexpr int kLanes = 64, kSimds = 1024;
-  constexpr int kItemsWanted = 4 * 1024, kRotLongRounds = 2;
-  int kRotItemPasses = 2, kRotLongMax = 16;
+  constexpr int kItemsWanted = 4 * 1024;
+  int kRotItemPasses = 2, kRotLongMax = 16, kRotLongRounds = 0;   // rounds: 0 = by the rule below
+  if (const char* e = std::getenv("FMMBEM_ROT_LONG_ROUNDS")) kRotLongRounds = std::max(0, std::atoi(e));
   // the two knobs of the cut, for the test that ANY cut of the list gives the same bits (tests/test_gpu_parity.py)
   if (const char* e = std::getenv("FMMBEM_ROT_ITEM_PASSES")) kRotItemPasses = std::max(1, std::atoi(e));
   if (const char* e = std::getenv("FMMBEM_ROT_LONG_MAX")) kRotLongMax = std::max(1, std::atoi(e));
@@ -683,6 +684,10 @@ void HostPlan::build_rot_items() {
   rot_item_ptr.clear();
   rot_passes = cut_rot_items(len, nominal, 0, rot_item_ptr);
   const int64_t all_passes = ((int64_t)rot_src.size() + kLanes - 1) / kLanes;
+  // ONE round of items over the SIMDs where items of at most kRotLongMax passes cover the list (a shard of a large operator, or a
+  // small operator: every item's first pass runs without operands fetched ahead, so fewer, longer items; one rank of eight of the
+  // bench workload: M2L 0.094 -> 0.085 ms, one of four 0.154 -> 0.146), two even rounds above that
+  if (kRotLongRounds == 0) kRotLongRounds = all_passes <= (int64_t)kRotLongMax * kSimds ? 1 : 2;
   const int64_t slots = (int64_t)kSimds * kRotLongRounds;
   int long_passes = (int)std::max<int64_t>(nominal / kLanes, std::min<int64_t>(kRotLongMax, (all_passes + slots - 1) / slots));
   for (;;) {
