@@ -319,6 +319,10 @@ class PlanAdapter {
     std::vector<double> v(9 * n_);
     std::vector<uint8_t> bc(n_);
     for (size_t i = 0; i < n_; ++i) {
+      // a default-constructed Panel has no vertices (the reference's MshReader.hpp leaves such panels behind when a file numbers
+      // other elements in front of its triangles): say so instead of reading through an empty vector
+      if (sources_[i].vertices.size() < 3)
+        throw std::invalid_argument("fmmbem: source " + std::to_string(i) + " has " + std::to_string(sources_[i].vertices.size()) + " vertices, a panel needs 3 (default-constructed Panel?)");
       for (int a = 0; a < 3; ++a)
         for (int c = 0; c < 3; ++c) v[9 * i + 3 * a + c] = sources_[i].vertices[a][c];
       bc[i] = sources_[i].BC == source_type::BC1;
