@@ -178,3 +178,54 @@ def test_default_constructed_panels_are_refused_with_a_message(tmp_path):
     exe = _compile(tmp_path, "LaplaceBEM")
     r = subprocess.run([exe, "-p", "6", "-mesh", os.path.join(ROOT, "tests", "golden", "tetra_mixed.msh")], capture_output=True, text=True)
     assert r.returncode not in (0, -11) and "has 0 vertices" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "StokesBEM_ref")), reason="oracle/_ref/StokesBEM_ref not built (make -C oracle ref)")
+@pytest.mark.parametrize("flags,label", [
+    (["-fgmres"], "FGMRES, Preconditioner: Identity"),
+    (["-fgmres", "-diag"], "FGMRES, Preconditioner: Block-Diagonal"),
+    (["-local"], "FGMRES, Preconditioner: Local Solve"),
+    (["-solver_tol", "1e-7"], "GMRES, Preconditioner: Identity"),
+])
+def test_reference_stokes_driver_flags(flags, label):
+    """The unmodified StokesBEM.cpp at r = 4, p = 10 with its flexible solver and its two preconditioners -- the reference's own
+    BlockDiagonalPC_Stokes.hpp and LocalPC_Stokes.hpp, each of which builds a second FMM_plan (block_diagonal / local_evaluation)
+    through the adapter -- beside examples/StokesBEM.py with the same flags: the same orders and residuals for the first ten
+    iterations, iteration counts within one, the same right-hand-side and area checks."""
+    exe = os.path.join(REFDIR, "StokesBEM_ref")
+    out = subprocess.run([exe, "-recursions", "4", "-p", "10"] + flags, capture_output=True, text=True, check=True).stdout
+    py = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "StokesBEM.py"), "-recursions", "4", "-p", "10"] + flags,
+                        capture_output=True, text=True, check=True).stdout
+    assert "Solver: " + label in out and "Solver: " + label in py
+
+    def history(text):
+        its = _lines(text, "it: ")
+        return ([float(ln.split("res:")[1].split(",")[0]) for ln in its], [int(ln.rsplit(":", 1)[1]) for ln in its])
+
+    (res, ps), (pres, pps) = history(out), history(py)
+    # the two Arnoldi processes (the reference's on the host, solver.py's on the device) agree to the printed digits for ten
+    # iterations; then their summation orders show through the p = 5 matvecs and the counts may differ by one
+    assert ps[:10] == pps[:10]
+    assert all(abs(a - b) <= 2e-3 * b for a, b in zip(res[:10], pres[:10]))
+    tol = float(flags[flags.index("-solver_tol") + 1]) if "-solver_tol" in flags else 1e-5
+    fin = _lines(out, "Final residual")[0]
+    assert float(fin.split(":")[1].split(",")[0]) < tol
+    n_cpp = int(fin.split("after")[1].split()[0])
+    n_py = len(pres) if pres[-1] < tol else len(pres) + 1        # solver.py's flexible loop prints the converged iteration, GMRES does not
+    assert abs(n_cpp - n_py) <= 1, (n_cpp, n_py)
+    for key in ("rhs error", "Area error"):
+        a, b = float(_lines(out, key)[0].split(":")[1]), float(_lines(py, key)[0].split(":")[1])
+        assert abs(a - b) <= 1e-4 * abs(b), key
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "StokesBEM_ref")), reason="oracle/_ref/StokesBEM_ref not built (make -C oracle ref)")
+def test_reference_stokes_driver_on_red_blood_cells():
+    """-rbc 4 (one cell, Triangulation::RedBloodCell) and -cells 2 (MultipleRedBloodCell): the reference's generators feed the plan;
+    both solves converge."""
+    exe = os.path.join(REFDIR, "StokesBEM_ref")
+    out = subprocess.run([exe, "-p", "8", "-rbc", "4"], capture_output=True, text=True, check=True).stdout
+    assert "RBC: initialised 512 triangles" in out and float(_lines(out, "Final residual")[0].split(":")[1].split(",")[0]) < 1e-5
+    out = subprocess.run([exe, "-recursions", "3", "-p", "8", "-cells", "2"], capture_output=True, text=True, check=True).stdout
+    assert float(_lines(out, "Final residual")[0].split(":")[1].split(",")[0]) < 1e-5
