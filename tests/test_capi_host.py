@@ -147,18 +147,20 @@ def test_rotation_m2l_work_list_items_are_runs_of_whole_targets():
 
 
 def test_long_m2l_items_fill_the_chip_in_even_rounds():
-    """HostPlan::build_rot_items, the cut for the orders that run one wavefront per SIMD: on an operator with many more passes
-    than the chip has SIMDs the items are long (up to 16 passes) and there are at most two rounds of 1 024 of them -- never a
-    handful beyond a round (measured: thirty items too many cost 0.92 ms against 0.54) -- and the lanes are full."""
+    """HostPlan::build_rot_items, the cut for the orders that run one wavefront per SIMD: the items are long (up to 16 passes) and
+    come in whole rounds of 1 024 -- ONE round where items of at most 16 passes cover the list (a shard, or an operator of this
+    size: every item's first pass runs without operands fetched ahead, so fewer and longer items), two even rounds above that, never
+    a handful beyond a round (measured: thirty items too many cost 0.92 ms against 0.54) -- and the lanes are full."""
     import fmm_bem_relaxed_amd as fb
     v = np.concatenate([fb.unit_sphere(8), fb.unit_sphere(8, center=(3.0, 0.0, 0.0))])
     plan = fb.FMM_plan(fb.LaplaceSphericalBEM(10, 3), v, host_only=True)
     work, short, long_items = plan.pairs("m2l_work"), plan.pairs("m2l_items"), plan.pairs("m2l_items_long")
     n_pass = lambda it: int(((it[:, 1] - it[:, 0] + 63) // 64).sum())
     assert len(work) > 64 * 1024 * 4                            # enough pairs for the rule to matter
-    assert len(long_items) <= 2048                              # two rounds over 1 024 SIMDs, not one item more
+    rounds = 1 if (len(work) + 63) // 64 <= 16 * 1024 else 2
+    assert rounds == 1 and len(long_items) <= 1024 * rounds     # whole rounds over 1 024 SIMDs, not one item more
     per_item = (long_items[:, 1] - long_items[:, 0] + 63) // 64
-    want = -(-(len(work) // 64) // 2048)                        # passes per item the rule aims at
+    want = -(-(len(work) // 64) // (1024 * rounds))             # passes per item the rule aims at
     assert np.median(per_item) in (want, want + 1) and per_item.max() <= 17
     assert np.mean(per_item >= want) > 0.95                     # the few short ones sit in front of targets longer than an item
     assert len(work) / (64.0 * n_pass(long_items)) > 0.95 > len(work) / (64.0 * n_pass(short))     # fuller lanes than the short cut
