@@ -9,7 +9,8 @@ mkdir -p ../variants /tmp/rotvar
   "$@" -c -o /tmp/rotvar/kr_$name.o kernels_m2l_rot.hip
 # the same check as the product build: a variant with a DPP hazard or an early touch of a load in flight computes wrong
 # numbers, and its timing means nothing
-# (ROT_NOCHECK=1: a timing-only experiment whose numbers are wrong anyway)
+# (ROT_NOCHECK=1: for a timing-only experiment whose NUMBERS are wrong anyway -- never for a build the checker refuses because a
+# load in flight is touched: the value touched may be an index or an address, and the unchecked p = 12 build of round 4 faulted on the GPU)
 [ -n "$ROT_NOCHECK" ] || python3 ../../tools/check_rot_isa.py /tmp/rotvar/kr_$name.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../variants/libfmmbem_hip_$name.so host_plan.o mesh_io.o kernels_near.o kernels_far.o kernels_m2l.o /tmp/rotvar/kr_$name.o kernels_m2m_rot.o kernels_l2l_rot.o kernels_shift.o krylov.o plan.o
 echo built ../variants/libfmmbem_hip_$name.so
