@@ -2,7 +2,9 @@
 """bench.py -- FMM matvecs/s of the LaplaceBEM operator on MI355X, with the P2P roofline and a CPU baseline.
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched through
-torch.distributed.run (one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
+torch.distributed.run (one rank per GPU, RCCL) -- by the driver, or, when WORLD_SIZE is not set, by bench.py itself
+(launch_ranks: N child processes, started before this process touches the GPU).  WORLD_SIZE != --gpus is an error line
+and exit code 2, never a silently different measurement.  Rank 0 prints ONE JSON line.
 
   step      one FMM matvec  y = A x  (near-field block SpMV + P2M/M2M/M2L/L2L/L2P at p=10), x and y
             resident in HBM, result replicated on every rank (one all-reduce per matvec when N > 1)
@@ -206,8 +208,42 @@ def preflight(args, fb, make_op, x, v, stokes, bc, rank, world, dev):
     return op_plain, info
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): start the N ranks as CHILD processes
+    through torch.distributed.run, one per GPU, and hand back the launcher's exit code.  Called before this process has
+    imported torch or touched the GPU (a process that has initialised HIP must not exec or fork GPU work), and as a child
+    process, never an exec.  Rank 0's JSON line goes to the stdout the children inherit.  tools/launch_scale.sh is the same
+    recipe for a shell."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] --gpus %d without a launcher: starting %d ranks: %s" % (args.gpus, args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(launch_ranks(args))
+    if env_world is not None and int(env_world) != args.gpus:
+        # a launcher that started W ranks for --gpus N would otherwise time W GPUs and be read as N (or the reverse)
+        STAGE[0] = "launch"
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(json.dumps({"error": "--gpus %d but the launcher set WORLD_SIZE=%s: start one rank per GPU (python -m "
+                                       "torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..., tools/launch_scale.sh) "
+                                       "or run `python bench.py --gpus %d` bare and let it start its own ranks"
+                                       % (args.gpus, env_world, args.gpus, args.gpus, args.gpus),
+                              "stage": "launch", "rank": 0, "n_gpus": int(env_world), "metric": "FMM matvecs/s", "value": None}), flush=True)
+        sys.exit(2)
     import datetime
     import threading
     import numpy as np
@@ -219,6 +255,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
+        if world > 1:
+            die(rank, world, "bench.py needs a GPU: the product has no CPU execution path", 4) if rank == 0 else os._exit(4)
         raise SystemExit("bench.py needs a GPU: the product has no CPU execution path")
     # one rank per GPU over RCCL.  FMMBEM_BENCH_BACKEND=gloo is a rehearsal aid for a one-GPU box: the ranks then share
     # device 0 and the collectives go through the host (numbers from such a run mean nothing).

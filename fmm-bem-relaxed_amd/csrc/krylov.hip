@@ -255,10 +255,52 @@ struct DevGuard {
   ~DevGuard() { if (on) (void)hipSetDevice(prev); }
 };
 
+// FMMBEM_KRYLOV_FAIL_GROW=k (tests only): the k-th allocation of the solver workspace in this process fails once, as an
+// out-of-memory would -- the retry path of ensure_ws cannot be exercised otherwise without filling 288 GB
 int grow(double** p, size_t doubles) {
   if (*p) (void)hipFree(*p);
   *p = nullptr;
+  static int calls = 0;
+  static const int fail_at = [] { const char* e = std::getenv("FMMBEM_KRYLOV_FAIL_GROW"); return e ? std::atoi(e) : 0; }();
+  if (fail_at > 0 && ++calls == fail_at) return fail(FMMBEM_ERR_ALLOC, "solver workspace: allocation failure injected by FMMBEM_KRYLOV_FAIL_GROW");
   KRY_HIP(hipMalloc(reinterpret_cast<void**>(p), sizeof(double) * std::max<size_t>(doubles, 1)));
+  return FMMBEM_OK;
+}
+
+// after a failed allocation: nothing of the workspace is trusted -- every buffer freed, every size zero, so that the next solve
+// on this plan allocates from scratch instead of launching on the null pointers a half-grown workspace holds
+void reset_ws(SolverWs* ws) {
+  for (double** p : {&ws->w, &ws->z, &ws->V, &ws->Z, &ws->d_h, &ws->d_y, &ws->d_scratch}) {
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+  }
+  if (ws->h_pin) (void)hipHostFree(ws->h_pin);
+  ws->h_pin = nullptr;
+  ws->n = ws->ld = 0;
+  ws->vcols = ws->zcols = ws->hcap = 0;
+}
+
+int grow_ws(SolverWs* ws, int64_t n, int vcols, int zcols) {
+  const int64_t ld = (n + 1) & ~int64_t(1);                      // even stride: every basis vector on a 16-byte boundary
+  if (ws->n != n) {
+    reset_ws(ws);
+    KRY_TRY(grow(&ws->w, (size_t)ld));
+    KRY_TRY(grow(&ws->z, (size_t)ld));
+    ws->n = n; ws->ld = ld;
+  }
+  if (ws->vcols < vcols) { ws->vcols = 0; KRY_TRY(grow(&ws->V, (size_t)ld * vcols)); ws->vcols = vcols; }
+  if (ws->zcols < zcols) { ws->zcols = 0; KRY_TRY(grow(&ws->Z, (size_t)ld * zcols)); ws->zcols = zcols; }
+  if (ws->hcap < vcols + 1) {
+    const int hcap = vcols + 1;
+    ws->hcap = 0;
+    KRY_TRY(grow(&ws->d_h, (size_t)hcap));
+    KRY_TRY(grow(&ws->d_y, (size_t)hcap));
+    KRY_TRY(grow(&ws->d_scratch, (size_t)fmmbem_mgs_scratch_doubles(hcap)));
+    if (ws->h_pin) (void)hipHostFree(ws->h_pin);
+    ws->h_pin = nullptr;
+    KRY_HIP(hipHostMalloc(reinterpret_cast<void**>(&ws->h_pin), sizeof(double) * (size_t)hcap, hipHostMallocDefault));
+    ws->hcap = hcap;                                             // sizes are committed only once every buffer of the group exists
+  }
   return FMMBEM_OK;
 }
 
@@ -266,23 +308,8 @@ int grow(double** p, size_t doubles) {
 int ensure_ws(SolverWs** slot, int device, int64_t n, int vcols, int zcols, SolverWs** out) {
   if (!*slot) { *slot = new SolverWs; (*slot)->device = device; }
   SolverWs* ws = *slot;
-  const int64_t ld = (n + 1) & ~int64_t(1);                      // even stride: every basis vector on a 16-byte boundary
-  if (ws->n != n) {
-    ws->n = n; ws->ld = ld; ws->vcols = ws->zcols = 0;
-    KRY_TRY(grow(&ws->w, (size_t)ld));
-    KRY_TRY(grow(&ws->z, (size_t)ld));
-  }
-  if (ws->vcols < vcols) { KRY_TRY(grow(&ws->V, (size_t)ld * vcols)); ws->vcols = vcols; }
-  if (ws->zcols < zcols) { KRY_TRY(grow(&ws->Z, (size_t)ld * zcols)); ws->zcols = zcols; }
-  if (ws->hcap < vcols + 1) {
-    ws->hcap = vcols + 1;
-    KRY_TRY(grow(&ws->d_h, (size_t)ws->hcap));
-    KRY_TRY(grow(&ws->d_y, (size_t)ws->hcap));
-    KRY_TRY(grow(&ws->d_scratch, (size_t)fmmbem_mgs_scratch_doubles(ws->hcap)));
-    if (ws->h_pin) (void)hipHostFree(ws->h_pin);
-    ws->h_pin = nullptr;
-    KRY_HIP(hipHostMalloc(reinterpret_cast<void**>(&ws->h_pin), sizeof(double) * (size_t)ws->hcap, hipHostMallocDefault));
-  }
+  const int rc = grow_ws(ws, n, vcols, zcols);
+  if (rc != FMMBEM_OK) { reset_ws(ws); return rc; }
   *out = ws;
   return FMMBEM_OK;
 }

@@ -130,3 +130,41 @@ def test_capi_stokes_order_rule(fb):
     assert itc == itp and [p for _, p, _ in log_c] == [p for _, p, _ in log_p] and min(p for _, p, _ in log_c) >= 5
     assert float(torch.linalg.vector_norm(xc - xp) / torch.linalg.vector_norm(xp)) <= 1e-9
     plan.close()
+
+
+_ALLOC_RETRY = r"""
+import sys
+import numpy as np, torch
+sys.path.insert(0, %r)
+import fmm_bem_relaxed_amd as fb
+v = fb.unit_sphere(4); n = len(v)
+plan = fb.FMM_plan(fb.LaplaceSphericalBEM(8, 3), v, p_max=8)
+rhs = fb.FMM_plan(fb.LaplaceSphericalBEM(8, 3), v, bc=np.ones(n, dtype=np.uint8), p_max=8)
+b = rhs.execute_torch(torch.ones(n, dtype=torch.float64, device="cuda"))
+so = fb.SolverOptions(residual=1e-6, max_iters=40, max_p=8)
+try:
+    fb.gmres_capi(plan, torch.zeros_like(b), b, so)
+    print("NOFAIL")
+except fb.FmmBemError as e:
+    print("FAILED", e.status if hasattr(e, "status") else "", str(e)[:200].replace("\n", " "))
+x, it, res, _ = fb.gmres_capi(plan, torch.zeros_like(b), b, so)            # the retry on the SAME plan
+x2, it2, res2 = fb.gmres(plan, torch.zeros_like(b), b, so)
+print("RETRY", it, it2, float(torch.linalg.vector_norm(x - x2) / torch.linalg.vector_norm(x2)), float(res))
+"""
+
+
+@pytest.mark.parametrize("k", [2, 3, 5, 6])
+def test_solver_workspace_survives_a_failed_allocation(k, tmp_path):
+    """an allocation of the solver workspace that fails (injected: the k-th one, FMMBEM_KRYLOV_FAIL_GROW) must leave
+    the workspace the plan keeps EMPTY, so that the next solve on the same plan allocates again -- not half-grown with its sizes
+    already committed, which made the retry launch kernels on null pointers (a GPU fault instead of FMMBEM_ERR_ALLOC)."""
+    import subprocess
+    import sys
+    script = tmp_path / "retry.py"
+    script.write_text(_ALLOC_RETRY % ROOT)
+    r = subprocess.run([sys.executable, str(script)], env=dict(os.environ, FMMBEM_KRYLOV_FAIL_GROW=str(k)), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.strip().splitlines()
+    assert lines[0].startswith("FAILED") and "injected" in lines[0], lines
+    tag, it, it2, diff, res = lines[1].split()
+    assert tag == "RETRY" and it == it2 and float(diff) <= 1e-10 and float(res) < 1e-6

@@ -18,6 +18,13 @@ REF = "/root/reference"
 REFDIR = os.path.join(ROOT, "oracle", "_ref")
 
 
+@pytest.fixture(autouse=True)
+def _scratch_cwd(tmp_path, monkeypatch):
+    """The reference's mesh generators dump test.vert / test.face into the working directory
+    (examples/BEM/Triangulation.hpp:123-134): every driver run of this file happens in a scratch directory, not in the tree."""
+    monkeypatch.chdir(tmp_path)
+
+
 def _compile(tmp_path, name):
     exe = str(tmp_path / name)
     lib = os.path.join(ROOT, "fmm-bem-relaxed_amd")

@@ -2,8 +2,9 @@
 # the flags its help text lists, on the GPU.  usage (GPU box): bash tools/reference_driver_flags.sh OUTDIR
 OUT=${1:-gpurun_out/drv}
 mkdir -p $OUT
-B=oracle/_ref/LaplaceBEM_ref
-run() { name=$1; shift; echo "== $name: $*"; timeout -k 10 300 $B "$@" > $OUT/$name.txt 2>&1; echo "rc $?"; grep -i "iteration\|error\|Solver:\|Precond\|time" $OUT/$name.txt | tail -8; }
+SCRATCH=$(mktemp -d)      # the reference generators dump test.vert / test.face into the working directory
+B=$PWD/oracle/_ref/LaplaceBEM_ref
+run() { name=$1; shift; echo "== $name: $*"; (cd $SCRATCH && timeout -k 10 300 $B "$@") > $OUT/$name.txt 2>&1; echo "rc $?"; grep -i "iteration\|error\|Solver:\|Precond\|time" $OUT/$name.txt | tail -8; }
 run default      -recursions 6 -p 12 -theta 0.5
 run fixed_p      -recursions 6 -p 12 -fixed_p
 run second_kind  -recursions 6 -p 12 -second_kind

@@ -2,8 +2,9 @@
 # flags, on the GPU.  usage (GPU box): bash tools/reference_stokes_driver_flags.sh OUTDIR
 OUT=${1:-gpurun_out/drv_stokes}
 mkdir -p $OUT
-B=oracle/_ref/StokesBEM_ref
-run() { name=$1; shift; echo "== $name: $*"; timeout -k 10 600 $B "$@" > $OUT/$name.txt 2>&1; echo "rc $?"; grep -i "Solver:\|Final residual\|rhs error\|Area error\|Fx\|drag\|setup\|solve :" $OUT/$name.txt | tail -8; }
+SCRATCH=$(mktemp -d)      # the reference generators dump test.vert / test.face into the working directory
+B=$PWD/oracle/_ref/StokesBEM_ref
+run() { name=$1; shift; echo "== $name: $*"; (cd $SCRATCH && timeout -k 10 600 $B "$@") > $OUT/$name.txt 2>&1; echo "rc $?"; grep -i "Solver:\|Final residual\|rhs error\|Area error\|Fx\|drag\|setup\|solve :" $OUT/$name.txt | tail -8; }
 run default      -recursions 4 -p 10
 run fixed_p      -recursions 4 -p 10 -fixed_p
 run pmin6        -recursions 4 -p 10 -pmin 6
