@@ -95,6 +95,11 @@ struct DevicePlan {
   double* near_sym = nullptr;
   const int64_t* near_sym_off;                        // [nl] offset of a leaf's block in near_sym (doubles)
   const int4* sym_items;      int sym_nitems = 0;     // {leaf, first panel row, panel rows, column-split?}, largest first
+  // Hybrid near field (near_stream_fraction < 1): near_rec[leaf] != 0 -> the leaf keeps no matrix block, its far-regime entries are
+  // recomputed every matvec and its near-regime pairs come from the side list; hyb_items = stream and recompute items of ONE
+  // persistent kernel, mixed: {leaf, first row, rows, bit 0 column-split (stream) | bit 1 recompute}
+  const uint8_t* near_rec = nullptr;
+  const int4* hyb_items = nullptr;  int hyb_nitems = 0;
   // boxes / expansions
   const double* box_center;
   double2 *M, *L, *Mh;

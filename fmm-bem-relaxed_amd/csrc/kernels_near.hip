@@ -194,6 +194,7 @@ __global__ __launch_bounds__(256) void near_assemble_kernel(DevicePlan d) {
   int* run_row0 = lds_i + kAsmChunk;                 // [max_runs]
   int* run_off = run_row0 + d.max_runs;              // [max_runs]
   for (int t = d.leaf_begin + blockIdx.x; t < d.leaf_end; t += gridDim.x) {
+    if (d.near_rec && d.near_rec[t]) continue;        // hybrid plan: this leaf keeps no matrix (its far regime is recomputed)
     const int ncols = d.near_ncols[t], stride = d.near_stride[t], nrows = d.leaf_nrows[t];
     const int row0 = d.leaf_row0[t];
     const Runs runs = load_runs(d, t, run_row0, run_off);
@@ -377,6 +378,7 @@ __global__ __launch_bounds__(256) void near_assemble_stokes_kernel(DevicePlan d)
   int* run_row0 = lds_i + kAsmChunk;
   int* run_off = run_row0 + d.max_runs;
   for (int t = d.leaf_begin + blockIdx.x; t < d.leaf_end; t += gridDim.x) {
+    if (d.near_rec && d.near_rec[t]) continue;        // hybrid plan: this leaf keeps no matrix (its far regime is recomputed)
     const int ncols = d.near_ncols[t], stride = d.near_stride[t], nrows = d.leaf_nrows[t];
     const int row0 = d.leaf_row0[t];
     const Runs runs = load_runs(d, t, run_row0, run_off);
@@ -461,6 +463,13 @@ __device__ __noinline__ double mf_far_general(const DevicePlan& d, int64_t j, do
 
 enum MfMode { kMfCount = 0, kMfFill = 1, kMfApply = 2 };
 
+// "this pair is listed": squared centroid distance against 8 A (1 + 1e-9).  ONE function with the contractions spelled out, used by
+// the kernels that list the pairs at plan creation and by every kernel that masks them in a matvec (mf_sweep, mf_sweep3_apply,
+// the hybrid kernels): a pair whose distance sits within rounding of the band must get the same verdict in all of them
+__device__ __forceinline__ bool mf_listed(double dx, double dy, double dz, double near2) {
+  return fma(dz, dz, fma(dy, dy, dx * dx)) <= near2;
+}
+
 // side_cnt (COUNT): listed pairs per tree-order row; side_ptr / side_col (FILL): the CSR being filled; APPLY: d.side_*
 // GEN: rules of more than three points (the points re-read per row by a called function, whose frame costs the kernel a third
 // of its registers: 209 instead of 139 VGPRs) -- the reference's K = 1, 3 take the kernel without it
@@ -521,8 +530,7 @@ __global__ __launch_bounds__(kWave) void mf_sweep_kernel(DevicePlan d, int* __re
           if (r < nr) {                                    // wave-uniform
             const double tx = tcx[r], ty = tcy[r], tz = tcz[r];
             const double dx = tx - sx, dy = ty - sy, dz = tz - sz;
-            const double d2 = dx * dx + dy * dy + dz * dz;
-            const bool slow = valid && d2 <= near2;       // a listed pair: the SAME expression at creation and in every matvec
+            const bool slow = valid && mf_listed(dx, dy, dz, near2);       // a listed pair: the SAME function at creation and in every matvec
             if constexpr (MODE == kMfApply) {
               const int dn = __builtin_amdgcn_readfirstlane(tbc[r]);      // the row's operator: a scalar branch, not a select per point
               double v = 0;
@@ -632,7 +640,7 @@ __global__ __launch_bounds__(kWave) void mf_sweep3_apply_kernel(DevicePlan d) {
           if (r < nr) {
             const double tx = tcx[r], ty = tcy[r], tz = tcz[r];
             const double dx = tx - sx, dy = ty - sy, dz = tz - sz;
-            const bool slow = valid && dx * dx + dy * dy + dz * dz <= near2;      // the expression of mf_sweep_kernel: the same pairs
+            const bool slow = valid && mf_listed(dx, dy, dz, near2);             // the function of mf_sweep_kernel: the same pairs
             const int trac = __builtin_amdgcn_readfirstlane(tbc[r]);
             double u0 = 0, u1 = 0, u2 = 0;
             if (nqr) {
@@ -1140,11 +1148,283 @@ __global__ __launch_bounds__(kSpmvWaves * kWave, kSymOcc) void near_spmv_sym3_ke
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Hybrid near field (fmmbem_options.near_stream_fraction < 1; round 5): ONE persistent kernel whose work items are of two kinds,
+// mixed in the order the workgroups are dealt them --
+//   * STREAM items: row ranges of target leaves whose blocks are stored (near_sym): near_spmv_sym3's arithmetic, HBM-bound, the
+//     VALU idle 95 % of the time;
+//   * RECOMPUTE items: row ranges of target leaves that keep NO matrix.  Their far-regime entries (K quadrature points per pair)
+//     are evaluated from the source panels' points -- lane = source panel, read once into registers (128 bytes against the
+//     48 bytes x rows the stored form would stream) and applied to the item's rows five at a time (the row's centroid is an LDS
+//     broadcast); the 15 partial sums of a row block cross the lanes through ONE 16-value halving butterfly (17 shuffles
+//     instead of 90) into the wavefront's own LDS slots; the near-regime pairs (semi-analytic / fine-rule / self entries, 4.5 %)
+//     were listed and evaluated once at plan creation (side_ptr / side_col / side_val, as the matrix-free plans do) and are added
+//     from the list, a row per wavefront.
+// On a CU the wavefronts of the 4-5 resident workgroups are at different items at any time, so the arithmetic of the recompute
+// items runs in the issue slots the stream items leave empty, and the matrix bytes of the recomputed leaves are never read
+// (nor stored: the footprint shrinks by the same share).  Every row is summed in a fixed order: column groups in order per
+// wavefront, the butterfly's tree, wavefronts 0..3, then the listed entries' tree.
+// Two existing kernels on two streams do NOT do this: profiles/r05a_near_split_step_a.txt (they serialise).
+// ---------------------------------------------------------------------------------------------
+constexpr int kHybRows = 5;                           // rows per block of a recompute item (3 sums each + 1 pad = 16 values)
+
+// v[0..15] per lane -> every lane returns the sum over all 64 lanes of value hyb_value_of(lane); fixed tree.
+// One halving step: the lanes whose `BIT` is set keep the upper W values, the others the lower W, and each adds what its
+// partner (lane ^ BIT) held of them.  (Written as a template per step: as one loop over the steps the compiler does not unroll
+// it, indexes v[] at run time and emits a 16-way select per access -- 1 400 instructions instead of 120.)
+template <int W, int BIT>
+__device__ __forceinline__ void hyb_halve(double (&v)[16], int lane) {
+  const bool hi = (lane & BIT) != 0;
+#pragma unroll
+  for (int k = 0; k < W; ++k) {
+    const double send = hi ? v[k] : v[k + W];
+    const double keep = hi ? v[k + W] : v[k];
+    v[k] = keep + __shfl_xor(send, BIT, kWave);
+  }
+}
+__device__ __forceinline__ double hyb_reduce16(double (&v)[16], int lane) {
+  hyb_halve<8, 32>(v, lane);
+  hyb_halve<4, 16>(v, lane);
+  hyb_halve<2, 8>(v, lane);
+  hyb_halve<1, 4>(v, lane);
+  double t = v[0];
+  t += __shfl_xor(t, 2, kWave);
+  t += __shfl_xor(t, 1, kWave);
+  return t;
+}
+__device__ __forceinline__ int hyb_value_of(int lane) { return (lane >> 2) & 15; }   // bits 5..2 of the lane, bit 5 = value bit 3
+
+#ifndef FMMBEM_HYB_OCC
+#define FMMBEM_HYB_OCC 3
+#endif
+#ifndef FMMBEM_HYB_CHUNK
+#define FMMBEM_HYB_CHUNK 1024
+#endif
+constexpr int kHybOcc = FMMBEM_HYB_OCC;               // workgroups per CU
+constexpr int kHybChunk = FMMBEM_HYB_CHUNK;           // source panels of x staged at a time
+constexpr int kHybMaxRows = 64;                       // rows of a recompute item (a leaf holds <= ncrit panels; the host cuts longer ranges)
+
+// MIXED: one kernel takes both kinds of items (d.hyb_items); !MIXED: the recompute items only (d.near_items), beside
+// near_spmv_sym3_kernel on a second stream -- each kernel then has its own register budget (launch_near_spmv)
+template <bool TRAC, bool MIXED>
+__global__ __launch_bounds__(kSpmvWaves * kWave, kHybOcc) void near_hybrid3_kernel(DevicePlan d) {
+  extern __shared__ double xs[];                      // [3][kHybChunk] doubles, then the run descriptors
+  __shared__ double part[kSpmvWaves][kColRows][3];
+  __shared__ double rpart[3 * kHybMaxRows];               // recompute items: the rows' sums over the far-regime pairs
+  __shared__ double rside[3 * kHybMaxRows];               // ... and the rows' listed entries
+  __shared__ double tcx[kHybMaxRows], tcy[kHybMaxRows], tcz[kHybMaxRows];
+  __shared__ int tbc[kHybMaxRows];
+  int* run_row0 = reinterpret_cast<int*>(xs + 3 * kHybChunk);
+  int* run_off = run_row0 + d.max_runs;
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, tid = threadIdx.x;
+  const int64_t N = d.n;
+  const double sc = 1. / 2 / d.mu;
+  constexpr int kRows = 1, kVecs = 3;
+  const int4* const items = MIXED ? d.hyb_items : d.near_items;
+  const int nitems = MIXED ? d.hyb_nitems : d.near_nitems;
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int4 it = items[item];
+    const int t = it.x, r0 = it.y, nrows = it.z;       // panel rows
+    const bool colsplit = (it.w & 1) != 0, recompute = !MIXED || (it.w & 2) != 0;
+    const int ncp = d.near_ncols[t];
+    const Runs runs = load_runs(d, t, run_row0, run_off);
+    if (MIXED && !recompute) {
+      // ---- stream item: near_spmv_sym3_kernel's body ----
+      const dvec2* blk = reinterpret_cast<const dvec2*>(d.near_sym + d.near_sym_off[t]) + (int64_t)r0 * 3 * ncp;
+      double* yt = d.yt + 3 * (int64_t)(d.leaf_row0[t] + r0);
+      for (int c0 = 0; c0 < ncp; c0 += kHybChunk) {
+        const int cw = ncp - c0 < kHybChunk ? ncp - c0 : kHybChunk;
+        if (c0) __syncthreads();
+        for (int c = tid; c < cw; c += blockDim.x) {
+          const double* xp = d.xt + 3 * (int64_t)column_to_row(runs, c0 + c);
+          xs[c] = xp[0]; xs[kHybChunk + c] = xp[1]; xs[2 * kHybChunk + c] = xp[2];
+        }
+        __syncthreads();
+        const int seg = colsplit ? ((((cw + kSpmvWaves - 1) / kSpmvWaves) + 3) & ~3) : cw;
+        const int v0 = colsplit ? wave * seg : 0, v1 = min(cw, v0 + seg);
+        const int rstep = colsplit ? 1 : kSpmvWaves;
+        for (int r = colsplit ? 0 : wave; r < nrows; r += colsplit ? kRows : kRows * kSpmvWaves) {
+          const dvec2* row[kRows];
+          double ax[kRows], ay[kRows], az[kRows];
+#pragma unroll
+          for (int i = 0; i < kRows; ++i) {
+            const int ri = r + i * rstep;
+            row[i] = blk + (int64_t)(ri < nrows ? ri : r) * 3 * ncp + c0;
+            ax[i] = ay[i] = az[i] = 0;
+          }
+          for (int c = v0 + lane; c < v1; c += kVecs * kWave) {
+            dvec2 v[kRows][kVecs][3];
+#pragma unroll
+            for (int u = 0; u < kVecs; ++u) {
+              const int cc = c + u * kWave;
+              const bool ok = cc < v1;
+#pragma unroll
+              for (int i = 0; i < kRows; ++i)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) v[i][u][k] = ok ? __builtin_nontemporal_load(&row[i][k * ncp + cc]) : dvec2{0, 0};
+            }
+#pragma unroll
+            for (int u = 0; u < kVecs; ++u) {
+              const int cc = c + u * kWave;
+              if (cc < v1) {
+                const double x0 = xs[cc], x1 = xs[kHybChunk + cc], x2 = xs[2 * kHybChunk + cc];
+#pragma unroll
+                for (int i = 0; i < kRows; ++i) {
+                  const dvec2 a = v[i][u][0], b = v[i][u][1], e = v[i][u][2];   // (xx,xy) (xz,yy) (yz,zz)
+                  ax[i] = fma(a.x, x0, fma(a.y, x1, fma(b.x, x2, ax[i])));
+                  ay[i] = fma(a.y, x0, fma(b.y, x1, fma(e.x, x2, ay[i])));
+                  az[i] = fma(b.x, x0, fma(e.x, x1, fma(e.y, x2, az[i])));
+                }
+              }
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < kRows; ++i) { ax[i] = wave_sum(ax[i]); ay[i] = wave_sum(ay[i]); az[i] = wave_sum(az[i]); }
+          if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < kRows; ++i) {
+              const int ri = r + i * rstep;
+              if (ri < nrows) {
+                if (colsplit) { part[wave][ri][0] = ax[i]; part[wave][ri][1] = ay[i]; part[wave][ri][2] = az[i]; }
+                else {
+                  double* y = yt + 3 * ri;
+                  y[0] = c0 ? y[0] + ax[i] : ax[i]; y[1] = c0 ? y[1] + ay[i] : ay[i]; y[2] = c0 ? y[2] + az[i] : az[i];
+                }
+              }
+            }
+          }
+        }
+        if (colsplit) {
+          __syncthreads();
+          if (tid < 3 * nrows) {
+            const int ri = tid / 3, a = tid % 3;
+            const double sum = ((part[0][ri][a] + part[1][ri][a]) + part[2][ri][a]) + part[3][ri][a];
+            yt[3 * ri + a] = c0 ? yt[3 * ri + a] + sum : sum;
+          }
+        }
+      }
+      __syncthreads();
+      continue;
+    }
+    // ---- recompute item ----
+    const int prow0 = d.leaf_row0[t] + r0;             // first tree-order panel row of the item
+    if (tid < nrows) {                                   // the rows' centroids: LDS broadcasts of the arithmetic below
+      const int64_t i = prow0 + tid;
+      tcx[tid] = d.cx[i]; tcy[tid] = d.cy[i]; tcz[tid] = d.cz[i];
+      if constexpr (TRAC) tbc[tid] = d.bc[i];
+    }
+    const double w0 = d.qw[0], w1 = d.nq > 1 ? d.qw[1] : 0.0;      // the rules the host admits: weights of points 1.. all equal
+    const int nq = d.nq;
+    for (int c0 = 0; c0 < ncp; c0 += kHybChunk) {
+      const int cw = ncp - c0 < kHybChunk ? ncp - c0 : kHybChunk;
+      if (c0) __syncthreads();
+      for (int c = tid; c < cw; c += blockDim.x) {
+        const double* xp = d.xt + 3 * (int64_t)column_to_row(runs, c0 + c);
+        xs[c] = xp[0]; xs[kHybChunk + c] = xp[1]; xs[2 * kHybChunk + c] = xp[2];
+      }
+      __syncthreads();
+      // a wavefront takes kHybRows rows at a time (blocks wave, wave + 4, ...) against ALL columns of the chunk: the rows' sums stay in
+      // its registers over the column groups and cross the lanes once per block
+      for (int rb = wave * kHybRows; rb < nrows; rb += kSpmvWaves * kHybRows) {
+        double v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = 0.0;
+        for (int cg = 0; cg * kWave < cw; ++cg) {
+          const int c = cg * kWave + lane;
+          const bool valid = c < cw;
+          const unsigned j = (unsigned)column_to_row(runs, c0 + (valid ? c : 0));
+          // this lane's source panel, once for the rows of the block
+          const double sx = d.cx[j], sy = d.cy[j], sz = d.cz[j], A = d.area[j];
+          const double near2 = valid ? 8.0 * A * (1.0 + 1e-9) : 1e300;      // lanes past the last column: every pair "listed", i.e. dropped
+          const double x0 = xs[valid ? c : 0], x1 = xs[kHybChunk + (valid ? c : 0)], x2 = xs[2 * kHybChunk + (valid ? c : 0)];
+          double nx = 0, ny = 0, nz = 0;
+          if constexpr (TRAC) { nx = d.nx[j]; ny = d.ny[j]; nz = d.nz[j]; }
+          double qx[4], qy[4], qz[4];                      // K = 1, 3, 4 (the host keeps hybrid plans to those rules)
+          const double* qp = d.quad + j;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const bool have = q < nq;
+            qx[q] = have ? qp[(q * 3 + 0) * N] : 0.0; qy[q] = have ? qp[(q * 3 + 1) * N] : 0.0; qz[q] = have ? qp[(q * 3 + 2) * N] : 1.0;
+          }
+          const double wA0 = w0 * A, wA1 = w1 * A;
+#pragma unroll
+          for (int r = 0; r < kHybRows; ++r) {
+            const int ri = rb + r < nrows ? rb + r : nrows - 1;      // rows past the end repeat the last one; their sums are not stored
+            const double tx = tcx[ri], ty = tcy[ri], tz = tcz[ri];
+            const bool slow = mf_listed(tx - sx, ty - sy, tz - sz, near2);
+            bool trac = false;
+            if constexpr (TRAC) trac = __builtin_amdgcn_readfirstlane(tbc[ri]) != 0;
+            double u0 = 0, u1 = 0, u2 = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const double wA = q ? (q < nq ? wA1 : 0.0) : wA0;
+              const double ex = tx - qx[q], ey = ty - qy[q], ez = tz - qz[q];
+              const double ir = rsqrt_pos(fma(ex, ex, fma(ey, ey, ez * ez)));
+              const double ir3 = ir * ir * ir, dxq = fma(ex, x0, fma(ey, x1, ez * x2));
+              if (TRAC && trac) {
+                const double g = wA * fma(ex, nx, fma(ey, ny, ez * nz)) * dxq * (ir3 * ir * ir);
+                u0 = fma(g, ex, u0); u1 = fma(g, ey, u1); u2 = fma(g, ez, u2);
+              } else {
+                const double f1 = wA * ir, g = wA * ir3 * dxq;
+                u0 = fma(f1, x0, fma(g, ex, u0)); u1 = fma(f1, x1, fma(g, ey, u1)); u2 = fma(f1, x2, fma(g, ez, u2));
+              }
+#ifndef FMMBEM_HYB_QSCHED
+#define FMMBEM_HYB_QSCHED 2
+#endif
+              // FMMBEM_HYB_QSCHED points at a time: left alone the scheduler interleaves all four points of a row (25 doubles of
+              // temporaries each) and the kernel needs 210 VGPRs
+              if ((q + 1) % FMMBEM_HYB_QSCHED == 0) __builtin_amdgcn_sched_barrier(0);
+            }
+            // a listed pair contributes through the list, not here: a select, not a product with zero (the self pair's point IS the
+            // centroid for K = 1, 4: its reciprocal distance is inf, the sums NaN)
+            const double f = (TRAC && trac) ? -3.0 : sc;
+            v[3 * r] += slow ? 0.0 : u0 * f; v[3 * r + 1] += slow ? 0.0 : u1 * f; v[3 * r + 2] += slow ? 0.0 : u2 * f;
+            __builtin_amdgcn_sched_barrier(0);             // one row after the other (left alone the scheduler interleaves them and spills)
+          }
+        }
+        const double tot = hyb_reduce16(v, lane);
+        const int k = hyb_value_of(lane);
+        if ((lane & 3) == 0 && k < 3 * kHybRows && 3 * rb + k < 3 * nrows) rpart[3 * rb + k] = c0 ? rpart[3 * rb + k] + tot : tot;
+      }
+    }
+    // the rows' listed entries: a row per wavefront, lane = entry
+    for (int ri = wave; ri < nrows; ri += kSpmvWaves) {
+      const int64_t i = prow0 + ri;
+      double s0 = 0, s1 = 0, s2 = 0;
+      for (int64_t k = d.side_ptr[i] + lane; k < d.side_ptr[i + 1]; k += kWave) {
+        const double* m = d.side_val + 9 * k;
+        const int64_t cj = d.side_col[k];
+        const double y0 = d.xt[3 * cj], y1 = d.xt[3 * cj + 1], y2 = d.xt[3 * cj + 2];
+        s0 = fma(m[0], y0, fma(m[1], y1, fma(m[2], y2, s0)));
+        s1 = fma(m[3], y0, fma(m[4], y1, fma(m[5], y2, s1)));
+        s2 = fma(m[6], y0, fma(m[7], y1, fma(m[8], y2, s2)));
+      }
+      s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
+      if (lane == 0) { rside[3 * ri] = s0; rside[3 * ri + 1] = s1; rside[3 * ri + 2] = s2; }
+    }
+    __syncthreads();
+    if (tid < 3 * nrows)
+      d.yt[3 * (int64_t)prow0 + tid] = rpart[tid] + rside[tid];
+    __syncthreads();                                  // xs / run descriptors / rpart / centroids are rewritten for the next item
+  }
+}
+
 // diag[original unknown] = A_near[u,u]: the self-interaction K(s,s) that Preconditioners::Diagonal divides by
 // (examples/BEM/Preconditioner.hpp:19-42).  selfcol[leaf] = first column of the leaf's own panels in its block.
 __global__ void near_diag_kernel(DevicePlan d, const int* __restrict__ selfcol, double* __restrict__ out) {
   const int t = d.leaf_begin + blockIdx.x;
   const int dof = d.dof, nrows = dof * d.leaf_nrows[t], stride = d.near_stride[t], row0 = d.leaf_row0[t];
+  if (d.near_rec && d.near_rec[t]) {                  // hybrid plan, recomputed leaf: the self entry is a listed (near-regime) pair
+    for (int r = threadIdx.x; r < nrows; r += blockDim.x) {
+      const int64_t i = row0 + r / dof;
+      const int a = r % dof;
+      double v = 0;
+      for (int64_t k = d.side_ptr[i]; k < d.side_ptr[i + 1]; ++k)
+        if (d.side_col[k] == i) v = dof == 3 ? d.side_val[9 * k + 4 * a] : d.side_val[k];
+      out[(int64_t)d.perm[i] * dof + a] = v;
+    }
+    return;
+  }
   if (d.near_sym) {                                   // Stokes, symmetric blocks: (a,a) of the self block of panel row tr
     const int ncp = d.near_ncols[t];
     const dvec2* sym = reinterpret_cast<const dvec2*>(d.near_sym + d.near_sym_off[t]);
@@ -1246,7 +1526,54 @@ hipError_t launch_gather_x(const DevicePlan& d, const double* x, hipStream_t s) 
   return hipGetLastError();
 }
 
+// Hybrid plans (near_stream_fraction < 1).  Two forms:
+//   side by side (default): near_spmv_sym3 over the stream items on `s`, the recompute kernel over the recompute items on `s2`
+//     (forked from and joined to `s` through the two events): kS workgroups per CU of the one (96 VGPRs), kR of the other
+//     (<= 168), sized so that BOTH are resident on every CU from start to end -- which two grids that each fill the chip never
+//     are (profiles/r05a_near_split_step_a.txt);
+//   mixed (FMMBEM_HYB_MODE=0): one kernel, both kinds of items in one list.
+hipError_t launch_near_hybrid(const DevicePlan& d, hipStream_t s, hipStream_t s2, hipEvent_t fork, hipEvent_t join) {
+  if (d.dof != 3 || !d.hyb_items) return hipErrorInvalidValue;
+  static const int mode = [] { const char* e = std::getenv("FMMBEM_HYB_MODE"); return e ? std::atoi(e) : 1; }();
+  static const int kS = [] { const char* e = std::getenv("FMMBEM_HYB_WG_STREAM"); return e ? std::atoi(e) : 3; }();
+  static const int kR = [] { const char* e = std::getenv("FMMBEM_HYB_WG_RECOMPUTE"); return e ? std::atoi(e) : 1; }();
+  const size_t ldsh = 3 * (size_t)kHybChunk * sizeof(double) + 2 * (size_t)d.max_runs * sizeof(int);
+  const dim3 b(kSpmvWaves * kWave);
+  const bool trac = d.stokes_traction_targets != 0;
+  if (mode == 0 || !s2) {
+    if (d.hyb_nitems <= 0) return hipSuccess;
+    const dim3 g(std::min(d.hyb_nitems, 256 * kHybOcc));
+    if (trac) hipLaunchKernelGGL((near_hybrid3_kernel<true, true>), g, b, ldsh, s, d);
+    else hipLaunchKernelGGL((near_hybrid3_kernel<false, true>), g, b, ldsh, s, d);
+    return hipGetLastError();
+  }
+  hipError_t e = hipSuccess;
+  const bool both = d.near_nitems > 0 && d.sym_nitems > 0;
+  if (both) {
+    if ((e = hipEventRecord(fork, s)) != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(s2, fork, 0)) != hipSuccess) return e;
+  }
+  if (d.near_nitems > 0) {                             // the recompute kernel first: its few, large workgroups must find room on every CU
+    const dim3 g(std::min(d.near_nitems, 256 * kR));
+    hipStream_t sr = both ? s2 : s;
+    if (trac) hipLaunchKernelGGL((near_hybrid3_kernel<true, false>), g, b, ldsh, sr, d);
+    else hipLaunchKernelGGL((near_hybrid3_kernel<false, false>), g, b, ldsh, sr, d);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+  }
+  if (d.sym_nitems > 0) {
+    const size_t lds3 = 3 * (size_t)kSymChunk * sizeof(double) + 2 * (size_t)d.max_runs * sizeof(int);
+    hipLaunchKernelGGL((near_spmv_sym3_kernel<1, 3>), dim3(std::min(d.sym_nitems, 256 * kS)), b, lds3, s, d);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+  }
+  if (both) {
+    if ((e = hipEventRecord(join, s2)) != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(s, join, 0)) != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
 hipError_t launch_near_spmv(const DevicePlan& d, hipStream_t s) {
+  if (d.hyb_items) return hipErrorInvalidValue;        // hybrid plans go through launch_near_hybrid
   if (d.near_nitems <= 0) return hipSuccess;
   if (d.dof == 3 && d.near_sym) {
     const size_t lds3 = 3 * (size_t)kSymChunk * sizeof(double) + 2 * (size_t)d.max_runs * sizeof(int);

@@ -8,6 +8,7 @@
 #include <chrono>
 #include <cmath>
 #include <complex>
+#include <cstdio>
 #include <cstring>
 #include <cstdlib>
 #include <memory>
@@ -194,6 +195,14 @@ struct fmmbem_plan {
   std::vector<ShiftOpDev> up_ops, down_ops;                    // M2M / L2L operators, index p - 1
   int64_t near_bytes = 0;
   int64_t near_side_entries = 0;                               // matrix-free plans: listed near-regime pairs (12 bytes each)
+  // hybrid near field (fmmbem_options.near_stream_fraction < 1): which leaves keep no matrix; host copies of the block offsets
+  bool hybrid = false;
+  std::vector<uint8_t> near_rec_host;                          // [leaf] 1 = recomputed
+  std::vector<int64_t> near_off_host, sym_off_host;            // [leaf] offsets of the stored blocks (introspection)
+  int64_t near_recomputed_pairs = 0;
+  hipStream_t hyb_stream = nullptr;                            // the recompute kernel runs beside the streaming one
+  hipEvent_t hyb_fork = nullptr, hyb_join = nullptr;
+  int build_side_lists();
   int64_t n_classes = 0;
   double build_host_ms = 0, build_assemble_ms = 0;
   // execute state
@@ -243,6 +252,9 @@ struct fmmbem_plan {
       for (auto& e : ev) (void)hipEventDestroy(e);
       for (auto& g : graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
       if (own_stream) (void)hipStreamDestroy(own_stream);
+      if (hyb_stream) (void)hipStreamDestroy(hyb_stream);
+      if (hyb_fork) (void)hipEventDestroy(hyb_fork);
+      if (hyb_join) (void)hipEventDestroy(hyb_join);
     }
   }
 };
@@ -259,6 +271,16 @@ static void rot_record(const double tr[3], double* o) {
   if (std::fabs(tr[0]) + std::fabs(tr[1]) < kEps) { o[3] = 1; o[4] = 0; }
   else if (std::fabs(tr[0]) < kEps) { o[3] = 0; o[4] = tr[1] > 0 ? 1.0 : -1.0; }
   else { const double h = 1.0 / std::sqrt(tr[0] * tr[0] + tr[1] * tr[1]); o[3] = tr[0] * h; o[4] = tr[1] * h; }
+}
+
+// EXPERIMENT (round 5; tools/near_split_experiment.py): FMMBEM_NEAR_SUBSET="a/b" keeps only the near-field
+// work items of the leaves l with l % b < a (a > 0) or l % b >= -a (a < 0), so that an assembled plan and a matrix-free plan of
+// the same geometry can each take a complementary part of the near field and run side by side on two streams.
+static bool near_subset_keeps(int leaf) {
+  int a = 0, b = 0;
+  const char* e = std::getenv("FMMBEM_NEAR_SUBSET");              // read per call: the experiment builds two plans with different subsets
+  if (!e || std::sscanf(e, "%d/%d", &a, &b) != 2 || b <= 0 || a == 0) return true;
+  return a > 0 ? leaf % b < a : leaf % b >= -a;
 }
 
 int fmmbem_plan::to_device() {
@@ -341,8 +363,40 @@ int fmmbem_plan::to_device() {
   int max_cols = 2, max_runs = 1;
   for (int l = 0; l < nl; ++l) {
     const int b = hp.leaf_box[l];
-    leaf_row0[l] = hp.box_body_begin[b];
     leaf_nrows[l] = hp.box_body_end[b] - hp.box_body_begin[b];
+  }
+  // Hybrid near field: the leaves that keep NO matrix.  Chosen on the WHOLE tree (every shard builds the same tree and reaches the
+  // same verdict for a leaf, so a shard's rows carry the bits of the single plan): the leaves with the most rows first -- a
+  // recomputed pair costs the same arithmetic wherever it sits, but the source panel's 128 bytes are read once per item and
+  // amortised over the item's rows -- until their pairs make up 1 - near_stream_fraction of all near pairs.
+  std::vector<uint8_t> rec(nl, 0);
+  {
+    double f = opts.near_stream_fraction;
+    if (const char* e = std::getenv("FMMBEM_NEAR_STREAM_FRACTION")) f = std::atof(e);
+    bool rule_ok = hp.rule.n <= (dof == 3 ? 4 : 3);               // the far-regime points of a source live in registers
+    for (int q = 2; q < hp.rule.n; ++q) rule_ok = rule_ok && hp.rule.w[q] == hp.rule.w[1];      // K = 1, 3, 4: two distinct weights at most
+    const bool stokes_sym_on = !(std::getenv("FMMBEM_STOKES_SYM") && std::atoi(std::getenv("FMMBEM_STOKES_SYM")) == 0);
+    hybrid = f < 1.0 && opts.sparse_local && hp.opt.evaluator == 0 && rule_ok && dof == 3 && stokes_sym_on;
+    if (hybrid) {
+      if (!(f >= 0.0)) f = 0.0;
+      std::vector<int> order(nl);
+      for (int l = 0; l < nl; ++l) order[l] = l;
+      std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return leaf_nrows[a] > leaf_nrows[b]; });
+      double all = 0;
+      for (int l = 0; l < nl; ++l) all += (double)leaf_nrows[l] * hp.near_ncols[l];
+      double acc = 0;
+      for (int l : order) {
+        if (acc >= (1.0 - f) * all) break;
+        rec[l] = 1;
+        acc += (double)leaf_nrows[l] * hp.near_ncols[l];
+      }
+      near_recomputed_pairs = 0;
+      for (int l = hp.leaf_begin; l < hp.leaf_end; ++l) if (rec[l]) near_recomputed_pairs += (int64_t)leaf_nrows[l] * hp.near_ncols[l];
+    }
+  }
+  for (int l = 0; l < nl; ++l) {
+    const int b = hp.leaf_box[l];
+    leaf_row0[l] = hp.box_body_begin[b];
     near_stride[l] = (dof * hp.near_ncols[l] + 1) & ~1;      // in unknowns (dof per panel), rows 16-B aligned
     // source leaves are ascending; leaves with consecutive indices own adjacent rows -> one run
     int col = 0, runs = 0;
@@ -358,7 +412,7 @@ int fmmbem_plan::to_device() {
     run_ptr[l + 1] = (int64_t)run_row0.size();
     if (l >= hp.leaf_begin && l < hp.leaf_end) {
       near_off[l] = total;
-      total += (int64_t)dof * leaf_nrows[l] * near_stride[l];
+      if (!rec[l]) total += (int64_t)dof * leaf_nrows[l] * near_stride[l];
       max_cols = std::max(max_cols, near_stride[l]);
       max_runs = std::max(max_runs, runs);
     }
@@ -386,6 +440,8 @@ int fmmbem_plan::to_device() {
       const int nr = idof * leaf_nrows[l];
       const int64_t row_bytes = opts.sparse_local ? (int64_t)near_stride[l] * 8 : (int64_t)hp.near_ncols[l] * 8;
       if (nr == 0 || row_bytes == 0) continue;
+      if (!near_subset_keeps(l)) continue;
+      if (hybrid) continue;                             // hybrid plans build their own lists below (these items feed kernels they do not run)
       int per = (int)std::max<int64_t>(1, kItemBytes / row_bytes);
       if (per >= 8) per &= ~7; else per = std::min(4, nr);
       const int cnt = (nr + per - 1) / per;
@@ -428,9 +484,11 @@ int fmmbem_plan::to_device() {
       for (int l = hp.leaf_begin; l < hp.leaf_end; ++l) {
         const int nr = leaf_nrows[l], ncp = hp.near_ncols[l];
         sym_off[l] = sym_total;
+        if (rec[l]) continue;                           // hybrid: no block, no stream item
         sym_total += (int64_t)6 * nr * ncp;
         const int64_t row_bytes = (int64_t)48 * ncp;
         if (nr == 0 || row_bytes == 0) continue;
+        if (!near_subset_keeps(l)) continue;
         int per = (int)std::max<int64_t>(1, kItemBytes / row_bytes);
         if (per >= 8) per &= ~7; else per = std::min(4, nr);
         const int cnt = (nr + per - 1) / per;
@@ -444,10 +502,57 @@ int fmmbem_plan::to_device() {
       d.sym_nitems = (int)packed.size();
       TRY(upload(packed, &d.sym_items));
       TRY(upload(sym_off, &d.near_sym_off));
-      TRY(alloc((size_t)sym_total, &d.near_sym, false));
+      TRY(alloc((size_t)std::max<int64_t>(sym_total, 1), &d.near_sym, false));
       near_bytes = sym_total * (int64_t)sizeof(double);
+      sym_off_host = sym_off;
+      if (hybrid) {
+        // recompute items: panel-row ranges of the recomputed leaves -- whole leaves, except that a range holds at most 64 rows
+        // (the kernel's LDS slots) and ~kRecPairs pairs (a coarse leaf of an adaptive tree sees 10^4 columns); rows in fives
+        constexpr int64_t kRecPairs = 16384;
+        struct RItem { int leaf, r0, nr; int64_t pairs; };
+        std::vector<RItem> ritems;
+        for (int l = hp.leaf_begin; l < hp.leaf_end; ++l) {
+          const int nr = leaf_nrows[l], ncp = hp.near_ncols[l];
+          if (!rec[l] || nr == 0 || ncp == 0) continue;
+          int per = (int)std::min<int64_t>(64, std::max<int64_t>(5, kRecPairs / ncp));
+          per = std::max(5, per / 5 * 5);
+          const int cnt = (nr + per - 1) / per;
+          per = ((nr + cnt - 1) / cnt + 4) / 5 * 5;
+          per = std::min(per, 60);
+          for (int r0 = 0; r0 < nr; r0 += per) { const int k = std::min(per, nr - r0); ritems.push_back({l, r0, k, (int64_t)k * ncp}); }
+        }
+        std::stable_sort(ritems.begin(), ritems.end(), [](const RItem& a, const RItem& b) { return a.pairs > b.pairs; });
+        // the side listing (mf_sweep COUNT / FILL) walks d.near_items: the recompute items, panel rows
+        std::vector<int4> rpacked(ritems.size());
+        for (size_t i = 0; i < ritems.size(); ++i) rpacked[i] = make_int4(ritems[i].leaf, ritems[i].r0, ritems[i].nr, 0);
+        d.near_nitems = (int)rpacked.size();
+        TRY(upload(rpacked, &d.near_items));
+        // ONE list for the hybrid kernel: both kinds largest first, merged so that at every point of the list the two kinds have
+        // been dealt the same share of their totals -- the workgroups of a CU are then at items of both kinds at any time, which
+        // is the point (arithmetic in the issue slots the streaming leaves empty); sorted by kind they would run one after the other
+        double tot_s = 0, tot_r = 0;
+        for (const auto& it : items) tot_s += (double)it.bytes;
+        for (const auto& it : ritems) tot_r += (double)it.pairs;
+        std::vector<int4> merged;
+        merged.reserve(items.size() + ritems.size());
+        size_t is = 0, ir = 0;
+        double cs = 0, cr = 0;
+        while (is < items.size() || ir < ritems.size()) {
+          const bool take_r = ir < ritems.size() && (is >= items.size() || cr / std::max(tot_r, 1.0) <= cs / std::max(tot_s, 1.0));
+          if (take_r) { const auto& it = ritems[ir++]; cr += (double)it.pairs; merged.push_back(make_int4(it.leaf, it.r0, it.nr, 2)); }
+          else { const auto& it = items[is++]; cs += (double)it.bytes; merged.push_back(make_int4(it.leaf, it.r0, it.nr, it.nr < 8 ? 1 : 0)); }
+        }
+        d.hyb_nitems = (int)merged.size();
+        TRY(upload(merged, &d.hyb_items));
+        HIP_TRY(hipStreamCreateWithFlags(&hyb_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&hyb_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&hyb_join, hipEventDisableTiming));
+        TRY(upload(rec, &d.near_rec));
+      }
     }
   }
+  near_rec_host = rec;
+  near_off_host = near_off;
 
   // boxes, expansions, tables
   TRY(upload(hp.box_center, &d.box_center));
@@ -798,8 +903,24 @@ int fmmbem_plan::to_device() {
     else HIP_TRY(launch_near_assemble(d, own_stream));
     HIP_TRY(hipStreamSynchronize(own_stream));
   }
-  else if (hp.row_end > hp.row_begin) {
-    // matrix-free: nothing is assembled, but the pairs of the near regimes -- the expensive 4.5 %, the same numbers every matvec
+  if ((!opts.sparse_local || hybrid) && hp.row_end > hp.row_begin) TRY(build_side_lists());
+  build_assemble_ms = now_ms() - t0;
+  mark("near assembly");
+  {                                                    // the plan itself, readable from the device
+    void* pd = nullptr;
+    HIP_TRY(hipMalloc(&pd, sizeof(DevicePlan)));
+    allocs.push_back(pd);
+    HIP_TRY(hipMemcpy(pd, &d, sizeof(DevicePlan), hipMemcpyHostToDevice));
+    d_dev = static_cast<const DevicePlan*>(pd);
+  }
+  return FMMBEM_OK;
+}
+
+// matrix-free plans (every owned row) and hybrid plans (the rows of the recomputed leaves; the others list nothing):
+int fmmbem_plan::build_side_lists() {
+  const int dof = d.dof;
+  {
+    // nothing is assembled for these rows, but the pairs of the near regimes -- the expensive 4.5 %, the same numbers every matvec
     // -- are listed per target row and evaluated once (kernels_near.hip, near_matfree third form): count, scan, fill, evaluate
     int* d_cnt = nullptr;
     TRY(alloc((size_t)hp.n, &d_cnt, true));
@@ -828,15 +949,6 @@ int fmmbem_plan::to_device() {
       (void)hipFree(tmp);
       allocs.erase(std::find(allocs.begin(), allocs.end(), tmp));
     }
-  }
-  build_assemble_ms = now_ms() - t0;
-  mark("near assembly");
-  {                                                    // the plan itself, readable from the device
-    void* pd = nullptr;
-    HIP_TRY(hipMalloc(&pd, sizeof(DevicePlan)));
-    allocs.push_back(pd);
-    HIP_TRY(hipMemcpy(pd, &d, sizeof(DevicePlan), hipMemcpyHostToDevice));
-    d_dev = static_cast<const DevicePlan*>(pd);
   }
   return FMMBEM_OK;
 }
@@ -957,8 +1069,10 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
     return FMMBEM_OK;
   }
   auto near_field = [&](hipStream_t ns) -> int {
+    if (std::getenv("FMMBEM_NEAR_SUBSET")) HIP_TRY(hipMemsetAsync(d.yt, 0, sizeof(double) * (size_t)d.n * d.dof, ns));   // experiment: rows of the other part read as zero
     HIP_TRY(begin(1, ns));
-    if (opts.sparse_local) HIP_TRY(launch_near_spmv(d, ns)); else HIP_TRY(launch_near_matfree(d, ns));
+    if (hybrid) HIP_TRY(launch_near_hybrid(d, ns, hyb_stream, hyb_fork, hyb_join));
+    else if (opts.sparse_local) HIP_TRY(launch_near_spmv(d, ns)); else HIP_TRY(launch_near_matfree(d, ns));
     HIP_TRY(end(1, ns));
     return FMMBEM_OK;
   };
@@ -1039,6 +1153,7 @@ void fmmbem_options_default(fmmbem_options* o) {
   o->shard_world = 1;
   o->quad_k_fine = 25;          // StokesSphericalBEM ctor default (kernel/StokesSphericalBEM.hpp:131)
   o->mu = 1e-3;
+  o->near_stream_fraction = 1.0;
 }
 
 int fmmbem_plan_create(const fmmbem_options* opts, size_t n_panels, const double* vertices, const uint8_t* bc,
@@ -1248,6 +1363,7 @@ int fmmbem_plan_stats(const fmmbem_plan* plan, fmmbem_stats* o) {
   o->m2l_items = (int64_t)(long_items ? h.rot_item_ptr_long : h.rot_item_ptr).size() - 1;
   o->m2l_passes = long_items ? h.rot_passes_long : h.rot_passes;
   o->near_side_entries = plan->near_side_entries;
+  o->near_recomputed_pairs = plan->near_recomputed_pairs;
   o->expansion_slots = plan->on_device ? plan->d.nslots : (plan->opts.kernel == FMMBEM_KERNEL_STOKES_BEM ? 8 : 2);
   o->m2l_kernel = plan->last_p > 0 ? (plan->use_rot(plan->last_p) ? 1 : plan->last_p <= 4 ? 3 : 2) : 0;
   o->rot_nop_orders = (int64_t)rot_nop_orders_m2l() | ((int64_t)rot_nop_orders_m2m() << 16) | ((int64_t)rot_nop_orders_l2l() << 32);

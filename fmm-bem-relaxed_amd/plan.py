@@ -30,6 +30,9 @@ class FMMOptions:
         # not in the reference: True applies exactly the L2L edges the reference's lazy evaluator queues, which on
         # adaptive trees leaves some boxes without their ancestors' far field (include/fmmbem.h, fmmbem_l2l_rule)
         self.reference_l2l = False
+        # not in the reference: share of the near-field pairs kept as a matrix; < 1: the rest is recomputed every matvec by the
+        # same kernel between its streamed items (include/fmmbem.h, fmmbem_options.near_stream_fraction)
+        self.near_stream_fraction = 1.0
 
     def set_mac_theta(self, theta):     # FMMOptions.hpp:50-52
         self.theta = float(theta)
@@ -206,6 +209,7 @@ class FMM_plan:
         o.host_only = 1 if host_only else 0
         o.evaluator = evaluator
         o.l2l_rule = _capi.L2L_REFERENCE if getattr(opts, "reference_l2l", False) else _capi.L2L_COMPLETE
+        o.near_stream_fraction = float(getattr(opts, "near_stream_fraction", 1.0))
         o.device = int(device)
         self.device = int(device)
         self.dof = 1

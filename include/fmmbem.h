@@ -95,6 +95,17 @@ typedef struct {
                                * all-to-all of the ones each receiver reads (fmmbem_plan_exchange_counts);
                                * 0: every shard repeats the whole upward pass                                  */
   int32_t  l2l_rule;          /* fmmbem_l2l_rule: which parent->child L2L edges the downward pass applies              */
+  double   near_stream_fraction; /* sparse_local = 1: share of the near-field pairs whose entries are STORED and streamed every
+                               * matvec (P2P_Lazy::to_matrix + Matvec<>, EvalP2P.hpp:47-98, Matvec.hpp:14-33).  1.0 (default): all
+                               * of them, the reference's assembled matrix.  0 <= f < 1, HYBRID: the target leaves with the most
+                               * rows keep no matrix until they hold 1 - f of the pairs; their far-regime entries are recomputed
+                               * every matvec from the quadrature points (what EvalInteractionLazy::eval_P2P_lists does,
+                               * EvalInteractionLazy.hpp:239-252) by the SAME kernel between its streamed items -- arithmetic in
+                               * the issue slots the HBM-bound stream leaves empty -- and their near-regime entries are evaluated
+                               * once.  Footprint and HBM bytes fall by 1 - f; a row's sum is formed in a fixed order, results
+                               * differ from f = 1 in the last bits.  Taken as 1 where the hybrid kernel does not apply (rules of
+                               * more than 3 / 4 points, the LOCAL / BLOCK_DIAGONAL evaluators).  FMMBEM_NEAR_STREAM_FRACTION
+                               * overrides it at creation (sweeps).                                                      */
 } fmmbem_options;
 
 /* Statistics of a plan and of its last execute (times in milliseconds, device-side HIP events). */
@@ -124,6 +135,8 @@ typedef struct {
                                  * tools/check_rot_isa.py): bit p-1 M2L, bit 16+p-1 M2M, bit 32+p-1 L2L.
                                  * 0 on the toolchain this was developed with; such an order runs ~30 % slower, not wrong */
   int32_t tree_coder_levels;    /* 10: the reference's 32-bit Morton coder built the tree; 21: the 64-bit coder had to (deeper tree) */
+  int64_t near_recomputed_pairs;/* hybrid plans (near_stream_fraction < 1): panel pairs of this shard that are recomputed every matvec
+                                 * instead of stored (near_nnz counts all of the shard's entries, near_bytes what is stored)         */
 } fmmbem_stats;
 
 typedef struct fmmbem_plan fmmbem_plan;
