@@ -57,6 +57,10 @@ def parse():
     ap.add_argument("--matrix-free", action="store_true",
                     help="sparse_local = false: the near field recomputed every matvec (EvalInteractionLazy, SURVEY a8) "
                          "instead of the assembled matrix; the roofline object then reports FP64 flop/s, not HBM GB/s")
+    ap.add_argument("--near-stream-fraction", type=float, default=1.0,
+                    help="share of the near-field pairs kept as a matrix (fmmbem_options.near_stream_fraction); < 1: the rest is "
+                         "recomputed every matvec beside the streamed part (Stokes workloads; the roofline object then states "
+                         "streamed bytes AND recomputed pairs)")
     ap.add_argument("--workload", choices=["laplace", "stokes_rbc", "stokes_rbc_traction"], default="laplace",
                     help="laplace: the BASELINE metric workload (default); stokes_rbc: SURVEY 8(d) config 4 "
                          "(StokesSphericalBEM velocity BC on RedBloodCell(r), p=8, k=4, K_fine=19, mu=1e-3)")
@@ -301,6 +305,7 @@ def main():
     opts.set_mac_theta(args.theta)
     opts.set_max_per_box(args.ncrit)
     opts.sparse_local = not args.matrix_free
+    opts.near_stream_fraction = args.near_stream_fraction
     if traction:
         bc = np.ones(len(v), dtype=np.uint8)
 
@@ -403,7 +408,9 @@ def main():
     # ---- roofline of the P2P kernel on this rank's shard (SURVEY.md section 8d "Algorithmic bytes, P2P") ----
     rows = st["owned_row_end"] - st["owned_row_begin"]
     # Stokes: the 3x3 block of a panel pair is symmetric and is streamed as 6 values, not the 9 of SURVEY 8d
-    p2p_bytes = st["near_nnz"] * 8 * (6 if stokes else 1) + n * 8 * dof + rows * 8 * dof
+    hybrid = st["near_recomputed_pairs"] > 0
+    # a hybrid plan streams only the blocks it stores (near_bytes); the recomputed pairs cost arithmetic, stated beside the bytes
+    p2p_bytes = (st["near_bytes"] if hybrid else st["near_nnz"] * 8 * (6 if stokes else 1)) + n * 8 * dof + rows * 8 * dof
     near_ms = st_near["ms_near"]                              # measured live over the timed region, on the launch stream
     p2p_gbs = p2p_bytes / (near_ms * 1e-3) / 1e9 if near_ms > 0 else 0.0
     traffic = None
@@ -470,7 +477,13 @@ def main():
                     {"kernel": "near_spmv (P2P)", "bound": "hbm", "achieved": p2p_gbs, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": p2p_gbs / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": p2p_bytes, "launch_ms": near_ms,
-                     "timed_launches": st_near["timed_executes"]},
+                     "timed_launches": st_near["timed_executes"],
+                     **({"near_stream_fraction": args.near_stream_fraction, "streamed_bytes": st["near_bytes"],
+                         "recomputed_pairs": st["near_recomputed_pairs"], "recomputed_quadrature_points": st["near_recomputed_pairs"] * (4 if stokes else 3),
+                         "listed_near_regime_pairs": st["near_side_entries"],
+                         "note": "hybrid near field: launch_ms spans the streaming kernel and the recompute kernel running side by side; "
+                                 "`achieved` counts the streamed bytes only, so it falls short of the HBM rate of the streaming kernel itself "
+                                 "when the recompute kernel is the longer of the two"} if hybrid else {})},
         "roofline_m2l": {"kernel": {1: "m2l_rot", 2: "m2l (double sum)", 3: "m2l_small (double sum, lanes = sources)"}.get(st["m2l_kernel"], "?"), "bound": "fp64 vector FMA", "achieved": m2l_tflops,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": m2l_tflops / FP64_PEAK_TFLOPS,
                          "executed_flops_per_launch": m2l_flops, "launch_ms": st["ms_m2l"],

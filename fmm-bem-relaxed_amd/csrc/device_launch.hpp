@@ -13,6 +13,7 @@ hipError_t launch_gather_x(const DevicePlan& d, const double* x, hipStream_t s);
 hipError_t launch_near_spmv(const DevicePlan& d, hipStream_t s);
 hipError_t launch_near_hybrid(const DevicePlan& d, hipStream_t s, hipStream_t s2, hipEvent_t fork, hipEvent_t join);   // near_stream_fraction < 1
 hipError_t launch_kernel_entries(const DevicePlan& d, int m, double* out, hipStream_t s);   // panels [0,m) targets, [m,2m) sources
+hipError_t launch_near_row_eval(const DevicePlan& d, int64_t prow, const int* cols, int n, double* out, hipStream_t s);
 hipError_t launch_near_diag(const DevicePlan& d, const int* selfcol, double* out, hipStream_t s);
 hipError_t launch_near_matfree(const DevicePlan& d, hipStream_t s);
 hipError_t launch_mf_side(const DevicePlan& d, int phase, int* side_cnt, const int64_t* side_ptr, int* side_col, const int* side_row,

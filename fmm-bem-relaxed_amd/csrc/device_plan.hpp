@@ -35,6 +35,15 @@ struct NearItem {
 };
 static_assert(sizeof(NearItem) == 48, "NearItem is read as three 16-byte pieces");
 
+// One unit of work of the recompute kernel (hybrid plans): rows [prow0, prow0 + nrows), nrows <= 20, of one recomputed leaf
+// against the leaf's ncp source panels; self-contained like NearItem
+struct RcItem {
+  int prow0, nrows, ncp, nruns;
+  int64_t run_begin;   // -> near_run_row0 / near_run_off
+  int leaf, pad;
+};
+static_assert(sizeof(RcItem) == 32, "RcItem is read as two 16-byte pieces");
+
 // M2M or L2L operator at one order p, terms dealt to virtual rows (shift_ops.hpp VOp); passed to the kernel by value.
 struct ShiftOpDev {
   const uint16_t *src, *y;     // [i * V + v]
@@ -96,10 +105,10 @@ struct DevicePlan {
   const int64_t* near_sym_off;                        // [nl] offset of a leaf's block in near_sym (doubles)
   const int4* sym_items;      int sym_nitems = 0;     // {leaf, first panel row, panel rows, column-split?}, largest first
   // Hybrid near field (near_stream_fraction < 1): near_rec[leaf] != 0 -> the leaf keeps no matrix block, its far-regime entries are
-  // recomputed every matvec and its near-regime pairs come from the side list; hyb_items = stream and recompute items of ONE
-  // persistent kernel, mixed: {leaf, first row, rows, bit 0 column-split (stream) | bit 1 recompute}
+  // recomputed every matvec (near_recompute3_kernel over rc_items) and its near-regime pairs come from the side list; the other
+  // leaves are streamed as ever (sym_items).  near_items = the recompute items as {leaf, first row, rows, 0} for the side listing
   const uint8_t* near_rec = nullptr;
-  const int4* hyb_items = nullptr;  int hyb_nitems = 0;
+  const RcItem* rc_items = nullptr;  int rc_nitems = 0;
   // boxes / expansions
   const double* box_center;
   double2 *M, *L, *Mh;

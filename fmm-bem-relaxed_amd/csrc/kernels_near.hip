@@ -1149,24 +1149,29 @@ __global__ __launch_bounds__(kSpmvWaves * kWave, kSymOcc) void near_spmv_sym3_ke
 }
 
 // ---------------------------------------------------------------------------------------------
-// Hybrid near field (fmmbem_options.near_stream_fraction < 1; round 5): ONE persistent kernel whose work items are of two kinds,
-// mixed in the order the workgroups are dealt them --
-//   * STREAM items: row ranges of target leaves whose blocks are stored (near_sym): near_spmv_sym3's arithmetic, HBM-bound, the
-//     VALU idle 95 % of the time;
-//   * RECOMPUTE items: row ranges of target leaves that keep NO matrix.  Their far-regime entries (K quadrature points per pair)
-//     are evaluated from the source panels' points -- lane = source panel, read once into registers (128 bytes against the
-//     48 bytes x rows the stored form would stream) and applied to the item's rows five at a time (the row's centroid is an LDS
-//     broadcast); the 15 partial sums of a row block cross the lanes through ONE 16-value halving butterfly (17 shuffles
-//     instead of 90) into the wavefront's own LDS slots; the near-regime pairs (semi-analytic / fine-rule / self entries, 4.5 %)
-//     were listed and evaluated once at plan creation (side_ptr / side_col / side_val, as the matrix-free plans do) and are added
-//     from the list, a row per wavefront.
-// On a CU the wavefronts of the 4-5 resident workgroups are at different items at any time, so the arithmetic of the recompute
-// items runs in the issue slots the stream items leave empty, and the matrix bytes of the recomputed leaves are never read
-// (nor stored: the footprint shrinks by the same share).  Every row is summed in a fixed order: column groups in order per
-// wavefront, the butterfly's tree, wavefronts 0..3, then the listed entries' tree.
-// Two existing kernels on two streams do NOT do this: profiles/r05a_near_split_step_a.txt (they serialise).
+// Hybrid near field (fmmbem_options.near_stream_fraction < 1; round 5).  The target leaves of such a plan are of two kinds:
+//   * STREAMED leaves keep their blocks (near_sym) and are served by near_spmv_sym3_kernel as before: HBM-bound, its VALU idle
+//     95 % of the time;
+//   * RECOMPUTED leaves keep NO matrix.  near_recompute3_kernel evaluates their far-regime entries (K quadrature points per pair)
+//     every matvec from the source panels' points; the near-regime pairs (semi-analytic / fine-rule / self entries, 4.5 %) were
+//     listed and evaluated once at plan creation (side_ptr / side_col / side_val, as the matrix-free plans do).
+// The two kernels run SIDE BY SIDE on two streams, each with its own register budget and a grid sized so that both are resident on
+// every CU from start to end (launch_near_hybrid): the arithmetic of the one runs in the issue slots the other leaves empty, and
+// the matrix bytes of the recomputed leaves are neither read nor stored.  (Two grids that each fill the chip serialise:
+// profiles/r05a_near_split_step_a.txt; one kernel that takes both kinds of items pays the larger register budget on its streaming
+// wavefronts and loses what it gains: profiles/r05b_*.)
+//
+// near_recompute3_kernel: persistent 256-thread workgroups, items = row ranges of <= 20 panel rows of one recomputed leaf (RcItem).
+//   * the item's source panels pass through LDS 256 at a time: thread = source panel, 19 doubles (4 points, centroid, area, the
+//     panel's charge; 22 with the normal for TRACTION targets) loaded into registers one chunk AHEAD -- of this item, or the first
+//     chunk of the next one -- while the current chunk is worked on, so that no wavefront ever waits for a dependent load inside
+//     an item; item records and run descriptors come two items ahead (the pipeline of near_spmv_pipe_kernel);
+//   * wavefront w owns rows 5w .. 5w+4 of the item: lane = source panel (LDS -> registers per group of 64), the 15 partial sums
+//     stay in the lane's registers over ALL columns of the item; the rows' listed entries are added into the same registers
+//     (lane = entry); ONE 16-value halving butterfly (17 shuffles instead of 90) ends the item and the lanes that hold the 15
+//     totals store them.  A row's sum is formed in a fixed order.
 // ---------------------------------------------------------------------------------------------
-constexpr int kHybRows = 5;                           // rows per block of a recompute item (3 sums each + 1 pad = 16 values)
+constexpr int kHybRows = 5;                           // rows per wavefront of a recompute item (3 sums each + 1 pad = 16 values)
 
 // v[0..15] per lane -> every lane returns the sum over all 64 lanes of value hyb_value_of(lane); fixed tree.
 // One halving step: the lanes whose `BIT` is set keep the upper W values, the others the lower W, and each adds what its
@@ -1194,218 +1199,193 @@ __device__ __forceinline__ double hyb_reduce16(double (&v)[16], int lane) {
 }
 __device__ __forceinline__ int hyb_value_of(int lane) { return (lane >> 2) & 15; }   // bits 5..2 of the lane, bit 5 = value bit 3
 
-#ifndef FMMBEM_HYB_OCC
-#define FMMBEM_HYB_OCC 3
+#ifndef FMMBEM_RC_OCC
+#define FMMBEM_RC_OCC 2
 #endif
-#ifndef FMMBEM_HYB_CHUNK
-#define FMMBEM_HYB_CHUNK 1024
+#ifndef FMMBEM_RC_QSCHED
+#define FMMBEM_RC_QSCHED 2
 #endif
-constexpr int kHybOcc = FMMBEM_HYB_OCC;               // workgroups per CU
-constexpr int kHybChunk = FMMBEM_HYB_CHUNK;           // source panels of x staged at a time
-constexpr int kHybMaxRows = 64;                       // rows of a recompute item (a leaf holds <= ncrit panels; the host cuts longer ranges)
+constexpr int kRcOcc = FMMBEM_RC_OCC;                 // register budget of the recompute kernel: 512 / kRcOcc VGPRs
+constexpr int kRcChunk = kSpmvWaves * kWave;          // source panels per chunk = threads of the workgroup
+constexpr int kRcItemRows = kSpmvWaves * kHybRows;    // 20: rows of an item
 
-// MIXED: one kernel takes both kinds of items (d.hyb_items); !MIXED: the recompute items only (d.near_items), beside
-// near_spmv_sym3_kernel on a second stream -- each kernel then has its own register budget (launch_near_spmv)
-template <bool TRAC, bool MIXED>
-__global__ __launch_bounds__(kSpmvWaves * kWave, kHybOcc) void near_hybrid3_kernel(DevicePlan d) {
-  extern __shared__ double xs[];                      // [3][kHybChunk] doubles, then the run descriptors
-  __shared__ double part[kSpmvWaves][kColRows][3];
-  __shared__ double rpart[3 * kHybMaxRows];               // recompute items: the rows' sums over the far-regime pairs
-  __shared__ double rside[3 * kHybMaxRows];               // ... and the rows' listed entries
-  __shared__ double tcx[kHybMaxRows], tcy[kHybMaxRows], tcz[kHybMaxRows];
-  __shared__ int tbc[kHybMaxRows];
-  int* run_row0 = reinterpret_cast<int*>(xs + 3 * kHybChunk);
-  int* run_off = run_row0 + d.max_runs;
+// y_tree[rows of the recomputed leaves] = the rows' LISTED entries (near-regime pairs, evaluated once at plan creation) times x:
+// a CSR product, a row per wavefront, lane = entry, the lanes added by wave_sum.  Runs in front of near_recompute3_kernel, which
+// adds the far regime to what this leaves in y.
+template <int DOF>
+__global__ __launch_bounds__(kSpmvWaves * kWave) void near_side_kernel(DevicePlan d) {
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  for (int item = blockIdx.x; item < d.rc_nitems; item += gridDim.x) {
+    const RcItem it = d.rc_items[item];
+    for (int r = wave; r < it.nrows; r += kSpmvWaves) {
+      const int64_t i = it.prow0 + r;
+      if constexpr (DOF == 3) {
+        double s0 = 0, s1 = 0, s2 = 0;
+        for (int64_t k = d.side_ptr[i] + lane; k < d.side_ptr[i + 1]; k += kWave) {
+          const double* m = d.side_val + 9 * k;
+          const int64_t cj = d.side_col[k];
+          const double y0 = d.xt[3 * cj], y1 = d.xt[3 * cj + 1], y2 = d.xt[3 * cj + 2];
+          s0 = fma(m[0], y0, fma(m[1], y1, fma(m[2], y2, s0)));
+          s1 = fma(m[3], y0, fma(m[4], y1, fma(m[5], y2, s1)));
+          s2 = fma(m[6], y0, fma(m[7], y1, fma(m[8], y2, s2)));
+        }
+        s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
+        if (lane == 0) { d.yt[3 * i] = s0; d.yt[3 * i + 1] = s1; d.yt[3 * i + 2] = s2; }
+      } else {
+        double s0 = 0;
+        for (int64_t k = d.side_ptr[i] + lane; k < d.side_ptr[i + 1]; k += kWave) s0 = fma(d.side_val[k], d.xt[d.side_col[k]], s0);
+        s0 = wave_sum(s0);
+        if (lane == 0) d.yt[i] = s0;
+      }
+    }
+  }
+}
+
+typedef __attribute__((address_space(4))) RcItem ConstRcItem;
+__device__ __forceinline__ RcItem load_rc_item(const ConstRcItem* r) {
+  RcItem o;
+  o.prow0 = r->prow0; o.nrows = r->nrows; o.ncp = r->ncp; o.nruns = r->nruns; o.run_begin = r->run_begin; o.leaf = r->leaf; o.pad = 0;
+  return o;
+}
+
+template <bool TRAC>
+__global__ __launch_bounds__(kSpmvWaves * kWave, kRcOcc) void near_recompute3_kernel(DevicePlan d) {
+  constexpr int F = TRAC ? 22 : 19;                   // doubles per source panel: 4 x (x,y,z), centroid, area, charge (3) [, normal]
+  extern __shared__ double src[];                     // [F][kRcChunk] doubles, then runbuf [2][2][max_runs] ints
+  int* const runbuf = reinterpret_cast<int*>(src + F * kRcChunk);
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, tid = threadIdx.x;
+  const int mr = d.max_runs, nitems = d.rc_nitems, step = gridDim.x;
   const int64_t N = d.n;
   const double sc = 1. / 2 / d.mu;
-  constexpr int kRows = 1, kVecs = 3;
-  const int4* const items = MIXED ? d.hyb_items : d.near_items;
-  const int nitems = MIXED ? d.hyb_nitems : d.near_nitems;
-  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-    const int4 it = items[item];
-    const int t = it.x, r0 = it.y, nrows = it.z;       // panel rows
-    const bool colsplit = (it.w & 1) != 0, recompute = !MIXED || (it.w & 2) != 0;
-    const int ncp = d.near_ncols[t];
-    const Runs runs = load_runs(d, t, run_row0, run_off);
-    if (MIXED && !recompute) {
-      // ---- stream item: near_spmv_sym3_kernel's body ----
-      const dvec2* blk = reinterpret_cast<const dvec2*>(d.near_sym + d.near_sym_off[t]) + (int64_t)r0 * 3 * ncp;
-      double* yt = d.yt + 3 * (int64_t)(d.leaf_row0[t] + r0);
-      for (int c0 = 0; c0 < ncp; c0 += kHybChunk) {
-        const int cw = ncp - c0 < kHybChunk ? ncp - c0 : kHybChunk;
-        if (c0) __syncthreads();
-        for (int c = tid; c < cw; c += blockDim.x) {
-          const double* xp = d.xt + 3 * (int64_t)column_to_row(runs, c0 + c);
-          xs[c] = xp[0]; xs[kHybChunk + c] = xp[1]; xs[2 * kHybChunk + c] = xp[2];
-        }
-        __syncthreads();
-        const int seg = colsplit ? ((((cw + kSpmvWaves - 1) / kSpmvWaves) + 3) & ~3) : cw;
-        const int v0 = colsplit ? wave * seg : 0, v1 = min(cw, v0 + seg);
-        const int rstep = colsplit ? 1 : kSpmvWaves;
-        for (int r = colsplit ? 0 : wave; r < nrows; r += colsplit ? kRows : kRows * kSpmvWaves) {
-          const dvec2* row[kRows];
-          double ax[kRows], ay[kRows], az[kRows];
+  const double w0 = d.qw[0], w1 = d.nq > 1 ? d.qw[1] : 0.0;        // the rules the host admits: weights of points 1.. all equal
+  const int nq = d.nq;
+  const ConstRcItem* recs = reinterpret_cast<const ConstRcItem*>(reinterpret_cast<uintptr_t>(d.rc_items));
+
+  int item = blockIdx.x;
+  if (item >= nitems) return;
+  RcItem it = load_rc_item(recs + item);
+  RcItem nx = load_rc_item(recs + (item + step < nitems ? item + step : nitems - 1));
+  for (int i = tid; i < it.nruns; i += blockDim.x) { runbuf[i] = d.near_run_row0[it.run_begin + i]; runbuf[mr + i] = d.near_run_off[it.run_begin + i]; }
+  for (int i = tid; i < nx.nruns; i += blockDim.x) { runbuf[2 * mr + i] = d.near_run_row0[nx.run_begin + i]; runbuf[3 * mr + i] = d.near_run_off[nx.run_begin + i]; }
+  __syncthreads();
+  // one source panel per thread into registers: column c of an item whose runs are `runs`
+  double pre[F];
+  auto fetch = [&](const Runs& runs, int c, int ncp) {
+    const unsigned j = (unsigned)column_to_row(runs, c < ncp ? c : 0);       // columns past the end repeat column 0; masked where they are used
+    const double* qp = d.quad + j;
 #pragma unroll
-          for (int i = 0; i < kRows; ++i) {
-            const int ri = r + i * rstep;
-            row[i] = blk + (int64_t)(ri < nrows ? ri : r) * 3 * ncp + c0;
-            ax[i] = ay[i] = az[i] = 0;
-          }
-          for (int c = v0 + lane; c < v1; c += kVecs * kWave) {
-            dvec2 v[kRows][kVecs][3];
-#pragma unroll
-            for (int u = 0; u < kVecs; ++u) {
-              const int cc = c + u * kWave;
-              const bool ok = cc < v1;
-#pragma unroll
-              for (int i = 0; i < kRows; ++i)
-#pragma unroll
-                for (int k = 0; k < 3; ++k) v[i][u][k] = ok ? __builtin_nontemporal_load(&row[i][k * ncp + cc]) : dvec2{0, 0};
-            }
-#pragma unroll
-            for (int u = 0; u < kVecs; ++u) {
-              const int cc = c + u * kWave;
-              if (cc < v1) {
-                const double x0 = xs[cc], x1 = xs[kHybChunk + cc], x2 = xs[2 * kHybChunk + cc];
-#pragma unroll
-                for (int i = 0; i < kRows; ++i) {
-                  const dvec2 a = v[i][u][0], b = v[i][u][1], e = v[i][u][2];   // (xx,xy) (xz,yy) (yz,zz)
-                  ax[i] = fma(a.x, x0, fma(a.y, x1, fma(b.x, x2, ax[i])));
-                  ay[i] = fma(a.y, x0, fma(b.y, x1, fma(e.x, x2, ay[i])));
-                  az[i] = fma(b.x, x0, fma(e.x, x1, fma(e.y, x2, az[i])));
-                }
-              }
-            }
-          }
-#pragma unroll
-          for (int i = 0; i < kRows; ++i) { ax[i] = wave_sum(ax[i]); ay[i] = wave_sum(ay[i]); az[i] = wave_sum(az[i]); }
-          if (lane == 0) {
-#pragma unroll
-            for (int i = 0; i < kRows; ++i) {
-              const int ri = r + i * rstep;
-              if (ri < nrows) {
-                if (colsplit) { part[wave][ri][0] = ax[i]; part[wave][ri][1] = ay[i]; part[wave][ri][2] = az[i]; }
-                else {
-                  double* y = yt + 3 * ri;
-                  y[0] = c0 ? y[0] + ax[i] : ax[i]; y[1] = c0 ? y[1] + ay[i] : ay[i]; y[2] = c0 ? y[2] + az[i] : az[i];
-                }
-              }
-            }
-          }
-        }
-        if (colsplit) {
-          __syncthreads();
-          if (tid < 3 * nrows) {
-            const int ri = tid / 3, a = tid % 3;
-            const double sum = ((part[0][ri][a] + part[1][ri][a]) + part[2][ri][a]) + part[3][ri][a];
-            yt[3 * ri + a] = c0 ? yt[3 * ri + a] + sum : sum;
-          }
-        }
-      }
-      __syncthreads();
-      continue;
+    for (int q = 0; q < 4; ++q) {
+      const bool have = q < nq;
+      pre[3 * q] = have ? qp[(q * 3 + 0) * N] : 0.0; pre[3 * q + 1] = have ? qp[(q * 3 + 1) * N] : 0.0; pre[3 * q + 2] = have ? qp[(q * 3 + 2) * N] : 1.0;
     }
-    // ---- recompute item ----
-    const int prow0 = d.leaf_row0[t] + r0;             // first tree-order panel row of the item
-    if (tid < nrows) {                                   // the rows' centroids: LDS broadcasts of the arithmetic below
-      const int64_t i = prow0 + tid;
-      tcx[tid] = d.cx[i]; tcy[tid] = d.cy[i]; tcz[tid] = d.cz[i];
-      if constexpr (TRAC) tbc[tid] = d.bc[i];
+    pre[12] = d.cx[j]; pre[13] = d.cy[j]; pre[14] = d.cz[j]; pre[15] = d.area[j];
+    const double* xp = d.xt + 3 * (size_t)j;
+    pre[16] = xp[0]; pre[17] = xp[1]; pre[18] = xp[2];
+    if constexpr (TRAC) { pre[19] = d.nx[j]; pre[20] = d.ny[j]; pre[21] = d.nz[j]; }
+  };
+  int rb = 0;
+  fetch(Runs{runbuf, runbuf + mr, it.nruns}, tid, it.ncp);
+  for (;; item += step) {
+    const bool more = item + step < nitems;
+    const int i2 = item + 2 * step;
+    const RcItem nn = load_rc_item(recs + (i2 < nitems ? i2 : nitems - 1));
+    const int nrows = it.nrows, ncp = it.ncp, prow0 = it.prow0;
+    const Runs runs{runbuf + rb * 2 * mr, runbuf + rb * 2 * mr + mr, it.nruns};
+    const Runs nruns{runbuf + (rb ^ 1) * 2 * mr, runbuf + (rb ^ 1) * 2 * mr + mr, nx.nruns};
+    int pr0 = 0, pr1 = 0;
+    const bool prun = i2 < nitems && tid < nn.nruns;     // max_runs <= blockDim.x is checked by the launcher
+    if (prun) { pr0 = d.near_run_row0[nn.run_begin + tid]; pr1 = d.near_run_off[nn.run_begin + tid]; }
+    // the rows dealt evenly: 17 rows are 5 + 4 + 4 + 4 (the wavefronts meet at two barriers per chunk: the slowest sets the pace)
+    const int rq = nrows / kSpmvWaves, rrem = nrows % kSpmvWaves;
+    const int rw = wave * rq + (wave < rrem ? wave : rrem);      // this wavefront's first row of the item
+    const int nrw = rq + (wave < rrem ? 1 : 0);                  // ... and how many it has (0: none)
+    // their centroids: wave-uniform loads, in registers for the whole item
+    double tx[kHybRows], ty[kHybRows], tz[kHybRows];
+    int tbw[kHybRows];
+#pragma unroll
+    for (int r = 0; r < kHybRows; ++r) {
+      const int64_t i = prow0 + rw + (r < nrw ? r : 0);
+      tx[r] = d.cx[i]; ty[r] = d.cy[i]; tz[r] = d.cz[i];
+      tbw[r] = TRAC ? d.bc[i] : 0;
     }
-    const double w0 = d.qw[0], w1 = d.nq > 1 ? d.qw[1] : 0.0;      // the rules the host admits: weights of points 1.. all equal
-    const int nq = d.nq;
-    for (int c0 = 0; c0 < ncp; c0 += kHybChunk) {
-      const int cw = ncp - c0 < kHybChunk ? ncp - c0 : kHybChunk;
-      if (c0) __syncthreads();
-      for (int c = tid; c < cw; c += blockDim.x) {
-        const double* xp = d.xt + 3 * (int64_t)column_to_row(runs, c0 + c);
-        xs[c] = xp[0]; xs[kHybChunk + c] = xp[1]; xs[2 * kHybChunk + c] = xp[2];
-      }
+    double v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = 0.0;
+    // the rows' listed (near-regime) entries were summed into y by near_side_kernel, launched in front of this one: the lanes that
+    // will hold the rows' totals fetch that value now and add to it at the end of the item
+    const bool mine = nrw > 0 && (lane & 3) == 0 && hyb_value_of(lane) < 3 * nrw;
+    const double ylist = mine ? d.yt[3 * (int64_t)(prow0 + rw) + hyb_value_of(lane)] : 0.0;
+    const int nchunks = (ncp + kRcChunk - 1) / kRcChunk;
+    for (int ck = 0; ck < nchunks; ++ck) {
+      __syncthreads();                                   // nobody reads the previous chunk (or the previous item's rows) any more
+#pragma unroll
+      for (int f = 0; f < F; ++f) src[f * kRcChunk + tid] = pre[f];
       __syncthreads();
-      // a wavefront takes kHybRows rows at a time (blocks wave, wave + 4, ...) against ALL columns of the chunk: the rows' sums stay in
-      // its registers over the column groups and cross the lanes once per block
-      for (int rb = wave * kHybRows; rb < nrows; rb += kSpmvWaves * kHybRows) {
-        double v[16];
+      // the chunk after this one -- of this item, or the first of the next -- in flight while this one is worked on
+      if (ck + 1 < nchunks) fetch(runs, (ck + 1) * kRcChunk + tid, ncp);
+      else if (more) fetch(nruns, tid, nx.ncp);
+      if (nrw <= 0) continue;                            // (wave-uniform) an item of fewer rows than wavefronts
+      const int cw = ncp - ck * kRcChunk < kRcChunk ? ncp - ck * kRcChunk : kRcChunk;
+      // a group of 64 source panels LDS -> registers one group ahead of the arithmetic (lane = source panel)
+      double cur[F], nxt[F];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = 0.0;
-        for (int cg = 0; cg * kWave < cw; ++cg) {
-          const int c = cg * kWave + lane;
-          const bool valid = c < cw;
-          const unsigned j = (unsigned)column_to_row(runs, c0 + (valid ? c : 0));
-          // this lane's source panel, once for the rows of the block
-          const double sx = d.cx[j], sy = d.cy[j], sz = d.cz[j], A = d.area[j];
-          const double near2 = valid ? 8.0 * A * (1.0 + 1e-9) : 1e300;      // lanes past the last column: every pair "listed", i.e. dropped
-          const double x0 = xs[valid ? c : 0], x1 = xs[kHybChunk + (valid ? c : 0)], x2 = xs[2 * kHybChunk + (valid ? c : 0)];
-          double nx = 0, ny = 0, nz = 0;
-          if constexpr (TRAC) { nx = d.nx[j]; ny = d.ny[j]; nz = d.nz[j]; }
-          double qx[4], qy[4], qz[4];                      // K = 1, 3, 4 (the host keeps hybrid plans to those rules)
-          const double* qp = d.quad + j;
+      for (int f = 0; f < F; ++f) cur[f] = src[f * kRcChunk + lane];
+      for (int cg = 0; cg * kWave < cw; ++cg) {
+        const int c = cg * kWave + lane;
+        const bool valid = c < cw;
+        if ((cg + 1) * kWave < cw) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const bool have = q < nq;
-            qx[q] = have ? qp[(q * 3 + 0) * N] : 0.0; qy[q] = have ? qp[(q * 3 + 1) * N] : 0.0; qz[q] = have ? qp[(q * 3 + 2) * N] : 1.0;
-          }
-          const double wA0 = w0 * A, wA1 = w1 * A;
+          for (int f = 0; f < F; ++f) nxt[f] = src[f * kRcChunk + c + kWave];
+        }
+        const double sx = cur[12], sy = cur[13], sz = cur[14], A = cur[15];
+        const double x0 = cur[16], x1 = cur[17], x2 = cur[18];
+        double nx_ = 0, ny_ = 0, nz_ = 0;
+        if constexpr (TRAC) { nx_ = cur[19]; ny_ = cur[20]; nz_ = cur[21]; }
+        const double near2 = valid ? 8.0 * A * (1.0 + 1e-9) : 1e300;        // lanes past the last column: every pair "listed", i.e. dropped
+        const double wA0 = w0 * A, wA1 = w1 * A;
 #pragma unroll
-          for (int r = 0; r < kHybRows; ++r) {
-            const int ri = rb + r < nrows ? rb + r : nrows - 1;      // rows past the end repeat the last one; their sums are not stored
-            const double tx = tcx[ri], ty = tcy[ri], tz = tcz[ri];
-            const bool slow = mf_listed(tx - sx, ty - sy, tz - sz, near2);
+        for (int r = 0; r < kHybRows; ++r) {
+          if (r < nrw) {                                   // wave-uniform
+            const bool slow = mf_listed(tx[r] - sx, ty[r] - sy, tz[r] - sz, near2);
             bool trac = false;
-            if constexpr (TRAC) trac = __builtin_amdgcn_readfirstlane(tbc[ri]) != 0;
+            if constexpr (TRAC) trac = __builtin_amdgcn_readfirstlane(tbw[r]) != 0;
             double u0 = 0, u1 = 0, u2 = 0;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               const double wA = q ? (q < nq ? wA1 : 0.0) : wA0;
-              const double ex = tx - qx[q], ey = ty - qy[q], ez = tz - qz[q];
+              const double ex = tx[r] - cur[3 * q], ey = ty[r] - cur[3 * q + 1], ez = tz[r] - cur[3 * q + 2];
               const double ir = rsqrt_pos(fma(ex, ex, fma(ey, ey, ez * ez)));
               const double ir3 = ir * ir * ir, dxq = fma(ex, x0, fma(ey, x1, ez * x2));
               if (TRAC && trac) {
-                const double g = wA * fma(ex, nx, fma(ey, ny, ez * nz)) * dxq * (ir3 * ir * ir);
+                const double g = wA * fma(ex, nx_, fma(ey, ny_, ez * nz_)) * dxq * (ir3 * ir * ir);
                 u0 = fma(g, ex, u0); u1 = fma(g, ey, u1); u2 = fma(g, ez, u2);
               } else {
                 const double f1 = wA * ir, g = wA * ir3 * dxq;
                 u0 = fma(f1, x0, fma(g, ex, u0)); u1 = fma(f1, x1, fma(g, ey, u1)); u2 = fma(f1, x2, fma(g, ez, u2));
               }
-#ifndef FMMBEM_HYB_QSCHED
-#define FMMBEM_HYB_QSCHED 2
-#endif
-              // FMMBEM_HYB_QSCHED points at a time: left alone the scheduler interleaves all four points of a row (25 doubles of
-              // temporaries each) and the kernel needs 210 VGPRs
-              if ((q + 1) % FMMBEM_HYB_QSCHED == 0) __builtin_amdgcn_sched_barrier(0);
+              // FMMBEM_RC_QSCHED points at a time: left alone the scheduler interleaves all four points of all five rows
+              if ((q + 1) % FMMBEM_RC_QSCHED == 0) __builtin_amdgcn_sched_barrier(0);
             }
             // a listed pair contributes through the list, not here: a select, not a product with zero (the self pair's point IS the
             // centroid for K = 1, 4: its reciprocal distance is inf, the sums NaN)
             const double f = (TRAC && trac) ? -3.0 : sc;
             v[3 * r] += slow ? 0.0 : u0 * f; v[3 * r + 1] += slow ? 0.0 : u1 * f; v[3 * r + 2] += slow ? 0.0 : u2 * f;
-            __builtin_amdgcn_sched_barrier(0);             // one row after the other (left alone the scheduler interleaves them and spills)
           }
+          __builtin_amdgcn_sched_barrier(0);               // one row after the other
         }
-        const double tot = hyb_reduce16(v, lane);
-        const int k = hyb_value_of(lane);
-        if ((lane & 3) == 0 && k < 3 * kHybRows && 3 * rb + k < 3 * nrows) rpart[3 * rb + k] = c0 ? rpart[3 * rb + k] + tot : tot;
+#pragma unroll
+        for (int f = 0; f < F; ++f) cur[f] = nxt[f];
       }
     }
-    // the rows' listed entries: a row per wavefront, lane = entry
-    for (int ri = wave; ri < nrows; ri += kSpmvWaves) {
-      const int64_t i = prow0 + ri;
-      double s0 = 0, s1 = 0, s2 = 0;
-      for (int64_t k = d.side_ptr[i] + lane; k < d.side_ptr[i + 1]; k += kWave) {
-        const double* m = d.side_val + 9 * k;
-        const int64_t cj = d.side_col[k];
-        const double y0 = d.xt[3 * cj], y1 = d.xt[3 * cj + 1], y2 = d.xt[3 * cj + 2];
-        s0 = fma(m[0], y0, fma(m[1], y1, fma(m[2], y2, s0)));
-        s1 = fma(m[3], y0, fma(m[4], y1, fma(m[5], y2, s1)));
-        s2 = fma(m[6], y0, fma(m[7], y1, fma(m[8], y2, s2)));
-      }
-      s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
-      if (lane == 0) { rside[3 * ri] = s0; rside[3 * ri + 1] = s1; rside[3 * ri + 2] = s2; }
+    if (nrw > 0) {
+      const double tot = hyb_reduce16(v, lane);
+      if (mine) d.yt[3 * (int64_t)(prow0 + rw) + hyb_value_of(lane)] = ylist + tot;
     }
-    __syncthreads();
-    if (tid < 3 * nrows)
-      d.yt[3 * (int64_t)prow0 + tid] = rpart[tid] + rside[tid];
-    __syncthreads();                                  // xs / run descriptors / rpart / centroids are rewritten for the next item
+    if (!more) break;
+    // hand over: the run descriptors of the item after the next into the half this item's occupied (every thread has passed a
+    // barrier since it last read them: they are read by fetch() only, one chunk ahead)
+    if (prun) { runbuf[rb * 2 * mr + tid] = pr0; runbuf[rb * 2 * mr + mr + tid] = pr1; }
+    it = nx; nx = nn; rb ^= 1;
   }
 }
 
@@ -1456,6 +1436,21 @@ __global__ void kernel_entries_kernel(DevicePlan d, int m, double* __restrict__ 
   } else {
     out[i] = laplace_entry(d, t, d.bc[i], (int64_t)m + i);
   }
+}
+
+// one near-matrix row of a plan's own panels, evaluated now (fmmbem_plan_get_near_row on a recomputed leaf of a hybrid plan):
+// out[c] (Laplace) or out[9 c ..] (Stokes) = K(panel prow, panel cols[c]) by the entry functions of the assembly
+__global__ void near_row_eval_kernel(DevicePlan d, int64_t prow, const int* __restrict__ cols, int n, double* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  const V3 t = {d.cx[prow], d.cy[prow], d.cz[prow]};
+  if (d.dof == 3) stokes_entry(d, t, d.bc[prow], cols[c], out + 9 * (size_t)c);
+  else out[c] = laplace_entry(d, t, d.bc[prow], cols[c]);
+}
+hipError_t launch_near_row_eval(const DevicePlan& d, int64_t prow, const int* cols, int n, double* out, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(near_row_eval_kernel, dim3((n + 63) / 64), dim3(64), 0, s, d, prow, cols, n, out);
+  return hipGetLastError();
 }
 
 hipError_t launch_kernel_entries(const DevicePlan& d, int m, double* out, hipStream_t s) {
@@ -1526,43 +1521,33 @@ hipError_t launch_gather_x(const DevicePlan& d, const double* x, hipStream_t s) 
   return hipGetLastError();
 }
 
-// Hybrid plans (near_stream_fraction < 1).  Two forms:
-//   side by side (default): near_spmv_sym3 over the stream items on `s`, the recompute kernel over the recompute items on `s2`
-//     (forked from and joined to `s` through the two events): kS workgroups per CU of the one (96 VGPRs), kR of the other
-//     (<= 168), sized so that BOTH are resident on every CU from start to end -- which two grids that each fill the chip never
-//     are (profiles/r05a_near_split_step_a.txt);
-//   mixed (FMMBEM_HYB_MODE=0): one kernel, both kinds of items in one list.
+// Hybrid plans (near_stream_fraction < 1): near_spmv_sym3 over the streamed leaves on `s`, near_recompute3 over the recomputed ones
+// on `s2` (forked from and joined to `s` through the two events): kS workgroups per CU of the one (96 VGPRs), kR of the other,
+// sized so that BOTH kernels are resident on every CU from start to end.
 hipError_t launch_near_hybrid(const DevicePlan& d, hipStream_t s, hipStream_t s2, hipEvent_t fork, hipEvent_t join) {
-  if (d.dof != 3 || !d.hyb_items) return hipErrorInvalidValue;
-  static const int mode = [] { const char* e = std::getenv("FMMBEM_HYB_MODE"); return e ? std::atoi(e) : 1; }();
-  static const int kS = [] { const char* e = std::getenv("FMMBEM_HYB_WG_STREAM"); return e ? std::atoi(e) : 3; }();
-  static const int kR = [] { const char* e = std::getenv("FMMBEM_HYB_WG_RECOMPUTE"); return e ? std::atoi(e) : 1; }();
-  const size_t ldsh = 3 * (size_t)kHybChunk * sizeof(double) + 2 * (size_t)d.max_runs * sizeof(int);
+  if (d.dof != 3 || !d.near_rec) return hipErrorInvalidValue;
+  static const int kS = [] { const char* e = std::getenv("FMMBEM_HYB_WG_STREAM"); return e ? std::atoi(e) : 2; }();
+  static const int kR = [] { const char* e = std::getenv("FMMBEM_HYB_WG_RECOMPUTE"); return e ? std::atoi(e) : 2; }();
   const dim3 b(kSpmvWaves * kWave);
   const bool trac = d.stokes_traction_targets != 0;
-  if (mode == 0 || !s2) {
-    if (d.hyb_nitems <= 0) return hipSuccess;
-    const dim3 g(std::min(d.hyb_nitems, 256 * kHybOcc));
-    if (trac) hipLaunchKernelGGL((near_hybrid3_kernel<true, true>), g, b, ldsh, s, d);
-    else hipLaunchKernelGGL((near_hybrid3_kernel<false, true>), g, b, ldsh, s, d);
-    return hipGetLastError();
-  }
   hipError_t e = hipSuccess;
-  const bool both = d.near_nitems > 0 && d.sym_nitems > 0;
+  const bool both = d.rc_nitems > 0 && d.sym_nitems > 0 && s2;
   if (both) {
     if ((e = hipEventRecord(fork, s)) != hipSuccess) return e;
     if ((e = hipStreamWaitEvent(s2, fork, 0)) != hipSuccess) return e;
   }
-  if (d.near_nitems > 0) {                             // the recompute kernel first: its few, large workgroups must find room on every CU
-    const dim3 g(std::min(d.near_nitems, 256 * kR));
+  if (d.rc_nitems > 0) {                               // the recompute kernel first: its few, large workgroups must find room on every CU
+    const dim3 g(std::min(d.rc_nitems, 256 * kR));
     hipStream_t sr = both ? s2 : s;
-    if (trac) hipLaunchKernelGGL((near_hybrid3_kernel<true, false>), g, b, ldsh, sr, d);
-    else hipLaunchKernelGGL((near_hybrid3_kernel<false, false>), g, b, ldsh, sr, d);
+    hipLaunchKernelGGL((near_side_kernel<3>), dim3(std::min(d.rc_nitems, 256 * 8)), b, 0, sr, d);
+    const size_t ldsr = (size_t)(trac ? 22 : 19) * kRcChunk * sizeof(double) + 4 * (size_t)d.max_runs * sizeof(int);
+    if (trac) hipLaunchKernelGGL((near_recompute3_kernel<true>), g, b, ldsr, sr, d);
+    else hipLaunchKernelGGL((near_recompute3_kernel<false>), g, b, ldsr, sr, d);
     if ((e = hipGetLastError()) != hipSuccess) return e;
   }
   if (d.sym_nitems > 0) {
     const size_t lds3 = 3 * (size_t)kSymChunk * sizeof(double) + 2 * (size_t)d.max_runs * sizeof(int);
-    hipLaunchKernelGGL((near_spmv_sym3_kernel<1, 3>), dim3(std::min(d.sym_nitems, 256 * kS)), b, lds3, s, d);
+    hipLaunchKernelGGL((near_spmv_sym3_kernel<1, 3>), dim3(std::min(d.sym_nitems, 256 * (d.rc_nitems > 0 ? kS : kSymOcc))), b, lds3, s, d);
     if ((e = hipGetLastError()) != hipSuccess) return e;
   }
   if (both) {
@@ -1573,7 +1558,7 @@ hipError_t launch_near_hybrid(const DevicePlan& d, hipStream_t s, hipStream_t s2
 }
 
 hipError_t launch_near_spmv(const DevicePlan& d, hipStream_t s) {
-  if (d.hyb_items) return hipErrorInvalidValue;        // hybrid plans go through launch_near_hybrid
+  if (d.near_rec) return hipErrorInvalidValue;         // hybrid plans go through launch_near_hybrid
   if (d.near_nitems <= 0) return hipSuccess;
   if (d.dof == 3 && d.near_sym) {
     const size_t lds3 = 3 * (size_t)kSymChunk * sizeof(double) + 2 * (size_t)d.max_runs * sizeof(int);

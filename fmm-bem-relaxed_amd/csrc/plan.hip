@@ -273,16 +273,6 @@ static void rot_record(const double tr[3], double* o) {
   else { const double h = 1.0 / std::sqrt(tr[0] * tr[0] + tr[1] * tr[1]); o[3] = tr[0] * h; o[4] = tr[1] * h; }
 }
 
-// EXPERIMENT (round 5; tools/near_split_experiment.py): FMMBEM_NEAR_SUBSET="a/b" keeps only the near-field
-// work items of the leaves l with l % b < a (a > 0) or l % b >= -a (a < 0), so that an assembled plan and a matrix-free plan of
-// the same geometry can each take a complementary part of the near field and run side by side on two streams.
-static bool near_subset_keeps(int leaf) {
-  int a = 0, b = 0;
-  const char* e = std::getenv("FMMBEM_NEAR_SUBSET");              // read per call: the experiment builds two plans with different subsets
-  if (!e || std::sscanf(e, "%d/%d", &a, &b) != 2 || b <= 0 || a == 0) return true;
-  return a > 0 ? leaf % b < a : leaf % b >= -a;
-}
-
 int fmmbem_plan::to_device() {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -387,6 +377,10 @@ int fmmbem_plan::to_device() {
       double acc = 0;
       for (int l : order) {
         if (acc >= (1.0 - f) * all) break;
+        if (hp.near_ncols[l] > 8192) continue;        // a coarse leaf of an adaptive tree (10^4 columns): one item would run alone at the end
+        int runs = 0;                                 // the recompute kernel prefetches an item's run descriptors one per thread
+        for (int64_t i = hp.near_ptr[l]; i < hp.near_ptr[l + 1]; ++i) runs += i == hp.near_ptr[l] || hp.near_src[i - 1] + 1 != hp.near_src[i];
+        if (runs > 256) continue;
         rec[l] = 1;
         acc += (double)leaf_nrows[l] * hp.near_ncols[l];
       }
@@ -440,7 +434,6 @@ int fmmbem_plan::to_device() {
       const int nr = idof * leaf_nrows[l];
       const int64_t row_bytes = opts.sparse_local ? (int64_t)near_stride[l] * 8 : (int64_t)hp.near_ncols[l] * 8;
       if (nr == 0 || row_bytes == 0) continue;
-      if (!near_subset_keeps(l)) continue;
       if (hybrid) continue;                             // hybrid plans build their own lists below (these items feed kernels they do not run)
       int per = (int)std::max<int64_t>(1, kItemBytes / row_bytes);
       if (per >= 8) per &= ~7; else per = std::min(4, nr);
@@ -488,8 +481,7 @@ int fmmbem_plan::to_device() {
         sym_total += (int64_t)6 * nr * ncp;
         const int64_t row_bytes = (int64_t)48 * ncp;
         if (nr == 0 || row_bytes == 0) continue;
-        if (!near_subset_keeps(l)) continue;
-        int per = (int)std::max<int64_t>(1, kItemBytes / row_bytes);
+          int per = (int)std::max<int64_t>(1, kItemBytes / row_bytes);
         if (per >= 8) per &= ~7; else per = std::min(4, nr);
         const int cnt = (nr + per - 1) / per;
         per = (nr + cnt - 1) / cnt;
@@ -506,44 +498,31 @@ int fmmbem_plan::to_device() {
       near_bytes = sym_total * (int64_t)sizeof(double);
       sym_off_host = sym_off;
       if (hybrid) {
-        // recompute items: panel-row ranges of the recomputed leaves -- whole leaves, except that a range holds at most 64 rows
-        // (the kernel's LDS slots) and ~kRecPairs pairs (a coarse leaf of an adaptive tree sees 10^4 columns); rows in fives
-        constexpr int64_t kRecPairs = 16384;
+        // recompute items: ranges of <= 20 panel rows of the recomputed leaves (four wavefronts x five rows, kernels_near.hip)
         struct RItem { int leaf, r0, nr; int64_t pairs; };
         std::vector<RItem> ritems;
         for (int l = hp.leaf_begin; l < hp.leaf_end; ++l) {
           const int nr = leaf_nrows[l], ncp = hp.near_ncols[l];
           if (!rec[l] || nr == 0 || ncp == 0) continue;
-          int per = (int)std::min<int64_t>(64, std::max<int64_t>(5, kRecPairs / ncp));
-          per = std::max(5, per / 5 * 5);
-          const int cnt = (nr + per - 1) / per;
-          per = ((nr + cnt - 1) / cnt + 4) / 5 * 5;
-          per = std::min(per, 60);
+          const int cnt = (nr + 19) / 20;
+          const int per = (nr + cnt - 1) / cnt;          // dealt evenly: the kernel gives a wavefront ceil(rows / 4) of an item's rows
           for (int r0 = 0; r0 < nr; r0 += per) { const int k = std::min(per, nr - r0); ritems.push_back({l, r0, k, (int64_t)k * ncp}); }
         }
         std::stable_sort(ritems.begin(), ritems.end(), [](const RItem& a, const RItem& b) { return a.pairs > b.pairs; });
         // the side listing (mf_sweep COUNT / FILL) walks d.near_items: the recompute items, panel rows
         std::vector<int4> rpacked(ritems.size());
-        for (size_t i = 0; i < ritems.size(); ++i) rpacked[i] = make_int4(ritems[i].leaf, ritems[i].r0, ritems[i].nr, 0);
+        std::vector<RcItem> rrecs(ritems.size());
+        for (size_t i = 0; i < ritems.size(); ++i) {
+          const RItem& it = ritems[i];
+          rpacked[i] = make_int4(it.leaf, it.r0, it.nr, 0);
+          RcItem& q = rrecs[i];
+          q.prow0 = leaf_row0[it.leaf] + it.r0; q.nrows = it.nr; q.ncp = hp.near_ncols[it.leaf];
+          q.run_begin = run_ptr[it.leaf]; q.nruns = (int)(run_ptr[it.leaf + 1] - run_ptr[it.leaf]); q.leaf = it.leaf; q.pad = 0;
+        }
         d.near_nitems = (int)rpacked.size();
         TRY(upload(rpacked, &d.near_items));
-        // ONE list for the hybrid kernel: both kinds largest first, merged so that at every point of the list the two kinds have
-        // been dealt the same share of their totals -- the workgroups of a CU are then at items of both kinds at any time, which
-        // is the point (arithmetic in the issue slots the streaming leaves empty); sorted by kind they would run one after the other
-        double tot_s = 0, tot_r = 0;
-        for (const auto& it : items) tot_s += (double)it.bytes;
-        for (const auto& it : ritems) tot_r += (double)it.pairs;
-        std::vector<int4> merged;
-        merged.reserve(items.size() + ritems.size());
-        size_t is = 0, ir = 0;
-        double cs = 0, cr = 0;
-        while (is < items.size() || ir < ritems.size()) {
-          const bool take_r = ir < ritems.size() && (is >= items.size() || cr / std::max(tot_r, 1.0) <= cs / std::max(tot_s, 1.0));
-          if (take_r) { const auto& it = ritems[ir++]; cr += (double)it.pairs; merged.push_back(make_int4(it.leaf, it.r0, it.nr, 2)); }
-          else { const auto& it = items[is++]; cs += (double)it.bytes; merged.push_back(make_int4(it.leaf, it.r0, it.nr, it.nr < 8 ? 1 : 0)); }
-        }
-        d.hyb_nitems = (int)merged.size();
-        TRY(upload(merged, &d.hyb_items));
+        d.rc_nitems = (int)rrecs.size();
+        TRY(upload(rrecs, &d.rc_items));
         HIP_TRY(hipStreamCreateWithFlags(&hyb_stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&hyb_fork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&hyb_join, hipEventDisableTiming));
@@ -1069,7 +1048,6 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
     return FMMBEM_OK;
   }
   auto near_field = [&](hipStream_t ns) -> int {
-    if (std::getenv("FMMBEM_NEAR_SUBSET")) HIP_TRY(hipMemsetAsync(d.yt, 0, sizeof(double) * (size_t)d.n * d.dof, ns));   // experiment: rows of the other part read as zero
     HIP_TRY(begin(1, ns));
     if (hybrid) HIP_TRY(launch_near_hybrid(d, ns, hyb_stream, hyb_fork, hyb_join));
     else if (opts.sparse_local) HIP_TRY(launch_near_spmv(d, ns)); else HIP_TRY(launch_near_matfree(d, ns));
@@ -1480,18 +1458,34 @@ int fmmbem_plan_get_near_row(const fmmbem_plan* plan, int64_t row, uint32_t* col
     if (!plan->on_device) return fail(FMMBEM_ERR_NO_DEVICE, "near values live on the device");
     if (!plan->opts.sparse_local) return fail(FMMBEM_ERR_INVALID, "matrix-free plan holds no near matrix");
     DEVICE_SCOPE(plan->opts.device);
-    int64_t off = 0;
-    for (int l = h.leaf_begin; l < leaf; ++l) {
-      const int b = h.leaf_box[l];
-      off += (int64_t)dof * (h.box_body_end[b] - h.box_body_begin[b]) * ((dof * h.near_ncols[l] + 1) & ~1);
+    if (!plan->near_rec_host.empty() && plan->near_rec_host[leaf]) {
+      // hybrid plan, recomputed leaf: no block is stored -- the row is evaluated now, by the entry functions of the assembly
+      const int ncp = h.near_ncols[leaf];
+      std::vector<int> pcol((size_t)ncp);
+      int at = 0;
+      for (int64_t s = h.near_ptr[leaf]; s < h.near_ptr[leaf + 1]; ++s) {
+        const int sb = h.leaf_box[h.near_src[s]];
+        for (int j = h.box_body_begin[sb]; j < h.box_body_end[sb]; ++j) pcol[at++] = j;
+      }
+      int* d_col = nullptr;
+      double* d_val = nullptr;
+      HIP_TRY(hipMalloc(&d_col, sizeof(int) * (size_t)ncp));
+      if (hipMalloc(&d_val, sizeof(double) * (size_t)ncp * dof * dof) != hipSuccess) { (void)hipFree(d_col); return fail(FMMBEM_ERR_ALLOC, "device allocation failed"); }
+      std::vector<double> blk((size_t)ncp * dof * dof);
+      hipError_t e = hipMemcpy(d_col, pcol.data(), sizeof(int) * (size_t)ncp, hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = launch_near_row_eval(plan->d, prow, d_col, ncp, d_val, plan->own_stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(plan->own_stream);
+      if (e == hipSuccess) e = hipMemcpy(blk.data(), d_val, sizeof(double) * blk.size(), hipMemcpyDeviceToHost);
+      (void)hipFree(d_col); (void)hipFree(d_val);
+      if (e != hipSuccess) return fail(FMMBEM_ERR_HIP, hipGetErrorString(e));
+      for (int c = 0; c < ncp; ++c)
+        for (int b = 0; b < dof; ++b) vals[dof * c + b] = blk[(size_t)c * dof * dof + comp * dof + b];
+      return FMMBEM_OK;
     }
+    const int64_t off = plan->near_off_host[leaf];
     if (plan->d.near_sym) {                            // Stokes, symmetric blocks: expand row `comp` of the panel row's 3x3 blocks
       const int ncp = h.near_ncols[leaf];
-      int64_t soff = 0;
-      for (int l = h.leaf_begin; l < leaf; ++l) {
-        const int b = h.leaf_box[l];
-        soff += (int64_t)6 * (h.box_body_end[b] - h.box_body_begin[b]) * h.near_ncols[l];
-      }
+      const int64_t soff = plan->sym_off_host[leaf];
       std::vector<double> six((size_t)6 * ncp);
       HIP_TRY(hipMemcpy(six.data(), plan->d.near_sym + soff + (prow - h.box_body_begin[tb]) * 6 * ncp, sizeof(double) * six.size(), hipMemcpyDeviceToHost));
       const double *p0 = six.data(), *p1 = p0 + 2 * ncp, *p2 = p1 + 2 * ncp;      // (xx,xy) (xz,yy) (yz,zz) per source panel

@@ -102,6 +102,10 @@ class FMMOptions {
   // exists and the two rules are one list, on clustered meshes the reference's list loses far field.
   // false (default): every child of a box that holds L;  true: exactly the reference's list.
   bool reference_l2l = false;
+  // Not in the reference: share of the near-field pairs kept as a matrix (1: the reference's assembled matrix); below 1 the target
+  // leaves with the most rows keep none and are recomputed every matvec beside the streamed rest (fmmbem.h near_stream_fraction):
+  // fewer HBM bytes and a smaller footprint at the same operator, last bits differ.  Stokes plans (measured optimum ~0.6).
+  double near_stream_fraction = 1.0;
   void set_mac_theta(double t) { MAC_ = DefaultMAC(t); }
   DefaultMAC MAC() { return MAC_; }
   void set_max_per_box(unsigned n) { NCRIT_ = n; }
@@ -336,6 +340,7 @@ class PlanAdapter {
     o.device = device_;
     o.evaluator = opts_.c_evaluator();
     o.l2l_rule = opts_.reference_l2l ? FMMBEM_L2L_REFERENCE : FMMBEM_L2L_COMPLETE;
+    o.near_stream_fraction = opts_.near_stream_fraction;
     sparse_ = o.sparse_local != 0;
     fmmbem_plan* fresh = nullptr;
     check(fmmbem_plan_create(&o, n_, v.data(), bc.data(), &fresh));
