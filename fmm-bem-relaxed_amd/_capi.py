@@ -40,7 +40,7 @@ class Stats(C.Structure):
                                    "ms_scatter", "ms_p2m", "ms_m2m", "ms_mh", "ms_m2l", "ms_l2l", "ms_l2p")] +
         [("timed_executes", C.c_int64), ("l2l_reference_omitted", C.c_int64), ("m2l_items", C.c_int64),
          ("m2l_passes", C.c_int64), ("near_side_entries", C.c_int64), ("m2l_kernel", C.c_int32), ("expansion_slots", C.c_int32),
-         ("rot_nop_orders", C.c_int64), ("tree_coder_levels", C.c_int32), ("near_recomputed_pairs", C.c_int64)])
+         ("rot_nop_orders", C.c_int64), ("tree_coder_levels", C.c_int32), ("geometry_shared", C.c_int32), ("near_recomputed_pairs", C.c_int64)])
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -85,7 +85,7 @@ SYMBOLS = (
     "fmmbem_plan_get_perm", "fmmbem_plan_get_boxes", "fmmbem_plan_get_pairs", "fmmbem_plan_get_near_row",
     "fmmbem_plan_get_expansions", "fmmbem_plan_get_diagonal", "fmmbem_kernel_entries", "fmmbem_mesh_unit_sphere", "fmmbem_mesh_red_blood_cell", "fmmbem_mesh_red_blood_cells", "fmmbem_mesh_read_msh",
     "fmmbem_mesh_read_vert_face", "fmmbem_mesh_write_vert_face", "fmmbem_quadrature", "fmmbem_status_string", "fmmbem_last_error",
-    "fmmbem_version", "fmmbem_host_register", "fmmbem_host_unregister", "fmmbem_solver_options_default", "fmmbem_gmres_device", "fmmbem_gmres",
+    "fmmbem_version", "fmmbem_plan_create_like", "fmmbem_host_register", "fmmbem_host_unregister", "fmmbem_solver_options_default", "fmmbem_gmres_device", "fmmbem_gmres",
 )
 
 
@@ -150,6 +150,7 @@ def lib():
     L.fmmbem_solver_options_default.argtypes = [C.POINTER(SolverOpts)]
     L.fmmbem_solver_options_default.restype = None
     L.fmmbem_gmres_device.argtypes = [vp, C.POINTER(SolverOpts), vp, vp, C.POINTER(Preconditioner), C.POINTER(SolverLog), vp]
+    L.fmmbem_plan_create_like.argtypes = [vp, vp, C.POINTER(vp)]
     L.fmmbem_gmres.argtypes = [vp, C.POINTER(SolverOpts), vp, vp, C.POINTER(Preconditioner), C.POINTER(SolverLog)]
     _lib = L
     return L

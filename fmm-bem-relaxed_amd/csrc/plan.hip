@@ -12,6 +12,8 @@
 #include <cstring>
 #include <cstdlib>
 #include <memory>
+#include <mutex>
+#include <thread>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -143,12 +145,36 @@ cplx i_pow(int q) {
 
 }  // namespace
 
+// What a plan holds that depends on the GEOMETRY and the options only -- the octree, the permutation, every pair list, the work
+// items and run descriptors, the panels' points, the operator tables -- on the host and in HBM.  Plans of the same panels that
+// differ in the boundary-condition flags alone (the drivers' right-hand-side plan beside the operator, examples/LaplaceBEM.cpp:
+// 209-232, StokesBEM.cpp:266-270) share ONE of these through a reference count (fmmbem_plan_create_like, and fmmbem_plan_create
+// itself when it recognises the geometry of a live plan); freed with the last plan that points to it.
+struct PlanShared {
+  HostPlan hp;
+  std::vector<void*> allocs;
+  int device = 0;
+  bool on_device = false;
+  uint64_t fingerprint[2] = {0, 0};                            // of the vertex bytes (original order), 0 0: not taken
+  ~PlanShared() {
+    if (!on_device) return;
+    DeviceGuard guard(device);
+    for (void* p : allocs) (void)hipFree(p);
+  }
+};
+
 struct fmmbem_plan {
   fmmbem_options opts;
-  HostPlan hp;
+  std::shared_ptr<PlanShared> shared;
+  HostPlan& hp;                                                // = shared->hp
   DevicePlan d;
   bool on_device = false;
-  std::vector<void*> allocs;
+  bool has_bc[2] = {false, false};                             // boundary-condition flags present among THIS plan's panels
+  std::vector<void*> allocs;                                   // what this plan alone owns: everything that depends on the flags
+  std::vector<void*>* alloc_list = nullptr;                    // where upload() / alloc() record: shared->allocs or allocs
+  int64_t near_total_doubles = 0, sym_total_doubles = 0;       // sizes of the stored near blocks (allocated per plan)
+  fmmbem_plan() : shared(std::make_shared<PlanShared>()), hp(shared->hp) { alloc_list = &shared->allocs; }
+  fmmbem_plan(const fmmbem_plan&) = default;                   // used by like(): shares `shared`; like() then replaces what must not be shared
   std::vector<std::pair<int, int>> m2m_launch, l2l_launch;     // (first, count) per level
   std::vector<std::pair<int, int>> m2m_shared_launch;          // sharded upward pass: parents spanning shards
   // the same launches for the rotation kernels (kernels_m2l_rot.hip with FMMBEM_ROT_OP = 1, 2): (first item, items, pairs)
@@ -222,7 +248,7 @@ struct fmmbem_plan {
     void* p = nullptr;
     const size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
     HIP_TRY(hipMalloc(&p, bytes));
-    allocs.push_back(p);
+    alloc_list->push_back(p);
     if (!v.empty()) HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     *out = static_cast<const T*>(p);
     return FMMBEM_OK;
@@ -232,7 +258,7 @@ struct fmmbem_plan {
     void* p = nullptr;
     const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
     HIP_TRY(hipMalloc(&p, bytes));
-    allocs.push_back(p);
+    alloc_list->push_back(p);
     if (zero) HIP_TRY(hipMemset(p, 0, bytes));
     *out = static_cast<T*>(p);
     return FMMBEM_OK;
@@ -241,7 +267,9 @@ struct fmmbem_plan {
   // kernels above; FMMBEM_M2L_ROT=0: the double sum at every order (A/B runs, tools/m2l_ab.py)
   int rot_max = kRotPmax;
   bool use_rot(int p) const { return p <= rot_max && m2l_rot_supported(p); }
-  int to_device();
+  int to_device();                                           // the geometry's share (-> shared), then to_device_bc
+  int to_device_bc(const uint8_t* bc_tree);                  // what depends on the boundary-condition flags (-> this plan)
+  static int like(const fmmbem_plan& base, const uint8_t* bc, fmmbem_plan** out);
   // phase 0: whole matvec; 1: upward half (gather, P2M, M2M of owned boxes, pack -> xbuf); 2: the rest (xbuf = gathered)
   int run(int p, const double* d_x, double* d_y, hipStream_t s, bool near_only, int phase = 0, double* xbuf = nullptr);
   ~fmmbem_plan() {
@@ -315,18 +343,8 @@ int fmmbem_plan::to_device() {
   d.leaf_begin = hp.leaf_begin; d.leaf_end = hp.leaf_end; d.row_begin = hp.row_begin; d.row_end = hp.row_end;
   for (int q = 0; q < hp.rule.n; ++q) d.qw[q] = hp.rule.w[q];
   d.kernel = opts.kernel;
-  d.n_act = 0;
   if (opts.kernel == FMMBEM_KERNEL_STOKES_BEM) {
-    // StokesSphericalBEM: M[2][4] per box (kernel/StokesSphericalBEM.hpp:143-153).  The TARGET's flag picks the operator
-    // (:377-389): velocity targets read the four potentials of the single layer (slots 0..3), TRACTION targets the seven of
-    // the double layer (slots 4..10, kernels_far.hip p2m_apply_kernel<3>); every source feeds the groups that have readers
     d.dof = 3; d.mu = opts.mu;
-    d.stokes_velocity_targets = hp.has_bc[0] ? 1 : 0;
-    d.stokes_traction_targets = (hp.has_bc[1] && hp.opt.evaluator == 0) ? 1 : 0;
-    if (!d.stokes_velocity_targets && !d.stokes_traction_targets) d.stokes_velocity_targets = 1;
-    d.nslots = d.stokes_traction_targets ? 11 : 8;
-    if (d.stokes_velocity_targets) for (int s = 0; s < 4; ++s) d.act[d.n_act++] = s;
-    if (d.stokes_traction_targets) for (int s = 4; s < 11; ++s) d.act[d.n_act++] = s;
     QuadRule fine;
     if (!quad_rule(opts.quad_k_fine, fine)) return fail(FMMBEM_ERR_INVALID, "invalid K_fine (valid: 1 3 4 7 13 17 19 25 79)");
     d.nqf = fine.n;
@@ -334,8 +352,7 @@ int fmmbem_plan::to_device() {
     for (int q = 0; q < fine.n; ++q) { for (int k = 0; k < 3; ++k) qf[4 * q + k] = fine.pts[q][k]; qf[4 * q + 3] = fine.w[q]; }
     TRY(upload(qf, &d.qf));
   } else {
-    d.dof = 1; d.nslots = 2;
-    for (int s = 0; s < 2; ++s) if (hp.has_bc[s]) d.act[d.n_act++] = s;
+    d.dof = 1;
   }
   const int dof = d.dof;
 
@@ -344,7 +361,7 @@ int fmmbem_plan::to_device() {
   TRY(upload(P.cx, &d.cx)); TRY(upload(P.cy, &d.cy)); TRY(upload(P.cz, &d.cz));
   TRY(upload(P.nx, &d.nx)); TRY(upload(P.ny, &d.ny)); TRY(upload(P.nz, &d.nz));
   TRY(upload(P.area, &d.area)); TRY(upload(P.quad, &d.quad)); TRY(upload(P.vert, &d.vert));
-  TRY(upload(P.bc, &d.bc)); TRY(upload(hp.perm, &d.perm));
+  TRY(upload(hp.perm, &d.perm));                       // (the flags: to_device_bc)
 
   // leaves and the near block structure
   std::vector<int> leaf_row0(nl), leaf_nrows(nl), near_stride(nl), run_row0, run_off;
@@ -464,8 +481,9 @@ int fmmbem_plan::to_device() {
     TRY(upload(recs, &d.near_recs));
   }
   const bool stokes_sym = dof == 3 && opts.sparse_local && !(std::getenv("FMMBEM_STOKES_SYM") && std::atoi(std::getenv("FMMBEM_STOKES_SYM")) == 0);
-  if (opts.sparse_local && !stokes_sym) TRY(alloc((size_t)total, &d.near_val, false));   // matrix-free mode keeps no matrix
-  else { d.near_val = nullptr; near_bytes = 0; }
+  near_total_doubles = (opts.sparse_local && !stokes_sym) ? total : 0;      // allocated in to_device_bc; matrix-free mode keeps no matrix
+  if (!near_total_doubles) near_bytes = 0;
+  d.near_val = nullptr;
   {
     // Stokes: the near blocks in their symmetric 6-value form, the only copy (FMMBEM_STOKES_SYM=0: the 9-value rows instead)
     if (stokes_sym) {
@@ -494,7 +512,7 @@ int fmmbem_plan::to_device() {
       d.sym_nitems = (int)packed.size();
       TRY(upload(packed, &d.sym_items));
       TRY(upload(sym_off, &d.near_sym_off));
-      TRY(alloc((size_t)std::max<int64_t>(sym_total, 1), &d.near_sym, false));
+      sym_total_doubles = std::max<int64_t>(sym_total, 1);          // allocated in to_device_bc
       near_bytes = sym_total * (int64_t)sizeof(double);
       sym_off_host = sym_off;
       if (hybrid) {
@@ -523,9 +541,6 @@ int fmmbem_plan::to_device() {
         TRY(upload(rpacked, &d.near_items));
         d.rc_nitems = (int)rrecs.size();
         TRY(upload(rrecs, &d.rc_items));
-        HIP_TRY(hipStreamCreateWithFlags(&hyb_stream, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&hyb_fork, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&hyb_join, hipEventDisableTiming));
         TRY(upload(rec, &d.near_rec));
       }
     }
@@ -535,9 +550,6 @@ int fmmbem_plan::to_device() {
 
   // boxes, expansions, tables
   TRY(upload(hp.box_center, &d.box_center));
-  TRY(alloc((size_t)nb * d.nslots * d.s_max, &d.M, true));
-  TRY(alloc((size_t)nb * d.nslots * d.s_max, &d.L, true));
-  TRY(alloc((size_t)nb * d.nslots * d.s_max, &d.Mh, true));
   TRY(upload(T.A, &d.tabA)); TRY(upload(T.invA, &d.tabInvA)); TRY(upload(T.pref, &d.tabPref));
   {
     // per-step constants of the harmonic recurrences in the m-major order P2M visits (n,m) at order p:
@@ -830,6 +842,58 @@ int fmmbem_plan::to_device() {
   }
 
   mark("m2l class tables");
+  shared->on_device = true;
+  shared->device = opts.device;
+  return to_device_bc(hp.panels.bc.data());
+}
+
+// Everything of a plan that depends on the boundary-condition flags: which expansion slots are live, the flags themselves, the
+// near-matrix values (the TARGET's flag picks the kernel), the P2M moments (the SOURCE's flag picks them), the expansions and the
+// work vectors.  bc_tree: the flags in tree order.  Allocations go to this plan, not to the shared block.
+int fmmbem_plan::to_device_bc(const uint8_t* bc_tree) {
+  DEVICE_SCOPE(opts.device);
+  alloc_list = &allocs;
+  const bool trace = std::getenv("FMMBEM_BUILD_TRACE") != nullptr;
+  double t_last = now_ms();
+  auto mark = [&](const char* what) {
+    if (!trace) return;
+    (void)hipDeviceSynchronize();
+    const double now = now_ms();
+    std::fprintf(stderr, "to_device %-28s %8.2f ms\n", what, now - t_last);
+    t_last = now;
+  };
+  const int dof = d.dof, nb = hp.nboxes;
+  d.n_act = 0;
+  if (opts.kernel == FMMBEM_KERNEL_STOKES_BEM) {
+    // StokesSphericalBEM: M[2][4] per box (kernel/StokesSphericalBEM.hpp:143-153).  The TARGET's flag picks the operator
+    // (:377-389): velocity targets read the four potentials of the single layer (slots 0..3), TRACTION targets the seven of
+    // the double layer (slots 4..10, kernels_far.hip p2m_apply_kernel<3>); every source feeds the groups that have readers
+    d.stokes_velocity_targets = has_bc[0] ? 1 : 0;
+    d.stokes_traction_targets = (has_bc[1] && hp.opt.evaluator == 0) ? 1 : 0;
+    if (!d.stokes_velocity_targets && !d.stokes_traction_targets) d.stokes_velocity_targets = 1;
+    d.nslots = d.stokes_traction_targets ? 11 : 8;
+    if (d.stokes_velocity_targets) for (int s = 0; s < 4; ++s) d.act[d.n_act++] = s;
+    if (d.stokes_traction_targets) for (int s = 4; s < 11; ++s) d.act[d.n_act++] = s;
+  } else {
+    d.nslots = 2;
+    for (int s = 0; s < 2; ++s) if (has_bc[s]) d.act[d.n_act++] = s;
+  }
+  {
+    uint8_t* dbc = nullptr;
+    TRY(alloc((size_t)hp.n, &dbc, false));
+    HIP_TRY(hipMemcpy(dbc, bc_tree, (size_t)hp.n, hipMemcpyHostToDevice));
+    d.bc = dbc;
+  }
+  if (near_total_doubles) TRY(alloc((size_t)near_total_doubles, &d.near_val, false));
+  if (sym_total_doubles) TRY(alloc((size_t)sym_total_doubles, &d.near_sym, false));
+  if (hybrid) {
+    HIP_TRY(hipStreamCreateWithFlags(&hyb_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&hyb_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&hyb_join, hipEventDisableTiming));
+  }
+  TRY(alloc((size_t)nb * d.nslots * d.s_max, &d.M, true));
+  TRY(alloc((size_t)nb * d.nslots * d.s_max, &d.L, true));
+  TRY(alloc((size_t)nb * d.nslots * d.s_max, &d.Mh, true));
   TRY(alloc((size_t)hp.n * dof, &d.xt, true));
   TRY(alloc((size_t)hp.n * dof, &d.yt, true));
   TRY(alloc((size_t)hp.n * dof, &stage_x, true));
@@ -1134,6 +1198,113 @@ void fmmbem_options_default(fmmbem_options* o) {
   o->near_stream_fraction = 1.0;
 }
 
+// ---- plans that share a geometry -----------------------------------------------------------------------------
+// Two independent 64-bit hashes of the vertex bytes (the panels in the caller's order), a few threads: 75 MB at N = 1M in ~5 ms
+static void fingerprint_vertices(const double* v, size_t n_panels, uint64_t out[2]) {
+  const size_t words = n_panels * 9;
+  const int nt = words < (1u << 20) ? 1 : (int)std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
+  std::vector<uint64_t> part((size_t)nt * 2);
+  auto work = [&](int t) {
+    const size_t w0 = words * t / nt, w1 = words * (t + 1) / nt;
+    uint64_t a = 0x9E3779B97F4A7C15ull + t, b = 0xC2B2AE3D27D4EB4Full ^ (uint64_t)t;
+    for (size_t i = w0; i < w1; ++i) {
+      uint64_t x;
+      std::memcpy(&x, v + i, 8);
+      a = (a ^ x) * 0x100000001B3ull; a ^= a >> 29;                       // FNV-style multiply-xor with a fold
+      b += x * 0xFF51AFD7ED558CCDull; b = (b << 27) | (b >> 37); b *= 0xC4CEB9FE1A85EC53ull;
+    }
+    part[2 * t] = a; part[2 * t + 1] = b;
+  };
+  if (nt == 1) work(0);
+  else {
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nt; ++t) pool.emplace_back(work, t);
+    for (auto& th : pool) th.join();
+  }
+  uint64_t a = n_panels, b = ~(uint64_t)n_panels;
+  for (int t = 0; t < nt; ++t) { a = (a ^ part[2 * t]) * 0x100000001B3ull; b = (b + part[2 * t + 1]) * 0xC4CEB9FE1A85EC53ull; b ^= b >> 31; }
+  out[0] = a; out[1] = b | 1;                                             // never 0 0
+}
+
+// the options that decide the geometry's share of a plan: everything but the flags (and mu, which only scales near values)
+static bool same_geometry_options(const fmmbem_options& a, const fmmbem_options& b) {
+  return a.kernel == b.kernel && a.p_max == b.p_max && a.quad_k == b.quad_k && a.theta == b.theta && a.ncrit == b.ncrit &&
+         a.sparse_local == b.sparse_local && a.host_only == b.host_only && a.device == b.device && a.shard_rank == b.shard_rank &&
+         a.shard_world == b.shard_world && a.quad_k_fine == b.quad_k_fine && a.evaluator == b.evaluator && a.mu == b.mu &&
+         a.shard_upward == b.shard_upward && a.l2l_rule == b.l2l_rule && a.near_stream_fraction == b.near_stream_fraction;
+}
+
+// live plans that own a geometry, most recent first (a handful: operator, preconditioner plans)
+struct fmmbem_plan_ref { std::mutex mu; fmmbem_plan* plan = nullptr; };
+static std::mutex g_cache_mu;
+static std::vector<std::shared_ptr<fmmbem_plan_ref>> g_cache;
+
+static std::shared_ptr<fmmbem_plan_ref> geometry_cache_find(const fmmbem_options& o, size_t n, const uint64_t fp[2]) {
+  std::lock_guard<std::mutex> lock(g_cache_mu);
+  for (auto& r : g_cache) {
+    std::lock_guard<std::mutex> l2(r->mu);
+    const fmmbem_plan* p = r->plan;
+    if (p && (size_t)p->hp.n == n && p->shared->fingerprint[0] == fp[0] && p->shared->fingerprint[1] == fp[1] && same_geometry_options(p->opts, o))
+      return r;
+  }
+  return nullptr;
+}
+static void geometry_cache_add(fmmbem_plan* p) {
+  auto r = std::make_shared<fmmbem_plan_ref>();
+  r->plan = p;
+  std::lock_guard<std::mutex> lock(g_cache_mu);
+  g_cache.insert(g_cache.begin(), r);
+  if (g_cache.size() > 8) g_cache.resize(8);
+}
+static void geometry_cache_remove(fmmbem_plan* p) {
+  std::lock_guard<std::mutex> lock(g_cache_mu);
+  for (size_t i = 0; i < g_cache.size();) {
+    bool gone;
+    { std::lock_guard<std::mutex> l2(g_cache[i]->mu); gone = g_cache[i]->plan == p; if (gone) g_cache[i]->plan = nullptr; }
+    if (gone) g_cache.erase(g_cache.begin() + (long)i); else ++i;
+  }
+}
+
+// A plan of `base`'s panels with other boundary-condition flags: shares base's PlanShared, builds what the flags decide.
+int fmmbem_plan::like(const fmmbem_plan& base, const uint8_t* bc, fmmbem_plan** out) {
+  *out = nullptr;
+  const double t0 = now_ms();
+  std::unique_ptr<fmmbem_plan> pl(new (std::nothrow) fmmbem_plan(base));       // memberwise: d, the launch lists, the table pointers
+  if (!pl) return fail(FMMBEM_ERR_ALLOC, "plan");
+  // ... and now everything that must NOT be shared with base (the copy constructor copied the handles): fresh or empty
+  pl->allocs.clear();
+  pl->alloc_list = &pl->allocs;
+  pl->ev.assign(pl->ev.size(), nullptr);
+  pl->graphs.clear();
+  pl->own_stream = nullptr; pl->hyb_stream = nullptr; pl->hyb_fork = pl->hyb_join = nullptr;
+  pl->d_dev = nullptr; pl->stage_x = pl->stage_y = nullptr; pl->solver_ws = nullptr; pl->d_cut = nullptr;
+  pl->result_slices = false; pl->pending_mask = 0; pl->pending_near = false;
+  pl->timing = 0; pl->last_p = 0; pl->ev_count = 0;
+  for (auto& m : pl->ev_mask) m = 0;
+  pl->near_side_entries = 0;
+  pl->d.side_ptr = nullptr; pl->d.side_col = nullptr; pl->d.side_val = nullptr;
+  pl->d.p2m_tab = nullptr; pl->d.p2m_tab_g = nullptr;
+  pl->d.near_val = nullptr; pl->d.near_sym = nullptr;
+  pl->build_host_ms = 0;
+  DEVICE_SCOPE(pl->opts.device);
+  HIP_TRY(hipStreamCreateWithFlags(&pl->own_stream, hipStreamNonBlocking));
+  for (auto& e : pl->ev) HIP_TRY(hipEventCreate(&e));
+  const HostPlan& h = pl->hp;
+  std::vector<uint8_t> bc_tree((size_t)h.n, 0);
+  pl->has_bc[0] = pl->has_bc[1] = false;
+  for (int64_t i = 0; i < h.n; ++i) {
+    const uint8_t f = bc ? (bc[h.perm[(size_t)i]] ? 1 : 0) : 0;
+    bc_tree[(size_t)i] = f;
+    pl->has_bc[f] = true;
+  }
+  const int rc = pl->to_device_bc(bc_tree.data());
+  if (rc != FMMBEM_OK) return rc;
+  pl->build_host_ms = now_ms() - t0 - pl->build_assemble_ms;
+  if (!(std::getenv("FMMBEM_PLAN_SHARE") && std::atoi(std::getenv("FMMBEM_PLAN_SHARE")) == 0)) geometry_cache_add(pl.get());   // any holder of the geometry can stand in for the first
+  *out = pl.release();
+  return FMMBEM_OK;
+}
+
 int fmmbem_plan_create(const fmmbem_options* opts, size_t n_panels, const double* vertices, const uint8_t* bc,
                        fmmbem_plan** out) {
   if (!opts || !out) return fail(FMMBEM_ERR_INVALID, "null argument");
@@ -1151,9 +1322,24 @@ int fmmbem_plan_create(const fmmbem_options* opts, size_t n_panels, const double
   if (!vertices || n_panels == 0) return fail(FMMBEM_ERR_INVALID, "no panels");
   if (opts->l2l_rule != FMMBEM_L2L_COMPLETE && opts->l2l_rule != FMMBEM_L2L_REFERENCE) return fail(FMMBEM_ERR_INVALID, "unknown l2l_rule");
   if (opts->evaluator < FMMBEM_EVAL_FMM || opts->evaluator > FMMBEM_EVAL_BLOCK_DIAGONAL) return fail(FMMBEM_ERR_INVALID, "unknown evaluator");
+  // The geometry of a live plan, recognised: same options, same panel count, same vertex bytes (two 64-bit hashes) -- only the
+  // boundary-condition flags may differ.  The new plan then shares that plan's tree, lists and tables (PlanShared) and builds
+  // only what the flags decide.  This is the drivers' second plan (examples/LaplaceBEM.cpp:218-232: the same panels with the
+  // flags switched, for the right-hand side); FMMBEM_PLAN_SHARE=0 turns the recognition off.
+  uint64_t fp[2] = {0, 0};
+  const bool share_on = !opts->host_only && !(std::getenv("FMMBEM_PLAN_SHARE") && std::atoi(std::getenv("FMMBEM_PLAN_SHARE")) == 0);
+  if (share_on) {
+    fingerprint_vertices(vertices, n_panels, fp);
+    std::shared_ptr<fmmbem_plan_ref> hit = geometry_cache_find(*opts, n_panels, fp);
+    if (hit) {
+      std::lock_guard<std::mutex> lock(hit->mu);
+      if (hit->plan) return fmmbem_plan::like(*hit->plan, bc, out);
+    }
+  }
   std::unique_ptr<fmmbem_plan> pl(new (std::nothrow) fmmbem_plan);
   if (!pl) return fail(FMMBEM_ERR_ALLOC, "plan");
   pl->opts = *opts;
+  pl->shared->fingerprint[0] = fp[0]; pl->shared->fingerprint[1] = fp[1];
   HostOptions ho;
   ho.p_max = opts->p_max; ho.quad_k = opts->quad_k; ho.theta = opts->theta; ho.ncrit = opts->ncrit;
   ho.shard_rank = opts->shard_rank; ho.shard_world = opts->shard_world < 1 ? 1 : opts->shard_world;
@@ -1169,6 +1355,7 @@ int fmmbem_plan_create(const fmmbem_options* opts, size_t n_panels, const double
   }
   if (!err.empty()) return fail(err.find("octree") != std::string::npos ? FMMBEM_ERR_TREE : FMMBEM_ERR_INVALID, err);
   pl->build_host_ms = now_ms() - t0;
+  pl->has_bc[0] = pl->hp.has_bc[0]; pl->has_bc[1] = pl->hp.has_bc[1];
   if (!opts->host_only) {
     try {
       const int rc = pl->to_device();
@@ -1178,12 +1365,23 @@ int fmmbem_plan_create(const fmmbem_options* opts, size_t n_panels, const double
     }
     // vertices are only needed on the device; keep the host copy small
     pl->hp.panels.vert.clear(); pl->hp.panels.vert.shrink_to_fit();
+    if (share_on) geometry_cache_add(pl.get());
   }
   *out = pl.release();
   return FMMBEM_OK;
 }
 
-void fmmbem_plan_destroy(fmmbem_plan* plan) { delete plan; }
+int fmmbem_plan_create_like(const fmmbem_plan* base, const uint8_t* bc, fmmbem_plan** out) {
+  if (!base || !out) return fail(FMMBEM_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (!base->on_device) return fail(FMMBEM_ERR_NO_DEVICE, "fmmbem_plan_create_like: the base plan was built host-only");
+  return fmmbem_plan::like(*base, bc, out);
+}
+
+void fmmbem_plan_destroy(fmmbem_plan* plan) {
+  if (plan) geometry_cache_remove(plan);
+  delete plan;
+}
 
 int fmmbem_plan_execute_device(fmmbem_plan* plan, int p, const double* d_x, double* d_y, void* stream) {
   if (!plan) return fail(FMMBEM_ERR_INVALID, "null plan");
@@ -1194,9 +1392,9 @@ int fmmbem_plan_execute_device(fmmbem_plan* plan, int p, const double* d_x, doub
 // condition present; Stokes four potentials for velocity targets, seven for TRACTION targets (to_device, d.act)
 static int64_t active_slots(const fmmbem_plan* plan) {
   const HostPlan& h = plan->hp;
-  if (plan->opts.kernel != FMMBEM_KERNEL_STOKES_BEM) return (int64_t)h.has_bc[0] + (int64_t)h.has_bc[1];
-  const bool trac = h.has_bc[1] && h.opt.evaluator == 0;
-  const bool vel = h.has_bc[0] || !trac;
+  if (plan->opts.kernel != FMMBEM_KERNEL_STOKES_BEM) return (int64_t)plan->has_bc[0] + (int64_t)plan->has_bc[1];
+  const bool trac = plan->has_bc[1] && h.opt.evaluator == 0;
+  const bool vel = plan->has_bc[0] || !trac;
   return (vel ? 4 : 0) + (trac ? 7 : 0);
 }
 
@@ -1342,11 +1540,12 @@ int fmmbem_plan_stats(const fmmbem_plan* plan, fmmbem_stats* o) {
   o->m2l_passes = long_items ? h.rot_passes_long : h.rot_passes;
   o->near_side_entries = plan->near_side_entries;
   o->near_recomputed_pairs = plan->near_recomputed_pairs;
+  o->geometry_shared = (int32_t)plan->shared.use_count();
   o->expansion_slots = plan->on_device ? plan->d.nslots : (plan->opts.kernel == FMMBEM_KERNEL_STOKES_BEM ? 8 : 2);
   o->m2l_kernel = plan->last_p > 0 ? (plan->use_rot(plan->last_p) ? 1 : plan->last_p <= 4 ? 3 : 2) : 0;
   o->rot_nop_orders = (int64_t)rot_nop_orders_m2l() | ((int64_t)rot_nop_orders_m2m() << 16) | ((int64_t)rot_nop_orders_l2l() << 32);
   o->tree_coder_levels = h.tree_levels_max;
-  o->expansions_active = (h.has_bc[0] ? 1 : 0) | (h.has_bc[1] ? 2 : 0);
+  o->expansions_active = (plan->has_bc[0] ? 1 : 0) | (plan->has_bc[1] ? 2 : 0);
   o->last_p = plan->last_p;
   o->build_host_ms = plan->build_host_ms; o->build_assemble_ms = plan->build_assemble_ms;
   if (plan->on_device && plan->ev_count > 0) {

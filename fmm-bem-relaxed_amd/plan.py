@@ -235,6 +235,26 @@ class FMM_plan:
         _capi.check(_capi.lib().fmmbem_plan_create(C.byref(o), self.n, v.ctypes.data_as(C.c_void_p), bcp, C.byref(h)))
         self._h = h
 
+    def like(self, bc, K=None):
+        """A plan of the same panels and options with other boundary-condition flags (fmmbem_plan_create_like): shares this
+        plan's tree, lists and tables; builds only the near-matrix values, P2M moments and expansions.  The drivers'
+        right-hand-side plan (examples/LaplaceBEM.cpp:218-232).  K: the kernel object the new plan reads its order from
+        (default: this plan's)."""
+        import copy
+        other = copy.copy(self)
+        other._K = K if K is not None else self._K
+        bcp = None
+        if bc is not None:
+            bc = np.ascontiguousarray(bc, dtype=np.uint8)
+            if bc.shape != (self.n,):
+                raise ValueError("bc must have one flag per panel")
+            bcp = bc.ctypes.data_as(C.c_void_p)
+        h = C.c_void_p()
+        other._h = None
+        _capi.check(_capi.lib().fmmbem_plan_create_like(self._h, bcp, C.byref(h)))
+        other._h = h
+        return other
+
     # ---- reference surface ----
     def kernel(self):
         return self._K
