@@ -260,7 +260,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         if world > 1:
-            die(rank, world, "bench.py needs a GPU: the product has no CPU execution path", 4) if rank == 0 else os._exit(4)
+            if rank != 0:
+                time.sleep(3.0)                              # rank 0 speaks first: a launcher that sees any rank fail kills the others
+                os._exit(4)
+            die(rank, world, "bench.py needs a GPU: the product has no CPU execution path", 4)
         raise SystemExit("bench.py needs a GPU: the product has no CPU execution path")
     # one rank per GPU over RCCL.  FMMBEM_BENCH_BACKEND=gloo is a rehearsal aid for a one-GPU box: the ranks then share
     # device 0 and the collectives go through the host (numbers from such a run mean nothing).

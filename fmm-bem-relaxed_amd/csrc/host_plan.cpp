@@ -351,33 +351,61 @@ std::string HostPlan::build(const HostOptions& o, int64_t n_panels, const double
     return dx * dx + dy * dy + dz * dz > rhs * rhs;
   };
   {
-    std::deque<std::pair<int, int>> fifo;
+    // The reference walks a FIFO (EvalInteractionLazySparse.hpp:68-110): pairs are taken in the order they were queued, so the
+    // queue is a sequence of GENERATIONS -- the children of generation g, in order, are generation g + 1 -- and the lists come out
+    // generation by generation, pair by pair.  A generation's pairs are independent: cut into contiguous chunks for a few
+    // threads, each chunk's output (next generation, P2P pairs, M2L pairs) appended in chunk order, the lists are the serial
+    // ones entry for entry (tests/test_capi_host.py, test_random_meshes.py compare them with the oracle's).
     // evaluator: 0 = EvalInteractionLazySparse; 1 = EvalLocalSparse.hpp:34-86, the same traversal with accepted
     // multipoles dropped (:120-127); 2 = EvalDiagonalSparse.hpp:33-49, every leaf with itself in box order
+    typedef std::pair<int, int> Pair;
+    std::vector<Pair> cur, next;
     if (opt.evaluator == 2) {
       for (int b = 0; b < nboxes; ++b)
         if (box_leaf[b]) { p2p_src.push_back(b); p2p_tgt.push_back(b); }
     } else {
-      fifo.emplace_back(0, 0);
+      cur.emplace_back(0, 0);
     }
-    while (!fifo.empty()) {
-      const auto [s, t] = fifo.front();
-      fifo.pop_front();
-      bool split_source;
-      if (box_leaf[s]) {
-        if (box_leaf[t]) { p2p_src.push_back(s); p2p_tgt.push_back(t); continue; }
-        split_source = false;
-      } else if (box_leaf[t]) {
-        split_source = true;
-      } else {
-        split_source = box_side[s] > box_side[t];        // ties split the target side (:98-108)
+    struct Out { std::vector<Pair> next, p2p, lr; };
+    auto walk = [&](const Pair* first, const Pair* last, Out& out) {
+      for (const Pair* it = first; it != last; ++it) {
+        const int s = it->first, t = it->second;
+        bool split_source;
+        if (box_leaf[s]) {
+          if (box_leaf[t]) { out.p2p.emplace_back(s, t); continue; }
+          split_source = false;
+        } else if (box_leaf[t]) {
+          split_source = true;
+        } else {
+          split_source = box_side[s] > box_side[t];        // ties split the target side (:98-108)
+        }
+        const int open = split_source ? s : t;
+        for (int c = box_child_begin[open]; c < box_child_end[open]; ++c) {
+          const int ns = split_source ? c : s, nt = split_source ? t : c;
+          if (accept(ns, nt)) { if (opt.evaluator == 0) out.lr.emplace_back(ns, nt); }
+          else out.next.emplace_back(ns, nt);
+        }
       }
-      const int open = split_source ? s : t;
-      for (int c = box_child_begin[open]; c < box_child_end[open]; ++c) {
-        const int ns = split_source ? c : s, nt = split_source ? t : c;
-        if (accept(ns, nt)) { if (opt.evaluator == 0) { lr_src.push_back(ns); lr_tgt.push_back(nt); } }
-        else fifo.emplace_back(ns, nt);
+    };
+    const int max_threads = (int)std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
+    std::vector<Out> outs;
+    while (!cur.empty()) {
+      const int nt = cur.size() < 8192 ? 1 : std::min<int>(max_threads, (int)(cur.size() / 4096));
+      outs.assign(nt, Out{});
+      if (nt == 1) walk(cur.data(), cur.data() + cur.size(), outs[0]);
+      else {
+        std::vector<std::thread> pool;
+        for (int k = 0; k < nt; ++k)
+          pool.emplace_back(walk, cur.data() + cur.size() * k / nt, cur.data() + cur.size() * (k + 1) / nt, std::ref(outs[k]));
+        for (auto& th : pool) th.join();
       }
+      next.clear();
+      for (const Out& o_ : outs) {
+        next.insert(next.end(), o_.next.begin(), o_.next.end());
+        for (const Pair& q : o_.p2p) { p2p_src.push_back(q.first); p2p_tgt.push_back(q.second); }
+        for (const Pair& q : o_.lr) { lr_src.push_back(q.first); lr_tgt.push_back(q.second); }
+      }
+      cur.swap(next);
     }
   }
 
@@ -562,22 +590,51 @@ std::string HostPlan::build(const HostOptions& o, int64_t n_panels, const double
   m2l_src.resize(m2l_pairs_owned);
   m2l_cls.resize(m2l_pairs_owned);
   {
-    std::vector<int> at(m2l_ptr.begin(), m2l_ptr.end() - 1);
-    std::unordered_map<IVec3, int, IVec3Hash> cls_of;
-    for (size_t i = 0; i < lr_tgt.size(); ++i) {
+    // Translation classes are numbered in the order their vectors first appear in the traversal-ordered pair list.  Three steps,
+    // the two long ones by a few threads: (1) every chunk of the list collects the vectors new TO IT, in order; (2) the chunks'
+    // finds are merged in chunk order -- the serial numbering; (3) every pair looks its class up.
+    const size_t np = lr_tgt.size();
+    const int nt = np < (1u << 16) ? 1 : (int)std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
+    auto vec_of = [&](size_t i) {
       const int s = lr_src[i], t = lr_tgt[i];
-      if (!owned_L[t]) continue;
-      const int32_t d[3] = {box_icoord[3 * t] - box_icoord[3 * s], box_icoord[3 * t + 1] - box_icoord[3 * s + 1],
-                            box_icoord[3 * t + 2] - box_icoord[3 * s + 2]};
-      const IVec3 key = {d[0], d[1], d[2]};                 // exact: half-cells of the finest level (up to 2^22 on a deep tree)
-      auto [it, fresh] = cls_of.try_emplace(key, (int)m2l_class_rep.size() / 2);
-      if (fresh) {
-        m2l_class_vec.insert(m2l_class_vec.end(), {d[0], d[1], d[2]});
-        m2l_class_rep.insert(m2l_class_rep.end(), {s, t});
+      return IVec3{box_icoord[3 * t] - box_icoord[3 * s], box_icoord[3 * t + 1] - box_icoord[3 * s + 1], box_icoord[3 * t + 2] - box_icoord[3 * s + 2]};
+    };
+    struct Found { IVec3 key; int s, t; };
+    std::vector<std::vector<Found>> found(nt);
+    auto scan = [&](int k) {
+      std::unordered_map<IVec3, int, IVec3Hash> mine;
+      for (size_t i = np * k / nt; i < np * (k + 1) / nt; ++i) {
+        if (!owned_L[lr_tgt[i]]) continue;
+        const IVec3 key = vec_of(i);                        // exact: half-cells of the finest level (up to 2^22 on a deep tree)
+        if (mine.try_emplace(key, 0).second) found[k].push_back({key, lr_src[i], lr_tgt[i]});
       }
+    };
+    auto run = [&](auto&& fn) {
+      if (nt == 1) { fn(0); return; }
+      std::vector<std::thread> pool;
+      for (int k = 0; k < nt; ++k) pool.emplace_back(fn, k);
+      for (auto& th : pool) th.join();
+    };
+    run(scan);
+    std::unordered_map<IVec3, int, IVec3Hash> cls_of;
+    for (int k = 0; k < nt; ++k)
+      for (const Found& f : found[k])
+        if (cls_of.try_emplace(f.key, (int)m2l_class_rep.size() / 2).second) {
+          m2l_class_vec.insert(m2l_class_vec.end(), {f.key.x, f.key.y, f.key.z});
+          m2l_class_rep.insert(m2l_class_rep.end(), {f.s, f.t});
+        }
+    std::vector<int> cls_pair(np, -1);
+    run([&](int k) {
+      for (size_t i = np * k / nt; i < np * (k + 1) / nt; ++i)
+        if (owned_L[lr_tgt[i]]) cls_pair[i] = cls_of.find(vec_of(i))->second;
+    });
+    std::vector<int> at(m2l_ptr.begin(), m2l_ptr.end() - 1);
+    for (size_t i = 0; i < np; ++i) {
+      const int t = lr_tgt[i];
+      if (!owned_L[t]) continue;
       const int slot = at[t]++;
-      m2l_src[slot] = s;
-      m2l_cls[slot] = it->second;
+      m2l_src[slot] = lr_src[i];
+      m2l_cls[slot] = cls_pair[i];
     }
   }
 
@@ -586,8 +643,19 @@ std::string HostPlan::build(const HostOptions& o, int64_t n_panels, const double
   // ---- panels in tree order, SoA (LaplaceSphericalBEM.hpp:64-97) ----
   PanelSoA& P = panels;
   const int nq = rule.n;
-  alloc_panels(P, n, nq);
   has_bc[0] = has_bc[1] = false;
+  if (o.panels_on_device) {
+    // the derived geometry is computed where it is used (0.2 GB written by the host and uploaded, 60-80 ms at N = 1M, otherwise)
+    P.bc.resize(n);
+    for (int64_t i = 0; i < n; ++i) {
+      const uint8_t flag = bc ? (bc[perm[i]] ? 1 : 0) : 0;
+      P.bc[i] = flag;
+      has_bc[flag] = true;
+    }
+    mark("flags");
+    return {};
+  }
+  alloc_panels(P, n, nq);
   // independent per panel: cut into ranges for a few host threads (half of this function's time at N = 1M when serial)
   const int nthreads = n < (1 << 16) ? 1 : (int)std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
   std::vector<std::array<uint8_t, 2>> seen_bc(nthreads, std::array<uint8_t, 2>{0, 0});

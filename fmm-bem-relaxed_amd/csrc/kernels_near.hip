@@ -1389,6 +1389,45 @@ __global__ __launch_bounds__(kSpmvWaves * kWave, kRcOcc) void near_recompute3_ke
   }
 }
 
+// Panel(p0, p1, p2) of kernel/LaplaceSphericalBEM.hpp:64-97 for every panel, in TREE order, from the caller's vertices (original
+// order) and the permutation: centroid, normal (p2-p0) x (p1-p0) / 2A, area, the rule's points, the vertices transposed.  The
+// arithmetic of host_plan.cpp fill_panel operation for operation, contraction OFF: the same bits as the host form (which a
+// host-only plan and fmmbem_kernel_entries still use).
+__global__ void panel_setup_kernel(int64_t n, const uint32_t* __restrict__ perm, const double* __restrict__ v_orig, int nq,
+                                   const double* __restrict__ pts, double* __restrict__ cx, double* __restrict__ cy,
+                                   double* __restrict__ cz, double* __restrict__ nx, double* __restrict__ ny, double* __restrict__ nz,
+                                   double* __restrict__ area, double* __restrict__ quad, double* __restrict__ vert) {
+#pragma clang fp contract(off)
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double* v = v_orig + 9 * (size_t)perm[i];
+  double p0[3], p1[3], p2[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { p0[k] = v[k]; p1[k] = v[3 + k]; p2[k] = v[6 + k]; }
+  cx[i] = (p0[0] + p1[0] + p2[0]) / 3;
+  cy[i] = (p0[1] + p1[1] + p2[1]) / 3;
+  cz[i] = (p0[2] + p1[2] + p2[2]) / 3;
+  const double a0[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
+  const double a1[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
+  const double c[3] = {a0[1] * a1[2] - a0[2] * a1[1], -(a0[0] * a1[2] - a0[2] * a1[0]), a0[0] * a1[1] - a0[1] * a1[0]};
+  const double A = 0.5 * sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+  area[i] = A;
+  nx[i] = c[0] / 2 / A; ny[i] = c[1] / 2 / A; nz[i] = c[2] / 2 / A;
+  for (int q = 0; q < nq; ++q)
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      quad[((size_t)q * 3 + k) * n + i] = p0[k] * pts[3 * q] + p1[k] * pts[3 * q + 1] + p2[k] * pts[3 * q + 2];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) vert[(size_t)k * n + i] = v[k];
+}
+hipError_t launch_panel_setup(int64_t n, const uint32_t* perm, const double* v_orig, int nq, const double* pts, double* cx, double* cy,
+                              double* cz, double* nx, double* ny, double* nz, double* area, double* quad, double* vert, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(panel_setup_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, perm, v_orig, nq, pts, cx, cy, cz, nx, ny,
+                     nz, area, quad, vert);
+  return hipGetLastError();
+}
+
 // diag[original unknown] = A_near[u,u]: the self-interaction K(s,s) that Preconditioners::Diagonal divides by
 // (examples/BEM/Preconditioner.hpp:19-42).  selfcol[leaf] = first column of the leaf's own panels in its block.
 __global__ void near_diag_kernel(DevicePlan d, const int* __restrict__ selfcol, double* __restrict__ out) {

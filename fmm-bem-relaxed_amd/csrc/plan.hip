@@ -267,8 +267,12 @@ struct fmmbem_plan {
   // kernels above; FMMBEM_M2L_ROT=0: the double sum at every order (A/B runs, tools/m2l_ab.py)
   int rot_max = kRotPmax;
   bool use_rot(int p) const { return p <= rot_max && m2l_rot_supported(p); }
+  const double* create_vertices = nullptr;                   // fmmbem_plan_create: the caller's vertices while to_device runs (panel set-up on the device)
   int to_device();                                           // the geometry's share (-> shared), then to_device_bc
-  int to_device_bc(const uint8_t* bc_tree);                  // what depends on the boundary-condition flags (-> this plan)
+  int to_device_bc(const uint8_t* bc_tree);
+  int to_device_bc_begin(const uint8_t* bc_tree);
+  int to_device_bc_end();
+  hipEvent_t asm_ev[2] = {nullptr, nullptr};     // what depends on the boundary-condition flags (-> this plan)
   static int like(const fmmbem_plan& base, const uint8_t* bc, fmmbem_plan** out);
   // phase 0: whole matvec; 1: upward half (gather, P2M, M2M of owned boxes, pack -> xbuf); 2: the rest (xbuf = gathered)
   int run(int p, const double* d_x, double* d_y, hipStream_t s, bool near_only, int phase = 0, double* xbuf = nullptr);
@@ -357,11 +361,34 @@ int fmmbem_plan::to_device() {
   const int dof = d.dof;
 
   // panels + permutation
-  const PanelSoA& P = hp.panels;
-  TRY(upload(P.cx, &d.cx)); TRY(upload(P.cy, &d.cy)); TRY(upload(P.cz, &d.cz));
-  TRY(upload(P.nx, &d.nx)); TRY(upload(P.ny, &d.ny)); TRY(upload(P.nz, &d.nz));
-  TRY(upload(P.area, &d.area)); TRY(upload(P.quad, &d.quad)); TRY(upload(P.vert, &d.vert));
-  TRY(upload(hp.perm, &d.perm));                       // (the flags: to_device_bc)
+  TRY(upload(hp.perm, &d.perm));
+  if (create_vertices) {
+    // the panels' derived geometry, computed on the device from the caller's vertices (kernels_near.hip panel_setup: the host
+    // form's arithmetic, bit for bit): 75 MB up instead of 0.2 GB written by the host and then uploaded
+    const size_t nn = (size_t)hp.n;
+    double *cx, *cy, *cz, *nx, *ny, *nz, *ar, *qd, *vt;
+    TRY(alloc(nn, &cx, false)); TRY(alloc(nn, &cy, false)); TRY(alloc(nn, &cz, false));
+    TRY(alloc(nn, &nx, false)); TRY(alloc(nn, &ny, false)); TRY(alloc(nn, &nz, false));
+    TRY(alloc(nn, &ar, false)); TRY(alloc(nn * 3 * hp.rule.n, &qd, false)); TRY(alloc(nn * 9, &vt, false));
+    double* v_orig = nullptr;
+    HIP_TRY(hipMalloc(&v_orig, sizeof(double) * 9 * nn));
+    std::vector<double> pts((size_t)hp.rule.n * 3);
+    for (int q = 0; q < hp.rule.n; ++q) for (int k = 0; k < 3; ++k) pts[3 * q + k] = hp.rule.pts[q][k];
+    const double* d_pts = nullptr;
+    hipError_t e = hipMemcpy(v_orig, create_vertices, sizeof(double) * 9 * nn, hipMemcpyHostToDevice);
+    int rc = e == hipSuccess ? upload(pts, &d_pts) : FMMBEM_ERR_HIP;
+    if (rc == FMMBEM_OK) e = launch_panel_setup(hp.n, d.perm, v_orig, hp.rule.n, d_pts, cx, cy, cz, nx, ny, nz, ar, qd, vt, own_stream);
+    if (rc == FMMBEM_OK && e == hipSuccess) e = hipStreamSynchronize(own_stream);
+    (void)hipFree(v_orig);
+    if (rc != FMMBEM_OK) return rc;
+    if (e != hipSuccess) return fail(FMMBEM_ERR_HIP, std::string("panel setup: ") + hipGetErrorString(e));
+    d.cx = cx; d.cy = cy; d.cz = cz; d.nx = nx; d.ny = ny; d.nz = nz; d.area = ar; d.quad = qd; d.vert = vt;
+  } else {
+    const PanelSoA& P = hp.panels;
+    TRY(upload(P.cx, &d.cx)); TRY(upload(P.cy, &d.cy)); TRY(upload(P.cz, &d.cz));
+    TRY(upload(P.nx, &d.nx)); TRY(upload(P.ny, &d.ny)); TRY(upload(P.nz, &d.nz));
+    TRY(upload(P.area, &d.area)); TRY(upload(P.quad, &d.quad)); TRY(upload(P.vert, &d.vert));
+  }
 
   // leaves and the near block structure
   std::vector<int> leaf_row0(nl), leaf_nrows(nl), near_stride(nl), run_row0, run_off;
@@ -569,6 +596,8 @@ int fmmbem_plan::to_device() {
   }
 
   mark("panels + near lists upload");
+  TRY(to_device_bc_begin(hp.panels.bc.data()));        // the near-matrix assembly runs on the GPU from here, under the host work below
+  alloc_list = &shared->allocs;
   // far-field lists
   std::vector<int> p2m_leaf, l2p_leaf;
   for (int b : hp.p2m_leaves) p2m_leaf.push_back(hp.box_leaf_index[b]);
@@ -844,25 +873,23 @@ int fmmbem_plan::to_device() {
   mark("m2l class tables");
   shared->on_device = true;
   shared->device = opts.device;
-  return to_device_bc(hp.panels.bc.data());
+  return to_device_bc_end();
 }
 
 // Everything of a plan that depends on the boundary-condition flags: which expansion slots are live, the flags themselves, the
 // near-matrix values (the TARGET's flag picks the kernel), the P2M moments (the SOURCE's flag picks them), the expansions and the
 // work vectors.  bc_tree: the flags in tree order.  Allocations go to this plan, not to the shared block.
 int fmmbem_plan::to_device_bc(const uint8_t* bc_tree) {
+  TRY(to_device_bc_begin(bc_tree));
+  return to_device_bc_end();
+}
+
+// First half: the flags, the near-matrix storage, and the assembly LAUNCHED (own_stream, asynchronous) -- to_device calls this as
+// soon as the panels and the near lists are in HBM, so that the 20-50 ms of panel integrals run on the GPU while the host goes on
+// tabulating and uploading the far-field operators.
+int fmmbem_plan::to_device_bc_begin(const uint8_t* bc_tree) {
   DEVICE_SCOPE(opts.device);
   alloc_list = &allocs;
-  const bool trace = std::getenv("FMMBEM_BUILD_TRACE") != nullptr;
-  double t_last = now_ms();
-  auto mark = [&](const char* what) {
-    if (!trace) return;
-    (void)hipDeviceSynchronize();
-    const double now = now_ms();
-    std::fprintf(stderr, "to_device %-28s %8.2f ms\n", what, now - t_last);
-    t_last = now;
-  };
-  const int dof = d.dof, nb = hp.nboxes;
   d.n_act = 0;
   if (opts.kernel == FMMBEM_KERNEL_STOKES_BEM) {
     // StokesSphericalBEM: M[2][4] per box (kernel/StokesSphericalBEM.hpp:143-153).  The TARGET's flag picks the operator
@@ -891,6 +918,30 @@ int fmmbem_plan::to_device_bc(const uint8_t* bc_tree) {
     HIP_TRY(hipEventCreateWithFlags(&hyb_fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&hyb_join, hipEventDisableTiming));
   }
+  // near-field assembly on the device, in flight from here on (everything it reads is uploaded; to_device_bc_end waits for it)
+  HIP_TRY(hipEventCreate(&asm_ev[0])); HIP_TRY(hipEventCreate(&asm_ev[1]));
+  HIP_TRY(hipEventRecord(asm_ev[0], own_stream));
+  if (opts.sparse_local) {
+    if (opts.kernel == FMMBEM_KERNEL_STOKES_BEM) HIP_TRY(launch_near_assemble_stokes(d, own_stream));
+    else HIP_TRY(launch_near_assemble(d, own_stream));
+  }
+  HIP_TRY(hipEventRecord(asm_ev[1], own_stream));
+  return FMMBEM_OK;
+}
+
+int fmmbem_plan::to_device_bc_end() {
+  DEVICE_SCOPE(opts.device);
+  alloc_list = &allocs;
+  const bool trace = std::getenv("FMMBEM_BUILD_TRACE") != nullptr;
+  double t_last = now_ms();
+  auto mark = [&](const char* what) {
+    if (!trace) return;
+    (void)hipDeviceSynchronize();
+    const double now = now_ms();
+    std::fprintf(stderr, "to_device %-28s %8.2f ms\n", what, now - t_last);
+    t_last = now;
+  };
+  const int dof = d.dof, nb = hp.nboxes;
   TRY(alloc((size_t)nb * d.nslots * d.s_max, &d.M, true));
   TRY(alloc((size_t)nb * d.nslots * d.s_max, &d.L, true));
   TRY(alloc((size_t)nb * d.nslots * d.s_max, &d.Mh, true));
@@ -939,16 +990,19 @@ int fmmbem_plan::to_device_bc(const uint8_t* bc_tree) {
     }
   }
   mark("p2m table");
-  // near-field assembly on the device
-  const double t0 = now_ms();
-  if (opts.sparse_local) {
-    if (opts.kernel == FMMBEM_KERNEL_STOKES_BEM) HIP_TRY(launch_near_assemble_stokes(d, own_stream));
-    else HIP_TRY(launch_near_assemble(d, own_stream));
-    HIP_TRY(hipStreamSynchronize(own_stream));
+  // the near-field assembly launched by to_device_bc_begin: its device time
+  HIP_TRY(hipStreamSynchronize(own_stream));
+  {
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, asm_ev[0], asm_ev[1]));
+    build_assemble_ms = ms;
+    (void)hipEventDestroy(asm_ev[0]); (void)hipEventDestroy(asm_ev[1]);
+    asm_ev[0] = asm_ev[1] = nullptr;
   }
+  const double t0 = now_ms();
   if ((!opts.sparse_local || hybrid) && hp.row_end > hp.row_begin) TRY(build_side_lists());
-  build_assemble_ms = now_ms() - t0;
-  mark("near assembly");
+  build_assemble_ms += now_ms() - t0;
+  mark("near assembly (waited for)");
   {                                                    // the plan itself, readable from the device
     void* pd = nullptr;
     HIP_TRY(hipMalloc(&pd, sizeof(DevicePlan)));
@@ -1277,6 +1331,7 @@ int fmmbem_plan::like(const fmmbem_plan& base, const uint8_t* bc, fmmbem_plan** 
   pl->ev.assign(pl->ev.size(), nullptr);
   pl->graphs.clear();
   pl->own_stream = nullptr; pl->hyb_stream = nullptr; pl->hyb_fork = pl->hyb_join = nullptr;
+  pl->asm_ev[0] = pl->asm_ev[1] = nullptr;
   pl->d_dev = nullptr; pl->stage_x = pl->stage_y = nullptr; pl->solver_ws = nullptr; pl->d_cut = nullptr;
   pl->result_slices = false; pl->pending_mask = 0; pl->pending_near = false;
   pl->timing = 0; pl->last_p = 0; pl->ev_count = 0;
@@ -1346,6 +1401,7 @@ int fmmbem_plan_create(const fmmbem_options* opts, size_t n_panels, const double
   ho.evaluator = opts->evaluator;
   ho.shard_upward = opts->shard_upward < 0 ? 0 : opts->shard_upward > 2 ? 2 : opts->shard_upward;
   ho.reference_l2l = opts->l2l_rule == FMMBEM_L2L_REFERENCE;
+  ho.panels_on_device = !opts->host_only && !(std::getenv("FMMBEM_PANELS_ON_HOST") && std::atoi(std::getenv("FMMBEM_PANELS_ON_HOST")) != 0);
   const double t0 = now_ms();
   std::string err;
   try {
@@ -1358,7 +1414,9 @@ int fmmbem_plan_create(const fmmbem_options* opts, size_t n_panels, const double
   pl->has_bc[0] = pl->hp.has_bc[0]; pl->has_bc[1] = pl->hp.has_bc[1];
   if (!opts->host_only) {
     try {
+      pl->create_vertices = ho.panels_on_device ? vertices : nullptr;
       const int rc = pl->to_device();
+      pl->create_vertices = nullptr;
       if (rc != FMMBEM_OK) return rc;
     } catch (const std::bad_alloc&) {
       return fail(FMMBEM_ERR_ALLOC, "host allocation failed while tabulating operators");
