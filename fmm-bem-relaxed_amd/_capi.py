@@ -17,7 +17,6 @@ MAX_QUAD = 79          # FMMBEM_MAX_QUAD
 KERNEL_LAPLACE_BEM, KERNEL_STOKES_BEM = 0, 1
 EVAL_FMM, EVAL_LOCAL, EVAL_BLOCK_DIAGONAL = 0, 1, 2
 L2L_COMPLETE, L2L_REFERENCE = 0, 1
-MAC_REFERENCE, MAC_BODY_EXTENT = 0, 1
 BC_POTENTIAL, BC_NORMAL_DERIV = 0, 1
 
 
@@ -27,7 +26,7 @@ class Options(C.Structure):
                 ("ncrit", C.c_uint32), ("sparse_local", C.c_int32), ("host_only", C.c_int32),
                 ("device", C.c_int32), ("shard_rank", C.c_int32), ("shard_world", C.c_int32),
                 ("quad_k_fine", C.c_int32), ("evaluator", C.c_int32), ("mu", C.c_double),
-                ("shard_upward", C.c_int32), ("l2l_rule", C.c_int32), ("near_stream_fraction", C.c_double), ("mac_rule", C.c_int32)]
+                ("shard_upward", C.c_int32), ("l2l_rule", C.c_int32), ("near_stream_fraction", C.c_double)]
 
 
 class Stats(C.Structure):

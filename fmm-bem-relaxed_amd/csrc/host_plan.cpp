@@ -344,39 +344,10 @@ std::string HostPlan::build(const HostOptions& o, int64_t n_panels, const double
   }
   mark("tree + box geometry");
   // ---- dual tree traversal (EvalInteractionLazySparse.hpp:68-110, :239-252) ----
-  // mac_rule 1 (NOT a reference rule; fmmbem.h FMMBEM_MAC_BODY_EXTENT): a box is measured by the largest distance of its panels'
-  // vertices from its centre -- what the convergence of the expansions about that centre depends on -- instead of half
-  // its side, which it is whatever it holds: a coarse leaf that clips a cap of the surface has its panels in one corner, 0.87
-  // sides from the centre, and the reference's rule accepts M2L into it that converges like 0.76^p
-  std::vector<double> box_rad;
-  if (o.mac_rule == 1) {
-    box_rad.assign(nboxes, 0.0);
-    auto radii = [&](int b0, int b1) {
-      for (int b = b0; b < b1; ++b) {
-        double m2 = 0;
-        for (int i = box_body_begin[b]; i < box_body_end[b]; ++i)
-          for (int k = 0; k < 3; ++k) {                    // the panel's vertices: every quadrature point and the centroid lie within
-            const double* pc = vertices + 9 * (size_t)perm[i] + 3 * k;
-            const double dx = pc[0] - box_center[3 * b], dy = pc[1] - box_center[3 * b + 1], dz = pc[2] - box_center[3 * b + 2];
-            const double r2 = dx * dx + dy * dy + dz * dz;
-            if (r2 > m2) m2 = r2;
-          }
-        box_rad[b] = std::sqrt(m2);
-      }
-    };
-    const int nt = n < (1 << 16) ? 1 : (int)std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
-    if (nt == 1) radii(0, nboxes);
-    else {                                               // a level holds all N bodies: cut the box list by level-interleaved strides
-      std::vector<std::thread> pool;
-      for (int t = 0; t < nt; ++t)
-        pool.emplace_back([&, t] { for (int b = t; b < nboxes; b += nt) radii(b, b + 1); });
-      for (auto& th : pool) th.join();
-    }
-  }
   auto accept = [&](int s, int t) {     // DefaultMAC, radius = side/2
     const double dx = box_center[3 * s] - box_center[3 * t], dy = box_center[3 * s + 1] - box_center[3 * t + 1],
                  dz = box_center[3 * s + 2] - box_center[3 * t + 2];
-    const double rhs = o.mac_rule == 1 ? (box_rad[s] + box_rad[t]) / o.theta : (box_side[s] / 2.0 + box_side[t] / 2.0) / o.theta;
+    const double rhs = (box_side[s] / 2.0 + box_side[t] / 2.0) / o.theta;
     return dx * dx + dy * dy + dz * dz > rhs * rhs;
   };
   {

@@ -52,7 +52,6 @@ struct HostOptions {
   int evaluator = 0;           // 0 FMM, 1 local only, 2 block diagonal (executor/make_executor.hpp:24-60)
   bool reference_l2l = false;  // keep only the parent->child L2L edges the reference's lazy rule keeps (see host_plan.cpp)
   int shard_upward = 0;        // shard_world > 1: 1, 2 = P2M/M2M only for boxes this shard owns (+ the few spanning shards); 2 = selective exchange lists
-  int mac_rule = 0;            // 0: DefaultMAC on half sides (the reference); 1: on the bodies' largest distance from the box centre
   bool panels_on_device = false;  // the caller derives the panels' geometry (centroid, normal, area, points) on the device from the
                                // vertices and the permutation (kernels_near.hip panel_setup): build() then fills only the flags
 };

@@ -1285,8 +1285,7 @@ static bool same_geometry_options(const fmmbem_options& a, const fmmbem_options&
   return a.kernel == b.kernel && a.p_max == b.p_max && a.quad_k == b.quad_k && a.theta == b.theta && a.ncrit == b.ncrit &&
          a.sparse_local == b.sparse_local && a.host_only == b.host_only && a.device == b.device && a.shard_rank == b.shard_rank &&
          a.shard_world == b.shard_world && a.quad_k_fine == b.quad_k_fine && a.evaluator == b.evaluator && a.mu == b.mu &&
-         a.shard_upward == b.shard_upward && a.l2l_rule == b.l2l_rule && a.near_stream_fraction == b.near_stream_fraction &&
-         a.mac_rule == b.mac_rule;
+         a.shard_upward == b.shard_upward && a.l2l_rule == b.l2l_rule && a.near_stream_fraction == b.near_stream_fraction;
 }
 
 // live plans that own a geometry, most recent first (a handful: operator, preconditioner plans)
@@ -1377,7 +1376,6 @@ int fmmbem_plan_create(const fmmbem_options* opts, size_t n_panels, const double
   }
   if (!vertices || n_panels == 0) return fail(FMMBEM_ERR_INVALID, "no panels");
   if (opts->l2l_rule != FMMBEM_L2L_COMPLETE && opts->l2l_rule != FMMBEM_L2L_REFERENCE) return fail(FMMBEM_ERR_INVALID, "unknown l2l_rule");
-  if (opts->mac_rule != FMMBEM_MAC_REFERENCE && opts->mac_rule != FMMBEM_MAC_BODY_EXTENT) return fail(FMMBEM_ERR_INVALID, "unknown mac_rule");
   if (opts->evaluator < FMMBEM_EVAL_FMM || opts->evaluator > FMMBEM_EVAL_BLOCK_DIAGONAL) return fail(FMMBEM_ERR_INVALID, "unknown evaluator");
   // The geometry of a live plan, recognised: same options, same panel count, same vertex bytes (two 64-bit hashes) -- only the
   // boundary-condition flags may differ.  The new plan then shares that plan's tree, lists and tables (PlanShared) and builds
@@ -1403,7 +1401,6 @@ int fmmbem_plan_create(const fmmbem_options* opts, size_t n_panels, const double
   ho.evaluator = opts->evaluator;
   ho.shard_upward = opts->shard_upward < 0 ? 0 : opts->shard_upward > 2 ? 2 : opts->shard_upward;
   ho.reference_l2l = opts->l2l_rule == FMMBEM_L2L_REFERENCE;
-  ho.mac_rule = opts->mac_rule;
   ho.panels_on_device = !opts->host_only && !(std::getenv("FMMBEM_PANELS_ON_HOST") && std::atoi(std::getenv("FMMBEM_PANELS_ON_HOST")) != 0);
   const double t0 = now_ms();
   std::string err;

@@ -33,9 +33,6 @@ class FMMOptions:
         # not in the reference: share of the near-field pairs kept as a matrix; < 1: the rest is recomputed every matvec by the
         # same kernel between its streamed items (include/fmmbem.h, fmmbem_options.near_stream_fraction)
         self.near_stream_fraction = 1.0
-        # not in the reference: True measures a box in the acceptance test by its bodies' largest distance from the box centre
-        # instead of half its side (include/fmmbem.h, fmmbem_mac_rule)
-        self.body_extent_mac = False
 
     def set_mac_theta(self, theta):     # FMMOptions.hpp:50-52
         self.theta = float(theta)
@@ -213,7 +210,6 @@ class FMM_plan:
         o.evaluator = evaluator
         o.l2l_rule = _capi.L2L_REFERENCE if getattr(opts, "reference_l2l", False) else _capi.L2L_COMPLETE
         o.near_stream_fraction = float(getattr(opts, "near_stream_fraction", 1.0))
-        o.mac_rule = _capi.MAC_BODY_EXTENT if getattr(opts, "body_extent_mac", False) else _capi.MAC_REFERENCE
         o.device = int(device)
         self.device = int(device)
         self.dof = 1

@@ -72,19 +72,6 @@ typedef enum {
   FMMBEM_L2L_REFERENCE = 1        /* exactly the reference's list, omissions included (bit parity on adaptive trees)  */
 } fmmbem_l2l_rule;
 
-/* Acceptance test of the dual traversal.  The reference's DefaultMAC (include/FMMOptions.hpp:21-31) accepts a pair of boxes iff
- * |c1 - c2|^2 > ((r1 + r2) / theta)^2 with r = HALF THE SIDE of the box, whatever it holds.  The expansions are about the box
- * centre, and what their convergence depends on is the distance of the bodies from that centre -- up to 0.87 side in a corner.
- * On trees whose coarse leaves clip a cap of the surface (leaf iff count <= ncrit, Octree.hpp:641; the two-sphere N = 1M bench
- * workload has such leaves on level 3) the M2L into those leaves converges like 0.76^p and carries the error of the whole
- * matvec: 9e-6 against the Direct sum at p = 10, theta = 0.5, reference and product alike. */
-typedef enum {
-  FMMBEM_MAC_REFERENCE = 0,       /* r = side / 2: the reference's lists, bit for bit (default)                               */
-  FMMBEM_MAC_BODY_EXTENT = 1      /* NOT a reference rule: r = largest distance of a vertex of the box's panels from the box centre
-                                   * (every quadrature point and centroid lies within).  Stricter everywhere (more near pairs and M2L pairs: see BASELINE.md for the
-                                   * cost), error falls like the textbook (r / (d - r))^p                                      */
-} fmmbem_mac_rule;
-
 typedef struct {
   int32_t  kernel;            /* fmmbem_kernel                                                     */
   int32_t  p_max;             /* largest expansion order any execute() will ask for (1..16)        */
@@ -119,7 +106,6 @@ typedef struct {
                                * differ from f = 1 in the last bits.  Taken as 1 where the hybrid kernel does not apply (rules of
                                * more than 3 / 4 points, the LOCAL / BLOCK_DIAGONAL evaluators).  FMMBEM_NEAR_STREAM_FRACTION
                                * overrides it at creation (sweeps).                                                      */
-  int32_t  mac_rule;          /* fmmbem_mac_rule */
 } fmmbem_options;
 
 /* Statistics of a plan and of its last execute (times in milliseconds, device-side HIP events). */

@@ -106,9 +106,6 @@ class FMMOptions {
   // leaves with the most rows keep none and are recomputed every matvec beside the streamed rest (fmmbem.h near_stream_fraction):
   // fewer HBM bytes and a smaller footprint at the same operator, last bits differ.  Stokes plans (measured optimum ~0.6).
   double near_stream_fraction = 1.0;
-  // Not in the reference: the acceptance test on the bodies' largest distance from the box centre instead of half the side
-  // (fmmbem.h fmmbem_mac_rule): what meets 1e-6 of Direct at p = 10 on trees with coarse leaves, at the price stated there.
-  bool body_extent_mac = false;
   void set_mac_theta(double t) { MAC_ = DefaultMAC(t); }
   DefaultMAC MAC() { return MAC_; }
   void set_max_per_box(unsigned n) { NCRIT_ = n; }
@@ -344,7 +341,6 @@ class PlanAdapter {
     o.evaluator = opts_.c_evaluator();
     o.l2l_rule = opts_.reference_l2l ? FMMBEM_L2L_REFERENCE : FMMBEM_L2L_COMPLETE;
     o.near_stream_fraction = opts_.near_stream_fraction;
-    o.mac_rule = opts_.body_extent_mac ? FMMBEM_MAC_BODY_EXTENT : FMMBEM_MAC_REFERENCE;
     sparse_ = o.sparse_local != 0;
     fmmbem_plan* fresh = nullptr;
     check(fmmbem_plan_create(&o, n_, v.data(), bc.data(), &fresh));

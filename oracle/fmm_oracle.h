@@ -54,8 +54,6 @@ typedef struct {
   int level;
   double center[3];
   double side;             /* side_length()                                    */
-  double rad;              /* NOT a reference quantity: largest distance of a vertex of the box's panels from its centre;
-                            * read by the acceptance test only under ORC_MAC_BODY_EXTENT (tree.c)                           */
   uint32_t bb, be;         /* body range in tree order (all boxes)             */
 } orc_box;
 
@@ -69,7 +67,6 @@ typedef struct orc_ctx {
   double qw[ORC_MAXK];     /* weights of the K rule                            */
   double theta;
   unsigned ncrit;
-  int mac_rule;            /* ORC_MAC_*                                        */
   orc_panel *panels;       /* ORIGINAL order                                   */
   double *quad;            /* n * nq * 3 quadrature point storage              */
   /* tree */
@@ -122,10 +119,6 @@ void orc_semi_analytical(double *G, double *dGdn, const double y0[3], const doub
 /* ---- tree.c ---- */
 enum { ORC_EVAL_FMM = 0, ORC_EVAL_LOCAL = 1, ORC_EVAL_BLOCK_DIAGONAL = 2 };
 orc_ctx *orc_create_eval(int n, const double *verts, const uint8_t *bc, int K, double theta, unsigned ncrit, int evaluator);
-/* not a reference rule: mac_rule = ORC_MAC_BODY_EXTENT measures a box by its bodies' distance from its centre instead of half
- * its side in the acceptance test (see tree.c); ORC_MAC_REFERENCE = orc_create_eval */
-enum { ORC_MAC_REFERENCE = 0, ORC_MAC_BODY_EXTENT = 1 };
-orc_ctx *orc_create_mac(int n, const double *verts, const uint8_t *bc, int K, double theta, unsigned ncrit, int evaluator, int mac_rule);
 orc_ctx *orc_create(int n, const double *verts, const uint8_t *bc, int K, double theta,
                     unsigned ncrit);
 void orc_complete_l2l(orc_ctx *c);   /* not a reference rule: see tree.c */

@@ -40,8 +40,6 @@ def lib():
         L.orc_create.argtypes = [i32, vp, vp, i32, dbl, C.c_uint]
         L.orc_create_eval.restype = vp
         L.orc_create_eval.argtypes = [i32, vp, vp, i32, dbl, C.c_uint, i32]
-        L.orc_create_mac.restype = vp
-        L.orc_create_mac.argtypes = [C.c_int, vp, vp, C.c_int, C.c_double, C.c_uint, C.c_int, C.c_int]
         L.orc_complete_l2l.restype = None
         L.orc_complete_l2l.argtypes = [vp]
         L.orc_destroy.argtypes = [vp]
@@ -147,10 +145,8 @@ FAITHFUL = 1
 class Oracle:
     """One FMM_plan<LaplaceSphericalBEM>-equivalent on the CPU (include/FMM_plan.hpp:34-90)."""
 
-    def __init__(self, vertices, bc=None, K=3, theta=0.5, ncrit=64, evaluator=0, complete_l2l=False, body_extent_mac=False):
+    def __init__(self, vertices, bc=None, K=3, theta=0.5, ncrit=64, evaluator=0, complete_l2l=False):
         """evaluator: 0 FMM, 1 local only (EvalLocalSparse), 2 block diagonal (EvalDiagonalSparse).
-        body_extent_mac: NOT a reference rule -- the acceptance test measures a box by its bodies' largest distance from the box
-        centre instead of half the side (tree.c mac()).
         complete_l2l: replace the reference's L2L list (which omits stats()['l2l_skipped'] edges on adaptive trees)
         by the complete one -- not a reference rule, see tree.c:orc_complete_l2l."""
         v = np.ascontiguousarray(vertices, dtype=np.float64).reshape(-1, 9)
@@ -158,7 +154,7 @@ class Oracle:
         if bc is None:
             bc = np.zeros(self.n, dtype=np.uint8)
         bc = np.ascontiguousarray(bc, dtype=np.uint8)
-        self._h = lib().orc_create_mac(self.n, _p(v), _p(bc), K, theta, ncrit, evaluator, 1 if body_extent_mac else 0)
+        self._h = lib().orc_create_eval(self.n, _p(v), _p(bc), K, theta, ncrit, evaluator)
         if not self._h:
             raise ValueError("orc_create failed (bad quadrature key or empty input)")
         if complete_l2l:
@@ -342,11 +338,11 @@ class StokesOracle(Oracle):
     """FMM_plan<StokesSphericalBEM>-equivalent on the CPU, velocity boundary condition only
     (kernel/StokesSphericalBEM.hpp:260-375, 391-432, 512-528; StokesSpherical.hpp:318-401)."""
 
-    def __init__(self, vertices, K=4, K_fine=19, mu=1e-3, theta=0.5, ncrit=64, evaluator=0, complete_l2l=False, bc=None, body_extent_mac=False):
+    def __init__(self, vertices, K=4, K_fine=19, mu=1e-3, theta=0.5, ncrit=64, evaluator=0, complete_l2l=False, bc=None):
         """bc: per-panel flags, 0 VELOCITY / 1 TRACTION.  The target's flag picks the integral of a near-matrix entry
         (StokesSphericalBEM.hpp:377-389); the far field is the velocity branch only, so matvec() refuses traction panels
         unless the evaluator is near-field-only (1, 2)."""
-        super().__init__(vertices, bc=bc, K=K, theta=theta, ncrit=ncrit, evaluator=evaluator, complete_l2l=complete_l2l, body_extent_mac=body_extent_mac)
+        super().__init__(vertices, bc=bc, K=K, theta=theta, ncrit=ncrit, evaluator=evaluator, complete_l2l=complete_l2l)
         if lib().orc_stokes_config(self._h, mu, K_fine):
             raise ValueError("invalid K_fine")
         self.mu = mu

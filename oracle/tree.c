@@ -72,11 +72,6 @@ static int mac(const orc_ctx *c, const orc_box *b1, const orc_box *b2) {
   double d[3] = { b1->center[0]-b2->center[0], b1->center[1]-b2->center[1], b1->center[2]-b2->center[2] };
   double r0 = d[0]*d[0] + d[1]*d[1] + d[2]*d[2];
   double rhs = (b1->side/2.0 + b2->side/2.0) / c->theta;
-  /* NOT a reference rule (ORC_MAC_BODY_EXTENT): the reference measures a box by half its side whatever it holds; the expansions
-   * are about the box CENTRE, and what their convergence depends on is how far the bodies sit from it -- up to 0.87 side in a
-   * corner.  On a tree whose coarse leaves clip a cap of the surface (leaf iff count <= ncrit, Octree.hpp:641) that is the
-   * error of the whole matvec.  Here the radius is the largest distance of a body from the centre. */
-  if (c->mac_rule == ORC_MAC_BODY_EXTENT) rhs = (b1->rad + b2->rad) / c->theta;
   return r0 > rhs*rhs;
 }
 
@@ -126,13 +121,9 @@ orc_ctx *orc_create(int n, const double *verts, const uint8_t *bc, int K, double
  *   ORC_EVAL_LOCAL           EvalLocalSparse.hpp:34-86: same traversal, accepted multipoles ignored (:120-127)
  *   ORC_EVAL_BLOCK_DIAGONAL  EvalDiagonalSparse.hpp:33-49: every leaf with itself, in box order */
 orc_ctx *orc_create_eval(int n, const double *verts, const uint8_t *bc, int K, double theta, unsigned ncrit, int evaluator) {
-  return orc_create_mac(n, verts, bc, K, theta, ncrit, evaluator, ORC_MAC_REFERENCE);
-}
-
-orc_ctx *orc_create_mac(int n, const double *verts, const uint8_t *bc, int K, double theta, unsigned ncrit, int evaluator, int mac_rule) {
   double qp[ORC_MAXK][3];
   orc_ctx *c = calloc(1, sizeof(*c));
-  c->n = n; c->K = K; c->theta = theta; c->ncrit = ncrit; c->mac_rule = mac_rule;
+  c->n = n; c->K = K; c->theta = theta; c->ncrit = ncrit;
   c->nq = orc_quadrature(K, qp, c->qw);
   if (c->nq < 0 || n <= 0) { free(c); return NULL; }
   c->panels = malloc(sizeof(orc_panel)*(size_t)n);
@@ -216,19 +207,6 @@ rebuild:;
   for (int i = 0; i < n; ++i) { c->perm[i] = codes[i].idx; c->code[i] = codes[i].code; }    /* :687-691 */
   free(codes); free(tmp);
   for (int b = 0; b < c->nboxes; ++b) box_geometry(c, &c->boxes[b]);
-  if (mac_rule == ORC_MAC_BODY_EXTENT)                 /* not a reference quantity: see mac() */
-    for (int b = 0; b < c->nboxes; ++b) {
-      orc_box *bx = &c->boxes[b];
-      double m2 = 0;
-      for (uint32_t i = bx->bb; i < bx->be; ++i)
-        for (int k = 0; k < 3; ++k) {                    /* the panel's vertices: every quadrature point and the centroid lie within */
-          const double *pc = c->panels[c->perm[i]].v[k];
-          double dx = pc[0] - bx->center[0], dy = pc[1] - bx->center[1], dz = pc[2] - bx->center[2];
-          double r2 = dx*dx + dy*dy + dz*dz;
-          if (r2 > m2) m2 = r2;
-        }
-      bx->rad = sqrt(m2);
-    }
 
   /* ---- dual tree traversal: EvalInteractionLazySparse.hpp:68-110, interact :239-252 ---- */
   pair_vec q = {0}, p2p = {0}, lr = {0};
