@@ -474,8 +474,13 @@ def main():
                                      else "1 all-gather of the multipoles + ") if op.split else "") +
                                    ("1 all-gather of the result slices per matvec" if op.y_collective == "allgather" else
                                     "1 all-reduce of y per matvec")))),
-                   "n_panels": n, "p": P, "near_nnz": st["near_nnz_total"], "m2l_pairs": st["m2l_pairs"],
-                   "boxes": st["n_boxes"], "leaves": st["n_leaves"]},
+                   "n_panels": n, "p": P, "theta": args.theta, "ncrit": args.ncrit, "near_nnz": st["near_nnz_total"], "m2l_pairs": st["m2l_pairs"],
+                   "boxes": st["n_boxes"], "leaves": st["n_leaves"],
+                   # which parent->child L2L edges ran: the plan's default is the COMPLETE list; the reference's lazy list omits
+                   # `l2l_reference_omitted` of them on this tree (0: the two rules are one list here, as on every mesh the reference's
+                   # generators produce -- FMMOptions.reference_l2l selects the reference's list where they differ)
+                   "l2l_rule": "complete", "l2l_reference_omitted": st["l2l_reference_omitted"],
+                   "near_stream_fraction": args.near_stream_fraction},
         "roofline": mf if args.matrix_free else
                     {"kernel": "near_spmv (P2P)", "bound": "hbm", "achieved": p2p_gbs, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": p2p_gbs / HBM_PEAK_GBS, "traffic": traffic,
