@@ -26,7 +26,7 @@ class Options(C.Structure):
                 ("ncrit", C.c_uint32), ("sparse_local", C.c_int32), ("host_only", C.c_int32),
                 ("device", C.c_int32), ("shard_rank", C.c_int32), ("shard_world", C.c_int32),
                 ("quad_k_fine", C.c_int32), ("evaluator", C.c_int32), ("mu", C.c_double),
-                ("shard_upward", C.c_int32), ("l2l_rule", C.c_int32), ("near_stream_fraction", C.c_double)]
+                ("shard_upward", C.c_int32), ("l2l_rule", C.c_int32), ("near_stream_fraction", C.c_double), ("n_devices", C.c_int32), ("devices", C.c_int32 * 8)]
 
 
 class Stats(C.Structure):
@@ -40,7 +40,7 @@ class Stats(C.Structure):
                                    "ms_scatter", "ms_p2m", "ms_m2m", "ms_mh", "ms_m2l", "ms_l2l", "ms_l2p")] +
         [("timed_executes", C.c_int64), ("l2l_reference_omitted", C.c_int64), ("m2l_items", C.c_int64),
          ("m2l_passes", C.c_int64), ("near_side_entries", C.c_int64), ("m2l_kernel", C.c_int32), ("expansion_slots", C.c_int32),
-         ("rot_nop_orders", C.c_int64), ("tree_coder_levels", C.c_int32), ("geometry_shared", C.c_int32), ("near_recomputed_pairs", C.c_int64)])
+         ("rot_nop_orders", C.c_int64), ("tree_coder_levels", C.c_int32), ("n_devices", C.c_int32), ("geometry_shared", C.c_int32), ("near_recomputed_pairs", C.c_int64)])
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -174,6 +175,10 @@ struct fmmbem_plan {
   std::vector<void*>* alloc_list = nullptr;                    // where upload() / alloc() record: shared->allocs or allocs
   int64_t near_total_doubles = 0, sym_total_doubles = 0;       // sizes of the stored near blocks (allocated per plan)
   fmmbem_plan() : shared(std::make_shared<PlanShared>()), hp(shared->hp) { alloc_list = &shared->allocs; }
+  explicit fmmbem_plan(std::shared_ptr<PlanShared> sh) : shared(std::move(sh)), hp(shared->hp) { alloc_list = &allocs; }   // the handle of a multi-device plan
+  // A plan over SEVERAL devices of one process (fmmbem_options.n_devices > 1): this handle then owns one shard plan per device and
+  // does the copies between them itself (MultiDevice, further down); everything else in this struct belongs to single-device plans
+  std::shared_ptr<struct MultiDevice> multi;
   fmmbem_plan(const fmmbem_plan&) = default;                   // used by like(): shares `shared`; like() then replaces what must not be shared
   std::vector<std::pair<int, int>> m2m_launch, l2l_launch;     // (first, count) per level
   std::vector<std::pair<int, int>> m2m_shared_launch;          // sharded upward pass: parents spanning shards
@@ -274,6 +279,7 @@ struct fmmbem_plan {
   int to_device_bc_end();
   hipEvent_t asm_ev[2] = {nullptr, nullptr};     // what depends on the boundary-condition flags (-> this plan)
   static int like(const fmmbem_plan& base, const uint8_t* bc, fmmbem_plan** out);
+  static int like_finish(std::unique_ptr<fmmbem_plan> pl, const uint8_t* bc, fmmbem_plan** out);
   // phase 0: whole matvec; 1: upward half (gather, P2M, M2M of owned boxes, pack -> xbuf); 2: the rest (xbuf = gathered)
   int run(int p, const double* d_x, double* d_y, hipStream_t s, bool near_only, int phase = 0, double* xbuf = nullptr);
   ~fmmbem_plan() {
@@ -1288,43 +1294,34 @@ static bool same_geometry_options(const fmmbem_options& a, const fmmbem_options&
          a.shard_upward == b.shard_upward && a.l2l_rule == b.l2l_rule && a.near_stream_fraction == b.near_stream_fraction;
 }
 
-// live plans that own a geometry, most recent first (a handful: operator, preconditioner plans)
-struct fmmbem_plan_ref { std::mutex mu; fmmbem_plan* plan = nullptr; };
+// live plans that hold a geometry, most recent first (a handful: operator, right-hand side, preconditioner plans).  ONE mutex: a
+// creation that finds its geometry here copies the holder's state under it (microseconds), fmmbem_plan_destroy takes it before it
+// deletes -- so a plan is never read while it goes away -- and the long part of the creation runs outside.
 static std::mutex g_cache_mu;
-static std::vector<std::shared_ptr<fmmbem_plan_ref>> g_cache;
+static std::vector<fmmbem_plan*> g_cache;
 
-static std::shared_ptr<fmmbem_plan_ref> geometry_cache_find(const fmmbem_options& o, size_t n, const uint64_t fp[2]) {
-  std::lock_guard<std::mutex> lock(g_cache_mu);
-  for (auto& r : g_cache) {
-    std::lock_guard<std::mutex> l2(r->mu);
-    const fmmbem_plan* p = r->plan;
-    if (p && (size_t)p->hp.n == n && p->shared->fingerprint[0] == fp[0] && p->shared->fingerprint[1] == fp[1] && same_geometry_options(p->opts, o))
-      return r;
-  }
-  return nullptr;
-}
 static void geometry_cache_add(fmmbem_plan* p) {
-  auto r = std::make_shared<fmmbem_plan_ref>();
-  r->plan = p;
   std::lock_guard<std::mutex> lock(g_cache_mu);
-  g_cache.insert(g_cache.begin(), r);
-  if (g_cache.size() > 8) g_cache.resize(8);
+  g_cache.insert(g_cache.begin(), p);
+  if (g_cache.size() > 32) g_cache.resize(32);
 }
 static void geometry_cache_remove(fmmbem_plan* p) {
   std::lock_guard<std::mutex> lock(g_cache_mu);
-  for (size_t i = 0; i < g_cache.size();) {
-    bool gone;
-    { std::lock_guard<std::mutex> l2(g_cache[i]->mu); gone = g_cache[i]->plan == p; if (gone) g_cache[i]->plan = nullptr; }
-    if (gone) g_cache.erase(g_cache.begin() + (long)i); else ++i;
-  }
+  g_cache.erase(std::remove(g_cache.begin(), g_cache.end(), p), g_cache.end());
 }
 
 // A plan of `base`'s panels with other boundary-condition flags: shares base's PlanShared, builds what the flags decide.
 int fmmbem_plan::like(const fmmbem_plan& base, const uint8_t* bc, fmmbem_plan** out) {
   *out = nullptr;
-  const double t0 = now_ms();
   std::unique_ptr<fmmbem_plan> pl(new (std::nothrow) fmmbem_plan(base));       // memberwise: d, the launch lists, the table pointers
   if (!pl) return fail(FMMBEM_ERR_ALLOC, "plan");
+  return like_finish(std::move(pl), bc, out);
+}
+
+// `pl`: a memberwise copy of a plan that holds the geometry (base may be gone by now: the shared block is reference counted)
+int fmmbem_plan::like_finish(std::unique_ptr<fmmbem_plan> pl, const uint8_t* bc, fmmbem_plan** out) {
+  *out = nullptr;
+  const double t0 = now_ms();
   // ... and now everything that must NOT be shared with base (the copy constructor copied the handles): fresh or empty
   pl->allocs.clear();
   pl->alloc_list = &pl->allocs;
@@ -1333,6 +1330,7 @@ int fmmbem_plan::like(const fmmbem_plan& base, const uint8_t* bc, fmmbem_plan** 
   pl->own_stream = nullptr; pl->hyb_stream = nullptr; pl->hyb_fork = pl->hyb_join = nullptr;
   pl->asm_ev[0] = pl->asm_ev[1] = nullptr;
   pl->d_dev = nullptr; pl->stage_x = pl->stage_y = nullptr; pl->solver_ws = nullptr; pl->d_cut = nullptr;
+  pl->multi.reset();
   pl->result_slices = false; pl->pending_mask = 0; pl->pending_near = false;
   pl->timing = 0; pl->last_p = 0; pl->ev_count = 0;
   for (auto& m : pl->ev_mask) m = 0;
@@ -1360,6 +1358,224 @@ int fmmbem_plan::like(const fmmbem_plan& base, const uint8_t* bc, fmmbem_plan** 
   return FMMBEM_OK;
 }
 
+
+// ---- one plan over several devices of ONE process (fmmbem_options.n_devices > 1; SURVEY.md section 8b "device list") ------
+// The reference's drivers build one plan in one process (examples/LaplaceBEM.cpp:209; FMM_plan.hpp:34-43).  This is that plan with
+// its target leaves sharded over the devices of the list: the handle owns one SHARD plan per device (the same shards the
+// one-process-per-GPU form drives through torch.distributed, distributed.py) and moves the data between them itself --
+//   x (on the first device)  -> a copy per device                                 hipMemcpyPeerAsync, one xGMI link each
+//   upward pass by the boxes' owners -> the multipoles each shard's lists read     peer copies of fmmbem_plan_exchange_counts' segments
+//   downward pass + near field of every shard -> its tree-order slice of y        -> peer copies into ONE buffer on the first device
+//   slices -> y in panel order (fmmbem_plan_assemble_slices_device)
+// every step on the shard's own stream, ordered by events: the host thread only enqueues.  xGMI is point to point, so plain peer
+// copies ARE the collective here (one link per peer, no ring); the same bits as a single plan (shards sum bitwise).
+// Not measured on more than one GPU (none has been available to this project); devices = {0, 0, ...} runs the whole path on one.
+struct ShardDeleter { void operator()(fmmbem_plan* p) const { fmmbem_plan_destroy(p); } };   // through the C entry point: the shards are known to the geometry cache
+struct MultiDevice {
+  std::vector<std::unique_ptr<fmmbem_plan, ShardDeleter>> shards;
+  std::vector<int> dev;
+  std::vector<double*> x, slice;                     // per shard, on its device: the replica of x, the result slice
+  double* gathered = nullptr;                        // on dev[0]: world * chunk doubles
+  size_t chunk = 0;
+  std::vector<int64_t> cut;
+  hipEvent_t ev_x = nullptr;
+  std::vector<hipEvent_t> ev_up, ev_done;
+  bool split = false;
+  struct Xch { std::vector<double*> send, recv; std::vector<std::vector<int64_t>> sc, rc; };
+  std::map<int, Xch> xch;                            // per order p
+  int world() const { return (int)shards.size(); }
+  ~MultiDevice() {
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    for (int r = 0; r < world(); ++r) {
+      (void)hipSetDevice(dev[r]);
+      if (r < (int)x.size() && x[r]) (void)hipFree(x[r]);
+      if (r < (int)slice.size() && slice[r]) (void)hipFree(slice[r]);
+      for (auto& kv : xch) { if (kv.second.send[r]) (void)hipFree(kv.second.send[r]); if (kv.second.recv[r]) (void)hipFree(kv.second.recv[r]); }
+      if (r < (int)ev_up.size() && ev_up[r]) (void)hipEventDestroy(ev_up[r]);
+      if (r < (int)ev_done.size() && ev_done[r]) (void)hipEventDestroy(ev_done[r]);
+    }
+    if (!dev.empty()) (void)hipSetDevice(dev[0]);
+    if (gathered) (void)hipFree(gathered);
+    if (ev_x) (void)hipEventDestroy(ev_x);
+    (void)hipSetDevice(prev);
+    shards.clear();
+  }
+};
+
+static int multi_finish(fmmbem_plan* h, std::shared_ptr<MultiDevice> m) {
+  const int W = m->world();
+  const fmmbem_plan& s0 = *m->shards[0];
+  const size_t nd = (size_t)s0.hp.n * s0.d.dof;
+  m->cut.resize((size_t)W + 1);
+  TRY(fmmbem_plan_shard_rows(m->shards[0].get(), m->cut.data()));
+  for (int r = 0; r < W; ++r) m->chunk = std::max(m->chunk, (size_t)(m->cut[r + 1] - m->cut[r]) * s0.d.dof);
+  m->chunk = std::max<size_t>(m->chunk, 1);
+  m->split = s0.split_upward;
+  m->x.assign(W, nullptr); m->slice.assign(W, nullptr); m->ev_up.assign(W, nullptr); m->ev_done.assign(W, nullptr);
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  struct Restore { int d; ~Restore() { (void)hipSetDevice(d); } } restore{prev};
+  for (int r = 0; r < W; ++r) {
+    HIP_TRY(hipSetDevice(m->dev[r]));
+    for (int q = 0; q < W; ++q)                        // direct peer copies where the hardware has them (an error here only means "already on" or "not available")
+      if (m->dev[q] != m->dev[r]) { if (hipDeviceEnablePeerAccess(m->dev[q], 0) != hipSuccess) (void)hipGetLastError(); }
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->x[r]), sizeof(double) * nd));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->slice[r]), sizeof(double) * m->chunk));
+    HIP_TRY(hipEventCreateWithFlags(&m->ev_up[r], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&m->ev_done[r], hipEventDisableTiming));
+    m->shards[r]->result_slices = true;
+    m->shards[r]->use_graphs = !(std::getenv("FMMBEM_GRAPH") && std::atoi(std::getenv("FMMBEM_GRAPH")) == 0);   // a shard's chain is short: the host must stay ahead of W of them
+  }
+  HIP_TRY(hipSetDevice(m->dev[0]));
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->gathered), sizeof(double) * m->chunk * (size_t)W));
+  HIP_TRY(hipEventCreateWithFlags(&m->ev_x, hipEventDisableTiming));
+  // the handle itself: what the host-pointer execute and the solver need on the first device
+  h->opts.device = m->dev[0];
+  h->on_device = true;
+  h->d.dof = s0.d.dof; h->d.n = s0.d.n;
+  h->has_bc[0] = s0.has_bc[0]; h->has_bc[1] = s0.has_bc[1];
+  HIP_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+  TRY(h->alloc(nd, &h->stage_x, true));
+  TRY(h->alloc(nd, &h->stage_y, true));
+  HIP_TRY(hipDeviceSynchronize());
+  h->multi = std::move(m);
+  return FMMBEM_OK;
+}
+
+static int multi_create(const fmmbem_options* opts, const std::vector<int>& devices, size_t n_panels, const double* vertices,
+                        const uint8_t* bc, fmmbem_plan** out) {
+  const int W = (int)devices.size();
+  if (W > 8) return fail(FMMBEM_ERR_UNSUPPORTED, "at most 8 devices per plan");
+  if (opts->shard_world > 1) return fail(FMMBEM_ERR_INVALID, "a plan over several devices is the whole operator: shard_world must be 1");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(FMMBEM_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU execution path)");
+  for (int d_ : devices) if (d_ < 0 || d_ >= ndev) return fail(FMMBEM_ERR_INVALID, "device ordinal out of range in the device list");
+  auto m = std::make_shared<MultiDevice>();
+  m->dev = devices;
+  m->shards.resize(W);
+  // the shards are built side by side: each is a plan_create of its own (host lists of the same tree, then its device's share)
+  std::vector<int> rc(W, FMMBEM_OK);
+  std::vector<std::string> err(W);
+  std::vector<std::thread> pool;
+  for (int r = 0; r < W; ++r)
+    pool.emplace_back([&, r] {
+      fmmbem_options o = *opts;
+      o.n_devices = 0; o.device = devices[r]; o.shard_rank = r; o.shard_world = W;
+      o.shard_upward = opts->shard_upward == 0 ? 0 : 2;            // 0: every device repeats the upward pass; else: owners + selective exchange
+      if (std::getenv("FMMBEM_MULTI_UPWARD")) o.shard_upward = std::atoi(std::getenv("FMMBEM_MULTI_UPWARD")) ? 2 : 0;
+      fmmbem_plan* p = nullptr;
+      rc[r] = fmmbem_plan_create(&o, n_panels, vertices, bc, &p);
+      if (rc[r] != FMMBEM_OK) err[r] = g_last_error;
+      m->shards[r].reset(p);
+    });
+  for (auto& th : pool) th.join();
+  for (int r = 0; r < W; ++r) if (rc[r] != FMMBEM_OK) return fail(rc[r], "shard " + std::to_string(r) + ": " + err[r]);
+  std::unique_ptr<fmmbem_plan> h(new (std::nothrow) fmmbem_plan(m->shards[0]->shared));
+  if (!h) return fail(FMMBEM_ERR_ALLOC, "plan");
+  h->opts = *opts;
+  TRY(multi_finish(h.get(), m));
+  *out = h.release();
+  return FMMBEM_OK;
+}
+
+// a multi-device plan of `base`'s panels with other flags: shard by shard (each shares its base shard's geometry)
+static int multi_like(const fmmbem_plan& base, const uint8_t* bc, fmmbem_plan** out) {
+  auto m = std::make_shared<MultiDevice>();
+  m->dev = base.multi->dev;
+  const int W = base.multi->world();
+  m->shards.resize(W);
+  for (int r = 0; r < W; ++r) {
+    fmmbem_plan* p = nullptr;
+    TRY(fmmbem_plan::like(*base.multi->shards[r], bc, &p));
+    m->shards[r].reset(p);
+  }
+  std::unique_ptr<fmmbem_plan> h(new (std::nothrow) fmmbem_plan(m->shards[0]->shared));
+  if (!h) return fail(FMMBEM_ERR_ALLOC, "plan");
+  h->opts = base.opts;
+  TRY(multi_finish(h.get(), m));
+  *out = h.release();
+  return FMMBEM_OK;
+}
+
+static int multi_xch(fmmbem_plan* h, int p, MultiDevice::Xch** out) {
+  MultiDevice& m = *h->multi;
+  auto it = m.xch.find(p);
+  if (it != m.xch.end()) { *out = &it->second; return FMMBEM_OK; }
+  const int W = m.world();
+  MultiDevice::Xch x;
+  x.send.assign(W, nullptr); x.recv.assign(W, nullptr); x.sc.resize(W); x.rc.resize(W);
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  struct Restore { int d; ~Restore() { (void)hipSetDevice(d); } } restore{prev};
+  for (int r = 0; r < W; ++r) {
+    x.sc[r].assign(W, 0); x.rc[r].assign(W, 0);
+    TRY(fmmbem_plan_exchange_counts(m.shards[r].get(), p, x.sc[r].data(), x.rc[r].data()));
+    int64_t ns = 0, nr = 0;
+    for (int q = 0; q < W; ++q) { ns += x.sc[r][q]; nr += x.rc[r][q]; }
+    HIP_TRY(hipSetDevice(m.dev[r]));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&x.send[r]), sizeof(double) * (size_t)std::max<int64_t>(ns, 1)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&x.recv[r]), sizeof(double) * (size_t)std::max<int64_t>(nr, 1)));
+  }
+  for (int r = 0; r < W; ++r)                          // what r sends q is what q expects from r, or the lists are broken
+    for (int q = 0; q < W; ++q)
+      if (x.sc[r][q] != x.rc[q][r]) return fail(FMMBEM_ERR_INVALID, "internal: exchange counts of the shards do not match");
+  *out = &m.xch.emplace(p, std::move(x)).first->second;
+  return FMMBEM_OK;
+}
+
+static int multi_execute_device(fmmbem_plan* h, int p, const double* d_x, double* d_y, hipStream_t s0) {
+  MultiDevice& m = *h->multi;
+  const int W = m.world();
+  if (!d_x || !d_y) return fail(FMMBEM_ERR_INVALID, "null vector");
+  const size_t nd = (size_t)h->hp.n * h->d.dof;
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  struct Restore { int d; ~Restore() { (void)hipSetDevice(d); } } restore{prev};
+  MultiDevice::Xch* xc = nullptr;
+  if (m.split) TRY(multi_xch(h, p, &xc));
+  HIP_TRY(hipSetDevice(m.dev[0]));
+  HIP_TRY(hipEventRecord(m.ev_x, s0));
+  for (int r = 0; r < W; ++r) {                        // x to every device; the owners' upward pass
+    fmmbem_plan& sh = *m.shards[r];
+    HIP_TRY(hipSetDevice(m.dev[r]));
+    HIP_TRY(hipStreamWaitEvent(sh.own_stream, m.ev_x, 0));
+    HIP_TRY(hipMemcpyPeerAsync(m.x[r], m.dev[r], d_x, m.dev[0], sizeof(double) * nd, sh.own_stream));
+    if (m.split) {
+      TRY(sh.run(p, m.x[r], nullptr, sh.own_stream, false, 1, xc->send[r]));
+      HIP_TRY(hipEventRecord(m.ev_up[r], sh.own_stream));
+    }
+  }
+  for (int q = 0; q < W; ++q) {                        // the multipoles q's lists read, its downward pass and near field, its slice home
+    fmmbem_plan& sh = *m.shards[q];
+    HIP_TRY(hipSetDevice(m.dev[q]));
+    if (m.split) {
+      int64_t roff = 0;
+      for (int r = 0; r < W; ++r) {
+        const int64_t cnt = xc->rc[q][r];
+        if (cnt > 0) {
+          int64_t soff = 0;
+          for (int k = 0; k < q; ++k) soff += xc->sc[r][k];
+          HIP_TRY(hipStreamWaitEvent(sh.own_stream, m.ev_up[r], 0));
+          HIP_TRY(hipMemcpyPeerAsync(xc->recv[q] + roff, m.dev[q], xc->send[r] + soff, m.dev[r], sizeof(double) * (size_t)cnt, sh.own_stream));
+        }
+        roff += cnt;
+      }
+      TRY(sh.run(p, nullptr, m.slice[q], sh.own_stream, false, 2, xc->recv[q]));
+    } else {
+      TRY(sh.run(p, m.x[q], m.slice[q], sh.own_stream, false));
+    }
+    const size_t rows = (size_t)(m.cut[q + 1] - m.cut[q]) * h->d.dof;
+    if (rows) HIP_TRY(hipMemcpyPeerAsync(m.gathered + (size_t)q * m.chunk, m.dev[0], m.slice[q], m.dev[q], sizeof(double) * rows, sh.own_stream));
+    HIP_TRY(hipEventRecord(m.ev_done[q], sh.own_stream));
+  }
+  HIP_TRY(hipSetDevice(m.dev[0]));
+  for (int q = 0; q < W; ++q) HIP_TRY(hipStreamWaitEvent(s0, m.ev_done[q], 0));
+  TRY(fmmbem_plan_assemble_slices_device(m.shards[0].get(), m.gathered, m.chunk, d_y, s0));
+  h->last_p = p;
+  return FMMBEM_OK;
+}
+
 int fmmbem_plan_create(const fmmbem_options* opts, size_t n_panels, const double* vertices, const uint8_t* bc,
                        fmmbem_plan** out) {
   if (!opts || !out) return fail(FMMBEM_ERR_INVALID, "null argument");
@@ -1381,15 +1597,35 @@ int fmmbem_plan_create(const fmmbem_options* opts, size_t n_panels, const double
   // boundary-condition flags may differ.  The new plan then shares that plan's tree, lists and tables (PlanShared) and builds
   // only what the flags decide.  This is the drivers' second plan (examples/LaplaceBEM.cpp:218-232: the same panels with the
   // flags switched, for the right-hand side); FMMBEM_PLAN_SHARE=0 turns the recognition off.
+  {
+    // a device list: the options' own, or FMMBEM_DEVICES=0,1,2,... for callers that cannot say (the reference's unmodified drivers)
+    std::vector<int> devices;
+    if (opts->n_devices > 1) devices.assign(opts->devices, opts->devices + std::min(opts->n_devices, 8));
+    else if (opts->n_devices == 0 && opts->shard_world <= 1 && !opts->host_only) {
+      if (const char* e = std::getenv("FMMBEM_DEVICES")) {
+        for (const char* c = e; *c;) { char* end = nullptr; const long v = std::strtol(c, &end, 10); if (end == c) break; devices.push_back((int)v); c = *end ? end + 1 : end; }
+        if (devices.size() < 2) devices.clear();
+      }
+    }
+    if (!devices.empty()) {
+      if (opts->host_only) return fail(FMMBEM_ERR_INVALID, "a device list and host_only exclude each other");
+      return multi_create(opts, devices, n_panels, vertices, bc, out);
+    }
+  }
   uint64_t fp[2] = {0, 0};
   const bool share_on = !opts->host_only && !(std::getenv("FMMBEM_PLAN_SHARE") && std::atoi(std::getenv("FMMBEM_PLAN_SHARE")) == 0);
   if (share_on) {
     fingerprint_vertices(vertices, n_panels, fp);
-    std::shared_ptr<fmmbem_plan_ref> hit = geometry_cache_find(*opts, n_panels, fp);
-    if (hit) {
-      std::lock_guard<std::mutex> lock(hit->mu);
-      if (hit->plan) return fmmbem_plan::like(*hit->plan, bc, out);
+    std::unique_ptr<fmmbem_plan> copy;
+    {
+      std::lock_guard<std::mutex> lock(g_cache_mu);
+      for (const fmmbem_plan* p : g_cache)
+        if ((size_t)p->hp.n == n_panels && p->shared->fingerprint[0] == fp[0] && p->shared->fingerprint[1] == fp[1] && same_geometry_options(p->opts, *opts)) {
+          copy.reset(new (std::nothrow) fmmbem_plan(*p));
+          break;
+        }
     }
+    if (copy) return fmmbem_plan::like_finish(std::move(copy), bc, out);
   }
   std::unique_ptr<fmmbem_plan> pl(new (std::nothrow) fmmbem_plan);
   if (!pl) return fail(FMMBEM_ERR_ALLOC, "plan");
@@ -1433,6 +1669,7 @@ int fmmbem_plan_create_like(const fmmbem_plan* base, const uint8_t* bc, fmmbem_p
   if (!base || !out) return fail(FMMBEM_ERR_INVALID, "null argument");
   *out = nullptr;
   if (!base->on_device) return fail(FMMBEM_ERR_NO_DEVICE, "fmmbem_plan_create_like: the base plan was built host-only");
+  if (base->multi) return multi_like(*base, bc, out);
   return fmmbem_plan::like(*base, bc, out);
 }
 
@@ -1443,6 +1680,7 @@ void fmmbem_plan_destroy(fmmbem_plan* plan) {
 
 int fmmbem_plan_execute_device(fmmbem_plan* plan, int p, const double* d_x, double* d_y, void* stream) {
   if (!plan) return fail(FMMBEM_ERR_INVALID, "null plan");
+  if (plan->multi) return multi_execute_device(plan, p, d_x, d_y, static_cast<hipStream_t>(stream));
   return plan->run(p, d_x, d_y, static_cast<hipStream_t>(stream), false);
 }
 
@@ -1458,6 +1696,7 @@ static int64_t active_slots(const fmmbem_plan* plan) {
 
 int fmmbem_plan_exchange_doubles(const fmmbem_plan* plan, int p, size_t* per_shard) {
   if (!plan || !per_shard) return fail(FMMBEM_ERR_INVALID, "null argument");
+  if (plan && plan->multi) return fail(FMMBEM_ERR_UNSUPPORTED, "not on a multi-device plan: it drives its shards itself");
   if (p < 1 || p > plan->hp.opt.p_max) return fail(FMMBEM_ERR_INVALID, "p outside [1, p_max]");
   // from the host lists, so that a host-only plan (CPU tests of the N > 1 path) answers too
   const HostPlan& h = plan->hp;
@@ -1469,6 +1708,7 @@ int fmmbem_plan_exchange_doubles(const fmmbem_plan* plan, int p, size_t* per_sha
 }
 
 int fmmbem_plan_exchange_counts(const fmmbem_plan* plan, int p, int64_t* send_doubles, int64_t* recv_doubles) {
+  if (plan && plan->multi) return fail(FMMBEM_ERR_UNSUPPORTED, "not on a multi-device plan: it drives its shards itself");
   if (!plan || !send_doubles || !recv_doubles) return fail(FMMBEM_ERR_INVALID, "null argument");
   if (p < 1 || p > plan->hp.opt.p_max) return fail(FMMBEM_ERR_INVALID, "p outside [1, p_max]");
   const HostPlan& h = plan->hp;
@@ -1485,16 +1725,19 @@ int fmmbem_plan_exchange_counts(const fmmbem_plan* plan, int p, int64_t* send_do
 }
 
 int fmmbem_plan_upward_device(fmmbem_plan* plan, int p, const double* d_x, double* d_send, void* stream) {
+  if (plan && plan->multi) return fail(FMMBEM_ERR_UNSUPPORTED, "not on a multi-device plan: it drives its shards itself");
   if (!plan) return fail(FMMBEM_ERR_INVALID, "null plan");
   return plan->run(p, d_x, nullptr, static_cast<hipStream_t>(stream), false, 1, d_send);
 }
 
 int fmmbem_plan_downward_device(fmmbem_plan* plan, int p, const double* d_recv, double* d_y, void* stream) {
+  if (plan && plan->multi) return fail(FMMBEM_ERR_UNSUPPORTED, "not on a multi-device plan: it drives its shards itself");
   if (!plan) return fail(FMMBEM_ERR_INVALID, "null plan");
   return plan->run(p, nullptr, d_y, static_cast<hipStream_t>(stream), false, 2, const_cast<double*>(d_recv));
 }
 
 int fmmbem_plan_near_split_device(fmmbem_plan* plan, double* d_y, void* stream) {
+  if (plan && plan->multi) return fail(FMMBEM_ERR_UNSUPPORTED, "not on a multi-device plan: it drives its shards itself");
   if (!plan) return fail(FMMBEM_ERR_INVALID, "null plan");
   return plan->run(plan->last_p > 0 ? plan->last_p : 1, nullptr, d_y, static_cast<hipStream_t>(stream), false, 3, nullptr);
 }
@@ -1510,6 +1753,7 @@ int fmmbem_plan_shard_rows(const fmmbem_plan* plan, int64_t* cut) {
 }
 
 int fmmbem_plan_set_result_slices(fmmbem_plan* plan, int enabled) {
+  if (plan && plan->multi) return fail(FMMBEM_ERR_UNSUPPORTED, "not on a multi-device plan: it drives its shards itself");
   if (!plan) return fail(FMMBEM_ERR_INVALID, "null plan");
   plan->result_slices = enabled != 0;
   return FMMBEM_OK;
@@ -1533,6 +1777,7 @@ int fmmbem_plan_assemble_slices_device(fmmbem_plan* plan, const double* d_slices
 }
 
 int fmmbem_plan_near_device(fmmbem_plan* plan, const double* d_x, double* d_y, void* stream) {
+  if (plan && plan->multi) return fail(FMMBEM_ERR_UNSUPPORTED, "not on a multi-device plan: it drives its shards itself");
   if (!plan) return fail(FMMBEM_ERR_INVALID, "null plan");
   return plan->run(1, d_x, d_y, static_cast<hipStream_t>(stream), true);
 }
@@ -1547,7 +1792,7 @@ int fmmbem_plan_execute(fmmbem_plan* plan, int p, const double* x, double* y) {
   const size_t bytes = sizeof(double) * (size_t)plan->hp.n * (plan->opts.kernel == FMMBEM_KERNEL_STOKES_BEM ? 3 : 1);
   hipStream_t s = plan->own_stream;
   HIP_TRY(hipMemcpyAsync(plan->stage_x, x, bytes, hipMemcpyHostToDevice, s));
-  const int rc = plan->run(p, plan->stage_x, plan->stage_y, s, false);
+  const int rc = plan->multi ? multi_execute_device(plan, p, plan->stage_x, plan->stage_y, s) : plan->run(p, plan->stage_x, plan->stage_y, s, false);
   if (rc != FMMBEM_OK) return rc;
   HIP_TRY(hipMemcpyAsync(y, plan->stage_y, bytes, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
@@ -1568,12 +1813,14 @@ int fmmbem_host_unregister(void* ptr) {
 
 int fmmbem_plan_set_graphs(fmmbem_plan* plan, int enabled) {
   if (!plan) return fail(FMMBEM_ERR_INVALID, "null plan");
+  if (plan->multi) { for (auto& sh : plan->multi->shards) sh->use_graphs = enabled != 0; return FMMBEM_OK; }
   plan->use_graphs = enabled != 0 && plan->on_device;
   return FMMBEM_OK;
 }
 
 int fmmbem_plan_set_timing(fmmbem_plan* plan, int enabled) {
   if (!plan) return fail(FMMBEM_ERR_INVALID, "null plan");
+  if (plan->multi) { for (auto& sh : plan->multi->shards) TRY(fmmbem_plan_set_timing(sh.get(), enabled)); return FMMBEM_OK; }
   plan->timing = plan->on_device ? (enabled == 2 ? 2 : enabled != 0) : 0;
   plan->ev_count = 0;
   return FMMBEM_OK;
@@ -1581,6 +1828,28 @@ int fmmbem_plan_set_timing(fmmbem_plan* plan, int enabled) {
 
 int fmmbem_plan_stats(const fmmbem_plan* plan, fmmbem_stats* o) {
   if (!plan || !o) return fail(FMMBEM_ERR_INVALID, "null argument");
+  if (plan->multi) {
+    // the whole operator: what the shards own summed, the tree's figures from any of them, stage times the LONGEST shard's
+    // (they run side by side), build times likewise
+    const MultiDevice& m = *plan->multi;
+    TRY(fmmbem_plan_stats(m.shards[0].get(), o));
+    for (int r = 1; r < m.world(); ++r) {
+      fmmbem_stats t;
+      TRY(fmmbem_plan_stats(m.shards[r].get(), &t));
+      o->near_nnz += t.near_nnz; o->m2l_pairs_owned += t.m2l_pairs_owned; o->near_bytes += t.near_bytes;
+      o->near_side_entries += t.near_side_entries; o->near_recomputed_pairs += t.near_recomputed_pairs;
+      o->m2m_ops = std::max(o->m2m_ops, t.m2m_ops); o->l2l_ops += t.l2l_ops; o->l2p_leaves += t.l2p_leaves; o->p2m_leaves += t.p2m_leaves;
+      o->m2l_items += t.m2l_items; o->m2l_passes += t.m2l_passes;
+      o->owned_leaf_end = t.owned_leaf_end; o->owned_row_end = t.owned_row_end;
+      o->build_host_ms = std::max(o->build_host_ms, t.build_host_ms); o->build_assemble_ms = std::max(o->build_assemble_ms, t.build_assemble_ms);
+      double* a[] = {&o->ms_total, &o->ms_gather, &o->ms_near, &o->ms_scatter, &o->ms_p2m, &o->ms_m2m, &o->ms_mh, &o->ms_m2l, &o->ms_l2l, &o->ms_l2p};
+      const double b[] = {t.ms_total, t.ms_gather, t.ms_near, t.ms_scatter, t.ms_p2m, t.ms_m2m, t.ms_mh, t.ms_m2l, t.ms_l2l, t.ms_l2p};
+      for (int k = 0; k < 10; ++k) *a[k] = std::max(*a[k], b[k]);
+    }
+    o->last_p = plan->last_p;
+    o->n_devices = m.world();
+    return FMMBEM_OK;
+  }
   const HostPlan& h = plan->hp;
   std::memset(o, 0, sizeof(*o));
   o->n_panels = h.n; o->n_boxes = h.nboxes; o->n_leaves = h.nleaves(); o->n_levels = h.nlevels;
@@ -1599,6 +1868,7 @@ int fmmbem_plan_stats(const fmmbem_plan* plan, fmmbem_stats* o) {
   o->near_side_entries = plan->near_side_entries;
   o->near_recomputed_pairs = plan->near_recomputed_pairs;
   o->geometry_shared = (int32_t)plan->shared.use_count();
+  o->n_devices = 1;
   o->expansion_slots = plan->on_device ? plan->d.nslots : (plan->opts.kernel == FMMBEM_KERNEL_STOKES_BEM ? 8 : 2);
   o->m2l_kernel = plan->last_p > 0 ? (plan->use_rot(plan->last_p) ? 1 : plan->last_p <= 4 ? 3 : 2) : 0;
   o->rot_nop_orders = (int64_t)rot_nop_orders_m2l() | ((int64_t)rot_nop_orders_m2m() << 16) | ((int64_t)rot_nop_orders_l2l() << 32);
@@ -1689,6 +1959,13 @@ int fmmbem_plan_get_pairs(const fmmbem_plan* plan, int which, int32_t* out, int6
 
 int fmmbem_plan_get_near_row(const fmmbem_plan* plan, int64_t row, uint32_t* cols, double* vals, int64_t* n) {
   if (!plan || !n) return fail(FMMBEM_ERR_INVALID, "null argument");
+  if (plan->multi) {
+    const MultiDevice& m = *plan->multi;
+    const int64_t prow = row / plan->d.dof;
+    for (int r = 0; r < m.world(); ++r)
+      if (prow >= m.cut[r] && prow < m.cut[r + 1]) return fmmbem_plan_get_near_row(m.shards[r].get(), row, cols, vals, n);
+    return fail(FMMBEM_ERR_INVALID, "row out of range");
+  }
   const HostPlan& h = plan->hp;
   const int dof = plan->opts.kernel == FMMBEM_KERNEL_STOKES_BEM ? 3 : 1;
   const int64_t prow = row / dof;                      // panel row (tree order); row counts unknowns
@@ -1761,6 +2038,17 @@ int fmmbem_plan_get_near_row(const fmmbem_plan* plan, int64_t row, uint32_t* col
 
 int fmmbem_plan_get_diagonal(const fmmbem_plan* plan, double* out) {
   if (!plan || !out) return fail(FMMBEM_ERR_INVALID, "null argument");
+  if (plan->multi) {                                   // every shard returns its own rows and zeros elsewhere
+    const MultiDevice& m = *plan->multi;
+    const size_t nd = (size_t)plan->hp.n * plan->d.dof;
+    std::vector<double> part(nd);
+    std::fill(out, out + nd, 0.0);
+    for (int r = 0; r < m.world(); ++r) {
+      TRY(fmmbem_plan_get_diagonal(m.shards[r].get(), part.data()));
+      for (size_t i = 0; i < nd; ++i) out[i] += part[i];
+    }
+    return FMMBEM_OK;
+  }
   if (!plan->on_device) return fail(FMMBEM_ERR_NO_DEVICE, "near values live on the device");
   if (!plan->opts.sparse_local) return fail(FMMBEM_ERR_INVALID, "matrix-free plan holds no near matrix");
   const HostPlan& h = plan->hp;
@@ -1794,6 +2082,7 @@ int fmmbem_plan_get_diagonal(const fmmbem_plan* plan, double* out) {
 }
 
 int fmmbem_plan_get_expansions(const fmmbem_plan* plan, int which, int p, double* out) {
+  if (plan && plan->multi) return fail(FMMBEM_ERR_UNSUPPORTED, "not on a multi-device plan: it drives its shards itself");
   if (!plan || !out) return fail(FMMBEM_ERR_INVALID, "null argument");
   if (!plan->on_device) return fail(FMMBEM_ERR_NO_DEVICE, "expansions live on the device");
   if (p < 1 || p > plan->hp.opt.p_max) return fail(FMMBEM_ERR_INVALID, "p outside [1, p_max]");
@@ -1906,7 +2195,7 @@ int fmmbem_version(void) { return FMMBEM_VERSION; }
 int fmmbem::plan_solver_info(fmmbem_plan* plan, int* device, int64_t* unknowns, int* p_max, fmmbem::SolverWs*** slot) {
   if (!plan) return fail(FMMBEM_ERR_INVALID, "null plan");
   if (!plan->on_device) return fail(FMMBEM_ERR_NO_DEVICE, "plan was built host-only; there is no CPU execution path");
-  if (plan->result_slices || plan->hp.opt.shard_world > 1)
+  if (!plan->multi && (plan->result_slices || plan->hp.opt.shard_world > 1))
     return fail(FMMBEM_ERR_UNSUPPORTED, "fmmbem_gmres runs on a whole operator; shards are driven by the caller's collectives (distributed.py)");
   *device = plan->opts.device;
   *unknowns = (int64_t)plan->hp.n * (plan->opts.kernel == FMMBEM_KERNEL_STOKES_BEM ? 3 : 1);

@@ -185,7 +185,7 @@ class FMM_plan:
     """
 
     def __init__(self, K, panels, opts=None, bc=None, p_max=None, device=0, shard=(0, 1), host_only=False,
-                 shard_upward=False):
+                 shard_upward=False, devices=None, replicate_upward=False):
         opts = opts if opts is not None else FMMOptions()
         # executor/make_executor.hpp:24-60: lazy_evaluation wins, then local_evaluation, then block_diagonal; the
         # non-lazy upward/interact/downward evaluators compute the same operator as the lazy ones
@@ -212,6 +212,14 @@ class FMM_plan:
         o.near_stream_fraction = float(getattr(opts, "near_stream_fraction", 1.0))
         o.device = int(device)
         self.device = int(device)
+        if devices is not None and len(devices) > 1:
+            # one plan over several devices of this process (fmmbem_options.n_devices): vectors live on devices[0]
+            if len(devices) > 8:
+                raise ValueError("at most 8 devices per plan")
+            o.n_devices = len(devices)
+            for i, dv in enumerate(devices):
+                o.devices[i] = int(dv)
+            o.device = self.device = int(devices[0])
         self.dof = 1
         if isinstance(K, StokesSphericalBEM):
             o.kernel = _capi.KERNEL_STOKES_BEM
@@ -222,6 +230,8 @@ class FMM_plan:
         self._shard_world = int(shard[1])
         # shard_upward: False / True (1: all-gather of the multipoles) / 2 (all-to-all of the ones each receiver reads)
         o.shard_upward = (2 if shard_upward == 2 else 1) if (shard_upward and int(shard[1]) > 1) else 0
+        if o.n_devices > 1:                    # inside a multi-device plan: owners + selective exchange, or every device repeats the upward pass
+            o.shard_upward = 0 if replicate_upward else 2
         self.shard_upward = bool(o.shard_upward)
         self.exchange_mode = int(o.shard_upward)
         self.p_max = o.p_max

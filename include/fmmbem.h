@@ -106,6 +106,14 @@ typedef struct {
                                * differ from f = 1 in the last bits.  Taken as 1 where the hybrid kernel does not apply (rules of
                                * more than 3 / 4 points, the LOCAL / BLOCK_DIAGONAL evaluators).  FMMBEM_NEAR_STREAM_FRACTION
                                * overrides it at creation (sweeps).                                                      */
+  int32_t  n_devices;         /* > 1: ONE plan over the devices listed in `devices` (at most 8; SURVEY 8b "device list"): the target leaves
+                               * are sharded over them inside the handle, which copies x to every device, exchanges the multipoles
+                               * the shards' lists read and brings the result slices home by peer copies over xGMI; x and y of
+                               * fmmbem_plan_execute_device / fmmbem_gmres_device live on devices[0].  The same bits as one device.
+                               * shard_upward = 0 then makes every device repeat the upward pass instead of exchanging multipoles.
+                               * 0 or 1: the single `device`.  With n_devices == 0 the environment variable FMMBEM_DEVICES=0,1,...
+                               * supplies a list (for callers that cannot: the reference's unmodified drivers)                  */
+  int32_t  devices[8];
 } fmmbem_options;
 
 /* Statistics of a plan and of its last execute (times in milliseconds, device-side HIP events). */
@@ -135,6 +143,8 @@ typedef struct {
                                  * tools/check_rot_isa.py): bit p-1 M2L, bit 16+p-1 M2M, bit 32+p-1 L2L.
                                  * 0 on the toolchain this was developed with; such an order runs ~30 % slower, not wrong */
   int32_t tree_coder_levels;    /* 10: the reference's 32-bit Morton coder built the tree; 21: the 64-bit coder had to (deeper tree) */
+  int32_t n_devices;            /* devices this plan runs on (fmmbem_options.n_devices / FMMBEM_DEVICES); the figures above are then the whole
+                                 * operator's: owned counts summed over the shards, stage times the longest shard's                    */
   int32_t geometry_shared;      /* plans alive that share this plan's tree, lists and tables (fmmbem_plan_create_like), itself included */
   int64_t near_recomputed_pairs;/* hybrid plans (near_stream_fraction < 1): panel pairs of this shard that are recomputed every matvec
                                  * instead of stored (near_nnz counts all of the shard's entries, near_bytes what is stored)         */

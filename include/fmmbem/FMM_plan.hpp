@@ -106,6 +106,10 @@ class FMMOptions {
   // leaves with the most rows keep none and are recomputed every matvec beside the streamed rest (fmmbem.h near_stream_fraction):
   // fewer HBM bytes and a smaller footprint at the same operator, last bits differ.  Stokes plans (measured optimum ~0.6).
   double near_stream_fraction = 1.0;
+  // Not in the reference: the devices ONE plan runs on (fmmbem.h fmmbem_options.n_devices): more than one entry shards the target
+  // leaves over them inside the plan; vectors handed to the device entry points live on the first.  Empty: the constructor's
+  // `device` argument (or the environment's FMMBEM_DEVICES list, which is how the reference's unmodified drivers get there).
+  std::vector<int> devices;
   void set_mac_theta(double t) { MAC_ = DefaultMAC(t); }
   DefaultMAC MAC() { return MAC_; }
   void set_max_per_box(unsigned n) { NCRIT_ = n; }
@@ -338,6 +342,11 @@ class PlanAdapter {
     o.theta = opts_.MAC().theta_;
     o.ncrit = opts_.NCRIT_;
     o.device = device_;
+    if (opts_.devices.size() > 1) {
+      o.n_devices = (int32_t)std::min<size_t>(opts_.devices.size(), 8);
+      for (int i = 0; i < o.n_devices; ++i) o.devices[i] = opts_.devices[(size_t)i];
+      o.device = o.devices[0];
+    }
     o.evaluator = opts_.c_evaluator();
     o.l2l_rule = opts_.reference_l2l ? FMMBEM_L2L_REFERENCE : FMMBEM_L2L_COMPLETE;
     o.near_stream_fraction = opts_.near_stream_fraction;
