@@ -16,6 +16,7 @@
 // a plan is deleted (the reference's copy is unsafe, FMM_plan.hpp:110).  There is no CPU fallback: every number comes from
 // the device, and without a HIP device the constructor throws.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <complex>
 #include <cstdint>
