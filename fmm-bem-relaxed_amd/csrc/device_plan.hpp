@@ -109,6 +109,7 @@ struct DevicePlan {
   // leaves are streamed as ever (sym_items).  near_items = the recompute items as {leaf, first row, rows, 0} for the side listing
   const uint8_t* near_rec = nullptr;
   const RcItem* rc_items = nullptr;  int rc_nitems = 0;
+  int near_nitems_stream = 0;                        // Laplace hybrid plans: the streamed items are near_recs[0 .. near_nitems_stream)
   // boxes / expansions
   const double* box_center;
   double2 *M, *L, *Mh;

@@ -1038,7 +1038,7 @@ template <int kRows, int kVecs>
 __global__ __launch_bounds__(kSpmvWaves * kWave, kSpmvOcc) void near_spmv_pipe_kernel(DevicePlan d) {
   extern __shared__ double xs_all[];
   __shared__ double part[kSpmvWaves][kColRows];
-  spmv_pipe_run<kRows, kVecs>(d, xs_all, part, blockIdx.x, gridDim.x, d.near_nitems);
+  spmv_pipe_run<kRows, kVecs>(d, xs_all, part, blockIdx.x, gridDim.x, d.near_rec ? d.near_nitems_stream : d.near_nitems);
 }
 
 }  // namespace
@@ -1177,8 +1177,8 @@ constexpr int kHybRows = 5;                           // rows per wavefront of a
 // One halving step: the lanes whose `BIT` is set keep the upper W values, the others the lower W, and each adds what its
 // partner (lane ^ BIT) held of them.  (Written as a template per step: as one loop over the steps the compiler does not unroll
 // it, indexes v[] at run time and emits a 16-way select per access -- 1 400 instructions instead of 120.)
-template <int W, int BIT>
-__device__ __forceinline__ void hyb_halve(double (&v)[16], int lane) {
+template <int W, int BIT, int NV>
+__device__ __forceinline__ void hyb_halve(double (&v)[NV], int lane) {
   const bool hi = (lane & BIT) != 0;
 #pragma unroll
   for (int k = 0; k < W; ++k) {
@@ -1197,6 +1197,17 @@ __device__ __forceinline__ double hyb_reduce16(double (&v)[16], int lane) {
   t += __shfl_xor(t, 1, kWave);
   return t;
 }
+// the same for 8 values: every lane returns the sum over all lanes of value (lane >> 3) & 7
+__device__ __forceinline__ double hyb_reduce8(double (&v)[8], int lane) {
+  hyb_halve<4, 32>(v, lane);
+  hyb_halve<2, 16>(v, lane);
+  hyb_halve<1, 8>(v, lane);
+  double t = v[0];
+  t += __shfl_xor(t, 4, kWave);
+  t += __shfl_xor(t, 2, kWave);
+  t += __shfl_xor(t, 1, kWave);
+  return t;
+}
 __device__ __forceinline__ int hyb_value_of(int lane) { return (lane >> 2) & 15; }   // bits 5..2 of the lane, bit 5 = value bit 3
 
 #ifndef FMMBEM_RC_OCC
@@ -1207,7 +1218,6 @@ __device__ __forceinline__ int hyb_value_of(int lane) { return (lane >> 2) & 15;
 #endif
 constexpr int kRcOcc = FMMBEM_RC_OCC;                 // register budget of the recompute kernel: 512 / kRcOcc VGPRs
 constexpr int kRcChunk = kSpmvWaves * kWave;          // source panels per chunk = threads of the workgroup
-constexpr int kRcItemRows = kSpmvWaves * kHybRows;    // 20: rows of an item
 
 // y_tree[rows of the recomputed leaves] = the rows' LISTED entries (near-regime pairs, evaluated once at plan creation) times x:
 // a CSR product, a row per wavefront, lane = entry, the lanes added by wave_sum.  Runs in front of near_recompute3_kernel, which
@@ -1389,6 +1399,132 @@ __global__ __launch_bounds__(kSpmvWaves * kWave, kRcOcc) void near_recompute3_ke
   }
 }
 
+// The same for LaplaceSphericalBEM (one unknown per panel): items of <= 32 rows, wavefront w owns up to 8 of them, one sum per row
+// (8 values through one butterfly); a source panel is 14 doubles (3 points, centroid, area, charge; 17 with the normal when the
+// plan has NORMAL_DERIV targets).  far regime: G = sum_q w_q A / |x - q| (kernel/LaplaceSphericalBEM.hpp:198-203), dG/dn =
+// sum_q w_q A (q - x).n / |q - x|^3 (:251-262) -- the arithmetic of mf_sweep_kernel.
+constexpr int kRc1Rows = 8;                           // rows per wavefront
+
+template <bool DN>
+__global__ __launch_bounds__(kSpmvWaves * kWave, kRcOcc) void near_recompute1_kernel(DevicePlan d) {
+  constexpr int F = DN ? 17 : 14;
+  extern __shared__ double src[];                     // [F][kRcChunk] doubles, then runbuf [2][2][max_runs] ints
+  int* const runbuf = reinterpret_cast<int*>(src + F * kRcChunk);
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, tid = threadIdx.x;
+  const int mr = d.max_runs, nitems = d.rc_nitems, step = gridDim.x;
+  const int64_t N = d.n;
+  const double w0 = d.qw[0], w1 = d.nq > 1 ? d.qw[1] : 0.0;        // the rules the host admits: weights of points 1.. all equal
+  const int nq = d.nq;
+  const ConstRcItem* recs = reinterpret_cast<const ConstRcItem*>(reinterpret_cast<uintptr_t>(d.rc_items));
+
+  int item = blockIdx.x;
+  if (item >= nitems) return;
+  RcItem it = load_rc_item(recs + item);
+  RcItem nx = load_rc_item(recs + (item + step < nitems ? item + step : nitems - 1));
+  for (int i = tid; i < it.nruns; i += blockDim.x) { runbuf[i] = d.near_run_row0[it.run_begin + i]; runbuf[mr + i] = d.near_run_off[it.run_begin + i]; }
+  for (int i = tid; i < nx.nruns; i += blockDim.x) { runbuf[2 * mr + i] = d.near_run_row0[nx.run_begin + i]; runbuf[3 * mr + i] = d.near_run_off[nx.run_begin + i]; }
+  __syncthreads();
+  double pre[F];
+  auto fetch = [&](const Runs& runs, int c, int ncp) {
+    const unsigned j = (unsigned)column_to_row(runs, c < ncp ? c : 0);       // columns past the end repeat column 0; masked where they are used
+    const double* qp = d.quad + j;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const bool have = q < nq;
+      pre[3 * q] = have ? qp[(q * 3 + 0) * N] : 0.0; pre[3 * q + 1] = have ? qp[(q * 3 + 1) * N] : 0.0; pre[3 * q + 2] = have ? qp[(q * 3 + 2) * N] : 1.0;
+    }
+    pre[9] = d.cx[j]; pre[10] = d.cy[j]; pre[11] = d.cz[j]; pre[12] = d.area[j];
+    pre[13] = d.xt[j];
+    if constexpr (DN) { pre[14] = d.nx[j]; pre[15] = d.ny[j]; pre[16] = d.nz[j]; }
+  };
+  int rb = 0;
+  fetch(Runs{runbuf, runbuf + mr, it.nruns}, tid, it.ncp);
+  for (;; item += step) {
+    const bool more = item + step < nitems;
+    const int i2 = item + 2 * step;
+    const RcItem nn = load_rc_item(recs + (i2 < nitems ? i2 : nitems - 1));
+    const int nrows = it.nrows, ncp = it.ncp, prow0 = it.prow0;
+    const Runs runs{runbuf + rb * 2 * mr, runbuf + rb * 2 * mr + mr, it.nruns};
+    const Runs nruns{runbuf + (rb ^ 1) * 2 * mr, runbuf + (rb ^ 1) * 2 * mr + mr, nx.nruns};
+    int pr0 = 0, pr1 = 0;
+    const bool prun = i2 < nitems && tid < nn.nruns;
+    if (prun) { pr0 = d.near_run_row0[nn.run_begin + tid]; pr1 = d.near_run_off[nn.run_begin + tid]; }
+    const int rq = nrows / kSpmvWaves, rrem = nrows % kSpmvWaves;
+    const int rw = wave * rq + (wave < rrem ? wave : rrem);      // this wavefront's first row of the item
+    const int nrw = rq + (wave < rrem ? 1 : 0);                  // ... and how many it has (0: none)
+    double tx[kRc1Rows], ty[kRc1Rows], tz[kRc1Rows];
+    int tbw[kRc1Rows];
+#pragma unroll
+    for (int r = 0; r < kRc1Rows; ++r) {
+      const int64_t i = prow0 + rw + (r < nrw ? r : 0);
+      tx[r] = d.cx[i]; ty[r] = d.cy[i]; tz[r] = d.cz[i];
+      tbw[r] = DN ? d.bc[i] : 0;
+    }
+    double v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = 0.0;
+    const int vidx = (lane >> 3) & 7;
+    const bool mine = nrw > 0 && (lane & 7) == 0 && vidx < nrw;
+    const double ylist = mine ? d.yt[prow0 + rw + vidx] : 0.0;      // the row's listed entries (near_side_kernel ran first)
+    const int nchunks = (ncp + kRcChunk - 1) / kRcChunk;
+    for (int ck = 0; ck < nchunks; ++ck) {
+      __syncthreads();
+#pragma unroll
+      for (int f = 0; f < F; ++f) src[f * kRcChunk + tid] = pre[f];
+      __syncthreads();
+      if (ck + 1 < nchunks) fetch(runs, (ck + 1) * kRcChunk + tid, ncp);
+      else if (more) fetch(nruns, tid, nx.ncp);
+      if (nrw <= 0) continue;
+      const int cw = ncp - ck * kRcChunk < kRcChunk ? ncp - ck * kRcChunk : kRcChunk;
+      double cur[F], nxt[F];
+#pragma unroll
+      for (int f = 0; f < F; ++f) cur[f] = src[f * kRcChunk + lane];
+      for (int cg = 0; cg * kWave < cw; ++cg) {
+        const int c = cg * kWave + lane;
+        const bool valid = c < cw;
+        if ((cg + 1) * kWave < cw) {
+#pragma unroll
+          for (int f = 0; f < F; ++f) nxt[f] = src[f * kRcChunk + c + kWave];
+        }
+        const double sx = cur[9], sy = cur[10], sz = cur[11], A = cur[12], xj = cur[13];
+        double nx_ = 0, ny_ = 0, nz_ = 0;
+        if constexpr (DN) { nx_ = cur[14]; ny_ = cur[15]; nz_ = cur[16]; }
+        const double near2 = valid ? 8.0 * A * (1.0 + 1e-9) : 1e300;        // lanes past the last column: every pair "listed", i.e. dropped
+        const double wA0 = w0 * A, wA1 = w1 * A;
+#pragma unroll
+        for (int r = 0; r < kRc1Rows; ++r) {
+          if (r < nrw) {                                   // wave-uniform
+            const bool slow = mf_listed(tx[r] - sx, ty[r] - sy, tz[r] - sz, near2);
+            bool dn = false;
+            if constexpr (DN) dn = __builtin_amdgcn_readfirstlane(tbw[r]) != 0;
+            double u = 0;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+              const double wA = q ? (q < nq ? wA1 : 0.0) : wA0;
+              const double ex = cur[3 * q] - tx[r], ey = cur[3 * q + 1] - ty[r], ez = cur[3 * q + 2] - tz[r];
+              const double ir = rsqrt_pos(fma(ex, ex, fma(ey, ey, ez * ez)));
+              if (DN && dn) u = fma(wA * fma(ex, nx_, fma(ey, ny_, ez * nz_)), ir * ir * ir, u);
+              else u = fma(wA, ir, u);
+            }
+            // a listed pair contributes through the list, not here (a select: K = 1 puts the self pair's point ON the centroid)
+            v[r] = fma(slow ? 0.0 : u, xj, v[r]);
+          }
+          __builtin_amdgcn_sched_barrier(0);               // one row after the other
+        }
+#pragma unroll
+        for (int f = 0; f < F; ++f) cur[f] = nxt[f];
+      }
+    }
+    if (nrw > 0) {
+      const double tot = hyb_reduce8(v, lane);
+      if (mine) d.yt[prow0 + rw + vidx] = ylist + tot;
+    }
+    if (!more) break;
+    if (prun) { runbuf[rb * 2 * mr + tid] = pr0; runbuf[rb * 2 * mr + mr + tid] = pr1; }
+    it = nx; nx = nn; rb ^= 1;
+  }
+}
+
 // Panel(p0, p1, p2) of kernel/LaplaceSphericalBEM.hpp:64-97 for every panel, in TREE order, from the caller's vertices (original
 // order) and the permutation: centroid, normal (p2-p0) x (p1-p0) / 2A, area, the rule's points, the vertices transposed.  The
 // arithmetic of host_plan.cpp fill_panel operation for operation, contraction OFF: the same bits as the host form (which a
@@ -1564,13 +1700,16 @@ hipError_t launch_gather_x(const DevicePlan& d, const double* x, hipStream_t s) 
 // on `s2` (forked from and joined to `s` through the two events): kS workgroups per CU of the one (96 VGPRs), kR of the other,
 // sized so that BOTH kernels are resident on every CU from start to end.
 hipError_t launch_near_hybrid(const DevicePlan& d, hipStream_t s, hipStream_t s2, hipEvent_t fork, hipEvent_t join) {
-  if (d.dof != 3 || !d.near_rec) return hipErrorInvalidValue;
-  static const int kS = [] { const char* e = std::getenv("FMMBEM_HYB_WG_STREAM"); return e ? std::atoi(e) : 2; }();
-  static const int kR = [] { const char* e = std::getenv("FMMBEM_HYB_WG_RECOMPUTE"); return e ? std::atoi(e) : 2; }();
+  if (!d.near_rec) return hipErrorInvalidValue;
+  const bool stokes = d.dof == 3;
+  static const int kS3 = [] { const char* e = std::getenv("FMMBEM_HYB_WG_STREAM"); return e ? std::atoi(e) : 2; }();
+  static const int kS1 = [] { const char* e = std::getenv("FMMBEM_HYB_WG_STREAM"); return e ? std::atoi(e) : 3; }();
+  static const int kR = [] { const char* e = std::getenv("FMMBEM_HYB_WG_RECOMPUTE"); return e ? std::atoi(e) : 1; }();
   const dim3 b(kSpmvWaves * kWave);
-  const bool trac = d.stokes_traction_targets != 0;
+  const bool flag1 = stokes ? d.stokes_traction_targets != 0 : (d.n_act > 1 || d.act[0] == 1);   // TRACTION / NORMAL_DERIV targets present
+  const int n_stream = stokes ? d.sym_nitems : d.near_nitems_stream;
   hipError_t e = hipSuccess;
-  const bool both = d.rc_nitems > 0 && d.sym_nitems > 0 && s2;
+  const bool both = d.rc_nitems > 0 && n_stream > 0 && s2;
   if (both) {
     if ((e = hipEventRecord(fork, s)) != hipSuccess) return e;
     if ((e = hipStreamWaitEvent(s2, fork, 0)) != hipSuccess) return e;
@@ -1578,15 +1717,27 @@ hipError_t launch_near_hybrid(const DevicePlan& d, hipStream_t s, hipStream_t s2
   if (d.rc_nitems > 0) {                               // the recompute kernel first: its few, large workgroups must find room on every CU
     const dim3 g(std::min(d.rc_nitems, 256 * kR));
     hipStream_t sr = both ? s2 : s;
-    hipLaunchKernelGGL((near_side_kernel<3>), dim3(std::min(d.rc_nitems, 256 * 8)), b, 0, sr, d);
-    const size_t ldsr = (size_t)(trac ? 22 : 19) * kRcChunk * sizeof(double) + 4 * (size_t)d.max_runs * sizeof(int);
-    if (trac) hipLaunchKernelGGL((near_recompute3_kernel<true>), g, b, ldsr, sr, d);
-    else hipLaunchKernelGGL((near_recompute3_kernel<false>), g, b, ldsr, sr, d);
+    if (stokes) {
+      hipLaunchKernelGGL((near_side_kernel<3>), dim3(std::min(d.rc_nitems, 256 * 8)), b, 0, sr, d);
+      const size_t ldsr = (size_t)(flag1 ? 22 : 19) * kRcChunk * sizeof(double) + 4 * (size_t)d.max_runs * sizeof(int);
+      if (flag1) hipLaunchKernelGGL((near_recompute3_kernel<true>), g, b, ldsr, sr, d);
+      else hipLaunchKernelGGL((near_recompute3_kernel<false>), g, b, ldsr, sr, d);
+    } else {
+      hipLaunchKernelGGL((near_side_kernel<1>), dim3(std::min(d.rc_nitems, 256 * 8)), b, 0, sr, d);
+      const size_t ldsr = (size_t)(flag1 ? 17 : 14) * kRcChunk * sizeof(double) + 4 * (size_t)d.max_runs * sizeof(int);
+      if (flag1) hipLaunchKernelGGL((near_recompute1_kernel<true>), g, b, ldsr, sr, d);
+      else hipLaunchKernelGGL((near_recompute1_kernel<false>), g, b, ldsr, sr, d);
+    }
     if ((e = hipGetLastError()) != hipSuccess) return e;
   }
-  if (d.sym_nitems > 0) {
-    const size_t lds3 = 3 * (size_t)kSymChunk * sizeof(double) + 2 * (size_t)d.max_runs * sizeof(int);
-    hipLaunchKernelGGL((near_spmv_sym3_kernel<1, 3>), dim3(std::min(d.sym_nitems, 256 * (d.rc_nitems > 0 ? kS : kSymOcc))), b, lds3, s, d);
+  if (n_stream > 0) {
+    if (stokes) {
+      const size_t lds3 = 3 * (size_t)kSymChunk * sizeof(double) + 2 * (size_t)d.max_runs * sizeof(int);
+      hipLaunchKernelGGL((near_spmv_sym3_kernel<1, 3>), dim3(std::min(n_stream, 256 * (d.rc_nitems > 0 ? kS3 : kSymOcc))), b, lds3, s, d);
+    } else {
+      const size_t lds2 = 2 * (size_t)kSpmvPipeChunk * sizeof(double) + 4 * (size_t)d.max_runs * sizeof(int);
+      hipLaunchKernelGGL((near_spmv_pipe_kernel<2, 4>), dim3(std::min(n_stream, 256 * (d.rc_nitems > 0 ? kS1 : kSpmvOcc))), b, lds2, s, d);
+    }
     if ((e = hipGetLastError()) != hipSuccess) return e;
   }
   if (both) {

@@ -416,7 +416,14 @@ int fmmbem_plan::to_device() {
     bool rule_ok = hp.rule.n <= (dof == 3 ? 4 : 3);               // the far-regime points of a source live in registers
     for (int q = 2; q < hp.rule.n; ++q) rule_ok = rule_ok && hp.rule.w[q] == hp.rule.w[1];      // K = 1, 3, 4: two distinct weights at most
     const bool stokes_sym_on = !(std::getenv("FMMBEM_STOKES_SYM") && std::atoi(std::getenv("FMMBEM_STOKES_SYM")) == 0);
-    hybrid = f < 1.0 && opts.sparse_local && hp.opt.evaluator == 0 && rule_ok && dof == 3 && stokes_sym_on;
+    // runs of consecutive source rows per leaf (the pipelined kernels prefetch an item's run descriptors one per thread)
+    std::vector<int> nruns_of(nl, 0);
+    int max_runs_owned = 1;
+    for (int l = 0; l < nl; ++l) {
+      for (int64_t i = hp.near_ptr[l]; i < hp.near_ptr[l + 1]; ++i) nruns_of[l] += i == hp.near_ptr[l] || hp.near_src[i - 1] + 1 != hp.near_src[i];
+      if (l >= hp.leaf_begin && l < hp.leaf_end) max_runs_owned = std::max(max_runs_owned, nruns_of[l]);
+    }
+    hybrid = f < 1.0 && opts.sparse_local && hp.opt.evaluator == 0 && rule_ok && (dof == 3 ? stokes_sym_on : max_runs_owned <= 256);
     if (hybrid) {
       if (!(f >= 0.0)) f = 0.0;
       std::vector<int> order(nl);
@@ -428,9 +435,7 @@ int fmmbem_plan::to_device() {
       for (int l : order) {
         if (acc >= (1.0 - f) * all) break;
         if (hp.near_ncols[l] > 8192) continue;        // a coarse leaf of an adaptive tree (10^4 columns): one item would run alone at the end
-        int runs = 0;                                 // the recompute kernel prefetches an item's run descriptors one per thread
-        for (int64_t i = hp.near_ptr[l]; i < hp.near_ptr[l + 1]; ++i) runs += i == hp.near_ptr[l] || hp.near_src[i - 1] + 1 != hp.near_src[i];
-        if (runs > 256) continue;
+        if (nruns_of[l] > 256) continue;
         rec[l] = 1;
         acc += (double)leaf_nrows[l] * hp.near_ncols[l];
       }
@@ -484,7 +489,7 @@ int fmmbem_plan::to_device() {
       const int nr = idof * leaf_nrows[l];
       const int64_t row_bytes = opts.sparse_local ? (int64_t)near_stride[l] * 8 : (int64_t)hp.near_ncols[l] * 8;
       if (nr == 0 || row_bytes == 0) continue;
-      if (hybrid) continue;                             // hybrid plans build their own lists below (these items feed kernels they do not run)
+      if (hybrid && (dof == 3 || rec[l])) continue;     // hybrid plans: Stokes builds its stream items below; a recomputed leaf has none
       int per = (int)std::max<int64_t>(1, kItemBytes / row_bytes);
       if (per >= 8) per &= ~7; else per = std::min(4, nr);
       const int cnt = (nr + per - 1) / per;
@@ -548,35 +553,38 @@ int fmmbem_plan::to_device() {
       sym_total_doubles = std::max<int64_t>(sym_total, 1);          // allocated in to_device_bc
       near_bytes = sym_total * (int64_t)sizeof(double);
       sym_off_host = sym_off;
-      if (hybrid) {
-        // recompute items: ranges of <= 20 panel rows of the recomputed leaves (four wavefronts x five rows, kernels_near.hip)
-        struct RItem { int leaf, r0, nr; int64_t pairs; };
-        std::vector<RItem> ritems;
-        for (int l = hp.leaf_begin; l < hp.leaf_end; ++l) {
-          const int nr = leaf_nrows[l], ncp = hp.near_ncols[l];
-          if (!rec[l] || nr == 0 || ncp == 0) continue;
-          const int cnt = (nr + 19) / 20;
-          const int per = (nr + cnt - 1) / cnt;          // dealt evenly: the kernel gives a wavefront ceil(rows / 4) of an item's rows
-          for (int r0 = 0; r0 < nr; r0 += per) { const int k = std::min(per, nr - r0); ritems.push_back({l, r0, k, (int64_t)k * ncp}); }
-        }
-        std::stable_sort(ritems.begin(), ritems.end(), [](const RItem& a, const RItem& b) { return a.pairs > b.pairs; });
-        // the side listing (mf_sweep COUNT / FILL) walks d.near_items: the recompute items, panel rows
-        std::vector<int4> rpacked(ritems.size());
-        std::vector<RcItem> rrecs(ritems.size());
-        for (size_t i = 0; i < ritems.size(); ++i) {
-          const RItem& it = ritems[i];
-          rpacked[i] = make_int4(it.leaf, it.r0, it.nr, 0);
-          RcItem& q = rrecs[i];
-          q.prow0 = leaf_row0[it.leaf] + it.r0; q.nrows = it.nr; q.ncp = hp.near_ncols[it.leaf];
-          q.run_begin = run_ptr[it.leaf]; q.nruns = (int)(run_ptr[it.leaf + 1] - run_ptr[it.leaf]); q.leaf = it.leaf; q.pad = 0;
-        }
-        d.near_nitems = (int)rpacked.size();
-        TRY(upload(rpacked, &d.near_items));
-        d.rc_nitems = (int)rrecs.size();
-        TRY(upload(rrecs, &d.rc_items));
-        TRY(upload(rec, &d.near_rec));
-      }
     }
+  }
+  if (hybrid) {
+    // recompute items: ranges of <= 20 (Stokes: four wavefronts x five rows) or 32 (Laplace: x eight) panel rows of the recomputed
+    // leaves (kernels_near.hip near_recompute3 / near_recompute1)
+    struct RItem { int leaf, r0, nr; int64_t pairs; };
+    std::vector<RItem> ritems;
+    for (int l = hp.leaf_begin; l < hp.leaf_end; ++l) {
+      const int nr = leaf_nrows[l], ncp = hp.near_ncols[l];
+      if (!rec[l] || nr == 0 || ncp == 0) continue;
+      const int cap = dof == 3 ? 20 : 32;
+        const int cnt = (nr + cap - 1) / cap;
+      const int per = (nr + cnt - 1) / cnt;          // dealt evenly: the kernel gives a wavefront ceil(rows / 4) of an item's rows
+      for (int r0 = 0; r0 < nr; r0 += per) { const int k = std::min(per, nr - r0); ritems.push_back({l, r0, k, (int64_t)k * ncp}); }
+    }
+    std::stable_sort(ritems.begin(), ritems.end(), [](const RItem& a, const RItem& b) { return a.pairs > b.pairs; });
+    // the side listing (mf_sweep COUNT / FILL) walks d.near_items: the recompute items, panel rows
+    std::vector<int4> rpacked(ritems.size());
+    std::vector<RcItem> rrecs(ritems.size());
+    for (size_t i = 0; i < ritems.size(); ++i) {
+      const RItem& it = ritems[i];
+      rpacked[i] = make_int4(it.leaf, it.r0, it.nr, 0);
+      RcItem& q = rrecs[i];
+      q.prow0 = leaf_row0[it.leaf] + it.r0; q.nrows = it.nr; q.ncp = hp.near_ncols[it.leaf];
+      q.run_begin = run_ptr[it.leaf]; q.nruns = (int)(run_ptr[it.leaf + 1] - run_ptr[it.leaf]); q.leaf = it.leaf; q.pad = 0;
+    }
+    d.near_nitems_stream = dof == 1 ? d.near_nitems : 0;   // (Laplace: the items built above are the streamed ones, near_recs)
+      d.near_nitems = (int)rpacked.size();
+    TRY(upload(rpacked, &d.near_items));
+    d.rc_nitems = (int)rrecs.size();
+    TRY(upload(rrecs, &d.rc_items));
+    TRY(upload(rec, &d.near_rec));
   }
   near_rec_host = rec;
   near_off_host = near_off;
