@@ -4,6 +4,7 @@
 // (fmmbem_kernel_entries); there is no host arithmetic of the kernels in this repository.
 #pragma once
 #include <cassert>
+#include <algorithm>
 #include <vector>
 
 #include "../FMM_plan.hpp"
@@ -39,16 +40,29 @@ class Direct {
     const size_t ns = (size_t)(s_last - s_first);
     if (!ns) return;
     constexpr size_t kv = sizeof(typename Kernel::kernel_value_type) / sizeof(double);
-    std::vector<double> sv(9 * ns), tv(9 * ns), out(kv * ns);
-    std::vector<uint8_t> tbc(ns);
+    // fmmbem_kernel_entries takes independent (target, source) pairs: a batch of targets against all sources per call, sized so
+    // that a call moves ~64 MB (the drivers hand this a few exterior points; DirectMatvec-style use with targets = sources is
+    // O(N^2) pairs through PCIe either way -- then in N^2 / batch calls instead of N)
+    const size_t batch = std::max<size_t>(1, std::min<size_t>((size_t)(t_last - t_first), ((size_t)1 << 19) / ns + 1));
+    std::vector<double> s1(9 * ns), sv(9 * ns * batch), tv(9 * ns * batch), out(kv * ns * batch);
+    std::vector<uint8_t> tbc(ns * batch);
     size_t j = 0;
-    for (SourceIter s = s_first; s != s_last; ++s, ++j) flat(*s, &sv[9 * j]);
+    for (SourceIter s = s_first; s != s_last; ++s, ++j) flat(*s, &s1[9 * j]);
+    for (size_t b = 0; b < batch; ++b) std::copy(s1.begin(), s1.end(), sv.begin() + (std::ptrdiff_t)(9 * ns * b));
     const fmmbem_options o = options_of(K);
-    for (; t_first != t_last; ++t_first, ++r_first) {
-      for (size_t q = 0; q < ns; ++q) { flat(*t_first, &tv[9 * q]); tbc[q] = t_first->BC == Kernel::source_type::BC1; }
-      fmmbem::check(fmmbem_kernel_entries(&o, ns, tv.data(), tbc.data(), sv.data(), out.data()));
-      ChargeIter c = c_first;
-      for (size_t q = 0; q < ns; ++q, ++c) add(*r_first, &out[kv * q], *c);
+    while (t_first != t_last) {
+      size_t nb = 0;
+      TargetIter t = t_first;
+      for (; t != t_last && nb < batch; ++t, ++nb) {
+        double one[9];
+        flat(*t, one);
+        for (size_t q = 0; q < ns; ++q) { std::copy(one, one + 9, &tv[9 * (nb * ns + q)]); tbc[nb * ns + q] = t->BC == Kernel::source_type::BC1; }
+      }
+      fmmbem::check(fmmbem_kernel_entries(&o, ns * nb, tv.data(), tbc.data(), sv.data(), out.data()));
+      for (size_t b = 0; b < nb; ++b, ++t_first, ++r_first) {
+        ChargeIter c = c_first;
+        for (size_t q = 0; q < ns; ++q, ++c) add(*r_first, &out[kv * (b * ns + q)], *c);
+      }
     }
   }
   /** Convenience function for std::vector (Direct.hpp:276-289) */

@@ -444,3 +444,33 @@ def test_shift_lanes_equal_the_one_pair_kernels_bit_for_bit(fb, oracle_mod, monk
         ref = o.expansions(p, which)
         scale = np.abs(ref).max(axis=2, keepdims=True) + 1e-300
         assert np.max(np.abs(got - ref) / scale) <= TOL_EXPANSION, which
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("p", [9, 10])
+def test_shift_lanes_wavefront_runs_of_parents_bit_for_bit(fb, monkeypatch, p):
+    """the M2M path of shift_lanes_kernel that plan.hip selects for levels of more than 1 024 parents (a contiguous run of
+    parents per wavefront, the pa[4][R] chain bookkeeping) -- UnitSphere(8) with 16 panels per leaf has such levels -- against the
+    one-pair-per-lane kernels: M, L and y bit for bit, and two shards summing to the whole bit for bit."""
+    v = fb.unit_sphere(8)
+    x = np.random.default_rng(5).standard_normal(len(v))
+    K = fb.LaplaceSphericalBEM(p, 3)
+    fo = fb.FMMOptions()
+    fo.set_max_per_box(16)
+    monkeypatch.setenv("FMMBEM_SHIFT_LANES", "1")
+    monkeypatch.setenv("FMMBEM_SHIFT_LANES_MAX", "1000000")          # every level through the wavefront kernel
+    pl = fb.FMM_plan(K, v, fo)
+    boxes = pl.boxes()
+    parents_per_level = np.bincount(boxes["level"][boxes["leaf"] == 0])
+    assert parents_per_level.max() > 1024
+    y = pl.execute(x)
+    M, L = pl.expansions("M", p), pl.expansions("L", p)
+    total = np.zeros_like(y)
+    for r in range(2):
+        total += fb.FMM_plan(K, v, fo, shard=(r, 2)).execute(x)
+    assert np.array_equal(total, y)
+    monkeypatch.setenv("FMMBEM_SHIFT_LANES", "0")
+    monkeypatch.setenv("FMMBEM_SHIFT_ROT_MIN", "0")
+    pl1 = fb.FMM_plan(K, v, fo)
+    assert np.array_equal(pl1.execute(x), y)
+    assert np.array_equal(pl1.expansions("M", p), M) and np.array_equal(pl1.expansions("L", p), L)
