@@ -1216,6 +1216,15 @@ __device__ __forceinline__ int hyb_value_of(int lane) { return (lane >> 2) & 15;
 #ifndef FMMBEM_RC_QSCHED
 #define FMMBEM_RC_QSCHED 2
 #endif
+#ifndef FMMBEM_RC_LDS_AHEAD
+#define FMMBEM_RC_LDS_AHEAD 1
+#endif
+#ifndef FMMBEM_RC_TARGET_REGS
+#define FMMBEM_RC_TARGET_REGS 1
+#endif
+#ifndef FMMBEM_RC_GLOBAL_AHEAD
+#define FMMBEM_RC_GLOBAL_AHEAD 1
+#endif
 constexpr int kRcOcc = FMMBEM_RC_OCC;                 // register budget of the recompute kernel: 512 / kRcOcc VGPRs
 constexpr int kRcChunk = kSpmvWaves * kWave;          // source panels per chunk = threads of the workgroup
 
@@ -1263,6 +1272,11 @@ __global__ __launch_bounds__(kSpmvWaves * kWave, kRcOcc) void near_recompute3_ke
   constexpr int F = TRAC ? 22 : 19;                   // doubles per source panel: 4 x (x,y,z), centroid, area, charge (3) [, normal]
   extern __shared__ double src[];                     // [F][kRcChunk] doubles, then runbuf [2][2][max_runs] ints
   int* const runbuf = reinterpret_cast<int*>(src + F * kRcChunk);
+#if !FMMBEM_RC_TARGET_REGS
+  constexpr int kRcTgtRows = kSpmvWaves * kHybRows;
+  __shared__ double tcs[3 * kRcTgtRows];
+  __shared__ int tbs[kRcTgtRows];
+#endif
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, tid = threadIdx.x;
   const int mr = d.max_runs, nitems = d.rc_nitems, step = gridDim.x;
   const int64_t N = d.n;
@@ -1310,6 +1324,7 @@ __global__ __launch_bounds__(kSpmvWaves * kWave, kRcOcc) void near_recompute3_ke
     const int rw = wave * rq + (wave < rrem ? wave : rrem);      // this wavefront's first row of the item
     const int nrw = rq + (wave < rrem ? 1 : 0);                  // ... and how many it has (0: none)
     // their centroids: wave-uniform loads, in registers for the whole item
+#if FMMBEM_RC_TARGET_REGS
     double tx[kHybRows], ty[kHybRows], tz[kHybRows];
     int tbw[kHybRows];
 #pragma unroll
@@ -1318,6 +1333,21 @@ __global__ __launch_bounds__(kSpmvWaves * kWave, kRcOcc) void near_recompute3_ke
       tx[r] = d.cx[i]; ty[r] = d.cy[i]; tz[r] = d.cz[i];
       tbw[r] = TRAC ? d.bc[i] : 0;
     }
+#define RC_TX(r) tx[r]
+#define RC_TY(r) ty[r]
+#define RC_TZ(r) tz[r]
+#define RC_TB(r) tbw[r]
+#else
+    // (two wavefronts per SIMD: the rows' centroids are LDS broadcasts of their row's arithmetic -- the other wavefront covers the
+    // latency, and the 30 registers they would hold are what lets the second wavefront in)
+    double t0 = 0, t1 = 0, t2 = 0;
+    int tb = 0;
+    if (tid < nrows) { const int64_t i = prow0 + tid; t0 = d.cx[i]; t1 = d.cy[i]; t2 = d.cz[i]; tb = TRAC ? d.bc[i] : 0; }
+#define RC_TX(r) tcs[rw + (r)]
+#define RC_TY(r) tcs[kRcTgtRows + rw + (r)]
+#define RC_TZ(r) tcs[2 * kRcTgtRows + rw + (r)]
+#define RC_TB(r) tbs[rw + (r)]
+#endif
     double v[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) v[k] = 0.0;
@@ -1327,26 +1357,44 @@ __global__ __launch_bounds__(kSpmvWaves * kWave, kRcOcc) void near_recompute3_ke
     const double ylist = mine ? d.yt[3 * (int64_t)(prow0 + rw) + hyb_value_of(lane)] : 0.0;
     const int nchunks = (ncp + kRcChunk - 1) / kRcChunk;
     for (int ck = 0; ck < nchunks; ++ck) {
+#if !FMMBEM_RC_GLOBAL_AHEAD
+      if (ck || item != (int)blockIdx.x) fetch(runs, ck * kRcChunk + tid, ncp);      // no prefetch: the chunk is fetched when it is needed
+#endif
       __syncthreads();                                   // nobody reads the previous chunk (or the previous item's rows) any more
 #pragma unroll
       for (int f = 0; f < F; ++f) src[f * kRcChunk + tid] = pre[f];
+#if !FMMBEM_RC_TARGET_REGS
+      if (ck == 0 && tid < nrows) { tcs[tid] = t0; tcs[kRcTgtRows + tid] = t1; tcs[2 * kRcTgtRows + tid] = t2; tbs[tid] = tb; }
+#endif
       __syncthreads();
+#if FMMBEM_RC_GLOBAL_AHEAD
       // the chunk after this one -- of this item, or the first of the next -- in flight while this one is worked on
       if (ck + 1 < nchunks) fetch(runs, (ck + 1) * kRcChunk + tid, ncp);
       else if (more) fetch(nruns, tid, nx.ncp);
+#endif
       if (nrw <= 0) continue;                            // (wave-uniform) an item of fewer rows than wavefronts
       const int cw = ncp - ck * kRcChunk < kRcChunk ? ncp - ck * kRcChunk : kRcChunk;
       // a group of 64 source panels LDS -> registers one group ahead of the arithmetic (lane = source panel)
-      double cur[F], nxt[F];
+      double cur[F];
+#if FMMBEM_RC_LDS_AHEAD
+      double nxt[F];
+#endif
 #pragma unroll
       for (int f = 0; f < F; ++f) cur[f] = src[f * kRcChunk + lane];
       for (int cg = 0; cg * kWave < cw; ++cg) {
         const int c = cg * kWave + lane;
         const bool valid = c < cw;
+#if FMMBEM_RC_LDS_AHEAD
         if ((cg + 1) * kWave < cw) {
 #pragma unroll
           for (int f = 0; f < F; ++f) nxt[f] = src[f * kRcChunk + c + kWave];
         }
+#else
+        if (cg) {
+#pragma unroll
+          for (int f = 0; f < F; ++f) cur[f] = src[f * kRcChunk + c];
+        }
+#endif
         const double sx = cur[12], sy = cur[13], sz = cur[14], A = cur[15];
         const double x0 = cur[16], x1 = cur[17], x2 = cur[18];
         double nx_ = 0, ny_ = 0, nz_ = 0;
@@ -1356,14 +1404,15 @@ __global__ __launch_bounds__(kSpmvWaves * kWave, kRcOcc) void near_recompute3_ke
 #pragma unroll
         for (int r = 0; r < kHybRows; ++r) {
           if (r < nrw) {                                   // wave-uniform
-            const bool slow = mf_listed(tx[r] - sx, ty[r] - sy, tz[r] - sz, near2);
+            const double txr = RC_TX(r), tyr = RC_TY(r), tzr = RC_TZ(r);
+            const bool slow = mf_listed(txr - sx, tyr - sy, tzr - sz, near2);
             bool trac = false;
-            if constexpr (TRAC) trac = __builtin_amdgcn_readfirstlane(tbw[r]) != 0;
+            if constexpr (TRAC) trac = __builtin_amdgcn_readfirstlane(RC_TB(r)) != 0;
             double u0 = 0, u1 = 0, u2 = 0;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               const double wA = q ? (q < nq ? wA1 : 0.0) : wA0;
-              const double ex = tx[r] - cur[3 * q], ey = ty[r] - cur[3 * q + 1], ez = tz[r] - cur[3 * q + 2];
+              const double ex = txr - cur[3 * q], ey = tyr - cur[3 * q + 1], ez = tzr - cur[3 * q + 2];
               const double ir = rsqrt_pos(fma(ex, ex, fma(ey, ey, ez * ez)));
               const double ir3 = ir * ir * ir, dxq = fma(ex, x0, fma(ey, x1, ez * x2));
               if (TRAC && trac) {
@@ -1383,8 +1432,10 @@ __global__ __launch_bounds__(kSpmvWaves * kWave, kRcOcc) void near_recompute3_ke
           }
           __builtin_amdgcn_sched_barrier(0);               // one row after the other
         }
+#if FMMBEM_RC_LDS_AHEAD
 #pragma unroll
         for (int f = 0; f < F; ++f) cur[f] = nxt[f];
+#endif
       }
     }
     if (nrw > 0) {
@@ -1398,6 +1449,10 @@ __global__ __launch_bounds__(kSpmvWaves * kWave, kRcOcc) void near_recompute3_ke
     it = nx; nx = nn; rb ^= 1;
   }
 }
+#undef RC_TX
+#undef RC_TY
+#undef RC_TZ
+#undef RC_TB
 
 // The same for LaplaceSphericalBEM (one unknown per panel): items of <= 32 rows, wavefront w owns up to 8 of them, one sum per row
 // (8 values through one butterfly); a source panel is 14 doubles (3 points, centroid, area, charge; 17 with the normal when the
