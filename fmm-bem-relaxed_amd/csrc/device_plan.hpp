@@ -160,6 +160,8 @@ struct DevicePlan {
                                                       // its own leaves only keeps only their records)
   // scratch
   double *xt, *yt;                                    // tree-order x and near result
+  double* ys = nullptr;                               // hybrid plans: the listed entries' sums of the recomputed rows (tree order)
+  const int4* side_items = nullptr;  int side_nitems = 0;   // ... work of near_side_kernel: {first entry, one past last, first row, one past last}
 };
 
 // One launch of the rotation kernel (kernels_m2l_rot.hip, compiled per operator): pairs (source box, class, target box) sorted by

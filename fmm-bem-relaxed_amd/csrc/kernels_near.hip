@@ -1219,6 +1219,9 @@ __device__ __forceinline__ int hyb_value_of(int lane) { return (lane >> 2) & 15;
 #ifndef FMMBEM_RC_LDS_AHEAD
 #define FMMBEM_RC_LDS_AHEAD 1
 #endif
+#ifndef FMMBEM_RC_PRIO
+#define FMMBEM_RC_PRIO 0
+#endif
 #ifndef FMMBEM_RC_TARGET_REGS
 #define FMMBEM_RC_TARGET_REGS 1
 #endif
@@ -1228,35 +1231,59 @@ __device__ __forceinline__ int hyb_value_of(int lane) { return (lane >> 2) & 15;
 constexpr int kRcOcc = FMMBEM_RC_OCC;                 // register budget of the recompute kernel: 512 / kRcOcc VGPRs
 constexpr int kRcChunk = kSpmvWaves * kWave;          // source panels per chunk = threads of the workgroup
 
-// y_tree[rows of the recomputed leaves] = the rows' LISTED entries (near-regime pairs, evaluated once at plan creation) times x:
-// a CSR product, a row per wavefront, lane = entry, the lanes added by wave_sum.  Runs in front of near_recompute3_kernel, which
-// adds the far regime to what this leaves in y.
+// ys[rows of the recomputed leaves] = the rows' LISTED entries (near-regime pairs, evaluated once at plan creation) times x:
+// a CSR product; a workgroup takes a run of rows with <= 256 entries, thread = entry for the products (LDS), then thread = row adds
+// its products in entry order.  On a stream of its own beside the recompute and
+// the streaming kernel (a latency-bound 0.3 ms that was on the recompute stream's critical path when it ran in front of that
+// kernel: profiles/r05z_stokes_hyb_kernel_stats.md); near_side_add_kernel adds ys to y once all three are done.
 template <int DOF>
 __global__ __launch_bounds__(kSpmvWaves * kWave) void near_side_kernel(DevicePlan d) {
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  __shared__ double prod[DOF][kSpmvWaves * kWave];
+  const int tid = threadIdx.x;
+  for (int item = blockIdx.x; item < d.side_nitems; item += gridDim.x) {
+    const int4 it = d.side_items[item];
+    const int e0 = it.x, e1 = it.y, r0 = it.z, nrows = it.w - it.z;
+    double acc[DOF];
+#pragma unroll
+    for (int a = 0; a < DOF; ++a) acc[a] = 0.0;
+    const int64_t mine_lo = tid < nrows ? d.side_ptr[r0 + tid] : 0, mine_hi = tid < nrows ? d.side_ptr[r0 + tid + 1] : 0;
+    for (int base = e0; base < e1; base += kSpmvWaves * kWave) {          // more than one pass only for a single row of > 256 entries
+      const int k = base + tid;
+      if (k < e1) {                                      // thread = entry: the product of the entry with the source's charge
+        const int64_t cj = d.side_col[k];
+        if constexpr (DOF == 3) {
+          const double* m = d.side_val + 9 * (int64_t)k;
+          const double y0 = d.xt[3 * cj], y1 = d.xt[3 * cj + 1], y2 = d.xt[3 * cj + 2];
+          prod[0][tid] = fma(m[0], y0, fma(m[1], y1, m[2] * y2));
+          prod[1][tid] = fma(m[3], y0, fma(m[4], y1, m[5] * y2));
+          prod[2][tid] = fma(m[6], y0, fma(m[7], y1, m[8] * y2));
+        } else {
+          prod[0][tid] = d.side_val[k] * d.xt[cj];
+        }
+      }
+      __syncthreads();
+      if (tid < nrows) {                                 // thread = row: its products, in entry order
+        const int lo = (int)(mine_lo > base ? mine_lo - base : 0);
+        const int hi = (int)((mine_hi < (int64_t)base + kSpmvWaves * kWave ? mine_hi : (int64_t)base + kSpmvWaves * kWave) - base);
+        for (int q = lo; q < hi; ++q)
+#pragma unroll
+          for (int a = 0; a < DOF; ++a) acc[a] += prod[a][q];
+      }
+      __syncthreads();
+    }
+    if (tid < nrows)
+#pragma unroll
+      for (int a = 0; a < DOF; ++a) d.ys[(int64_t)DOF * (r0 + tid) + a] = acc[a];
+  }
+}
+
+// y_tree[rows of the recomputed leaves] += their listed entries' sums (near_side_kernel), once both kernels are done
+__global__ void near_side_add_kernel(DevicePlan d) {
   for (int item = blockIdx.x; item < d.rc_nitems; item += gridDim.x) {
     const RcItem it = d.rc_items[item];
-    for (int r = wave; r < it.nrows; r += kSpmvWaves) {
-      const int64_t i = it.prow0 + r;
-      if constexpr (DOF == 3) {
-        double s0 = 0, s1 = 0, s2 = 0;
-        for (int64_t k = d.side_ptr[i] + lane; k < d.side_ptr[i + 1]; k += kWave) {
-          const double* m = d.side_val + 9 * k;
-          const int64_t cj = d.side_col[k];
-          const double y0 = d.xt[3 * cj], y1 = d.xt[3 * cj + 1], y2 = d.xt[3 * cj + 2];
-          s0 = fma(m[0], y0, fma(m[1], y1, fma(m[2], y2, s0)));
-          s1 = fma(m[3], y0, fma(m[4], y1, fma(m[5], y2, s1)));
-          s2 = fma(m[6], y0, fma(m[7], y1, fma(m[8], y2, s2)));
-        }
-        s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
-        if (lane == 0) { d.yt[3 * i] = s0; d.yt[3 * i + 1] = s1; d.yt[3 * i + 2] = s2; }
-      } else {
-        double s0 = 0;
-        for (int64_t k = d.side_ptr[i] + lane; k < d.side_ptr[i + 1]; k += kWave) s0 = fma(d.side_val[k], d.xt[d.side_col[k]], s0);
-        s0 = wave_sum(s0);
-        if (lane == 0) d.yt[i] = s0;
-      }
-    }
+    const int n = it.nrows * d.dof;
+    const int64_t u0 = (int64_t)it.prow0 * d.dof;
+    for (int k = threadIdx.x; k < n; k += blockDim.x) d.yt[u0 + k] += d.ys[u0 + k];
   }
 }
 
@@ -1269,6 +1296,9 @@ __device__ __forceinline__ RcItem load_rc_item(const ConstRcItem* r) {
 
 template <bool TRAC>
 __global__ __launch_bounds__(kSpmvWaves * kWave, kRcOcc) void near_recompute3_kernel(DevicePlan d) {
+#if FMMBEM_RC_PRIO
+  __builtin_amdgcn_s_setprio(FMMBEM_RC_PRIO);          // this kernel's wavefronts issue ahead of the streaming kernel's on the SIMD they share
+#endif
   constexpr int F = TRAC ? 22 : 19;                   // doubles per source panel: 4 x (x,y,z), centroid, area, charge (3) [, normal]
   extern __shared__ double src[];                     // [F][kRcChunk] doubles, then runbuf [2][2][max_runs] ints
   int* const runbuf = reinterpret_cast<int*>(src + F * kRcChunk);
@@ -1351,10 +1381,7 @@ __global__ __launch_bounds__(kSpmvWaves * kWave, kRcOcc) void near_recompute3_ke
     double v[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) v[k] = 0.0;
-    // the rows' listed (near-regime) entries were summed into y by near_side_kernel, launched in front of this one: the lanes that
-    // will hold the rows' totals fetch that value now and add to it at the end of the item
-    const bool mine = nrw > 0 && (lane & 3) == 0 && hyb_value_of(lane) < 3 * nrw;
-    const double ylist = mine ? d.yt[3 * (int64_t)(prow0 + rw) + hyb_value_of(lane)] : 0.0;
+    const bool mine = nrw > 0 && (lane & 3) == 0 && hyb_value_of(lane) < 3 * nrw;      // the lanes that will hold the rows' totals
     const int nchunks = (ncp + kRcChunk - 1) / kRcChunk;
     for (int ck = 0; ck < nchunks; ++ck) {
 #if !FMMBEM_RC_GLOBAL_AHEAD
@@ -1440,7 +1467,7 @@ __global__ __launch_bounds__(kSpmvWaves * kWave, kRcOcc) void near_recompute3_ke
     }
     if (nrw > 0) {
       const double tot = hyb_reduce16(v, lane);
-      if (mine) d.yt[3 * (int64_t)(prow0 + rw) + hyb_value_of(lane)] = ylist + tot;
+      if (mine) d.yt[3 * (int64_t)(prow0 + rw) + hyb_value_of(lane)] = tot;       // (the rows' listed entries: near_side_kernel / near_side_add_kernel)
     }
     if (!more) break;
     // hand over: the run descriptors of the item after the next into the half this item's occupied (every thread has passed a
@@ -1462,6 +1489,9 @@ constexpr int kRc1Rows = 8;                           // rows per wavefront
 
 template <bool DN>
 __global__ __launch_bounds__(kSpmvWaves * kWave, kRcOcc) void near_recompute1_kernel(DevicePlan d) {
+#if FMMBEM_RC_PRIO
+  __builtin_amdgcn_s_setprio(FMMBEM_RC_PRIO);          // this kernel's wavefronts issue ahead of the streaming kernel's on the SIMD they share
+#endif
   constexpr int F = DN ? 17 : 14;
   extern __shared__ double src[];                     // [F][kRcChunk] doubles, then runbuf [2][2][max_runs] ints
   int* const runbuf = reinterpret_cast<int*>(src + F * kRcChunk);
@@ -1520,7 +1550,6 @@ __global__ __launch_bounds__(kSpmvWaves * kWave, kRcOcc) void near_recompute1_ke
     for (int k = 0; k < 8; ++k) v[k] = 0.0;
     const int vidx = (lane >> 3) & 7;
     const bool mine = nrw > 0 && (lane & 7) == 0 && vidx < nrw;
-    const double ylist = mine ? d.yt[prow0 + rw + vidx] : 0.0;      // the row's listed entries (near_side_kernel ran first)
     const int nchunks = (ncp + kRcChunk - 1) / kRcChunk;
     for (int ck = 0; ck < nchunks; ++ck) {
       __syncthreads();
@@ -1572,7 +1601,7 @@ __global__ __launch_bounds__(kSpmvWaves * kWave, kRcOcc) void near_recompute1_ke
     }
     if (nrw > 0) {
       const double tot = hyb_reduce8(v, lane);
-      if (mine) d.yt[prow0 + rw + vidx] = ylist + tot;
+      if (mine) d.yt[prow0 + rw + vidx] = tot;
     }
     if (!more) break;
     if (prun) { runbuf[rb * 2 * mr + tid] = pr0; runbuf[rb * 2 * mr + mr + tid] = pr1; }
@@ -1751,10 +1780,10 @@ hipError_t launch_gather_x(const DevicePlan& d, const double* x, hipStream_t s) 
   return hipGetLastError();
 }
 
-// Hybrid plans (near_stream_fraction < 1): near_spmv_sym3 over the streamed leaves on `s`, near_recompute3 over the recomputed ones
-// on `s2` (forked from and joined to `s` through the two events): kS workgroups per CU of the one (96 VGPRs), kR of the other,
-// sized so that BOTH kernels are resident on every CU from start to end.
-hipError_t launch_near_hybrid(const DevicePlan& d, hipStream_t s, hipStream_t s2, hipEvent_t fork, hipEvent_t join) {
+// Hybrid plans (near_stream_fraction < 1): the streaming kernel over the stored leaves on `s`; the recompute kernel over the others and
+// the listed entries' product on two streams forked from and joined to `s`: kS workgroups per CU of the one (88-96 VGPRs), kR of
+// the other (187-235), sized so that BOTH are resident on every CU from start to end; the third finds room in what is left.
+hipError_t launch_near_hybrid(const DevicePlan& d, hipStream_t s, const HybridStreams& hs) {
   if (!d.near_rec) return hipErrorInvalidValue;
   const bool stokes = d.dof == 3;
   static const int kS3 = [] { const char* e = std::getenv("FMMBEM_HYB_WG_STREAM"); return e ? std::atoi(e) : 2; }();
@@ -1764,24 +1793,21 @@ hipError_t launch_near_hybrid(const DevicePlan& d, hipStream_t s, hipStream_t s2
   const bool flag1 = stokes ? d.stokes_traction_targets != 0 : (d.n_act > 1 || d.act[0] == 1);   // TRACTION / NORMAL_DERIV targets present
   const int n_stream = stokes ? d.sym_nitems : d.near_nitems_stream;
   hipError_t e = hipSuccess;
-  const bool both = d.rc_nitems > 0 && n_stream > 0 && s2;
-  if (both) {
-    if ((e = hipEventRecord(fork, s)) != hipSuccess) return e;
-    if ((e = hipStreamWaitEvent(s2, fork, 0)) != hipSuccess) return e;
-  }
-  if (d.rc_nitems > 0) {                               // the recompute kernel first: its few, large workgroups must find room on every CU
+  if (d.rc_nitems > 0) {
+    // fork: the recompute kernel (its few, large workgroups must find room on every CU: launched first) and the listed entries'
+    // product, each on a stream of its own beside the streaming kernel on `s`
+    if ((e = hipEventRecord(hs.fork, s)) != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(hs.recompute, hs.fork, 0)) != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(hs.side, hs.fork, 0)) != hipSuccess) return e;
     const dim3 g(std::min(d.rc_nitems, 256 * kR));
-    hipStream_t sr = both ? s2 : s;
     if (stokes) {
-      hipLaunchKernelGGL((near_side_kernel<3>), dim3(std::min(d.rc_nitems, 256 * 8)), b, 0, sr, d);
       const size_t ldsr = (size_t)(flag1 ? 22 : 19) * kRcChunk * sizeof(double) + 4 * (size_t)d.max_runs * sizeof(int);
-      if (flag1) hipLaunchKernelGGL((near_recompute3_kernel<true>), g, b, ldsr, sr, d);
-      else hipLaunchKernelGGL((near_recompute3_kernel<false>), g, b, ldsr, sr, d);
+      if (flag1) hipLaunchKernelGGL((near_recompute3_kernel<true>), g, b, ldsr, hs.recompute, d);
+      else hipLaunchKernelGGL((near_recompute3_kernel<false>), g, b, ldsr, hs.recompute, d);
     } else {
-      hipLaunchKernelGGL((near_side_kernel<1>), dim3(std::min(d.rc_nitems, 256 * 8)), b, 0, sr, d);
       const size_t ldsr = (size_t)(flag1 ? 17 : 14) * kRcChunk * sizeof(double) + 4 * (size_t)d.max_runs * sizeof(int);
-      if (flag1) hipLaunchKernelGGL((near_recompute1_kernel<true>), g, b, ldsr, sr, d);
-      else hipLaunchKernelGGL((near_recompute1_kernel<false>), g, b, ldsr, sr, d);
+      if (flag1) hipLaunchKernelGGL((near_recompute1_kernel<true>), g, b, ldsr, hs.recompute, d);
+      else hipLaunchKernelGGL((near_recompute1_kernel<false>), g, b, ldsr, hs.recompute, d);
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
   }
@@ -1795,9 +1821,18 @@ hipError_t launch_near_hybrid(const DevicePlan& d, hipStream_t s, hipStream_t s2
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
   }
-  if (both) {
-    if ((e = hipEventRecord(join, s2)) != hipSuccess) return e;
-    if ((e = hipStreamWaitEvent(s, join, 0)) != hipSuccess) return e;
+  if (d.rc_nitems > 0) {
+    if (d.side_nitems > 0) {
+      if (stokes) hipLaunchKernelGGL((near_side_kernel<3>), dim3(std::min(d.side_nitems, 256 * 4)), b, 0, hs.side, d);
+      else hipLaunchKernelGGL((near_side_kernel<1>), dim3(std::min(d.side_nitems, 256 * 4)), b, 0, hs.side, d);
+    }
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if ((e = hipEventRecord(hs.join_recompute, hs.recompute)) != hipSuccess) return e;
+    if ((e = hipEventRecord(hs.join_side, hs.side)) != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(s, hs.join_recompute, 0)) != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(s, hs.join_side, 0)) != hipSuccess) return e;
+    hipLaunchKernelGGL(near_side_add_kernel, dim3(std::min(d.rc_nitems, 256 * 8)), dim3(64), 0, s, d);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
   }
   return hipSuccess;
 }

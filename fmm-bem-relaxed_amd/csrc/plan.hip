@@ -231,8 +231,7 @@ struct fmmbem_plan {
   std::vector<uint8_t> near_rec_host;                          // [leaf] 1 = recomputed
   std::vector<int64_t> near_off_host, sym_off_host;            // [leaf] offsets of the stored blocks (introspection)
   int64_t near_recomputed_pairs = 0;
-  hipStream_t hyb_stream = nullptr;                            // the recompute kernel runs beside the streaming one
-  hipEvent_t hyb_fork = nullptr, hyb_join = nullptr;
+  HybridStreams hyb;                                           // the recompute kernel and the listed entries run beside the streaming one
   int build_side_lists();
   int64_t n_classes = 0;
   double build_host_ms = 0, build_assemble_ms = 0;
@@ -290,9 +289,9 @@ struct fmmbem_plan {
       for (auto& e : ev) (void)hipEventDestroy(e);
       for (auto& g : graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
       if (own_stream) (void)hipStreamDestroy(own_stream);
-      if (hyb_stream) (void)hipStreamDestroy(hyb_stream);
-      if (hyb_fork) (void)hipEventDestroy(hyb_fork);
-      if (hyb_join) (void)hipEventDestroy(hyb_join);
+      if (hyb.recompute) (void)hipStreamDestroy(hyb.recompute);
+      if (hyb.side) (void)hipStreamDestroy(hyb.side);
+      for (hipEvent_t e : {hyb.fork, hyb.join_recompute, hyb.join_side}) if (e) (void)hipEventDestroy(e);
     }
   }
 };
@@ -928,9 +927,12 @@ int fmmbem_plan::to_device_bc_begin(const uint8_t* bc_tree) {
   if (near_total_doubles) TRY(alloc((size_t)near_total_doubles, &d.near_val, false));
   if (sym_total_doubles) TRY(alloc((size_t)sym_total_doubles, &d.near_sym, false));
   if (hybrid) {
-    HIP_TRY(hipStreamCreateWithFlags(&hyb_stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&hyb_fork, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&hyb_join, hipEventDisableTiming));
+    HIP_TRY(hipStreamCreateWithFlags(&hyb.recompute, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&hyb.side, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&hyb.fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&hyb.join_recompute, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&hyb.join_side, hipEventDisableTiming));
+    TRY(alloc((size_t)hp.n * d.dof, &d.ys, true));
   }
   // near-field assembly on the device, in flight from here on (everything it reads is uploaded; to_device_bc_end waits for it)
   HIP_TRY(hipEventCreate(&asm_ev[0])); HIP_TRY(hipEventCreate(&asm_ev[1]));
@@ -1056,6 +1058,22 @@ int fmmbem_plan::build_side_lists() {
     HIP_TRY(hipStreamSynchronize(own_stream));
     d.side_col = d_col; d.side_val = d_val;
     near_side_entries = nside;
+    if (hybrid) {
+      // work items of near_side_kernel: runs of consecutive rows that hold <= 256 listed entries together (a workgroup takes the
+      // entries one per thread, then a thread per row adds the row's products in entry order); a row of more than 256 is an item
+      // of its own, taken 256 at a time
+      std::vector<int4> sitems;
+      int64_t i = hp.row_begin;
+      while (i < hp.row_end) {
+        if (cnt[(size_t)i] == 0) { ++i; continue; }
+        int64_t j = i + 1;
+        while (j < hp.row_end && cnt[(size_t)j] > 0 && ptr[(size_t)j + 1] - ptr[(size_t)i] <= 256 && j - i < 256) ++j;
+        sitems.push_back(make_int4((int)ptr[(size_t)i], (int)ptr[(size_t)j], (int)i, (int)j));
+        i = j;
+      }
+      d.side_nitems = (int)sitems.size();
+      TRY(upload(sitems, &d.side_items));
+    }
     for (void* tmp : {(void*)d_cnt, (void*)const_cast<int*>(d_row)}) {        // creation-time scratch
       (void)hipFree(tmp);
       allocs.erase(std::find(allocs.begin(), allocs.end(), tmp));
@@ -1181,7 +1199,7 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
   }
   auto near_field = [&](hipStream_t ns) -> int {
     HIP_TRY(begin(1, ns));
-    if (hybrid) HIP_TRY(launch_near_hybrid(d, ns, hyb_stream, hyb_fork, hyb_join));
+    if (hybrid) HIP_TRY(launch_near_hybrid(d, ns, hyb));
     else if (opts.sparse_local) HIP_TRY(launch_near_spmv(d, ns)); else HIP_TRY(launch_near_matfree(d, ns));
     HIP_TRY(end(1, ns));
     return FMMBEM_OK;
@@ -1335,7 +1353,7 @@ int fmmbem_plan::like_finish(std::unique_ptr<fmmbem_plan> pl, const uint8_t* bc,
   pl->alloc_list = &pl->allocs;
   pl->ev.assign(pl->ev.size(), nullptr);
   pl->graphs.clear();
-  pl->own_stream = nullptr; pl->hyb_stream = nullptr; pl->hyb_fork = pl->hyb_join = nullptr;
+  pl->own_stream = nullptr; pl->hyb = HybridStreams{}; pl->d.ys = nullptr;
   pl->asm_ev[0] = pl->asm_ev[1] = nullptr;
   pl->d_dev = nullptr; pl->stage_x = pl->stage_y = nullptr; pl->solver_ws = nullptr; pl->d_cut = nullptr;
   pl->multi.reset();
