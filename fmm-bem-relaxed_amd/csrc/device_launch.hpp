@@ -16,6 +16,8 @@ hipError_t launch_near_hybrid(const DevicePlan& d, hipStream_t s, const HybridSt
 hipError_t launch_kernel_entries(const DevicePlan& d, int m, double* out, hipStream_t s);   // panels [0,m) targets, [m,2m) sources
 hipError_t launch_panel_setup(int64_t n, const uint32_t* perm, const double* v_orig, int nq, const double* pts, double* cx, double* cy,
                               double* cz, double* nx, double* ny, double* nz, double* area, double* quad, double* vert, hipStream_t s);
+int rcg_item_rows();
+hipError_t launch_rc_pack(const DevicePlan& d, double* rc_src, double* rc_nrm, hipStream_t s);
 hipError_t launch_near_row_eval(const DevicePlan& d, int64_t prow, const int* cols, int n, double* out, hipStream_t s);
 hipError_t launch_near_diag(const DevicePlan& d, const int* selfcol, double* out, hipStream_t s);
 hipError_t launch_near_matfree(const DevicePlan& d, hipStream_t s);

@@ -748,9 +748,15 @@ __global__ __launch_bounds__(256) void near_matfree_stokes_kernel(DevicePlan d) 
 
 // dof unknowns per panel, interleaved (Stokes: Vec<3,double> per panel); one thread per unknown
 __global__ void gather_x_kernel(const uint32_t* __restrict__ perm, const double* __restrict__ x,
-                                double* __restrict__ xt, int64_t n, int dof) {
+                                double* __restrict__ xt, int64_t n, int dof, double* __restrict__ xt4) {
   const int64_t u = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (u < n * dof) { const int64_t i = u / dof; const int a = (int)(u - i * dof); xt[u] = x[(int64_t)perm[i] * dof + a]; }
+  if (u < n * dof) {
+    const int64_t i = u / dof;
+    const int a = (int)(u - i * dof);
+    const double v = x[(int64_t)perm[i] * dof + a];
+    xt[u] = v;
+    if (xt4) xt4[4 * i + a] = v;                        // hybrid Stokes plans: the charge padded to 32 bytes per panel (near_recompute3g)
+  }
 }
 
 __global__ void scatter_y_kernel(const uint32_t* __restrict__ perm, const double* __restrict__ yt, double* __restrict__ y,
@@ -1481,6 +1487,212 @@ __global__ __launch_bounds__(kSpmvWaves * kWave, kRcOcc) void near_recompute3_ke
 #undef RC_TZ
 #undef RC_TB
 
+// ---------------------------------------------------------------------------------------------
+// near_recompute3g_kernel: the same items and the same arithmetic with the source panels loaded STRAIGHT INTO LDS
+// (global_load_lds_dwordx4: no register holds a prefetch), so that the kernel fits 160 VGPRs and TWO of its workgroups are
+// resident per CU beside two streaming ones -- at one wavefront per SIMD every VALU instruction costs ~3 ns whatever it is
+// (the lone-wavefront issue rate of the M2L study), at two the gaps of the one are the other's.
+//   * packed per-panel records built once per plan (rc_src: 4 points, centroid, area = 16 doubles = 8 pieces of 16 bytes;
+//     rc_nrm: the normal) and the charges padded to 4 doubles per panel by gather_x (xt4): a source panel is 10 (12) pieces;
+//   * a chunk is 128 source panels: wavefront w loads pieces 2i + (w >> 1), i = 0.., of the 64 panels of half (w & 1) -- one
+//     global_load_lds per piece, destination = wave-uniform LDS base + lane x 16, i.e. the image [piece][panel] the arithmetic
+//     reads back with ds_read_b128; two buffers: the chunk after this one (of this item, or the first of the next) is in flight
+//     while this one is worked on; ONE barrier per chunk (s_waitcnt vmcnt(0) + raw s_barrier: the loads of the next chunk are
+//     issued behind it, so nothing is drained early);
+//   * the rows' centroids (pieces 6 and 7 of the rows' own records) and the run descriptors of the item after the next arrive the
+//     same way; item records by scalar loads.  No ordinary vector load is left in the loop (hipcc waits vmcnt(0) at the first
+//     use of one while a global_load_lds is in flight).
+// ---------------------------------------------------------------------------------------------
+#ifndef FMMBEM_RCG_OCC
+#define FMMBEM_RCG_OCC 3
+#endif
+#ifndef FMMBEM_RCG_QSCHED
+#define FMMBEM_RCG_QSCHED 1
+#endif
+constexpr int kRcgChunk = 128;                        // source panels per chunk
+#ifndef FMMBEM_RCG_ROWS
+#define FMMBEM_RCG_ROWS 5                             /* S2 R2, f = 0.6 (near ms): 5 rows 1.50, 4 rows 1.56-1.58 (profiles/r05h) */
+#endif
+constexpr int kRcgRows = FMMBEM_RCG_ROWS;             // rows per block (3 sums each through the 16-value butterfly)
+constexpr int kRcgBlocks = 16 / FMMBEM_RCG_ROWS;      // row blocks per wavefront: items of up to 4 x 15 = 60 (4 x 16 = 64) rows, i.e. whole leaves
+constexpr int kRcgTgt = 64;                           // target slots per item
+typedef __attribute__((address_space(1))) const void* GldsSrc;
+typedef __attribute__((address_space(3))) void* GldsDst;
+__device__ __forceinline__ void glds16(const double* g, double* l) { __builtin_amdgcn_global_load_lds((GldsSrc)g, (GldsDst)l, 16, 0, 0); }
+__device__ __forceinline__ void glds4(const int* g, int* l) { __builtin_amdgcn_global_load_lds((GldsSrc)g, (GldsDst)l, 4, 0, 0); }
+__device__ __forceinline__ void glds_wait_and_meet() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+template <bool TRAC>
+__global__ __launch_bounds__(kSpmvWaves * kWave, FMMBEM_RCG_OCC) void near_recompute3g_kernel(DevicePlan d) {
+  constexpr int P = TRAC ? 12 : 10;                   // 16-byte pieces per source panel
+  constexpr int kBufD = P * kRcgChunk * 2;            // doubles per chunk buffer
+  extern __shared__ double lds[];                     // buf [2][P][128][2], tgt [2][2][64][2] doubles, then runs [3][2][max_runs] ints
+  double* const tgt_all = lds + 2 * kBufD;
+  int* const runbuf = reinterpret_cast<int*>(tgt_all + 2 * 2 * kRcgTgt * 2);
+  __shared__ int tflag_all[TRAC ? 2 * kRcgTgt : 1];   // TRACTION plans: the rows' flags (two items in flight)
+  __shared__ double tot_all[kSpmvWaves * kRcgBlocks * 16];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, tid = threadIdx.x;
+  const int mr = d.max_runs, nitems = d.rc_nitems, step = gridDim.x;
+  const double sc = 1. / 2 / d.mu;
+  const double w0 = d.qw[0], w1 = d.nq > 1 ? d.qw[1] : 0.0;        // the rules the host admits: weights of points 1.. all equal
+  const int nq = d.nq;
+  const ConstRcItem* recs = reinterpret_cast<const ConstRcItem*>(reinterpret_cast<uintptr_t>(d.rc_items));
+  const int half = wave & 1, grp = wave >> 1;
+
+  int item = blockIdx.x;
+  if (item >= nitems) return;
+  RcItem it = load_rc_item(recs + item);
+  RcItem nx = load_rc_item(recs + (item + step < nitems ? item + step : nitems - 1));
+  // run descriptors: slot of an item = (its ordinal in this workgroup's sequence) % 3
+  auto runs_of = [&](int slot, int nruns) { return Runs{runbuf + slot * 2 * mr, runbuf + slot * 2 * mr + mr, nruns}; };
+  for (int i = tid; i < it.nruns; i += blockDim.x) { runbuf[i] = d.near_run_row0[it.run_begin + i]; runbuf[mr + i] = d.near_run_off[it.run_begin + i]; }
+  for (int i = tid; i < nx.nruns; i += blockDim.x) { runbuf[2 * mr + i] = d.near_run_row0[nx.run_begin + i]; runbuf[3 * mr + i] = d.near_run_off[nx.run_begin + i]; }
+  __syncthreads();
+  // one chunk of an item's source panels, and an item's row centroids, straight into LDS
+  auto issue_chunk = [&](const Runs& runs, int c0, int ncp, double* buf) {
+    const int c = c0 + kWave * half + lane;
+    const size_t j = (size_t)column_to_row(runs, c < ncp ? c : 0);           // columns past the end repeat column 0; masked where they are used
+    const double* rs = d.rc_src + 16 * j;
+    const double* rx = d.xt4 + 4 * j;
+    double* dst = buf + (size_t)(kWave * half) * 2;
+#pragma unroll
+    for (int i = 0; i < P / 2; ++i) {
+      const int k = 2 * i + grp;                        // this wavefront's piece of the step
+      const double* g = k < 8 ? rs + 2 * k : k < 10 ? rx + 2 * (k - 8) : d.rc_nrm + 4 * j + 2 * (k - 10);
+      glds16(g, dst + (size_t)k * kRcgChunk * 2);
+    }
+  };
+  auto issue_targets = [&](const RcItem& r, double* tg, int slot) {
+    if (wave < 2 && lane < r.nrows) glds16(d.rc_src + 16 * (size_t)(r.prow0 + lane) + 12 + 2 * wave, tg + (size_t)wave * kRcgTgt * 2);
+    if constexpr (TRAC) { if (wave == 2 && lane < r.nrows) tflag_all[slot * kRcgTgt + lane] = d.bc[r.prow0 + lane]; }
+  };
+  int seq = 0;                                           // ordinal of `it` in this workgroup's sequence
+  int gk = 0;                                            // chunks issued so far: the buffer parity
+  issue_chunk(runs_of(0, it.nruns), 0, it.ncp, lds);
+  issue_targets(it, tgt_all, 0);
+  for (;; item += step, ++seq) {
+    const bool more = item + step < nitems;
+    const int i2 = item + 2 * step;
+    const RcItem nn = load_rc_item(recs + (i2 < nitems ? i2 : nitems - 1));
+    const int nrows = it.nrows, ncp = it.ncp, prow0 = it.prow0;
+    const Runs runs = runs_of(seq % 3, it.nruns), nruns = runs_of((seq + 1) % 3, nx.nruns);
+    if (i2 < nitems && wave >= 2) {                      // the run descriptors of the item after the next: wavefront 2 the rows, 3 the offsets
+      const int* g = wave == 2 ? d.near_run_row0 : d.near_run_off;
+      int* l = runbuf + ((seq + 2) % 3) * 2 * mr + (wave == 2 ? 0 : mr);
+      for (int b = 0; b < nn.nruns; b += kWave)
+        if (b + lane < nn.nruns) glds4(g + nn.run_begin + b + lane, l + b);
+    }
+    const int rq = nrows / kSpmvWaves, rrem = nrows % kSpmvWaves;
+    const int rw = wave * rq + (wave < rrem ? wave : rrem);      // this wavefront's first row of the item
+    const int nrw = rq + (wave < rrem ? 1 : 0);                  // ... and how many it has (0: none)
+    const double* const tg = tgt_all + (size_t)(seq & 1) * 2 * kRcgTgt * 2;
+    const int* const tflag = tflag_all + (TRAC ? (seq & 1) * kRcgTgt : 0);
+    // a wavefront's rows in blocks of kRcgRows: the block's sums cross the lanes once per CHUNK into the wavefront's LDS slots -- a
+    // whole leaf (up to 64 rows) is ONE item, its source panels are loaded once, and a chunk is worked on for as many row blocks as
+    // the wavefront has (the time the next chunk's loads have to arrive in)
+    const int nblk = (nrw + kRcgRows - 1) / kRcgRows;
+    double* const totw = tot_all + wave * (kRcgBlocks * 16);       // this wavefront's row sums: [block][value]
+    if (lane < kRcgBlocks * 16) totw[lane] = 0.0;
+    const int nchunks = (ncp + kRcgChunk - 1) / kRcgChunk;
+    for (int ck = 0; ck < nchunks; ++ck, ++gk) {
+      const double* const buf = lds + (size_t)(gk & 1) * kBufD;
+      glds_wait_and_meet();                              // this chunk has landed for everybody; nobody reads the other buffer any more
+      {                                                  // the chunk after this one -- of this item, or the first of the next with its rows
+        double* const nb = lds + (size_t)((gk + 1) & 1) * kBufD;
+        if (ck + 1 < nchunks) issue_chunk(runs, (ck + 1) * kRcgChunk, ncp, nb);
+        else if (more) { issue_chunk(nruns, 0, nx.ncp, nb); issue_targets(nx, tgt_all + (size_t)((seq + 1) & 1) * 2 * kRcgTgt * 2, (seq + 1) & 1); }
+      }
+      const int cw = ncp - ck * kRcgChunk < kRcgChunk ? ncp - ck * kRcgChunk : kRcgChunk;
+      const dvec2* const bp = reinterpret_cast<const dvec2*>(buf);
+      const dvec2* const tp = reinterpret_cast<const dvec2*>(tg);
+#pragma unroll 1
+      for (int blk = 0; blk < nblk; ++blk) {             // (not unrolled: one copy of the block's code, 153 VGPRs)
+        const int rb = rw + blk * kRcgRows, nrb = nrw - blk * kRcgRows < kRcgRows ? nrw - blk * kRcgRows : kRcgRows;
+        double v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = 0.0;
+        for (int cg = 0; cg * kWave < cw; ++cg) {
+          const int c = cg * kWave + lane;
+          const bool valid = c < cw;
+          dvec2 pc[P];
+#pragma unroll
+          for (int k = 0; k < P; ++k) pc[k] = bp[k * kRcgChunk + c];
+          const double qx[4] = {pc[0].x, pc[1].y, pc[3].x, pc[4].y}, qy[4] = {pc[0].y, pc[2].x, pc[3].y, pc[5].x}, qz[4] = {pc[1].x, pc[2].y, pc[4].x, pc[5].y};
+          const double sx = pc[6].x, sy = pc[6].y, sz = pc[7].x, A = pc[7].y;
+          const double x0 = pc[8].x, x1 = pc[8].y, x2 = pc[9].x;
+          double nx_ = 0, ny_ = 0, nz_ = 0;
+          if constexpr (TRAC) { nx_ = pc[10].x; ny_ = pc[10].y; nz_ = pc[11].x; }
+          const double near2 = valid ? 8.0 * A * (1.0 + 1e-9) : 1e300;      // lanes past the last column: every pair "listed", i.e. dropped
+          const double wA0 = w0 * A, wA1 = w1 * A;
+#pragma unroll
+          for (int r = 0; r < kRcgRows; ++r) {
+            if (r < nrb) {                                 // wave-uniform
+              const dvec2 ta = tp[rb + r], tb = tp[kRcgTgt + rb + r];     // the row's centroid: LDS broadcasts
+              const double txr = ta.x, tyr = ta.y, tzr = tb.x;
+              const bool slow = mf_listed(txr - sx, tyr - sy, tzr - sz, near2);
+              bool trac = false;
+              if constexpr (TRAC) trac = tflag[rb + r] != 0;
+              double u0 = 0, u1 = 0, u2 = 0;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const double wA = q ? (q < nq ? wA1 : 0.0) : wA0;
+                const double ex = txr - qx[q], ey = tyr - qy[q], ez = tzr - qz[q];
+                const double ir = rsqrt_pos(fma(ex, ex, fma(ey, ey, ez * ez)));
+                const double ir3 = ir * ir * ir, dxq = fma(ex, x0, fma(ey, x1, ez * x2));
+                if (TRAC && trac) {
+                  const double g = wA * fma(ex, nx_, fma(ey, ny_, ez * nz_)) * dxq * (ir3 * ir * ir);
+                  u0 = fma(g, ex, u0); u1 = fma(g, ey, u1); u2 = fma(g, ez, u2);
+                } else {
+                  const double f1 = wA * ir, g = wA * ir3 * dxq;
+                  u0 = fma(f1, x0, fma(g, ex, u0)); u1 = fma(f1, x1, fma(g, ey, u1)); u2 = fma(f1, x2, fma(g, ez, u2));
+                }
+                if ((q + 1) % FMMBEM_RCG_QSCHED == 0) __builtin_amdgcn_sched_barrier(0);
+              }
+              const double f = (TRAC && trac) ? -3.0 : sc;
+              v[3 * r] += slow ? 0.0 : u0 * f; v[3 * r + 1] += slow ? 0.0 : u1 * f; v[3 * r + 2] += slow ? 0.0 : u2 * f;
+            }
+            __builtin_amdgcn_sched_barrier(0);             // one row after the other
+          }
+        }
+        const double t = hyb_reduce16(v, lane);           // every lane: the total of value (lane >> 2) & 15 of this block and chunk
+        if ((lane & 3) == 0) totw[blk * 16 + hyb_value_of(lane)] += t;      // (the wavefront's own LDS slots: 153 VGPRs instead of 167)
+      }
+    }
+    {
+      const int blk = lane >> 4, val = lane & 15;          // lane = (block, value)
+      const int nrb = nrw - blk * kRcgRows < kRcgRows ? nrw - blk * kRcgRows : kRcgRows;
+      if (val < 3 * nrb) d.yt[3 * (int64_t)(prow0 + rw + blk * kRcgRows) + val] = totw[lane];
+    }
+    if (!more) break;
+    it = nx; nx = nn;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // nothing of this wavefront in flight when it ends
+}
+
+// the packed records of near_recompute3g_kernel, once per plan: rc_src[panel][16] = 4 points (x, y, z each), centroid, area;
+// rc_nrm[panel][4] = normal, 0
+__global__ void rc_pack_kernel(DevicePlan d, double* __restrict__ rc_src, double* __restrict__ rc_nrm) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= d.n) return;
+  const int64_t N = d.n;
+  double* o = rc_src + 16 * i;
+  for (int q = 0; q < 4; ++q) {
+    const bool have = q < d.nq;
+    o[3 * q] = have ? d.quad[(q * 3 + 0) * N + i] : 0.0; o[3 * q + 1] = have ? d.quad[(q * 3 + 1) * N + i] : 0.0; o[3 * q + 2] = have ? d.quad[(q * 3 + 2) * N + i] : 1.0;
+  }
+  o[12] = d.cx[i]; o[13] = d.cy[i]; o[14] = d.cz[i]; o[15] = d.area[i];
+  rc_nrm[4 * i] = d.nx[i]; rc_nrm[4 * i + 1] = d.ny[i]; rc_nrm[4 * i + 2] = d.nz[i]; rc_nrm[4 * i + 3] = 0.0;
+}
+int rcg_item_rows() { return kSpmvWaves * kRcgBlocks * kRcgRows; }      // rows an item of near_recompute3g_kernel may hold (host: plan.hip)
+hipError_t launch_rc_pack(const DevicePlan& d, double* rc_src, double* rc_nrm, hipStream_t s) {
+  hipLaunchKernelGGL(rc_pack_kernel, dim3((unsigned)((d.n + 255) / 256)), dim3(256), 0, s, d, rc_src, rc_nrm);
+  return hipGetLastError();
+}
+
 // The same for LaplaceSphericalBEM (one unknown per panel): items of <= 32 rows, wavefront w owns up to 8 of them, one sum per row
 // (8 values through one butterfly); a source panel is 14 doubles (3 points, centroid, area, charge; 17 with the normal when the
 // plan has NORMAL_DERIV targets).  far regime: G = sum_q w_q A / |x - q| (kernel/LaplaceSphericalBEM.hpp:198-203), dG/dn =
@@ -1776,7 +1988,7 @@ hipError_t launch_mf_side(const DevicePlan& d, int phase, int* side_cnt, const i
 
 hipError_t launch_gather_x(const DevicePlan& d, const double* x, hipStream_t s) {
   const int bs = 256;
-  hipLaunchKernelGGL(gather_x_kernel, dim3((unsigned)((d.n * d.dof + bs - 1) / bs)), dim3(bs), 0, s, d.perm, x, d.xt, d.n, d.dof);
+  hipLaunchKernelGGL(gather_x_kernel, dim3((unsigned)((d.n * d.dof + bs - 1) / bs)), dim3(bs), 0, s, d.perm, x, d.xt, d.n, d.dof, d.xt4);
   return hipGetLastError();
 }
 
@@ -1800,7 +2012,13 @@ hipError_t launch_near_hybrid(const DevicePlan& d, hipStream_t s, const HybridSt
     if ((e = hipStreamWaitEvent(hs.recompute, hs.fork, 0)) != hipSuccess) return e;
     if ((e = hipStreamWaitEvent(hs.side, hs.fork, 0)) != hipSuccess) return e;
     const dim3 g(std::min(d.rc_nitems, 256 * kR));
-    if (stokes) {
+    if (stokes && d.rc_src) {                            // sources straight into LDS: two workgroups per CU
+      static const int kRg = [] { const char* e = std::getenv("FMMBEM_HYB_WG_RECOMPUTE"); return e ? std::atoi(e) : 2; }();
+      const dim3 gg(std::min(d.rc_nitems, 256 * kRg));
+      const size_t ldsg = (size_t)2 * (flag1 ? 12 : 10) * kRcgChunk * 2 * sizeof(double) + (size_t)2 * 2 * kRcgTgt * 2 * sizeof(double) + 6 * (size_t)d.max_runs * sizeof(int);
+      if (flag1) hipLaunchKernelGGL((near_recompute3g_kernel<true>), gg, b, ldsg, hs.recompute, d);
+      else hipLaunchKernelGGL((near_recompute3g_kernel<false>), gg, b, ldsg, hs.recompute, d);
+    } else if (stokes) {
       const size_t ldsr = (size_t)(flag1 ? 22 : 19) * kRcChunk * sizeof(double) + 4 * (size_t)d.max_runs * sizeof(int);
       if (flag1) hipLaunchKernelGGL((near_recompute3_kernel<true>), g, b, ldsr, hs.recompute, d);
       else hipLaunchKernelGGL((near_recompute3_kernel<false>), g, b, ldsr, hs.recompute, d);
@@ -1814,7 +2032,10 @@ hipError_t launch_near_hybrid(const DevicePlan& d, hipStream_t s, const HybridSt
   if (n_stream > 0) {
     if (stokes) {
       const size_t lds3 = 3 * (size_t)kSymChunk * sizeof(double) + 2 * (size_t)d.max_runs * sizeof(int);
-      hipLaunchKernelGGL((near_spmv_sym3_kernel<1, 3>), dim3(std::min(n_stream, 256 * (d.rc_nitems > 0 ? kS3 : kSymOcc))), b, lds3, s, d);
+      // beside the recompute kernel: two source-panel vectors in flight per lane instead of three (2.11 against 2.10 ms alone) --
+      // 88 VGPRs or fewer, so that 2 x 168 (two recompute workgroups) + 2 x 88 fit the 512 registers of a SIMD
+      if (d.rc_nitems > 0) hipLaunchKernelGGL((near_spmv_sym3_kernel<1, 2>), dim3(std::min(n_stream, 256 * kS3)), b, lds3, s, d);
+      else hipLaunchKernelGGL((near_spmv_sym3_kernel<1, 3>), dim3(std::min(n_stream, 256 * kSymOcc)), b, lds3, s, d);
     } else {
       const size_t lds2 = 2 * (size_t)kSpmvPipeChunk * sizeof(double) + 4 * (size_t)d.max_runs * sizeof(int);
       hipLaunchKernelGGL((near_spmv_pipe_kernel<2, 4>), dim3(std::min(n_stream, 256 * (d.rc_nitems > 0 ? kS1 : kSpmvOcc))), b, lds2, s, d);

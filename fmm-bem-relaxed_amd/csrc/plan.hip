@@ -562,7 +562,10 @@ int fmmbem_plan::to_device() {
     for (int l = hp.leaf_begin; l < hp.leaf_end; ++l) {
       const int nr = leaf_nrows[l], ncp = hp.near_ncols[l];
       if (!rec[l] || nr == 0 || ncp == 0) continue;
-      const int cap = dof == 3 ? 20 : 32;
+      // Stokes, sources straight into LDS (near_recompute3g): a whole leaf of up to 60 rows is one item -- its source panels are
+      // loaded once; otherwise four wavefronts x five (Laplace: eight) rows
+      const bool glds_kernel = dof == 3 && !(std::getenv("FMMBEM_RC_GLDS") && std::atoi(std::getenv("FMMBEM_RC_GLDS")) == 0);
+      const int cap = glds_kernel ? rcg_item_rows() : dof == 3 ? 20 : 32;
         const int cnt = (nr + cap - 1) / cap;
       const int per = (nr + cnt - 1) / cnt;          // dealt evenly: the kernel gives a wavefront ceil(rows / 4) of an item's rows
       for (int r0 = 0; r0 < nr; r0 += per) { const int k = std::min(per, nr - r0); ritems.push_back({l, r0, k, (int64_t)k * ncp}); }
@@ -584,6 +587,14 @@ int fmmbem_plan::to_device() {
     d.rc_nitems = (int)rrecs.size();
     TRY(upload(rrecs, &d.rc_items));
     TRY(upload(rec, &d.near_rec));
+    if (dof == 3 && !(std::getenv("FMMBEM_RC_GLDS") && std::atoi(std::getenv("FMMBEM_RC_GLDS")) == 0)) {
+      // packed per-panel records of near_recompute3g_kernel (its sources go straight into LDS, 16 bytes at a time)
+      double *rs = nullptr, *rn = nullptr;
+      TRY(alloc((size_t)hp.n * 16, &rs, false)); TRY(alloc((size_t)hp.n * 4, &rn, false));
+      HIP_TRY(launch_rc_pack(d, rs, rn, own_stream));
+      HIP_TRY(hipStreamSynchronize(own_stream));
+      d.rc_src = rs; d.rc_nrm = rn;
+    }
   }
   near_rec_host = rec;
   near_off_host = near_off;
@@ -933,6 +944,7 @@ int fmmbem_plan::to_device_bc_begin(const uint8_t* bc_tree) {
     HIP_TRY(hipEventCreateWithFlags(&hyb.join_recompute, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&hyb.join_side, hipEventDisableTiming));
     TRY(alloc((size_t)hp.n * d.dof, &d.ys, true));
+    if (d.rc_src) TRY(alloc((size_t)hp.n * 4, &d.xt4, true));
   }
   // near-field assembly on the device, in flight from here on (everything it reads is uploaded; to_device_bc_end waits for it)
   HIP_TRY(hipEventCreate(&asm_ev[0])); HIP_TRY(hipEventCreate(&asm_ev[1]));
@@ -1353,7 +1365,7 @@ int fmmbem_plan::like_finish(std::unique_ptr<fmmbem_plan> pl, const uint8_t* bc,
   pl->alloc_list = &pl->allocs;
   pl->ev.assign(pl->ev.size(), nullptr);
   pl->graphs.clear();
-  pl->own_stream = nullptr; pl->hyb = HybridStreams{}; pl->d.ys = nullptr;
+  pl->own_stream = nullptr; pl->hyb = HybridStreams{}; pl->d.ys = nullptr; pl->d.xt4 = nullptr;
   pl->asm_ev[0] = pl->asm_ev[1] = nullptr;
   pl->d_dev = nullptr; pl->stage_x = pl->stage_y = nullptr; pl->solver_ws = nullptr; pl->d_cut = nullptr;
   pl->multi.reset();
