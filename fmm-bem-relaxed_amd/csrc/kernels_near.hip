@@ -1156,28 +1156,24 @@ __global__ __launch_bounds__(kSpmvWaves * kWave, kSymOcc) void near_spmv_sym3_ke
 
 // ---------------------------------------------------------------------------------------------
 // Hybrid near field (fmmbem_options.near_stream_fraction < 1; round 5).  The target leaves of such a plan are of two kinds:
-//   * STREAMED leaves keep their blocks (near_sym) and are served by near_spmv_sym3_kernel as before: HBM-bound, its VALU idle
-//     95 % of the time;
-//   * RECOMPUTED leaves keep NO matrix.  near_recompute3_kernel evaluates their far-regime entries (K quadrature points per pair)
-//     every matvec from the source panels' points; the near-regime pairs (semi-analytic / fine-rule / self entries, 4.5 %) were
-//     listed and evaluated once at plan creation (side_ptr / side_col / side_val, as the matrix-free plans do).
-// The two kernels run SIDE BY SIDE on two streams, each with its own register budget and a grid sized so that both are resident on
-// every CU from start to end (launch_near_hybrid): the arithmetic of the one runs in the issue slots the other leaves empty, and
+//   * STREAMED leaves keep their blocks (near_sym / near_val) and are served by near_spmv_sym3 / near_spmv_pipe as before:
+//     HBM-bound, the VALU idle 95 % of the time;
+//   * RECOMPUTED leaves keep NO matrix.  near_recompute3g (Stokes) / near_recompute1 (Laplace) evaluate their far-regime entries (K
+//     quadrature points per pair) every matvec from the source panels' points; the near-regime pairs (semi-analytic / fine-rule /
+//     self entries, 4.5 %) were listed and evaluated once at plan creation (side_ptr / side_col / side_val, as the matrix-free
+//     plans do) and are applied by near_side_kernel.
+// The kernels run SIDE BY SIDE on streams of their own, each with its own register budget and a grid sized so that all are resident
+// on every CU from start to end (launch_near_hybrid): the arithmetic of the one runs in the issue slots the other leaves empty, and
 // the matrix bytes of the recomputed leaves are neither read nor stored.  (Two grids that each fill the chip serialise:
 // profiles/r05a_near_split_step_a.txt; one kernel that takes both kinds of items pays the larger register budget on its streaming
-// wavefronts and loses what it gains: profiles/r05b_*.)
+// wavefronts and loses what it gains; a register-prefetch form of the Stokes kernel at one workgroup per CU measured 2 % behind
+// the shipped one and is gone: profiles/r05b_hybrid_near_stokes_sweeps.txt.)
 //
-// near_recompute3_kernel: persistent 256-thread workgroups, items = row ranges of <= 20 panel rows of one recomputed leaf (RcItem).
-//   * the item's source panels pass through LDS 256 at a time: thread = source panel, 19 doubles (4 points, centroid, area, the
-//     panel's charge; 22 with the normal for TRACTION targets) loaded into registers one chunk AHEAD -- of this item, or the first
-//     chunk of the next one -- while the current chunk is worked on, so that no wavefront ever waits for a dependent load inside
-//     an item; item records and run descriptors come two items ahead (the pipeline of near_spmv_pipe_kernel);
-//   * wavefront w owns rows 5w .. 5w+4 of the item: lane = source panel (LDS -> registers per group of 64), the 15 partial sums
-//     stay in the lane's registers over ALL columns of the item; the rows' listed entries are added into the same registers
-//     (lane = entry); ONE 16-value halving butterfly (17 shuffles instead of 90) ends the item and the lanes that hold the 15
-//     totals store them.  A row's sum is formed in a fixed order.
+// Common to the recompute kernels: persistent 256-thread workgroups; lane = source panel, the partial sums of a wavefront's rows
+// stay in the lane's registers over the columns and cross the lanes through ONE 16- (8-) value halving butterfly (17 shuffles
+// instead of 90); item records by scalar loads, run descriptors two items ahead; a row's sum is formed in a fixed order.
 // ---------------------------------------------------------------------------------------------
-constexpr int kHybRows = 5;                           // rows per wavefront of a recompute item (3 sums each + 1 pad = 16 values)
+
 
 // v[0..15] per lane -> every lane returns the sum over all 64 lanes of value hyb_value_of(lane); fixed tree.
 // One halving step: the lanes whose `BIT` is set keep the upper W values, the others the lower W, and each adds what its
@@ -1219,20 +1215,8 @@ __device__ __forceinline__ int hyb_value_of(int lane) { return (lane >> 2) & 15;
 #ifndef FMMBEM_RC_OCC
 #define FMMBEM_RC_OCC 2
 #endif
-#ifndef FMMBEM_RC_QSCHED
-#define FMMBEM_RC_QSCHED 2
-#endif
-#ifndef FMMBEM_RC_LDS_AHEAD
-#define FMMBEM_RC_LDS_AHEAD 1
-#endif
 #ifndef FMMBEM_RC_PRIO
 #define FMMBEM_RC_PRIO 0
-#endif
-#ifndef FMMBEM_RC_TARGET_REGS
-#define FMMBEM_RC_TARGET_REGS 1
-#endif
-#ifndef FMMBEM_RC_GLOBAL_AHEAD
-#define FMMBEM_RC_GLOBAL_AHEAD 1
 #endif
 constexpr int kRcOcc = FMMBEM_RC_OCC;                 // register budget of the recompute kernel: 512 / kRcOcc VGPRs
 constexpr int kRcChunk = kSpmvWaves * kWave;          // source panels per chunk = threads of the workgroup
@@ -1300,197 +1284,10 @@ __device__ __forceinline__ RcItem load_rc_item(const ConstRcItem* r) {
   return o;
 }
 
-template <bool TRAC>
-__global__ __launch_bounds__(kSpmvWaves * kWave, kRcOcc) void near_recompute3_kernel(DevicePlan d) {
-#if FMMBEM_RC_PRIO
-  __builtin_amdgcn_s_setprio(FMMBEM_RC_PRIO);          // this kernel's wavefronts issue ahead of the streaming kernel's on the SIMD they share
-#endif
-  constexpr int F = TRAC ? 22 : 19;                   // doubles per source panel: 4 x (x,y,z), centroid, area, charge (3) [, normal]
-  extern __shared__ double src[];                     // [F][kRcChunk] doubles, then runbuf [2][2][max_runs] ints
-  int* const runbuf = reinterpret_cast<int*>(src + F * kRcChunk);
-#if !FMMBEM_RC_TARGET_REGS
-  constexpr int kRcTgtRows = kSpmvWaves * kHybRows;
-  __shared__ double tcs[3 * kRcTgtRows];
-  __shared__ int tbs[kRcTgtRows];
-#endif
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, tid = threadIdx.x;
-  const int mr = d.max_runs, nitems = d.rc_nitems, step = gridDim.x;
-  const int64_t N = d.n;
-  const double sc = 1. / 2 / d.mu;
-  const double w0 = d.qw[0], w1 = d.nq > 1 ? d.qw[1] : 0.0;        // the rules the host admits: weights of points 1.. all equal
-  const int nq = d.nq;
-  const ConstRcItem* recs = reinterpret_cast<const ConstRcItem*>(reinterpret_cast<uintptr_t>(d.rc_items));
-
-  int item = blockIdx.x;
-  if (item >= nitems) return;
-  RcItem it = load_rc_item(recs + item);
-  RcItem nx = load_rc_item(recs + (item + step < nitems ? item + step : nitems - 1));
-  for (int i = tid; i < it.nruns; i += blockDim.x) { runbuf[i] = d.near_run_row0[it.run_begin + i]; runbuf[mr + i] = d.near_run_off[it.run_begin + i]; }
-  for (int i = tid; i < nx.nruns; i += blockDim.x) { runbuf[2 * mr + i] = d.near_run_row0[nx.run_begin + i]; runbuf[3 * mr + i] = d.near_run_off[nx.run_begin + i]; }
-  __syncthreads();
-  // one source panel per thread into registers: column c of an item whose runs are `runs`
-  double pre[F];
-  auto fetch = [&](const Runs& runs, int c, int ncp) {
-    const unsigned j = (unsigned)column_to_row(runs, c < ncp ? c : 0);       // columns past the end repeat column 0; masked where they are used
-    const double* qp = d.quad + j;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const bool have = q < nq;
-      pre[3 * q] = have ? qp[(q * 3 + 0) * N] : 0.0; pre[3 * q + 1] = have ? qp[(q * 3 + 1) * N] : 0.0; pre[3 * q + 2] = have ? qp[(q * 3 + 2) * N] : 1.0;
-    }
-    pre[12] = d.cx[j]; pre[13] = d.cy[j]; pre[14] = d.cz[j]; pre[15] = d.area[j];
-    const double* xp = d.xt + 3 * (size_t)j;
-    pre[16] = xp[0]; pre[17] = xp[1]; pre[18] = xp[2];
-    if constexpr (TRAC) { pre[19] = d.nx[j]; pre[20] = d.ny[j]; pre[21] = d.nz[j]; }
-  };
-  int rb = 0;
-  fetch(Runs{runbuf, runbuf + mr, it.nruns}, tid, it.ncp);
-  for (;; item += step) {
-    const bool more = item + step < nitems;
-    const int i2 = item + 2 * step;
-    const RcItem nn = load_rc_item(recs + (i2 < nitems ? i2 : nitems - 1));
-    const int nrows = it.nrows, ncp = it.ncp, prow0 = it.prow0;
-    const Runs runs{runbuf + rb * 2 * mr, runbuf + rb * 2 * mr + mr, it.nruns};
-    const Runs nruns{runbuf + (rb ^ 1) * 2 * mr, runbuf + (rb ^ 1) * 2 * mr + mr, nx.nruns};
-    int pr0 = 0, pr1 = 0;
-    const bool prun = i2 < nitems && tid < nn.nruns;     // max_runs <= blockDim.x is checked by the launcher
-    if (prun) { pr0 = d.near_run_row0[nn.run_begin + tid]; pr1 = d.near_run_off[nn.run_begin + tid]; }
-    // the rows dealt evenly: 17 rows are 5 + 4 + 4 + 4 (the wavefronts meet at two barriers per chunk: the slowest sets the pace)
-    const int rq = nrows / kSpmvWaves, rrem = nrows % kSpmvWaves;
-    const int rw = wave * rq + (wave < rrem ? wave : rrem);      // this wavefront's first row of the item
-    const int nrw = rq + (wave < rrem ? 1 : 0);                  // ... and how many it has (0: none)
-    // their centroids: wave-uniform loads, in registers for the whole item
-#if FMMBEM_RC_TARGET_REGS
-    double tx[kHybRows], ty[kHybRows], tz[kHybRows];
-    int tbw[kHybRows];
-#pragma unroll
-    for (int r = 0; r < kHybRows; ++r) {
-      const int64_t i = prow0 + rw + (r < nrw ? r : 0);
-      tx[r] = d.cx[i]; ty[r] = d.cy[i]; tz[r] = d.cz[i];
-      tbw[r] = TRAC ? d.bc[i] : 0;
-    }
-#define RC_TX(r) tx[r]
-#define RC_TY(r) ty[r]
-#define RC_TZ(r) tz[r]
-#define RC_TB(r) tbw[r]
-#else
-    // (two wavefronts per SIMD: the rows' centroids are LDS broadcasts of their row's arithmetic -- the other wavefront covers the
-    // latency, and the 30 registers they would hold are what lets the second wavefront in)
-    double t0 = 0, t1 = 0, t2 = 0;
-    int tb = 0;
-    if (tid < nrows) { const int64_t i = prow0 + tid; t0 = d.cx[i]; t1 = d.cy[i]; t2 = d.cz[i]; tb = TRAC ? d.bc[i] : 0; }
-#define RC_TX(r) tcs[rw + (r)]
-#define RC_TY(r) tcs[kRcTgtRows + rw + (r)]
-#define RC_TZ(r) tcs[2 * kRcTgtRows + rw + (r)]
-#define RC_TB(r) tbs[rw + (r)]
-#endif
-    double v[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = 0.0;
-    const bool mine = nrw > 0 && (lane & 3) == 0 && hyb_value_of(lane) < 3 * nrw;      // the lanes that will hold the rows' totals
-    const int nchunks = (ncp + kRcChunk - 1) / kRcChunk;
-    for (int ck = 0; ck < nchunks; ++ck) {
-#if !FMMBEM_RC_GLOBAL_AHEAD
-      if (ck || item != (int)blockIdx.x) fetch(runs, ck * kRcChunk + tid, ncp);      // no prefetch: the chunk is fetched when it is needed
-#endif
-      __syncthreads();                                   // nobody reads the previous chunk (or the previous item's rows) any more
-#pragma unroll
-      for (int f = 0; f < F; ++f) src[f * kRcChunk + tid] = pre[f];
-#if !FMMBEM_RC_TARGET_REGS
-      if (ck == 0 && tid < nrows) { tcs[tid] = t0; tcs[kRcTgtRows + tid] = t1; tcs[2 * kRcTgtRows + tid] = t2; tbs[tid] = tb; }
-#endif
-      __syncthreads();
-#if FMMBEM_RC_GLOBAL_AHEAD
-      // the chunk after this one -- of this item, or the first of the next -- in flight while this one is worked on
-      if (ck + 1 < nchunks) fetch(runs, (ck + 1) * kRcChunk + tid, ncp);
-      else if (more) fetch(nruns, tid, nx.ncp);
-#endif
-      if (nrw <= 0) continue;                            // (wave-uniform) an item of fewer rows than wavefronts
-      const int cw = ncp - ck * kRcChunk < kRcChunk ? ncp - ck * kRcChunk : kRcChunk;
-      // a group of 64 source panels LDS -> registers one group ahead of the arithmetic (lane = source panel)
-      double cur[F];
-#if FMMBEM_RC_LDS_AHEAD
-      double nxt[F];
-#endif
-#pragma unroll
-      for (int f = 0; f < F; ++f) cur[f] = src[f * kRcChunk + lane];
-      for (int cg = 0; cg * kWave < cw; ++cg) {
-        const int c = cg * kWave + lane;
-        const bool valid = c < cw;
-#if FMMBEM_RC_LDS_AHEAD
-        if ((cg + 1) * kWave < cw) {
-#pragma unroll
-          for (int f = 0; f < F; ++f) nxt[f] = src[f * kRcChunk + c + kWave];
-        }
-#else
-        if (cg) {
-#pragma unroll
-          for (int f = 0; f < F; ++f) cur[f] = src[f * kRcChunk + c];
-        }
-#endif
-        const double sx = cur[12], sy = cur[13], sz = cur[14], A = cur[15];
-        const double x0 = cur[16], x1 = cur[17], x2 = cur[18];
-        double nx_ = 0, ny_ = 0, nz_ = 0;
-        if constexpr (TRAC) { nx_ = cur[19]; ny_ = cur[20]; nz_ = cur[21]; }
-        const double near2 = valid ? 8.0 * A * (1.0 + 1e-9) : 1e300;        // lanes past the last column: every pair "listed", i.e. dropped
-        const double wA0 = w0 * A, wA1 = w1 * A;
-#pragma unroll
-        for (int r = 0; r < kHybRows; ++r) {
-          if (r < nrw) {                                   // wave-uniform
-            const double txr = RC_TX(r), tyr = RC_TY(r), tzr = RC_TZ(r);
-            const bool slow = mf_listed(txr - sx, tyr - sy, tzr - sz, near2);
-            bool trac = false;
-            if constexpr (TRAC) trac = __builtin_amdgcn_readfirstlane(RC_TB(r)) != 0;
-            double u0 = 0, u1 = 0, u2 = 0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const double wA = q ? (q < nq ? wA1 : 0.0) : wA0;
-              const double ex = txr - cur[3 * q], ey = tyr - cur[3 * q + 1], ez = tzr - cur[3 * q + 2];
-              const double ir = rsqrt_pos(fma(ex, ex, fma(ey, ey, ez * ez)));
-              const double ir3 = ir * ir * ir, dxq = fma(ex, x0, fma(ey, x1, ez * x2));
-              if (TRAC && trac) {
-                const double g = wA * fma(ex, nx_, fma(ey, ny_, ez * nz_)) * dxq * (ir3 * ir * ir);
-                u0 = fma(g, ex, u0); u1 = fma(g, ey, u1); u2 = fma(g, ez, u2);
-              } else {
-                const double f1 = wA * ir, g = wA * ir3 * dxq;
-                u0 = fma(f1, x0, fma(g, ex, u0)); u1 = fma(f1, x1, fma(g, ey, u1)); u2 = fma(f1, x2, fma(g, ez, u2));
-              }
-              // FMMBEM_RC_QSCHED points at a time: left alone the scheduler interleaves all four points of all five rows
-              if ((q + 1) % FMMBEM_RC_QSCHED == 0) __builtin_amdgcn_sched_barrier(0);
-            }
-            // a listed pair contributes through the list, not here: a select, not a product with zero (the self pair's point IS the
-            // centroid for K = 1, 4: its reciprocal distance is inf, the sums NaN)
-            const double f = (TRAC && trac) ? -3.0 : sc;
-            v[3 * r] += slow ? 0.0 : u0 * f; v[3 * r + 1] += slow ? 0.0 : u1 * f; v[3 * r + 2] += slow ? 0.0 : u2 * f;
-          }
-          __builtin_amdgcn_sched_barrier(0);               // one row after the other
-        }
-#if FMMBEM_RC_LDS_AHEAD
-#pragma unroll
-        for (int f = 0; f < F; ++f) cur[f] = nxt[f];
-#endif
-      }
-    }
-    if (nrw > 0) {
-      const double tot = hyb_reduce16(v, lane);
-      if (mine) d.yt[3 * (int64_t)(prow0 + rw) + hyb_value_of(lane)] = tot;       // (the rows' listed entries: near_side_kernel / near_side_add_kernel)
-    }
-    if (!more) break;
-    // hand over: the run descriptors of the item after the next into the half this item's occupied (every thread has passed a
-    // barrier since it last read them: they are read by fetch() only, one chunk ahead)
-    if (prun) { runbuf[rb * 2 * mr + tid] = pr0; runbuf[rb * 2 * mr + mr + tid] = pr1; }
-    it = nx; nx = nn; rb ^= 1;
-  }
-}
-#undef RC_TX
-#undef RC_TY
-#undef RC_TZ
-#undef RC_TB
-
 // ---------------------------------------------------------------------------------------------
-// near_recompute3g_kernel: the same items and the same arithmetic with the source panels loaded STRAIGHT INTO LDS
-// (global_load_lds_dwordx4: no register holds a prefetch), so that the kernel fits 160 VGPRs and TWO of its workgroups are
-// resident per CU beside two streaming ones -- at one wavefront per SIMD every VALU instruction costs ~3 ns whatever it is
+// near_recompute3g_kernel (StokesSphericalBEM): the source panels are loaded STRAIGHT INTO LDS (global_load_lds_dwordx4: no
+// register holds a prefetch), so that the kernel fits 168 VGPRs and TWO of its workgroups are resident per CU beside two
+// streaming ones (88 VGPRs: near_spmv_sym3<1, 2>) -- at one wavefront per SIMD every VALU instruction costs ~3 ns whatever it is
 // (the lone-wavefront issue rate of the M2L study), at two the gaps of the one are the other's.
 //   * packed per-panel records built once per plan (rc_src: 4 points, centroid, area = 16 doubles = 8 pieces of 16 bytes;
 //     rc_nrm: the normal) and the charges padded to 4 doubles per panel by gather_x (xt4): a source panel is 10 (12) pieces;
@@ -2012,16 +1809,12 @@ hipError_t launch_near_hybrid(const DevicePlan& d, hipStream_t s, const HybridSt
     if ((e = hipStreamWaitEvent(hs.recompute, hs.fork, 0)) != hipSuccess) return e;
     if ((e = hipStreamWaitEvent(hs.side, hs.fork, 0)) != hipSuccess) return e;
     const dim3 g(std::min(d.rc_nitems, 256 * kR));
-    if (stokes && d.rc_src) {                            // sources straight into LDS: two workgroups per CU
+    if (stokes) {                                        // sources straight into LDS: two workgroups per CU
       static const int kRg = [] { const char* e = std::getenv("FMMBEM_HYB_WG_RECOMPUTE"); return e ? std::atoi(e) : 2; }();
       const dim3 gg(std::min(d.rc_nitems, 256 * kRg));
       const size_t ldsg = (size_t)2 * (flag1 ? 12 : 10) * kRcgChunk * 2 * sizeof(double) + (size_t)2 * 2 * kRcgTgt * 2 * sizeof(double) + 6 * (size_t)d.max_runs * sizeof(int);
       if (flag1) hipLaunchKernelGGL((near_recompute3g_kernel<true>), gg, b, ldsg, hs.recompute, d);
       else hipLaunchKernelGGL((near_recompute3g_kernel<false>), gg, b, ldsg, hs.recompute, d);
-    } else if (stokes) {
-      const size_t ldsr = (size_t)(flag1 ? 22 : 19) * kRcChunk * sizeof(double) + 4 * (size_t)d.max_runs * sizeof(int);
-      if (flag1) hipLaunchKernelGGL((near_recompute3_kernel<true>), g, b, ldsr, hs.recompute, d);
-      else hipLaunchKernelGGL((near_recompute3_kernel<false>), g, b, ldsr, hs.recompute, d);
     } else {
       const size_t ldsr = (size_t)(flag1 ? 17 : 14) * kRcChunk * sizeof(double) + 4 * (size_t)d.max_runs * sizeof(int);
       if (flag1) hipLaunchKernelGGL((near_recompute1_kernel<true>), g, b, ldsr, hs.recompute, d);

@@ -564,8 +564,7 @@ int fmmbem_plan::to_device() {
       if (!rec[l] || nr == 0 || ncp == 0) continue;
       // Stokes, sources straight into LDS (near_recompute3g): a whole leaf of up to 60 rows is one item -- its source panels are
       // loaded once; otherwise four wavefronts x five (Laplace: eight) rows
-      const bool glds_kernel = dof == 3 && !(std::getenv("FMMBEM_RC_GLDS") && std::atoi(std::getenv("FMMBEM_RC_GLDS")) == 0);
-      const int cap = glds_kernel ? rcg_item_rows() : dof == 3 ? 20 : 32;
+      const int cap = dof == 3 ? rcg_item_rows() : 32;
         const int cnt = (nr + cap - 1) / cap;
       const int per = (nr + cnt - 1) / cnt;          // dealt evenly: the kernel gives a wavefront ceil(rows / 4) of an item's rows
       for (int r0 = 0; r0 < nr; r0 += per) { const int k = std::min(per, nr - r0); ritems.push_back({l, r0, k, (int64_t)k * ncp}); }
@@ -587,7 +586,7 @@ int fmmbem_plan::to_device() {
     d.rc_nitems = (int)rrecs.size();
     TRY(upload(rrecs, &d.rc_items));
     TRY(upload(rec, &d.near_rec));
-    if (dof == 3 && !(std::getenv("FMMBEM_RC_GLDS") && std::atoi(std::getenv("FMMBEM_RC_GLDS")) == 0)) {
+    if (dof == 3) {
       // packed per-panel records of near_recompute3g_kernel (its sources go straight into LDS, 16 bytes at a time)
       double *rs = nullptr, *rn = nullptr;
       TRY(alloc((size_t)hp.n * 16, &rs, false)); TRY(alloc((size_t)hp.n * 4, &rn, false));
