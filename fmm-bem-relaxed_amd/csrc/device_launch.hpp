@@ -11,7 +11,7 @@ namespace fmmbem {
 hipError_t launch_near_assemble(const DevicePlan& d, hipStream_t s);
 hipError_t launch_gather_x(const DevicePlan& d, const double* x, hipStream_t s);
 hipError_t launch_near_spmv(const DevicePlan& d, hipStream_t s);
-struct HybridStreams { hipStream_t recompute = nullptr, side = nullptr; hipEvent_t fork = nullptr, join_recompute = nullptr, join_side = nullptr; };
+struct HybridStreams { hipStream_t recompute = nullptr; hipEvent_t fork = nullptr, join_recompute = nullptr; };
 hipError_t launch_near_hybrid(const DevicePlan& d, hipStream_t s, const HybridStreams& hs);   // near_stream_fraction < 1
 hipError_t launch_kernel_entries(const DevicePlan& d, int m, double* out, hipStream_t s);   // panels [0,m) targets, [m,2m) sources
 hipError_t launch_panel_setup(int64_t n, const uint32_t* perm, const double* v_orig, int nq, const double* pts, double* cx, double* cy,

@@ -163,7 +163,7 @@ struct DevicePlan {
   const double *rc_src = nullptr, *rc_nrm = nullptr;  // hybrid Stokes plans: packed per-panel records of near_recompute3g_kernel ([n][16], [n][4])
   double* xt4 = nullptr;                              // ... and the tree-order charges padded to 4 doubles per panel (gather_x)
   double* ys = nullptr;                               // hybrid plans: the listed entries' sums of the recomputed rows (tree order)
-  const int4* side_items = nullptr;  int side_nitems = 0;   // ... work of near_side_kernel: {first entry, one past last, first row, one past last}
+  const int4* side_items = nullptr;  int side_nitems = 0;   // ... work of near_side_items: {first entry, one past last, first row, one past last}
 };
 
 // One launch of the rotation kernel (kernels_m2l_rot.hip, compiled per operator): pairs (source box, class, target box) sorted by

@@ -1161,7 +1161,7 @@ __global__ __launch_bounds__(kSpmvWaves * kWave, kSymOcc) void near_spmv_sym3_ke
 //   * RECOMPUTED leaves keep NO matrix.  near_recompute3g (Stokes) / near_recompute1 (Laplace) evaluate their far-regime entries (K
 //     quadrature points per pair) every matvec from the source panels' points; the near-regime pairs (semi-analytic / fine-rule /
 //     self entries, 4.5 %) were listed and evaluated once at plan creation (side_ptr / side_col / side_val, as the matrix-free
-//     plans do) and are applied by near_side_kernel.
+//     plans do) and are applied by near_side_items, the tail of the recompute kernels.
 // The kernels run SIDE BY SIDE on streams of their own, each with its own register budget and a grid sized so that all are resident
 // on every CU from start to end (launch_near_hybrid): the arithmetic of the one runs in the issue slots the other leaves empty, and
 // the matrix bytes of the recomputed leaves are neither read nor stored.  (Two grids that each fill the chip serialise:
@@ -1223,12 +1223,14 @@ constexpr int kRcChunk = kSpmvWaves * kWave;          // source panels per chunk
 
 // ys[rows of the recomputed leaves] = the rows' LISTED entries (near-regime pairs, evaluated once at plan creation) times x:
 // a CSR product; a workgroup takes a run of rows with <= 256 entries, thread = entry for the products (LDS), then thread = row adds
-// its products in entry order.  On a stream of its own beside the recompute and
-// the streaming kernel (a latency-bound 0.3 ms that was on the recompute stream's critical path when it ran in front of that
-// kernel: profiles/r05z_stokes_hyb_kernel_stats.md); near_side_add_kernel adds ys to y once all three are done.
+// its products in entry order.  The recompute kernels run this as the TAIL of their own item loop -- a workgroup that is out of
+// recompute items takes listed entries -- so that it needs no residency of its own: as a third kernel beside the two it either
+// sat on the recompute stream's critical path (0.34 ms in front of that kernel) or, on a stream of its own, took the registers
+// the recompute workgroups were sized for and starved them until the streaming kernel had finished (profiles/r05b: the f = 0.4
+// trace).  near_side_add_kernel adds ys to y after the join.
 template <int DOF>
-__global__ __launch_bounds__(kSpmvWaves * kWave) void near_side_kernel(DevicePlan d) {
-  __shared__ double prod[DOF][kSpmvWaves * kWave];
+__device__ __forceinline__ void near_side_items(const DevicePlan& d, double* prod /* [DOF][256] doubles of LDS */) {
+  constexpr int kT = kSpmvWaves * kWave;
   const int tid = threadIdx.x;
   for (int item = blockIdx.x; item < d.side_nitems; item += gridDim.x) {
     const int4 it = d.side_items[item];
@@ -1237,27 +1239,27 @@ __global__ __launch_bounds__(kSpmvWaves * kWave) void near_side_kernel(DevicePla
 #pragma unroll
     for (int a = 0; a < DOF; ++a) acc[a] = 0.0;
     const int64_t mine_lo = tid < nrows ? d.side_ptr[r0 + tid] : 0, mine_hi = tid < nrows ? d.side_ptr[r0 + tid + 1] : 0;
-    for (int base = e0; base < e1; base += kSpmvWaves * kWave) {          // more than one pass only for a single row of > 256 entries
+    for (int base = e0; base < e1; base += kT) {         // more than one pass only for a single row of > 256 entries
       const int k = base + tid;
       if (k < e1) {                                      // thread = entry: the product of the entry with the source's charge
         const int64_t cj = d.side_col[k];
         if constexpr (DOF == 3) {
           const double* m = d.side_val + 9 * (int64_t)k;
           const double y0 = d.xt[3 * cj], y1 = d.xt[3 * cj + 1], y2 = d.xt[3 * cj + 2];
-          prod[0][tid] = fma(m[0], y0, fma(m[1], y1, m[2] * y2));
-          prod[1][tid] = fma(m[3], y0, fma(m[4], y1, m[5] * y2));
-          prod[2][tid] = fma(m[6], y0, fma(m[7], y1, m[8] * y2));
+          prod[tid] = fma(m[0], y0, fma(m[1], y1, m[2] * y2));
+          prod[kT + tid] = fma(m[3], y0, fma(m[4], y1, m[5] * y2));
+          prod[2 * kT + tid] = fma(m[6], y0, fma(m[7], y1, m[8] * y2));
         } else {
-          prod[0][tid] = d.side_val[k] * d.xt[cj];
+          prod[tid] = d.side_val[k] * d.xt[cj];
         }
       }
       __syncthreads();
       if (tid < nrows) {                                 // thread = row: its products, in entry order
         const int lo = (int)(mine_lo > base ? mine_lo - base : 0);
-        const int hi = (int)((mine_hi < (int64_t)base + kSpmvWaves * kWave ? mine_hi : (int64_t)base + kSpmvWaves * kWave) - base);
+        const int hi = (int)((mine_hi < (int64_t)base + kT ? mine_hi : (int64_t)base + kT) - base);
         for (int q = lo; q < hi; ++q)
 #pragma unroll
-          for (int a = 0; a < DOF; ++a) acc[a] += prod[a][q];
+          for (int a = 0; a < DOF; ++a) acc[a] += prod[a * kT + q];
       }
       __syncthreads();
     }
@@ -1267,7 +1269,7 @@ __global__ __launch_bounds__(kSpmvWaves * kWave) void near_side_kernel(DevicePla
   }
 }
 
-// y_tree[rows of the recomputed leaves] += their listed entries' sums (near_side_kernel), once both kernels are done
+// y_tree[rows of the recomputed leaves] += their listed entries' sums (near_side_items), once both kernels are done
 __global__ void near_side_add_kernel(DevicePlan d) {
   for (int item = blockIdx.x; item < d.rc_nitems; item += gridDim.x) {
     const RcItem it = d.rc_items[item];
@@ -1467,7 +1469,9 @@ __global__ __launch_bounds__(kSpmvWaves * kWave, FMMBEM_RCG_OCC) void near_recom
     if (!more) break;
     it = nx; nx = nn;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // nothing of this wavefront in flight when it ends
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // nothing of this wavefront in flight from here on
+  __syncthreads();
+  near_side_items<3>(d, lds);                            // the tail: the recomputed rows' listed entries (the chunk buffers are free)
 }
 
 // the packed records of near_recompute3g_kernel, once per plan: rc_src[panel][16] = 4 points (x, y, z each), centroid, area;
@@ -1616,6 +1620,8 @@ __global__ __launch_bounds__(kSpmvWaves * kWave, kRcOcc) void near_recompute1_ke
     if (prun) { runbuf[rb * 2 * mr + tid] = pr0; runbuf[rb * 2 * mr + mr + tid] = pr1; }
     it = nx; nx = nn; rb ^= 1;
   }
+  __syncthreads();
+  near_side_items<1>(d, src);                            // the tail: the recomputed rows' listed entries
 }
 
 // Panel(p0, p1, p2) of kernel/LaplaceSphericalBEM.hpp:64-97 for every panel, in TREE order, from the caller's vertices (original
@@ -1789,9 +1795,9 @@ hipError_t launch_gather_x(const DevicePlan& d, const double* x, hipStream_t s) 
   return hipGetLastError();
 }
 
-// Hybrid plans (near_stream_fraction < 1): the streaming kernel over the stored leaves on `s`; the recompute kernel over the others and
-// the listed entries' product on two streams forked from and joined to `s`: kS workgroups per CU of the one (88-96 VGPRs), kR of
-// the other (187-235), sized so that BOTH are resident on every CU from start to end; the third finds room in what is left.
+// Hybrid plans (near_stream_fraction < 1): the streaming kernel over the stored leaves on `s`; the recompute kernel over the others (and
+// the listed entries) on a stream forked from and joined to `s`: kS workgroups per CU of the one (84-88 VGPRs), kR of the other
+// (167-187), sized so that BOTH are resident on every CU from start to end.
 hipError_t launch_near_hybrid(const DevicePlan& d, hipStream_t s, const HybridStreams& hs) {
   if (!d.near_rec) return hipErrorInvalidValue;
   const bool stokes = d.dof == 3;
@@ -1803,11 +1809,10 @@ hipError_t launch_near_hybrid(const DevicePlan& d, hipStream_t s, const HybridSt
   const int n_stream = stokes ? d.sym_nitems : d.near_nitems_stream;
   hipError_t e = hipSuccess;
   if (d.rc_nitems > 0) {
-    // fork: the recompute kernel (its few, large workgroups must find room on every CU: launched first) and the listed entries'
-    // product, each on a stream of its own beside the streaming kernel on `s`
+    // fork: the recompute kernel (its few, large workgroups must find room on every CU: launched first) on a stream of its own
+    // beside the streaming kernel on `s`; it takes the listed entries' product as the tail of its item loop
     if ((e = hipEventRecord(hs.fork, s)) != hipSuccess) return e;
     if ((e = hipStreamWaitEvent(hs.recompute, hs.fork, 0)) != hipSuccess) return e;
-    if ((e = hipStreamWaitEvent(hs.side, hs.fork, 0)) != hipSuccess) return e;
     const dim3 g(std::min(d.rc_nitems, 256 * kR));
     if (stokes) {                                        // sources straight into LDS: two workgroups per CU
       static const int kRg = [] { const char* e = std::getenv("FMMBEM_HYB_WG_RECOMPUTE"); return e ? std::atoi(e) : 2; }();
@@ -1836,15 +1841,8 @@ hipError_t launch_near_hybrid(const DevicePlan& d, hipStream_t s, const HybridSt
     if ((e = hipGetLastError()) != hipSuccess) return e;
   }
   if (d.rc_nitems > 0) {
-    if (d.side_nitems > 0) {
-      if (stokes) hipLaunchKernelGGL((near_side_kernel<3>), dim3(std::min(d.side_nitems, 256 * 4)), b, 0, hs.side, d);
-      else hipLaunchKernelGGL((near_side_kernel<1>), dim3(std::min(d.side_nitems, 256 * 4)), b, 0, hs.side, d);
-    }
-    if ((e = hipGetLastError()) != hipSuccess) return e;
     if ((e = hipEventRecord(hs.join_recompute, hs.recompute)) != hipSuccess) return e;
-    if ((e = hipEventRecord(hs.join_side, hs.side)) != hipSuccess) return e;
     if ((e = hipStreamWaitEvent(s, hs.join_recompute, 0)) != hipSuccess) return e;
-    if ((e = hipStreamWaitEvent(s, hs.join_side, 0)) != hipSuccess) return e;
     hipLaunchKernelGGL(near_side_add_kernel, dim3(std::min(d.rc_nitems, 256 * 8)), dim3(64), 0, s, d);
     if ((e = hipGetLastError()) != hipSuccess) return e;
   }

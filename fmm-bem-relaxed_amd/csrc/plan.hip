@@ -290,8 +290,7 @@ struct fmmbem_plan {
       for (auto& g : graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
       if (own_stream) (void)hipStreamDestroy(own_stream);
       if (hyb.recompute) (void)hipStreamDestroy(hyb.recompute);
-      if (hyb.side) (void)hipStreamDestroy(hyb.side);
-      for (hipEvent_t e : {hyb.fork, hyb.join_recompute, hyb.join_side}) if (e) (void)hipEventDestroy(e);
+      for (hipEvent_t e : {hyb.fork, hyb.join_recompute}) if (e) (void)hipEventDestroy(e);
     }
   }
 };
@@ -938,10 +937,8 @@ int fmmbem_plan::to_device_bc_begin(const uint8_t* bc_tree) {
   if (sym_total_doubles) TRY(alloc((size_t)sym_total_doubles, &d.near_sym, false));
   if (hybrid) {
     HIP_TRY(hipStreamCreateWithFlags(&hyb.recompute, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&hyb.side, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&hyb.fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&hyb.join_recompute, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&hyb.join_side, hipEventDisableTiming));
     TRY(alloc((size_t)hp.n * d.dof, &d.ys, true));
     if (d.rc_src) TRY(alloc((size_t)hp.n * 4, &d.xt4, true));
   }
@@ -1070,7 +1067,7 @@ int fmmbem_plan::build_side_lists() {
     d.side_col = d_col; d.side_val = d_val;
     near_side_entries = nside;
     if (hybrid) {
-      // work items of near_side_kernel: runs of consecutive rows that hold <= 256 listed entries together (a workgroup takes the
+      // work items of near_side_items (kernels_near.hip): runs of consecutive rows that hold <= 256 listed entries together (a workgroup takes the
       // entries one per thread, then a thread per row adds the row's products in entry order); a row of more than 256 is an item
       // of its own, taken 256 at a time
       std::vector<int4> sitems;
