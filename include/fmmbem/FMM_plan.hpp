@@ -105,7 +105,7 @@ class FMMOptions {
   bool reference_l2l = false;
   // Not in the reference: share of the near-field pairs kept as a matrix (1: the reference's assembled matrix); below 1 the target
   // leaves with the most rows keep none and are recomputed every matvec beside the streamed rest (fmmbem.h near_stream_fraction):
-  // fewer HBM bytes and a smaller footprint at the same operator, last bits differ.  Stokes plans (measured optimum ~0.6).
+  // fewer HBM bytes and a smaller footprint at the same operator, last bits differ.  Stokes plans (measured optimum 0.5-0.55).
   double near_stream_fraction = 1.0;
   // Not in the reference: the devices ONE plan runs on (fmmbem.h fmmbem_options.n_devices): more than one entry shards the target
   // leaves over them inside the plan; vectors handed to the device entry points live on the first.  Empty: the constructor's
