@@ -90,3 +90,67 @@ def test_the_references_own_driver_over_a_device_list(tmp_path):
     assert outs[0] == outs[1] and len(outs[0]) > 0
     ps = [int(ln.split("fmm_req_p:")[1].split()[0].strip(",")) for ln in outs[0] if "fmm_req_p:" in ln]
     assert ps[:5] == [12, 3, 2, 1, 1] or len(ps) == 0
+
+
+def test_multi_device_with_the_other_near_field_forms(fb):
+    """The device list composes with the plan's other options: a hybrid near field (every shard makes the whole tree's leaf choice, so
+    the shards' rows are the single hybrid plan's rows bit for bit), the matrix-free near field, a Stokes hybrid plan with TRACTION
+    targets, and the evaluators that hold no far field."""
+    import torch
+    v = np.concatenate([fb.unit_sphere(6), fb.unit_sphere(5, center=(2.5, 0.0, 0.3))])
+    n = len(v)
+    x = drand48(n, seed=13)
+    K = fb.LaplaceSphericalBEM(9, 3)
+    for make in ("hybrid", "matfree", "local"):
+        o = fb.FMMOptions()
+        if make == "hybrid":
+            o.near_stream_fraction = 0.5
+        elif make == "matfree":
+            o.sparse_local = False
+        else:
+            o.local_evaluation, o.lazy_evaluation = True, False
+        single = fb.FMM_plan(K, v, o, p_max=9)
+        multi = fb.FMM_plan(K, v, o, p_max=9, devices=[0, 0, 0])
+        assert np.array_equal(multi.execute(x), single.execute(x)), make
+        if make == "hybrid":
+            assert multi.stats()["near_recomputed_pairs"] == single.stats()["near_recomputed_pairs"] > 0
+        single.close()
+        multi.close()
+    vs = fb.unit_sphere(5)
+    ns = len(vs)
+    KS = fb.StokesSphericalBEM(7, 4, 1e-3)
+    KS.set_Kfine(19)
+    xs = drand48(3 * ns, seed=14).reshape(ns, 3)
+    bc = (np.arange(ns) % 3 != 0).astype(np.uint8)
+    o = fb.FMMOptions()
+    o.near_stream_fraction = 0.5
+    a = fb.FMM_plan(KS, vs, o, bc=bc).execute(xs)
+    b = fb.FMM_plan(KS, vs, o, bc=bc, devices=[0, 0]).execute(xs)
+    assert np.array_equal(a, b)
+
+
+def test_sharded_operator_with_a_hybrid_near_field(fb):
+    """ShardedFMM's split execute (upward / exchange / downward, the near field in between) on hybrid shards, two gloo-free shards
+    driven by hand: the near field of a shard runs its three kernels on their streams inside fmmbem_plan_near_split_device."""
+    import torch
+    v = fb.unit_sphere(6)
+    n = len(v)
+    K = fb.LaplaceSphericalBEM(8, 3)
+    o = fb.FMMOptions()
+    o.near_stream_fraction = 0.6
+    x = torch.from_numpy(drand48(n, seed=4)).cuda()
+    whole = fb.FMM_plan(K, v, o, p_max=8).execute_torch(x)
+    shards = [fb.FMM_plan(K, v, o, p_max=8, shard=(r, 2), shard_upward=True) for r in range(2)]
+    per = shards[0].exchange_doubles(8)
+    send = [torch.zeros(per, dtype=torch.float64, device="cuda") for _ in range(2)]
+    s = torch.cuda.current_stream().cuda_stream
+    for r in range(2):
+        shards[r].upward_device(x.data_ptr(), send[r].data_ptr(), s, 8)
+    recv = torch.cat(send)
+    total = torch.zeros_like(x)
+    for r in range(2):
+        y = torch.zeros_like(x)
+        shards[r].near_split_device(y.data_ptr(), s)
+        shards[r].downward_device(recv.data_ptr(), y.data_ptr(), s, 8)
+        total += y
+    assert torch.equal(total, whole)
