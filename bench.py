@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--matrix-free", action="store_true",
                     help="sparse_local = false: the near field recomputed every matvec (EvalInteractionLazy, SURVEY a8) "
                          "instead of the assembled matrix; the roofline object then reports FP64 flop/s, not HBM GB/s")
+    ap.add_argument("--one-process", action="store_true",
+                    help="--gpus N in ONE process: one plan over the device list 0..N-1 (fmmbem_options.n_devices; peer copies over xGMI "
+                         "instead of torch.distributed collectives).  Not the form the SCALE driver launches; an alternative to compare with it")
     ap.add_argument("--near-stream-fraction", type=float, default=1.0,
                     help="share of the near-field pairs kept as a matrix (fmmbem_options.near_stream_fraction); < 1: the rest is "
                          "recomputed every matvec beside the streamed part (Stokes workloads; the roofline object then states "
@@ -236,9 +239,15 @@ def main():
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     env_world = os.environ.get("WORLD_SIZE")
+    one_process = args.one_process and args.gpus > 1
+    if one_process:
+        if env_world not in (None, "1"):
+            raise SystemExit("--one-process runs without a launcher")
+        env_world = "1"
+        os.environ["WORLD_SIZE"] = "1"
     if env_world is None and args.gpus > 1:
         sys.exit(launch_ranks(args))
-    if env_world is not None and int(env_world) != args.gpus:
+    if env_world is not None and int(env_world) != args.gpus and not one_process:
         # a launcher that started W ranks for --gpus N would otherwise time W GPUs and be read as N (or the reverse)
         STAGE[0] = "launch"
         if int(os.environ.get("RANK", "0")) == 0:
@@ -314,8 +323,24 @@ def main():
 
     build = {}
 
+    class OneProcess:
+        """One plan over the device list (MultiDevice in csrc/plan.hip) behind the attributes the rest of this file reads."""
+        split, y_collective = False, "peer copies of tree-order slices"
+
+        def __init__(self):
+            ndev = torch.cuda.device_count()
+            self.devices = [i % ndev for i in range(args.gpus)]        # a box with fewer GPUs names them again (a rehearsal, not a measurement)
+            self.plan = fb.FMM_plan(K, v, opts, bc=bc, devices=self.devices)
+
+        def execute(self, xx, out=None):
+            return self.plan.execute_torch(xx, out=out)
+
     def make_op(which):
         t_b = time.time()
+        if one_process:
+            o = OneProcess()
+            build[id(o)] = time.time() - t_b
+            return o
         if which == "plain":                                 # upward pass repeated, ONE all_reduce(sum) of y per matvec
             o = fb.ShardedFMM(K, v, opts, bc=bc, device=local_rank, shard_upward=False, y_collective="allreduce")
         else:                                                # distributed.py's defaults (the FMMBEM_* switches apply)
@@ -461,7 +486,7 @@ def main():
     out = {
         "metric": (("FMM matvecs/s (StokesBEM red blood cell, %s) + achieved HBM GB/s on P2P" % ("TRACTION targets: double layer" if traction else "velocity BC")) if stokes else
                    "FMM matvecs/s (LaplaceBEM sphere N=1e6 p=10) + achieved HBM GB/s on P2P"),
-        "value": args.steps / elapsed, "unit": "matvecs/s", "n_gpus": world, "steps": args.steps,
+        "value": args.steps / elapsed, "unit": "matvecs/s", "n_gpus": args.gpus if one_process else world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": ("StokesSphericalBEM " + ("TRACTION targets (stresslet)" if traction else "velocity BC") + ", RedBloodCell(r=%d), N=%d panels (%d unknowns), p=%d, k=4, "
@@ -469,11 +494,13 @@ def main():
                                 % (args.recursions, n, 3 * n, P, args.theta, args.ncrit, world)) if stokes else
                                ("LaplaceSphericalBEM, %d disjoint UnitSphere(r=%d), N=%d panels, p=%d, k=3, theta=%g, "
                                 "ncrit=%d, all POTENTIAL; target leaves sharded over %d GPU(s), %s"
-                                % (args.spheres, args.recursions, n, P, args.theta, args.ncrit, world,
-                                   ((("1 all-to-all of the multipoles each shard reads + " if op.plan.exchange_mode == 2
-                                     else "1 all-gather of the multipoles + ") if op.split else "") +
-                                   ("1 all-gather of the result slices per matvec" if op.y_collective == "allgather" else
-                                    "1 all-reduce of y per matvec")))),
+                                % (args.spheres, args.recursions, n, P, args.theta, args.ncrit, args.gpus if one_process else world,
+                                   ("ONE process, one plan over the device list: x, the multipoles each shard reads and the result slices by peer copies"
+                                    if one_process else
+                                    ((("1 all-to-all of the multipoles each shard reads + " if op.plan.exchange_mode == 2
+                                       else "1 all-gather of the multipoles + ") if op.split else "") +
+                                     ("1 all-gather of the result slices per matvec" if op.y_collective == "allgather" else
+                                      "1 all-reduce of y per matvec"))))),
                    "n_panels": n, "p": P, "theta": args.theta, "ncrit": args.ncrit, "near_nnz": st["near_nnz_total"], "m2l_pairs": st["m2l_pairs"],
                    "boxes": st["n_boxes"], "leaves": st["n_leaves"],
                    # which parent->child L2L edges ran: the plan's default is the COMPLETE list; the reference's lazy list omits
@@ -502,6 +529,7 @@ def main():
         "stage_ms_note": "a second pass of %d matvecs with HIP events around every stage, outside the timed region (the events "
                          "themselves lengthen such a matvec; `ms_per_step` is the un-instrumented figure)" % min(args.steps, 10),
         "per_rank": per_rank, "replicas_equal": replicas_equal, "preflight": pre,
+        "one_process": ({"devices": op.devices, "transport": "hipMemcpyPeerAsync ordered by events (no collective library)"} if one_process else None),
         "collectives": None if world == 1 else {"upward": ("all-to-all of the multipoles each shard reads" if op.plan.exchange_mode == 2 else "all-gather of multipoles") if op.split else "none (upward pass repeated)",
                                                 "result": op.y_collective},
         "plan_build_s": build_s, "near_assemble_s": st["build_assemble_ms"] * 1e-3,

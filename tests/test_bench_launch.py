@@ -59,3 +59,14 @@ def test_bare_gpus_2_runs_the_sharded_path_on_one_card():
     assert out["replicas_equal"] is True
     assert len(out["per_rank"]) == 2
     assert out["rel_l2_vs_direct_sample"] < 1e-5
+
+
+@pytest.mark.gpu
+def test_one_process_form_over_a_device_list():
+    """`--gpus 2 --one-process`: one plan over two list entries (the one GPU named twice here) inside this process -- the same line
+    format, n_gpus = 2, the result checked against the Direct sum as ever."""
+    r, lines = _run(["--gpus", "2", "--one-process", "--steps", "2", "--warmup", "1", "--recursions", "6", "--no-cpu-baseline"], timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = lines[-1]
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["one_process"]["devices"] == [0, 0]
+    assert out["rel_l2_vs_direct_sample"] < 1e-5
