@@ -86,6 +86,7 @@ SYMBOLS = (
     "fmmbem_plan_get_expansions", "fmmbem_plan_get_diagonal", "fmmbem_kernel_entries", "fmmbem_mesh_unit_sphere", "fmmbem_mesh_red_blood_cell", "fmmbem_mesh_red_blood_cells", "fmmbem_mesh_read_msh",
     "fmmbem_mesh_read_vert_face", "fmmbem_mesh_write_vert_face", "fmmbem_quadrature", "fmmbem_status_string", "fmmbem_last_error",
     "fmmbem_version", "fmmbem_plan_create_like", "fmmbem_host_register", "fmmbem_host_unregister", "fmmbem_solver_options_default", "fmmbem_gmres_device", "fmmbem_gmres",
+    "fmmbem_ops_create", "fmmbem_ops_destroy", "fmmbem_ops_slots", "fmmbem_ops_p2m", "fmmbem_ops_m2m", "fmmbem_ops_m2l", "fmmbem_ops_l2l", "fmmbem_ops_l2p",
 )
 
 
@@ -152,6 +153,14 @@ def lib():
     L.fmmbem_gmres_device.argtypes = [vp, C.POINTER(SolverOpts), vp, vp, C.POINTER(Preconditioner), C.POINTER(SolverLog), vp]
     L.fmmbem_plan_create_like.argtypes = [vp, vp, C.POINTER(vp)]
     L.fmmbem_gmres.argtypes = [vp, C.POINTER(SolverOpts), vp, vp, C.POINTER(Preconditioner), C.POINTER(SolverLog)]
+    L.fmmbem_ops_create.argtypes = [C.POINTER(Options), C.POINTER(vp)]
+    L.fmmbem_ops_destroy.argtypes = [vp]
+    L.fmmbem_ops_destroy.restype = None
+    L.fmmbem_ops_slots.argtypes = [vp]
+    L.fmmbem_ops_p2m.argtypes = [vp, i32, C.c_size_t, vp, vp, vp, vp, vp]
+    for fn in (L.fmmbem_ops_m2m, L.fmmbem_ops_m2l, L.fmmbem_ops_l2l):
+        fn.argtypes = [vp, i32, i32, vp, vp, vp]
+    L.fmmbem_ops_l2p.argtypes = [vp, i32, vp, vp, C.c_size_t, vp, vp, vp]
     _lib = L
     return L
 

@@ -44,7 +44,115 @@ class FMMOptions:
         return self.ncrit
 
 
-class LaplaceSphericalBEM:
+class _SingleOperators:
+    """The translation operators one at a time -- P2M, M2M, M2L, L2L, L2P of kernel/KernelSkeleton.hpp:62-212 as the BEM kernels
+    define them (kernel/LaplaceSphericalBEM.hpp:307-476, kernel/StokesSphericalBEM.hpp:391-530) -- run by the device kernels of
+    the matvec on a two-box plan (fmmbem_ops_*, csrc/ops.hip).  Argument order and the "+=" into the last argument are the
+    reference's; an expansion is a complex array (slots, p (p + 1) / 2), slots = 2 (Laplace: G, dG/dn) or 4 (Stokes: the stokeslet
+    group M[0]); panels are (n, 3, 3) vertex arrays with one boundary-condition flag each (None: all 0)."""
+    _ops = None
+    device = 0
+
+    def _handle(self):
+        if self._ops is None or self._ops[1] != (self.K, getattr(self, "Mu", None), self.device):
+            self._close()
+            o = _capi.Options()
+            _capi.lib().fmmbem_options_default(C.byref(o))
+            o.p_max, o.quad_k, o.device = _capi.PMAX, self.K, int(self.device)
+            if isinstance(self, StokesSphericalBEM):
+                o.kernel, o.mu = _capi.KERNEL_STOKES_BEM, self.Mu
+            h = C.c_void_p()
+            _capi.check(_capi.lib().fmmbem_ops_create(C.byref(o), C.byref(h)))
+            self._ops = (h, (self.K, getattr(self, "Mu", None), self.device))
+        return self._ops[0]
+
+    def _close(self):
+        if self._ops is not None:
+            _capi.lib().fmmbem_ops_destroy(self._ops[0])
+            self._ops = None
+
+    def __del__(self):
+        try:
+            self._close()
+        except Exception:
+            pass
+
+    def slots(self):
+        """expansions per box that P2M writes and L2P reads (multipole_type's size)"""
+        return 4 if isinstance(self, StokesSphericalBEM) else 2
+
+    def init_multipole(self, slots=None):
+        """a zeroed multipole_type / local_type at the current order (init_multipole / init_local, LaplaceSphericalBEM.hpp:143-156)"""
+        return np.zeros((self.slots() if slots is None else slots, self.P * (self.P + 1) // 2), dtype=np.complex128)
+
+    init_local = init_multipole
+
+    def _expansion(self, E, writable):
+        S = self.P * (self.P + 1) // 2
+        if not (isinstance(E, np.ndarray) and E.dtype == np.complex128 and E.ndim == 2 and E.shape[1] == S and E.flags.c_contiguous):
+            raise ValueError("an expansion is a C-contiguous complex128 array (slots, p (p + 1) / 2) at the kernel's current p")
+        if writable and not E.flags.writeable:
+            raise ValueError("the target expansion must be writable")
+        return E
+
+    @staticmethod
+    def _panels(panels, bc):
+        v = np.ascontiguousarray(panels, dtype=np.float64).reshape(-1, 9)
+        b = None
+        if bc is not None:
+            b = np.ascontiguousarray(bc, dtype=np.uint8)
+            if b.shape != (len(v),):
+                raise ValueError("one boundary-condition flag per panel")
+        return v, b
+
+    def P2M(self, sources, charges, center, M, bc=None):
+        """M += the moments of the sources about center (P2M(source, charge, center, M), vectorised over the sources)"""
+        v, b = self._panels(sources, bc)
+        M = self._expansion(M, True)
+        if M.shape[0] != self.slots():
+            raise ValueError("P2M writes %d expansions" % self.slots())
+        q = np.ascontiguousarray(charges, dtype=np.float64).reshape(-1)
+        if q.size != len(v) * (3 if isinstance(self, StokesSphericalBEM) else 1):
+            raise ValueError("one charge per source")
+        c = np.ascontiguousarray(center, dtype=np.float64)
+        vp = C.c_void_p
+        _capi.check(_capi.lib().fmmbem_ops_p2m(self._handle(), self.P, len(v), v.ctypes.data_as(vp), None if b is None else b.ctypes.data_as(vp),
+                                                q.ctypes.data_as(vp), c.ctypes.data_as(vp), M.ctypes.data_as(vp)))
+
+    def _shift(self, fn, source, target, translation):
+        source, target = self._expansion(source, False), self._expansion(target, True)
+        if source.shape != target.shape:
+            raise ValueError("source and target expansions differ in shape")
+        t = np.ascontiguousarray(translation, dtype=np.float64)
+        vp = C.c_void_p
+        _capi.check(fn(self._handle(), self.P, source.shape[0], source.ctypes.data_as(vp), target.ctypes.data_as(vp), t.ctypes.data_as(vp)))
+
+    def M2M(self, Msource, Mtarget, translation):
+        """Mtarget += the source multipole moved by translation = centre(target) - centre(source)"""
+        self._shift(_capi.lib().fmmbem_ops_m2m, Msource, Mtarget, translation)
+
+    def M2L(self, Msource, Ltarget, translation):
+        self._shift(_capi.lib().fmmbem_ops_m2l, Msource, Ltarget, translation)
+
+    def L2L(self, Lsource, Ltarget, translation):
+        self._shift(_capi.lib().fmmbem_ops_l2l, Lsource, Ltarget, translation)
+
+    def L2P(self, L, center, targets, result, bc=None):
+        """result += the local expansion about center evaluated at the targets' centroids (L2P(L, center, target, result))"""
+        v, b = self._panels(targets, bc)
+        L = self._expansion(L, False)
+        if L.shape[0] != self.slots():
+            raise ValueError("L2P reads %d expansions" % self.slots())
+        dof = 3 if isinstance(self, StokesSphericalBEM) else 1
+        if not (isinstance(result, np.ndarray) and result.dtype == np.float64 and result.size == len(v) * dof and result.flags.c_contiguous):
+            raise ValueError("result must be a C-contiguous float64 array with one value (Stokes: three) per target")
+        c = np.ascontiguousarray(center, dtype=np.float64)
+        vp = C.c_void_p
+        _capi.check(_capi.lib().fmmbem_ops_l2p(self._handle(), self.P, L.ctypes.data_as(vp), c.ctypes.data_as(vp), len(v), v.ctypes.data_as(vp),
+                                                None if b is None else b.ctypes.data_as(vp), result.ctypes.data_as(vp)))
+
+
+class LaplaceSphericalBEM(_SingleOperators):
     """Kernel descriptor: expansion order p and Gauss rule key k (kernel/LaplaceSphericalBEM.hpp:131)."""
     POTENTIAL, NORMAL_DERIV = _capi.BC_POTENTIAL, _capi.BC_NORMAL_DERIV
 
@@ -60,7 +168,7 @@ class LaplaceSphericalBEM:
         self.P = int(p)
 
 
-class StokesSphericalBEM:
+class StokesSphericalBEM(_SingleOperators):
     """Kernel descriptor of kernel/StokesSphericalBEM.hpp:131-141: order p, Gauss key k, viscosity mu and the
     near-regime rule K_fine (ctor default 25; examples/StokesBEM.cpp:128-129,218 uses 19).  Only the VELOCITY
     boundary condition (stokeslet single layer, the operator the solve uses) is built; charges and results are

@@ -239,6 +239,35 @@ int fmmbem_plan_get_diagonal(const fmmbem_plan *plan, double *out);
 int fmmbem_kernel_entries(const fmmbem_options *opts, size_t n, const double *target_vertices, const uint8_t *target_bc,
                           const double *source_vertices, double *out);
 
+/* ---- the translation operators one at a time: the KernelSkeleton contract (kernel/KernelSkeleton.hpp:62-212) --------------
+ * What the reference's kernel classes offer beside operator(): P2M, M2M, M2L, L2L, L2P as kernel/LaplaceSphericalBEM.hpp:307-476
+ * and kernel/StokesSphericalBEM.hpp:391-530 define them (each "+=" into its last argument), for code that drives single operators
+ * (tests/single_level.cpp, ExpansionTraits<K>::is_valid_fmm of include/KernelTraits.hpp:188-194).  Every call runs the SAME device
+ * kernels a plan's matvec runs, on a two-box plan that holds just the call's operands (csrc/ops.hip); operands and results are
+ * host buffers.  M2P (the treecode's operator) is not offered.
+ *   fmmbem_ops_create reads opts->kernel, p_max (1..16), quad_k, mu, device.  A handle is not thread-safe.
+ *   An expansion: [slot][p (p + 1) / 2] complex as (re, im) pairs, coefficient (n, m >= 0) at n (n + 1) / 2 + m -- the reference's
+ *   stored half (kernel/LaplaceSpherical.hpp:187-206).  fmmbem_ops_slots: the slots P2M writes and L2P reads -- Laplace 2
+ *   (multipole_type[0] = G moments of POTENTIAL sources, [1] = dG/dn moments of NORMAL_DERIV sources, :323-344; L2P adds r0 at a
+ *   POTENTIAL target and subtracts r1 at a NORMAL_DERIV target, :448-476), Stokes 4 (the stokeslet group M[0][0..3] of VELOCITY
+ *   sources, StokesSphericalBEM.hpp:414-430; L2P at VELOCITY targets with the 1 / (2 mu), :512-522).  Stokes TRACTION sources
+ *   and targets are FMMBEM_ERR_UNSUPPORTED here: the reference's stresslet moments (:432-466) are not the far field this library
+ *   computes for those rows (see FMMBEM_KERNEL_STOKES_BEM above).
+ *   M2M / M2L / L2L act on n_slots (1..12) expansions alike -- pass both groups of a Stokes multipole_type as 8.
+ *   translation = centre of the target expansion - centre of the source expansion (executor/M2M.hpp, M2L.hpp:40, L2L.hpp).
+ *   vertices: n x 9; bc: n flags or NULL (all 0); charges: n x dof; result: n x dof, added to. */
+typedef struct fmmbem_ops fmmbem_ops;
+int fmmbem_ops_create(const fmmbem_options *opts, fmmbem_ops **out);
+void fmmbem_ops_destroy(fmmbem_ops *ops);
+int fmmbem_ops_slots(const fmmbem_ops *ops);
+int fmmbem_ops_p2m(fmmbem_ops *ops, int p, size_t n, const double *vertices, const uint8_t *bc, const double *charges,
+                   const double center[3], double *M);
+int fmmbem_ops_m2m(fmmbem_ops *ops, int p, int n_slots, const double *M_source, double *M_target, const double translation[3]);
+int fmmbem_ops_m2l(fmmbem_ops *ops, int p, int n_slots, const double *M_source, double *L_target, const double translation[3]);
+int fmmbem_ops_l2l(fmmbem_ops *ops, int p, int n_slots, const double *L_source, double *L_target, const double translation[3]);
+int fmmbem_ops_l2p(fmmbem_ops *ops, int p, const double *L, const double center[3], size_t n, const double *vertices,
+                   const uint8_t *bc, double *result);
+
 /* ---- the orthogonalisation step of the callers above the matvec (examples/BEM/GMRES.hpp:203-212: modified Gram-Schmidt of
  * w against V_0 .. V_{ncols-1}, then the normalised next basis vector), device vectors, ONE call per Arnoldi column:
  *   for k < ncols:  h[k] = <w, V_k>;  w -= h[k] V_k;      h[ncols] = |w|;   vnext = w / h[ncols]

@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <limits>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -73,6 +74,68 @@ struct PanelT {
   }
   operator point_type() const { return center; }
   void switch_BC() { BC = BC == BC0 ? BC1 : BC0; }
+};
+
+// The translation operators one at a time (kernel/KernelSkeleton.hpp:62-212): the kernel classes below forward P2M, M2M, M2L,
+// L2L, L2P to fmmbem_ops_* (the matvec's own device kernels on a two-box plan, csrc/ops.hip) with the reference's argument
+// lists, so that ExpansionTraits<Kernel>::is_valid_fmm (include/KernelTraits.hpp:188-194) holds for them and code that drives
+// single operators (tests/single_level.cpp) compiles.  The handle is made at the first call and shared by copies of the kernel.
+class SingleOperators {
+ public:
+  typedef std::complex<double> complex;
+  typedef std::vector<complex> expansion;
+  fmmbem_ops* handle(int kernel, unsigned K, double mu, int device) const {
+    if (!h_ || h_->kernel != kernel || h_->K != K || h_->mu != mu || h_->device != device) {
+      fmmbem_options o;
+      fmmbem_options_default(&o);
+      o.kernel = kernel; o.p_max = 16; o.quad_k = (int)K; o.mu = mu; o.device = device;
+      fmmbem_ops* raw = nullptr;
+      check(fmmbem_ops_create(&o, &raw));
+      h_ = std::make_shared<Handle>(raw, kernel, K, mu, device);
+    }
+    return h_->ops;
+  }
+  // [slot][S] complex <-> the C ABI's (re, im) pairs
+  static std::vector<double> pack(const std::vector<const expansion*>& e, int P) {
+    const size_t S = (size_t)P * (P + 1) / 2;
+    std::vector<double> out(2 * S * e.size());
+    for (size_t s = 0; s < e.size(); ++s) {
+      if (e[s]->size() != S) throw Error(FMMBEM_ERR_INVALID, "an expansion of another order than the kernel's p (init_multipole / init_local size it)");
+      for (size_t i = 0; i < S; ++i) { out[2 * (s * S + i)] = (*e[s])[i].real(); out[2 * (s * S + i) + 1] = (*e[s])[i].imag(); }
+    }
+    return out;
+  }
+  static void unpack(const std::vector<double>& in, const std::vector<expansion*>& e, int P) {
+    const size_t S = (size_t)P * (P + 1) / 2;
+    for (size_t s = 0; s < e.size(); ++s)
+      for (size_t i = 0; i < S; ++i) (*e[s])[i] = complex(in[2 * (s * S + i)], in[2 * (s * S + i) + 1]);
+  }
+  template <class Fn>
+  void shift(Fn fn, fmmbem_ops* ops, int P, const std::vector<const expansion*>& src, const std::vector<expansion*>& tgt,
+             const Vec<3, double>& translation) const {
+    if (src.size() != tgt.size()) throw Error(FMMBEM_ERR_INVALID, "source and target hold different numbers of expansions");
+    const std::vector<double> a = pack(src, P);
+    std::vector<double> b = pack(std::vector<const expansion*>(tgt.begin(), tgt.end()), P);
+    const double t[3] = {translation[0], translation[1], translation[2]};
+    check(fn(ops, P, (int)src.size(), a.data(), b.data(), t));
+    unpack(b, tgt, P);
+  }
+  template <class Panel>
+  static void vertices_of(const Panel& p, double v[9]) {
+    if (p.vertices.size() != 3) throw Error(FMMBEM_ERR_INVALID, "a panel without vertices");
+    for (int a = 0; a < 3; ++a)
+      for (int c = 0; c < 3; ++c) v[3 * a + c] = p.vertices[a][c];
+  }
+
+ private:
+  struct Handle {
+    fmmbem_ops* ops; int kernel; unsigned K; double mu; int device;
+    Handle(fmmbem_ops* o, int k, unsigned q, double m, int d) : ops(o), kernel(k), K(q), mu(m), device(d) {}
+    ~Handle() { fmmbem_ops_destroy(ops); }
+    Handle(const Handle&) = delete;
+    Handle& operator=(const Handle&) = delete;
+  };
+  mutable std::shared_ptr<Handle> h_;
 };
 
 }  // namespace fmmbem
@@ -187,8 +250,49 @@ class LaplaceSphericalBEM {
     return out;
   }
 
+  // ---- the single operators of kernel/LaplaceSphericalBEM.hpp:143-156, 307-476 (M2P, the treecode's, is not offered) ----
+  void init_multipole(multipole_type& M, const point_type&, unsigned) const { M.assign(2, std::vector<complex>((size_t)P * (P + 1) / 2, 0.)); }
+  void init_local(local_type& L, const point_type&, unsigned) const { L.assign(2, std::vector<complex>((size_t)P * (P + 1) / 2, 0.)); }
+  // M[0] += the G moments of a POTENTIAL source, M[1] += the dG/dn moments of a NORMAL_DERIV source (:323-344)
+  void P2M(const source_type& source, const charge_type& charge, const point_type& center, multipole_type& M) const {
+    double v[9];
+    fmmbem::SingleOperators::vertices_of(source, v);
+    const uint8_t bc = source.BC == Panel::NORMAL_DERIV ? FMMBEM_BC_NORMAL_DERIV : FMMBEM_BC_POTENTIAL;
+    const double c[3] = {center[0], center[1], center[2]};
+    std::vector<double> m = fmmbem::SingleOperators::pack(cptrs(M), P);
+    fmmbem::check(fmmbem_ops_p2m(ops_.handle(FMMBEM_KERNEL_LAPLACE_BEM, K, 1.0, device), P, 1, v, &bc, &charge, c, m.data()));
+    fmmbem::SingleOperators::unpack(m, ptrs(M), P);
+  }
+  void M2M(const multipole_type& source, multipole_type& target, const point_type& translation) const {
+    ops_.shift(fmmbem_ops_m2m, ops_.handle(FMMBEM_KERNEL_LAPLACE_BEM, K, 1.0, device), P, cptrs(source), ptrs(target), translation);
+  }
+  void M2L(const multipole_type& source, local_type& target, const point_type& translation) const {
+    ops_.shift(fmmbem_ops_m2l, ops_.handle(FMMBEM_KERNEL_LAPLACE_BEM, K, 1.0, device), P, cptrs(source), ptrs(target), translation);
+  }
+  void L2L(const local_type& source, local_type& target, const point_type& translation) const {
+    ops_.shift(fmmbem_ops_l2l, ops_.handle(FMMBEM_KERNEL_LAPLACE_BEM, K, 1.0, device), P, cptrs(source), ptrs(target), translation);
+  }
+  // result += r0 at a POTENTIAL target, -= r1 at a NORMAL_DERIV target (:448-476)
+  void L2P(const local_type& L, const point_type& center, const target_type& target, result_type& result) const {
+    double v[9];
+    fmmbem::SingleOperators::vertices_of(target, v);
+    const uint8_t bc = target.BC == Panel::NORMAL_DERIV ? FMMBEM_BC_NORMAL_DERIV : FMMBEM_BC_POTENTIAL;
+    const double c[3] = {center[0], center[1], center[2]};
+    const std::vector<double> l = fmmbem::SingleOperators::pack(cptrs(L), P);
+    fmmbem::check(fmmbem_ops_l2p(ops_.handle(FMMBEM_KERNEL_LAPLACE_BEM, K, 1.0, device), P, l.data(), c, 1, v, &bc, &result));
+  }
+
  protected:
   int P;
+  fmmbem::SingleOperators ops_;
+  static std::vector<const std::vector<complex>*> cptrs(const multipole_type& E) {
+    if (E.size() != 2) throw fmmbem::Error(FMMBEM_ERR_INVALID, "a LaplaceSphericalBEM expansion holds two coefficient vectors (init_multipole / init_local)");
+    return {&E[0], &E[1]};
+  }
+  static std::vector<std::vector<complex>*> ptrs(multipole_type& E) {
+    if (E.size() != 2) throw fmmbem::Error(FMMBEM_ERR_INVALID, "a LaplaceSphericalBEM expansion holds two coefficient vectors (init_multipole / init_local)");
+    return {&E[0], &E[1]};
+  }
 };
 
 // kernel/StokesSphericalBEM.hpp:9-141 -- Vec<3,double> charges/results, Mat3 kernel values, p, K, K_fine, mu.
@@ -244,8 +348,60 @@ class StokesSphericalBEM {
     return m;
   }
 
+  // ---- the single operators of kernel/StokesSphericalBEM.hpp:143-153, 391-530.  M[0][0..3]: the stokeslet group that VELOCITY
+  // sources feed and VELOCITY targets read; M[1][0..3] is carried through M2M / M2L / L2L like the reference carries it, but
+  // P2M of a TRACTION source and L2P at a TRACTION target throw FMMBEM_ERR_UNSUPPORTED (include/fmmbem.h: the plans' far field
+  // for those rows is not the reference's stresslet moments) ----
+  void init_multipole(multipole_type& M, const point_type&, unsigned) const {
+    M.assign(2, std::vector<std::vector<complex>>(4, std::vector<complex>((size_t)P * (P + 1) / 2, 0.)));
+  }
+  void init_local(local_type& L, const point_type&, unsigned) const {
+    L.assign(2, std::vector<std::vector<complex>>(4, std::vector<complex>((size_t)P * (P + 1) / 2, 0.)));
+  }
+  void P2M(const source_type& source, const charge_type& charge, const point_type& center, multipole_type& M) const {
+    double v[9];
+    fmmbem::SingleOperators::vertices_of(source, v);
+    const uint8_t bc = source.BC == Panel::TRACTION;
+    const double c[3] = {center[0], center[1], center[2]}, f[3] = {charge[0], charge[1], charge[2]};
+    std::vector<double> m = fmmbem::SingleOperators::pack(cptrs(M, 1), P);
+    fmmbem::check(fmmbem_ops_p2m(ops_.handle(FMMBEM_KERNEL_STOKES_BEM, K, Mu, device), P, 1, v, &bc, f, c, m.data()));
+    fmmbem::SingleOperators::unpack(m, ptrs(M, 1), P);
+  }
+  void M2M(const multipole_type& source, multipole_type& target, const point_type& translation) const {
+    ops_.shift(fmmbem_ops_m2m, ops_.handle(FMMBEM_KERNEL_STOKES_BEM, K, Mu, device), P, cptrs(source, 2), ptrs(target, 2), translation);
+  }
+  void M2L(const multipole_type& source, local_type& target, const point_type& translation) const {
+    ops_.shift(fmmbem_ops_m2l, ops_.handle(FMMBEM_KERNEL_STOKES_BEM, K, Mu, device), P, cptrs(source, 2), ptrs(target, 2), translation);
+  }
+  void L2L(const local_type& source, local_type& target, const point_type& translation) const {
+    ops_.shift(fmmbem_ops_l2l, ops_.handle(FMMBEM_KERNEL_STOKES_BEM, K, Mu, device), P, cptrs(source, 2), ptrs(target, 2), translation);
+  }
+  void L2P(const local_type& L, const point_type& center, const target_type& target, result_type& result) const {
+    double v[9], r[3] = {result[0], result[1], result[2]};
+    fmmbem::SingleOperators::vertices_of(target, v);
+    const uint8_t bc = target.BC == Panel::TRACTION;
+    const double c[3] = {center[0], center[1], center[2]};
+    const std::vector<double> l = fmmbem::SingleOperators::pack(cptrs(L, 1), P);
+    fmmbem::check(fmmbem_ops_l2p(ops_.handle(FMMBEM_KERNEL_STOKES_BEM, K, Mu, device), P, l.data(), c, 1, v, &bc, r));
+    for (int k = 0; k < 3; ++k) result[k] = r[k];
+  }
+
  protected:
   int P;
+  fmmbem::SingleOperators ops_;
+  // the first `groups` groups of an M[2][4] as a list of coefficient vectors
+  static std::vector<const std::vector<complex>*> cptrs(const multipole_type& E, size_t groups) {
+    if (E.size() != 2 || E[0].size() != 4 || E[1].size() != 4) throw fmmbem::Error(FMMBEM_ERR_INVALID, "a StokesSphericalBEM expansion is M[2][4] (init_multipole / init_local)");
+    std::vector<const std::vector<complex>*> out;
+    for (size_t g = 0; g < groups; ++g) for (size_t e = 0; e < 4; ++e) out.push_back(&E[g][e]);
+    return out;
+  }
+  static std::vector<std::vector<complex>*> ptrs(multipole_type& E, size_t groups) {
+    if (E.size() != 2 || E[0].size() != 4 || E[1].size() != 4) throw fmmbem::Error(FMMBEM_ERR_INVALID, "a StokesSphericalBEM expansion is M[2][4] (init_multipole / init_local)");
+    std::vector<std::vector<complex>*> out;
+    for (size_t g = 0; g < groups; ++g) for (size_t e = 0; e < 4; ++e) out.push_back(&E[g][e]);
+    return out;
+  }
 };
 
 namespace fmmbem {

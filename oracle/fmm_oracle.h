@@ -157,6 +157,11 @@ int  orc_stokes_matvec(orc_ctx *c, int P, const double *x, double *y, int flags,
 void orc_stokes_direct(const orc_ctx *c, const double *x, double *y, int row_begin, int row_end);
 void orc_stokes_direct_rows(const orc_ctx *c, const double *x, double *y_out, int nrows, const int32_t *rows);
 void orc_red_blood_cell_map(long n, double *verts);
+/* single P2M / L2P on caller-supplied panels (kernel 0 Laplace [2][S], 1 Stokes velocity group [4][S]); += */
+int orc_single_p2m(int kernel, int P, int K, double mu, int n, const double *verts, const uint8_t *bc, const double *charges,
+                   const double center[3], cplx *M);
+int orc_single_l2p(int kernel, int P, int K, double mu, const cplx *L, const double center[3], int n, const double *verts,
+                   const uint8_t *bc, double *result);
 
 #define ORC_FLAG_FAITHFUL 1   /* both expansions, serial SpMV/M2M/L2L like the reference */
 #define ORC_FLAG_TARGET_RANGE 2

@@ -74,6 +74,10 @@ def lib():
         L.orc_m2m.argtypes = [vp, vp, vp, vp]
         L.orc_m2l.argtypes = [vp, vp, vp, vp]
         L.orc_l2l.argtypes = [vp, vp, vp, vp]
+        L.orc_single_p2m.argtypes = [i32, i32, i32, dbl, i32, vp, vp, vp, vp, vp]
+        L.orc_single_p2m.restype = i32
+        L.orc_single_l2p.argtypes = [i32, i32, i32, dbl, vp, vp, i32, vp, vp, vp]
+        L.orc_single_l2p.restype = i32
         L.orc_semi_analytical.argtypes = [vp, vp, vp, vp, vp, vp, i32]
         L.orc_quadrature.argtypes = [i32, vp, vp]
         L.orc_quadrature.restype = i32
@@ -318,6 +322,33 @@ class Tables:
 
     def l2l(self, Ls, tr):
         return self._op(lib().orc_l2l, Ls, tr)
+
+
+def single_p2m(kernel, P, K, verts, bc, charges, center, mu=1.0):
+    """KernelSkeleton::P2M of the BEM kernels on caller-supplied panels: the expansions [2 or 4][S] of sources about `center`
+    (kernel/LaplaceSphericalBEM.hpp:307-352; kernel/StokesSphericalBEM.hpp:391-432, VELOCITY sources)."""
+    verts = np.ascontiguousarray(verts, dtype=np.float64).reshape(-1, 9)
+    n = len(verts)
+    bc = np.zeros(n, dtype=np.uint8) if bc is None else np.ascontiguousarray(bc, dtype=np.uint8)
+    charges = np.ascontiguousarray(charges, dtype=np.float64)
+    M = np.zeros((4 if kernel else 2, P * (P + 1) // 2), dtype=np.complex128)
+    center = np.ascontiguousarray(center, dtype=np.float64)
+    if lib().orc_single_p2m(kernel, P, K, mu, n, _p(verts), _p(bc), _p(charges), _p(center), _p(M)) != 0:
+        raise ValueError("bad P or K")
+    return M
+
+
+def single_l2p(kernel, P, K, L, center, verts, bc, mu=1.0):
+    """KernelSkeleton::L2P of the BEM kernels (kernel/LaplaceSphericalBEM.hpp:448-476; StokesSphericalBEM.hpp:512-522)."""
+    verts = np.ascontiguousarray(verts, dtype=np.float64).reshape(-1, 9)
+    n = len(verts)
+    bc = np.zeros(n, dtype=np.uint8) if bc is None else np.ascontiguousarray(bc, dtype=np.uint8)
+    L = np.ascontiguousarray(L, dtype=np.complex128)
+    out = np.zeros(n * (3 if kernel else 1))
+    center = np.ascontiguousarray(center, dtype=np.float64)
+    if lib().orc_single_l2p(kernel, P, K, mu, _p(L), _p(center), n, _p(verts), _p(bc), _p(out)) != 0:
+        raise ValueError("bad P or K")
+    return out
 
 
 def cart2sph(d):

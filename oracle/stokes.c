@@ -369,3 +369,47 @@ void orc_stokes_get_expansions(const orc_ctx *c, int P, int which, double *out) 
 void orc_stokes_entries(const orc_ctx *c, int npairs, const int32_t *ti, const int32_t *sj, double *out) {
   for (int k = 0; k < npairs; ++k) orc_stokes_entry(c, &c->panels[ti[k]], &c->panels[sj[k]], out + 9*k);
 }
+
+/* ---- single operators on caller-supplied panels (checkers of the product's fmmbem_ops_p2m / fmmbem_ops_l2p) ----
+ * kernel == 0: LaplaceSphericalBEM::P2M / L2P (kernel/LaplaceSphericalBEM.hpp:307-352, 448-476), expansions [2][S];
+ * kernel == 1: StokesSphericalBEM::P2M (VELOCITY branch, :391-432) / L2P (:512-522), expansions [4][S].
+ * M and result are added to, as the reference's operators do.  Returns 0, or -1 for a bad P / K. */
+int orc_single_p2m(int kernel, int P, int K, double mu, int n, const double *verts, const uint8_t *bc, const double *charges,
+                   const double center[3], cplx *M) {
+  (void)mu;
+  orc_tables *t = orc_tables_create(P);
+  orc_ctx *c = calloc(1, sizeof *c);
+  double pts[ORC_MAXK][3], qstore[3*ORC_MAXK];
+  if (!t || !c) { free(c); if (t) orc_tables_destroy(t); return -1; }
+  c->nq = orc_quadrature(K, pts, c->qw);
+  if (c->nq < 0) { free(c); orc_tables_destroy(t); return -1; }
+  const int S = P*(P+1)/2;
+  for (int i = 0; i < n; ++i) {
+    orc_panel p;
+    orc_panel_init(&p, verts + 9*(size_t)i, bc ? bc[i] : 0, c->nq, (const double (*)[3])pts, qstore);
+    if (kernel == 0) orc_p2m_panel(t, &p, c->nq, c->qw, charges[i], center, M, M + S);
+    else stokes_p2m_panel(t, c, &p, charges + 3*(size_t)i, center, M);
+  }
+  free(c); orc_tables_destroy(t);
+  return 0;
+}
+
+int orc_single_l2p(int kernel, int P, int K, double mu, const cplx *L, const double center[3], int n, const double *verts,
+                   const uint8_t *bc, double *result) {
+  orc_tables *t = orc_tables_create(P);
+  orc_ctx *c = calloc(1, sizeof *c);
+  double pts[ORC_MAXK][3], qstore[3*ORC_MAXK];
+  if (!t || !c) { free(c); if (t) orc_tables_destroy(t); return -1; }
+  c->nq = orc_quadrature(K, pts, c->qw);
+  if (c->nq < 0) { free(c); orc_tables_destroy(t); return -1; }
+  c->mu = mu;
+  const int S = P*(P+1)/2;
+  for (int i = 0; i < n; ++i) {
+    orc_panel p;
+    orc_panel_init(&p, verts + 9*(size_t)i, bc ? bc[i] : 0, c->nq, (const double (*)[3])pts, qstore);
+    if (kernel == 0) orc_l2p_panel(t, L, L + S, center, &p, result + i);
+    else stokes_l2p_panel(t, c, L, center, &p, result + 3*(size_t)i);
+  }
+  free(c); orc_tables_destroy(t);
+  return 0;
+}

@@ -13,7 +13,7 @@ from conftest import ROOT
 
 def test_library_exports_every_declared_symbol(fb):
     header = open(os.path.join(ROOT, "include", "fmmbem.h")).read()
-    declared = set(re.findall(r"^(?:int|void|const char \*)\s*(fmmbem_[a-z_]+)\s*\(", header, flags=re.M))
+    declared = set(re.findall(r"^(?:int|void|const char \*)\s*(fmmbem_[a-z0-9_]+)\s*\(", header, flags=re.M))
     assert declared == set(fb.SYMBOLS)
     lib = ctypes.CDLL(fb.LIB_PATH)
     for name in declared:

@@ -58,6 +58,41 @@ def test_device_solver_call_sites_compile(tmp_path, gpu_available):
             assert r.returncode == 2 and "no HIP device" in r.stdout
 
 
+REF_INCLUDE = "/root/reference/include"          # KernelTraits.hpp, executor/INITM.hpp, INITL.hpp: Boost-free
+
+
+def test_kernel_classes_meet_the_kernel_contract(tmp_path, gpu_available):
+    """kernel/KernelSkeleton.hpp:62-212: the adapter's kernel classes have init_multipole / init_local / P2M / M2M / M2L / L2L /
+    L2P with the reference's argument lists (tests/cpp/traits_contract.cpp drives them the way tests/single_level.cpp does); in
+    the build container the REFERENCE's own include/KernelTraits.hpp, read in place, static_asserts is_valid_fmm on them."""
+    variants = [()]
+    if os.path.isdir(REF_INCLUDE):
+        variants.append(("-DUSE_REFERENCE_TRAITS", "-I" + REF_INCLUDE))
+    for extra in variants:
+        exe = _build(tmp_path, "traits_contract", extra=extra)
+        if not gpu_available:
+            r = subprocess.run([exe], capture_output=True, text=True)
+            assert r.returncode == 2 and "no HIP device" in r.stdout
+
+
+@pytest.mark.gpu
+def test_single_operator_chain_through_the_adapter(tmp_path):
+    """INITM, P2M, M2M, M2L, INITL, L2L, L2P of both kernel classes against K(t, s) * c summed over the sources; and the same
+    program built in the container around the reference's KernelTraits.hpp / INITM.hpp / INITL.hpp (oracle/_ref, when present)"""
+    exes = [_build(tmp_path, "traits_contract")]
+    ref = os.path.join(ROOT, "oracle", "_ref", "traits_contract_ref")
+    if os.path.exists(ref):
+        exes.append(ref)
+    for exe in exes:
+        r = subprocess.run([exe], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        vals = {ln.split()[0]: ln.split() for ln in r.stdout.splitlines()}
+        assert float(vals["laplace"][3]) < 2e-6 and float(vals["stokes"][3]) < 2e-6
+        assert vals["refused"] == ["refused", "1", "unsupported", "1"]
+        if exe == ref:
+            assert vals["traits"] == ["traits", "is_valid_fmm", "1", "1"]
+
+
 def test_adapter_compiles_and_reports_missing_device(tmp_path, gpu_available):
     exe = _build(tmp_path)
     if gpu_available:
