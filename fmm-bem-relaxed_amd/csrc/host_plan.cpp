@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <cmath>
 #include <thread>
 #include <cstdlib>
@@ -179,6 +180,18 @@ inline int level_of_key(uint64_t key) { return (63 - __builtin_clzll(key)) / 3; 
 
 template <class Code> struct CodedT { Code code; uint32_t idx; };
 
+// a few host threads over [0, n) in contiguous shares: body(begin, end, share)
+inline int host_threads(int64_t n, int64_t grain) {
+  return (int)std::max<int64_t>(1, std::min<int64_t>(std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency())), n / std::max<int64_t>(1, grain)));
+}
+template <class F>
+void par_shares(int nt, int64_t n, F&& body) {
+  if (nt <= 1) { body((int64_t)0, n, 0); return; }
+  std::vector<std::thread> pool;
+  for (int t = 0; t < nt; ++t) pool.emplace_back([&, t] { body(n * t / nt, n * (t + 1) / nt, t); });
+  for (auto& th : pool) th.join();
+}
+
 // Octree.hpp:617-692 on codes of L bits per dimension: BFS construction with stable 8-way bucketing per box, then the box
 // geometry (:334-355 through :109-113, :243-248).  Returns false when a box on level L still holds more than ncrit bodies.
 template <class Code>
@@ -188,16 +201,23 @@ bool build_tree(HostPlan& hp, unsigned L, const std::vector<double>& cen, double
   for (int k = 0; k < 3; ++k) hp.cell[k] = (ext_hi[k] - hp.pmin[k]) / std::ldexp(1.0, (int)L);
   // ---- Morton codes (Octree.hpp:118-129) ----
   std::vector<Coded> codes(n), scratch(n);
-  for (int64_t i = 0; i < n; ++i) {
-    Code s[3];
-    for (int k = 0; k < 3; ++k) {
-      double v = cen[3 * i + k];
-      v -= hp.pmin[k];
-      v /= hp.cell[k];
-      s[k] = (Code)(uint32_t)v;
+  const bool serial = n < (1 << 15) || (std::getenv("FMMBEM_TREE_SERIAL") && std::atoi(std::getenv("FMMBEM_TREE_SERIAL")) != 0);
+  par_shares(serial ? 1 : host_threads(n, 1 << 14), n, [&](int64_t i0, int64_t i1, int) {
+    for (int64_t i = i0; i < i1; ++i) {
+      Code s[3];
+      for (int k = 0; k < 3; ++k) {
+        double v = cen[3 * i + k];
+        v -= hp.pmin[k];
+        v /= hp.cell[k];
+        s[k] = (Code)(uint32_t)v;
+      }
+      codes[i] = {(Code)(spread3(s[0]) | (spread3(s[1]) << 1) | (spread3(s[2]) << 2)), (uint32_t)i};
     }
-    codes[i] = {(Code)(spread3(s[0]) | (spread3(s[1]) << 1) | (spread3(s[2]) << 2)), (uint32_t)i};
-  }
+  });
+  const bool trace_t = std::getenv("FMMBEM_BUILD_TRACE") != nullptr;
+  auto tt = std::chrono::steady_clock::now();
+  auto tmark = [&](const char* w) { if (!trace_t) return; const auto now = std::chrono::steady_clock::now(); std::fprintf(stderr, "  build_tree %-20s %8.2f ms\n", w, std::chrono::duration<double, std::milli>(now - tt).count()); tt = now; };
+  tmark("codes");
   std::vector<Code> key(1, (Code)1);
   hp.box_parent.assign(1, 0);
   hp.box_body_begin.assign(1, 0);
@@ -207,8 +227,109 @@ bool build_tree(HostPlan& hp, unsigned L, const std::vector<double>& cen, double
   hp.box_leaf.assign(1, 0);
   hp.box_level.assign(1, 0);
   hp.level_off.assign(1, 0);
+  {
+    // (room for the boxes: the appends below are the serial share of both forms)
+    const size_t guess = (size_t)(n / std::max(1u, ncrit / 4)) + 64;
+    key.reserve(guess);
+    for (auto* v : {&hp.box_parent, &hp.box_body_begin, &hp.box_body_end, &hp.box_child_begin, &hp.box_child_end, &hp.box_level}) v->reserve(guess);
+    hp.box_leaf.reserve(guess);
+  }
   int deepest = 0;
-  for (size_t k = 0; k < key.size(); ++k) {
+  if (!serial) {
+    // The same tree by a route a few threads can share.  The subdivision below is a most-significant-digit radix sort that stops
+    // at the leaves, every pass stable: a box's bodies end up (a) between the bodies of the boxes before and after it in Morton
+    // order and (b) in their ORIGINAL order among themselves.  So: sort all bodies by (code, index) once -- a stable
+    // least-significant-digit radix sort, the passes shared by the threads -- read the boxes off the sorted codes level by level
+    // (a box's children begin where the digit of the next level changes), and put every leaf's bodies back in index order.
+    const int nt = host_threads(n, 1 << 14);
+    {
+      const int total_bits = 3 * (int)L, digit = total_bits <= 32 ? 10 : 11, B = 1 << digit;
+      std::vector<int64_t> hist((size_t)nt * B);
+      for (int shift = 0; shift < total_bits; shift += digit) {
+        std::fill(hist.begin(), hist.end(), 0);
+        par_shares(nt, n, [&](int64_t i0, int64_t i1, int t) {
+          int64_t* h = hist.data() + (size_t)t * B;
+          for (int64_t i = i0; i < i1; ++i) ++h[(size_t)((codes[i].code >> shift) & (Code)(B - 1))];
+        });
+        int64_t run = 0;                               // bucket-major, then share: what keeps the pass stable
+        for (int b = 0; b < B; ++b)
+          for (int t = 0; t < nt; ++t) { const int64_t c = hist[(size_t)t * B + b]; hist[(size_t)t * B + b] = run; run += c; }
+        par_shares(nt, n, [&](int64_t i0, int64_t i1, int t) {
+          int64_t* h = hist.data() + (size_t)t * B;
+          for (int64_t i = i0; i < i1; ++i) scratch[(size_t)h[(size_t)((codes[i].code >> shift) & (Code)(B - 1))]++] = codes[i];
+        });
+        codes.swap(scratch);
+      }
+    }
+    tmark("radix sort");
+    // level (1 .. L) of the first octal digit in which body i differs from body i - 1; L + 1: the same finest cell
+    std::vector<uint8_t> dl(n, 0);
+    par_shares(nt, n, [&](int64_t i0, int64_t i1, int) {
+      for (int64_t i = std::max<int64_t>(i0, 1); i < i1; ++i) {
+        const Code x = codes[i].code ^ codes[i - 1].code;
+        dl[i] = x == 0 ? (uint8_t)(L + 1) : (uint8_t)(L - (unsigned)((sizeof(Code) == 8 ? 63 - __builtin_clzll((uint64_t)x) : 31 - __builtin_clz((uint32_t)x)) / 3));
+      }
+    });
+    tmark("digit levels");
+    struct Kids { int n; int start[8]; uint8_t oct[8]; };
+    std::vector<Kids> kids;
+    for (size_t lev_first = 0, lev_end = 1; lev_first < lev_end;) {     // the boxes [lev_first, lev_end) of one level
+      const int lev = hp.box_level[lev_first];
+      const size_t nbx = lev_end - lev_first;
+      kids.assign(nbx, Kids{});
+      std::atomic<bool> too_deep{false};
+      // shares of boxes with about the same number of bodies
+      const int ntl = nbx < 64 ? 1 : nt;
+      par_shares(ntl, (int64_t)nbx, [&](int64_t k0, int64_t k1, int) {
+        for (int64_t kk = k0; kk < k1; ++kk) {
+          const size_t k = lev_first + (size_t)kk;
+          const int b0 = hp.box_body_begin[k], b1 = hp.box_body_end[k];
+          Kids& q = kids[(size_t)kk];
+          q.n = 0;
+          if ((unsigned)(b1 - b0) <= ncrit) continue;
+          if (lev >= (int)L) { too_deep = true; continue; }
+          const unsigned shift = 3 * (L - lev - 1);
+          q.start[0] = b0; q.oct[0] = (uint8_t)((codes[b0].code >> shift) & 7); q.n = 1;
+          for (int i = b0 + 1; i < b1; ++i)
+            if (dl[i] == lev + 1) { q.start[q.n] = i; q.oct[q.n] = (uint8_t)((codes[i].code >> shift) & 7); ++q.n; }
+        }
+      });
+      if (too_deep) return false;
+      for (size_t kk = 0; kk < nbx; ++kk) {            // the children, numbered as the queue of the serial form numbers them
+        const size_t k = lev_first + kk;
+        const Kids& q = kids[kk];
+        if (q.n == 0) { hp.box_leaf[k] = 1; continue; }
+        hp.box_child_begin[k] = (int)key.size();
+        for (int c = 0; c < q.n; ++c) {
+          const Code kc = (Code)((key[k] << 3) | (Code)q.oct[c]);
+          const int l = level_of_key(kc);
+          if (l > deepest) { deepest = l; hp.level_off.push_back((int)key.size()); }
+          key.push_back(kc);
+          hp.box_parent.push_back((int)k);
+          hp.box_body_begin.push_back(q.start[c]);
+          hp.box_body_end.push_back(c + 1 < q.n ? q.start[c + 1] : hp.box_body_end[k]);
+          hp.box_child_begin.push_back(0);
+          hp.box_child_end.push_back(0);
+          hp.box_leaf.push_back(0);
+          hp.box_level.push_back(l);
+        }
+        hp.box_child_end[k] = (int)key.size();
+      }
+      lev_first = lev_end;
+      lev_end = key.size();
+    }
+    tmark("boxes by level");
+    // a leaf's bodies in their original order (what the stable passes of the serial form leave)
+    {
+      const int64_t nbx = (int64_t)key.size();
+      par_shares(nt, nbx, [&](int64_t k0, int64_t k1, int) {
+        for (int64_t k = k0; k < k1; ++k)
+          if (hp.box_leaf[k])
+            std::sort(codes.begin() + hp.box_body_begin[k], codes.begin() + hp.box_body_end[k], [](const Coded& a, const Coded& b) { return a.idx < b.idx; });
+      });
+    }
+  }
+  for (size_t k = 0; serial && k < key.size(); ++k) {
     const int b0 = hp.box_body_begin[k], b1 = hp.box_body_end[k];
     if ((unsigned)(b1 - b0) <= ncrit) { hp.box_leaf[k] = 1; continue; }
     const int lev = hp.box_level[k];
@@ -238,6 +359,7 @@ bool build_tree(HostPlan& hp, unsigned L, const std::vector<double>& cen, double
     }
     hp.box_child_end[k] = (int)key.size();
   }
+  tmark("leaf order / serial subdivision");
   hp.nboxes = (int)key.size();
   hp.level_off.push_back(hp.nboxes);
   hp.nlevels = (int)hp.level_off.size() - 1;
@@ -264,6 +386,7 @@ bool build_tree(HostPlan& hp, unsigned L, const std::vector<double>& cen, double
     }
     hp.box_side[b] = root_side / std::ldexp(1.0, lev);
   }
+  tmark("perm + geometry");
   return true;
 }
 }  // namespace
@@ -316,18 +439,26 @@ std::string HostPlan::build(const HostOptions& o, int64_t n_panels, const double
 
   // ---- panel centroids in original order (tree is built on them, LaplaceSphericalBEM.hpp:99) ----
   std::vector<double> cen(3 * n);
-  for (int64_t i = 0; i < n; ++i)
-    for (int k = 0; k < 3; ++k)
-      cen[3 * i + k] = (vertices[9 * i + k] + vertices[9 * i + 3 + k] + vertices[9 * i + 6 + k]) / 3;
-
-  // ---- bounding cube, inflated by 1+1e-6 (Octree.hpp:67-79) ----
+  // ---- bounding cube, inflated by 1+1e-6 (Octree.hpp:67-79) ----  (minima and maxima: the same whatever the order)
   double lo[3], hi[3];
-  for (int k = 0; k < 3; ++k) lo[k] = hi[k] = cen[k];
-  for (int64_t i = 1; i < n; ++i)
-    for (int k = 0; k < 3; ++k) {
-      lo[k] = std::min(lo[k], cen[3 * i + k]);
-      hi[k] = std::max(hi[k], cen[3 * i + k]);
-    }
+  {
+    const int nt = host_threads(n, 1 << 15);
+    std::vector<double> part((size_t)nt * 6);
+    par_shares(nt, n, [&](int64_t i0, int64_t i1, int t) {
+      double l[3], h[3];
+      for (int64_t i = i0; i < i1; ++i)
+        for (int k = 0; k < 3; ++k) {
+          const double c = (vertices[9 * i + k] + vertices[9 * i + 3 + k] + vertices[9 * i + 6 + k]) / 3;
+          cen[3 * i + k] = c;
+          if (i == i0) l[k] = h[k] = c;
+          else { l[k] = std::min(l[k], c); h[k] = std::max(h[k], c); }
+        }
+      for (int k = 0; k < 3; ++k) { part[(size_t)t * 6 + k] = l[k]; part[(size_t)t * 6 + 3 + k] = h[k]; }
+    });
+    for (int k = 0; k < 3; ++k) { lo[k] = part[k]; hi[k] = part[3 + k]; }
+    for (int t = 1; t < nt; ++t)
+      for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], part[(size_t)t * 6 + k]); hi[k] = std::max(hi[k], part[(size_t)t * 6 + 3 + k]); }
+  }
   const double ext = std::max({std::fabs(hi[0] - lo[0]), std::fabs(hi[1] - lo[1]), std::fabs(hi[2] - lo[2])});
   for (int k = 0; k < 3; ++k) {
     hi[k] = std::max(hi[k], lo[k] + ext * (1 + 1e-6));
@@ -739,19 +870,28 @@ void HostPlan::build_rot_items() {
   rot_item_ptr_long.assign(1, 0);
   rot_passes = rot_passes_long = 0;
   std::vector<int> tg;                                 // owned targets with sources, box order
+  // The pairs of the rotation kernel are the M2L pairs of the owned targets that hold a local expansion, in box order.  Where
+  // that is EVERY pair of the CSR lists (any plan that is not a shard), the lists are not copied: rot_alias, and the device
+  // arrays are shared too (plan.hip) -- three arrays of 4 bytes per pair less to build and to upload (~10 M pairs at N = 1M)
+  rot_alias = true;
+  for (int b = 0; b < nboxes && rot_alias; ++b)
+    if (m2l_ptr[b + 1] > m2l_ptr[b] && !(has_L[b] && owned_L[b])) rot_alias = false;
+  int64_t n_pairs = 0;
   for (int b = 0; b < nboxes; ++b) {
     if (!(has_L[b] && owned_L[b])) continue;
     if (m2l_ptr[b + 1] == m2l_ptr[b]) { rot_empty.push_back(b); continue; }
     tg.push_back(b);
-    for (int i = m2l_ptr[b]; i < m2l_ptr[b + 1]; ++i) { rot_src.push_back(m2l_src[i]); rot_cls.push_back(m2l_cls[i]); rot_tgt.push_back(b); }
+    n_pairs += m2l_ptr[b + 1] - m2l_ptr[b];
+    if (!rot_alias)
+      for (int i = m2l_ptr[b]; i < m2l_ptr[b + 1]; ++i) { rot_src.push_back(m2l_src[i]); rot_cls.push_back(m2l_cls[i]); rot_tgt.push_back(b); }
   }
-  const int64_t want = (int64_t)rot_src.size() / ((int64_t)kLanes * kItemsWanted);
+  const int64_t want = n_pairs / ((int64_t)kLanes * kItemsWanted);
   const int nominal = kLanes * (int)std::min<int64_t>(kRotItemPasses, std::max<int64_t>(1, want));
   std::vector<int> len(tg.size());
   for (size_t i = 0; i < tg.size(); ++i) len[i] = m2l_ptr[tg[i] + 1] - m2l_ptr[tg[i]];
   rot_item_ptr.clear();
   rot_passes = cut_rot_items(len, nominal, 0, rot_item_ptr);
-  const int64_t all_passes = ((int64_t)rot_src.size() + kLanes - 1) / kLanes;
+  const int64_t all_passes = (n_pairs + kLanes - 1) / kLanes;
   // ONE round of items over the SIMDs where items of at most kRotLongMax passes cover the list (a shard of a large operator, or a
   // small operator: every item's first pass runs without operands fetched ahead, so fewer, longer items; one rank of eight of the
   // bench workload: M2L 0.094 -> 0.085 ms, one of four 0.154 -> 0.146), two even rounds above that

@@ -122,6 +122,7 @@ struct HostPlan {
   // work list of the rotation M2L kernel (kernels_m2l_rot.hip): the owned pairs, whole targets packed into ITEMS of at most
   // 64 pairs (one wavefront pass, lane = pair); a target with more than 64 sources is an item of its own (several passes)
   std::vector<int> rot_src, rot_cls, rot_tgt, rot_item_ptr, rot_empty;   // rot_empty: owned targets with no source at all
+  bool rot_alias = false;              // the pair list IS m2l_src / m2l_cls (targets by m2l_ptr): rot_src / rot_cls / rot_tgt stay empty
   int64_t rot_passes = 0;
   // the same pairs cut into LONG items for the orders that run one wavefront per SIMD (p >= 9): there the chip holds 1 024
   // wavefronts at a time, the first pass of an item stands in the open, and two even rounds of long items beat seven of short ones

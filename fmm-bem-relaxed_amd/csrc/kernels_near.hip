@@ -112,19 +112,18 @@ __constant__ double kFine[16][4] = {
 
 // One near-matrix entry: target centroid t with BC flag, source panel j (tree index).
 // kernel/LaplaceSphericalBEM.hpp:273-297 -> eval_G (:159-205) / eval_dGdn (:208-264)
-__device__ inline double laplace_entry(const DevicePlan& d, V3 t, int tbc, int64_t j) {
+// In two parts, so that the assembly can run the expensive regime with full wavefronts: laplace_entry_far gives the entry of a
+// pair in the far regime (the K stored Gauss points; also the 2 pi of a NORMAL_DERIV self pair) or says `deferred`;
+// laplace_entry_near gives the near regime (semi-analytic G, :166-178; the 16-point rule for dG/dn, :222-243).
+__device__ inline double laplace_entry_far(const DevicePlan& d, V3 t, int tbc, int64_t j, bool& deferred) {
   const int64_t N = d.n;
   const V3 c = {d.cx[j], d.cy[j], d.cz[j]};
   const double A = d.area[j];
   const double dist = norm(sub(t, c));
   const bool nearby = sqrt(2 * A) / dist >= 0.5;
+  deferred = false;
   if (tbc == 0) {                                   // POTENTIAL target: int G
-    if (nearby) {
-      const V3 v0 = {d.vert[0 * N + j], d.vert[1 * N + j], d.vert[2 * N + j]};
-      const V3 v1 = {d.vert[3 * N + j], d.vert[4 * N + j], d.vert[5 * N + j]};
-      const V3 v2 = {d.vert[6 * N + j], d.vert[7 * N + j], d.vert[8 * N + j]};
-      return semi_analytic_G(v0, v1, v2, t);
-    }
+    if (nearby) { deferred = true; return 0; }
     double r = 0;
     for (int q = 0; q < d.nq; ++q) {
       const V3 qp = {d.quad[(q * 3 + 0) * N + j], d.quad[(q * 3 + 1) * N + j], d.quad[(q * 3 + 2) * N + j]};
@@ -134,22 +133,9 @@ __device__ inline double laplace_entry(const DevicePlan& d, V3 t, int tbc, int64
   }
   // NORMAL_DERIV target: int dG/dn
   if (dist < 1e-8) return 2 * M_PI;
+  if (nearby) { deferred = true; return 0; }
   const V3 nrm = {d.nx[j], d.ny[j], d.nz[j]};
   double r = 0;
-  if (nearby) {
-    const V3 v0 = {d.vert[0 * N + j], d.vert[1 * N + j], d.vert[2 * N + j]};
-    const V3 v1 = {d.vert[3 * N + j], d.vert[4 * N + j], d.vert[5 * N + j]};
-    const V3 v2 = {d.vert[6 * N + j], d.vert[7 * N + j], d.vert[8 * N + j]};
-    for (int q = 0; q < 16; ++q) {
-      const V3 pt = {v0.x * kFine[q][0] + v1.x * kFine[q][1] + v2.x * kFine[q][2],
-                     v0.y * kFine[q][0] + v1.y * kFine[q][1] + v2.y * kFine[q][2],
-                     v0.z * kFine[q][0] + v1.z * kFine[q][1] + v2.z * kFine[q][2]};
-      const V3 dx = sub(pt, t);
-      const double r2 = dx.x * dx.x + dx.y * dx.y + dx.z * dx.z;
-      r += kFine[q][3] * A * (dx.x * nrm.x + dx.y * nrm.y + dx.z * nrm.z) / (r2 * sqrt(r2));
-    }
-    return r;
-  }
   for (int q = 0; q < d.nq; ++q) {
     const V3 qp = {d.quad[(q * 3 + 0) * N + j], d.quad[(q * 3 + 1) * N + j], d.quad[(q * 3 + 2) * N + j]};
     const V3 dx = sub(qp, t);
@@ -157,6 +143,30 @@ __device__ inline double laplace_entry(const DevicePlan& d, V3 t, int tbc, int64
     r += d.qw[q] * A * (dx.x * nrm.x + dx.y * nrm.y + dx.z * nrm.z) / (r2 * sqrt(r2));
   }
   return r;
+}
+__device__ inline double laplace_entry_near(const DevicePlan& d, V3 t, int tbc, int64_t j) {
+  const int64_t N = d.n;
+  const V3 v0 = {d.vert[0 * N + j], d.vert[1 * N + j], d.vert[2 * N + j]};
+  const V3 v1 = {d.vert[3 * N + j], d.vert[4 * N + j], d.vert[5 * N + j]};
+  const V3 v2 = {d.vert[6 * N + j], d.vert[7 * N + j], d.vert[8 * N + j]};
+  if (tbc == 0) return semi_analytic_G(v0, v1, v2, t);
+  const double A = d.area[j];
+  const V3 nrm = {d.nx[j], d.ny[j], d.nz[j]};
+  double r = 0;
+  for (int q = 0; q < 16; ++q) {
+    const V3 pt = {v0.x * kFine[q][0] + v1.x * kFine[q][1] + v2.x * kFine[q][2],
+                   v0.y * kFine[q][0] + v1.y * kFine[q][1] + v2.y * kFine[q][2],
+                   v0.z * kFine[q][0] + v1.z * kFine[q][1] + v2.z * kFine[q][2]};
+    const V3 dx = sub(pt, t);
+    const double r2 = dx.x * dx.x + dx.y * dx.y + dx.z * dx.z;
+    r += kFine[q][3] * A * (dx.x * nrm.x + dx.y * nrm.y + dx.z * nrm.z) / (r2 * sqrt(r2));
+  }
+  return r;
+}
+__device__ inline double laplace_entry(const DevicePlan& d, V3 t, int tbc, int64_t j) {
+  bool deferred;
+  const double v = laplace_entry_far(d, t, tbc, j, deferred);
+  return deferred ? laplace_entry_near(d, t, tbc, j) : v;
 }
 
 // Column staging shared by near_assemble and near_spmv.  The columns of a target leaf's row block are
@@ -187,9 +197,19 @@ __device__ inline int column_to_row(const Runs& r, int c) {
 
 // ---------------------------------------------------------------------------------------------
 // near_assemble: workgroups stride over the owned target leaves, one thread per matrix entry.
+// The near regime is 4.5 % of the entries and a hundred times the work of the others (semi_analytic_G: three edges x a 5-point
+// polar rule of logarithms and arc tangents); taken where it is met, nearly every wavefront holds a few such lanes and all 64
+// wait for them (46 ms at N = 1M, the far regime alone is ~4).  So a pass over kAsmBatch entries per thread evaluates the far
+// regime in place and QUEUES the near-regime entries in LDS; the workgroup then takes the queue with full wavefronts.  Same
+// functions per entry, same values.
 // ---------------------------------------------------------------------------------------------
+constexpr int kAsmBatch = 8;                          // entries per thread in one pass
 __global__ __launch_bounds__(256) void near_assemble_kernel(DevicePlan d) {
   extern __shared__ int lds_i[];
+  // the queue is drained when it holds a round of 256 or more (and at the end of a chunk): ~90 entries join per pass, taken pass by
+  // pass they would fill 36 % of the lanes.  Room for what is left below a round plus one pass in which every entry joins
+  __shared__ int queue[256 * (kAsmBatch + 1)];
+  __shared__ int queued;
   int* colmap = lds_i;                               // [kAsmChunk]
   int* run_row0 = lds_i + kAsmChunk;                 // [max_runs]
   int* run_off = run_row0 + d.max_runs;              // [max_runs]
@@ -203,16 +223,35 @@ __global__ __launch_bounds__(256) void near_assemble_kernel(DevicePlan d) {
       const int cw = stride - c0 < kAsmChunk ? stride - c0 : kAsmChunk;
       if (c0) __syncthreads();
       for (int c = threadIdx.x; c < cw; c += blockDim.x) colmap[c] = c0 + c < ncols ? column_to_row(runs, c0 + c) : -1;
+      if (threadIdx.x == 0) queued = 0;
       __syncthreads();
       const int total = nrows * cw;
-      for (int e = threadIdx.x; e < total; e += blockDim.x) {
-        const int r = e / cw, c = e - r * cw;
-        double v = 0;                                 // padding column (odd ncols) stays zero
-        if (colmap[c] >= 0) {
-          const int64_t i = row0 + r;
-          v = laplace_entry(d, V3{d.cx[i], d.cy[i], d.cz[i]}, d.bc[i], colmap[c]);
+      for (int e0 = 0; e0 < total; e0 += 256 * kAsmBatch) {
+        for (int u = 0; u < kAsmBatch; ++u) {
+          const int e = e0 + u * 256 + (int)threadIdx.x;
+          if (e >= total) break;
+          const int r = e / cw, c = e - r * cw;
+          double v = 0;                               // padding column (odd ncols) stays zero
+          bool deferred = false;
+          if (colmap[c] >= 0) {
+            const int64_t i = row0 + r;
+            v = laplace_entry_far(d, V3{d.cx[i], d.cy[i], d.cz[i]}, d.bc[i], colmap[c], deferred);
+          }
+          if (deferred) queue[atomicAdd(&queued, 1)] = e;
+          else blk[(int64_t)r * stride + c0 + c] = v;
         }
-        blk[(int64_t)r * stride + c0 + c] = v;
+        __syncthreads();
+        const int nq = queued;
+        __syncthreads();                              // everybody has read the count: the next pass may add to it
+        if (nq < 256 && e0 + 256 * kAsmBatch < total) continue;
+        for (int k = threadIdx.x; k < nq; k += 256) {
+          const int e = queue[k];
+          const int r = e / cw, c = e - r * cw;
+          const int64_t i = row0 + r;
+          blk[(int64_t)r * stride + c0 + c] = laplace_entry_near(d, V3{d.cx[i], d.cy[i], d.cz[i]}, d.bc[i], colmap[c]);
+        }
+        if (threadIdx.x == 0) queued = 0;              // (read by all before the barrier above; written again only after the one below)
+        __syncthreads();
       }
     }
     __syncthreads();

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <future>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -78,6 +79,69 @@ double now_ms() {
 }
 
 }  // namespace
+
+// the class tables of a plan are a few thousand independent rows of harmonics: a few threads take them in contiguous shares
+template <class F>
+static void parallel_rows(int64_t n, int64_t min_per_thread, F&& body) {
+  const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency())), n / std::max<int64_t>(1, min_per_thread)));
+  if (nt <= 1) { body((int64_t)0, n); return; }
+  std::vector<std::thread> pool;
+  for (int t = 0; t < nt; ++t) pool.emplace_back([&, t] { body(n * t / nt, n * (t + 1) / nt); });
+  for (auto& th : pool) th.join();
+}
+
+// Tables that depend on the expansion ORDER alone -- the constant streams of the three rotation kernels, the lanes' tables of the
+// one-pair-per-wavefront shifts, the lane and scatter maps of the double-sum M2L: ~30 ms of host arithmetic that used to sit on
+// every plan's critical path.  Built once per process, on a thread of their own that fmmbem_plan_create starts BEFORE it builds
+// the tree; to_device waits for them where it uploads them.
+struct OrderTables {
+  std::vector<double> rot_all, ups, dns;
+  int rot_off[kRotPmax] = {}, shift_off[kRotPmax] = {};
+  std::vector<double> urc, uxc, drc, dxc;
+  std::vector<int32_t> urs, uxs, drs, dxs;
+  size_t sl_rot_off[kShiftLanesPmax + 1] = {}, sl_ax_off[kShiftLanesPmax + 1] = {};
+  std::vector<int32_t> lanes, scat;
+  int scat_off[kPmax] = {};
+  bool lanes_ok = true;
+};
+static std::shared_ptr<const OrderTables> build_order_tables() {
+  auto t = std::make_shared<OrderTables>();
+  std::vector<double> one;
+  for (int q = 1; q <= kRotPmax; ++q) {
+    t->rot_off[q - 1] = (int)t->rot_all.size();
+    build_rot_stream(q, one); t->rot_all.insert(t->rot_all.end(), one.begin(), one.end());
+    t->shift_off[q - 1] = (int)t->ups.size();
+    build_rot_stream(q, one, kRotM2M); t->ups.insert(t->ups.end(), one.begin(), one.end());
+    // both shifts have the same number of axial terms: one offset table serves the two streams
+    build_rot_stream(q, one, kRotL2L); t->dns.insert(t->dns.end(), one.begin(), one.end());
+  }
+  ShiftLaneTables lt;
+  for (int q = 1; q <= kShiftLanesPmax; ++q) {
+    t->sl_rot_off[q] = t->urc.size(); t->sl_ax_off[q] = t->uxc.size();
+    build_shift_lane_tables(q, kRotM2M, lt);
+    t->urc.insert(t->urc.end(), lt.rot_c.begin(), lt.rot_c.end()); t->urs.insert(t->urs.end(), lt.rot_s.begin(), lt.rot_s.end());
+    t->uxc.insert(t->uxc.end(), lt.ax_c.begin(), lt.ax_c.end()); t->uxs.insert(t->uxs.end(), lt.ax_s.begin(), lt.ax_s.end());
+    build_shift_lane_tables(q, kRotL2L, lt);
+    t->drc.insert(t->drc.end(), lt.rot_c.begin(), lt.rot_c.end()); t->drs.insert(t->drs.end(), lt.rot_s.begin(), lt.rot_s.end());
+    t->dxc.insert(t->dxc.end(), lt.ax_c.begin(), lt.ax_c.end()); t->dxs.insert(t->dxs.end(), lt.ax_s.begin(), lt.ax_s.end());
+  }
+  std::vector<int32_t> m;
+  for (int p = 1; p <= kPmax; ++p) {
+    if (!m2l_lane_map(p, m)) t->lanes_ok = false;
+    t->lanes.insert(t->lanes.end(), m.begin(), m.end());
+    m2l_scatter_map(p, m);
+    t->scat_off[p - 1] = (int)t->scat.size();
+    t->scat.insert(t->scat.end(), m.begin(), m.end());
+  }
+  return t;
+}
+static std::shared_future<std::shared_ptr<const OrderTables>> order_tables() {
+  static std::mutex mu;
+  static std::shared_future<std::shared_ptr<const OrderTables>> fut;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!fut.valid()) fut = std::async(std::launch::async, build_order_tables).share();
+  return fut;
+}
 
 // What a plan holds that depends on the GEOMETRY and the options only -- the octree, the permutation, every pair list, the work
 // items and run descriptors, the panels' points, the operator tables -- on the host and in HBM.  Plans of the same panels that
@@ -229,6 +293,13 @@ struct fmmbem_plan {
 };
 
 #define TRY(expr) do { int rc_ = (expr); if (rc_ != FMMBEM_OK) return rc_; } while (0)
+
+// rot_tgt of a plan whose rotation pairs are its CSR lists: pair i belongs to the box b with m2l_ptr[b] <= i < m2l_ptr[b + 1]
+__global__ void expand_csr_targets_kernel(const int* __restrict__ ptr, int nboxes, int* __restrict__ tgt) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nboxes) return;
+  for (int i = ptr[b]; i < ptr[b + 1]; ++i) tgt[i] = b;
+}
 
 int fmmbem_plan::to_device() {
   int ndev = 0;
@@ -689,14 +760,10 @@ int fmmbem_plan::to_device() {
         l2l_rot.push_back(sr);
       }
       TRY(upload(rs, &dn_rsrc)); TRY(upload(rc, &dn_rcls)); TRY(upload(rt, &dn_rtgt)); TRY(upload(ri, &dn_ritem));
-      std::vector<double> ups, dns, one;
-      for (int q = 1; q <= kRotPmax; ++q) {
-        shift_stream_off[q - 1] = (int)ups.size();
-        build_rot_stream(q, one, kRotM2M); ups.insert(ups.end(), one.begin(), one.end());
-        // both operators have the same number of axial terms: one offset table serves the two streams
-        build_rot_stream(q, one, kRotL2L); dns.insert(dns.end(), one.begin(), one.end());
-      }
-      TRY(upload(ups, &up_stream)); TRY(upload(dns, &dn_stream));
+      const std::shared_ptr<const OrderTables> otp = order_tables().get();      // (built on a thread of their own since plan_create began)
+      const OrderTables& ot = *otp;
+      for (int q = 1; q <= kRotPmax; ++q) shift_stream_off[q - 1] = ot.shift_off[q - 1];
+      TRY(upload(ot.ups, &up_stream)); TRY(upload(ot.dns, &dn_stream));
       {                                                // one pair per wavefront: class tables and the lanes' tables per order
         const int nclass = (int)up_rec_h.size() / 8, cs = sl_class_doubles(pm);
         std::vector<double> cu((size_t)nclass * cs), cd((size_t)nclass * cs);
@@ -705,20 +772,9 @@ int fmmbem_plan::to_device() {
           sl_class_table(dn_rec_h.data() + (size_t)c * 8, pm, kRotL2L, cd.data() + (size_t)c * cs);
         }
         TRY(upload(cu, &sl_up_class)); TRY(upload(cd, &sl_dn_class));
-        std::vector<double> urc, uxc, drc, dxc;
-        std::vector<int32_t> urs, uxs, drs, dxs;
-        ShiftLaneTables t;
-        for (int q = 1; q <= kShiftLanesPmax && q <= pm; ++q) {
-          sl_rot_off[q] = urc.size(); sl_ax_off[q] = uxc.size();
-          build_shift_lane_tables(q, kRotM2M, t);
-          urc.insert(urc.end(), t.rot_c.begin(), t.rot_c.end()); urs.insert(urs.end(), t.rot_s.begin(), t.rot_s.end());
-          uxc.insert(uxc.end(), t.ax_c.begin(), t.ax_c.end()); uxs.insert(uxs.end(), t.ax_s.begin(), t.ax_s.end());
-          build_shift_lane_tables(q, kRotL2L, t);
-          drc.insert(drc.end(), t.rot_c.begin(), t.rot_c.end()); drs.insert(drs.end(), t.rot_s.begin(), t.rot_s.end());
-          dxc.insert(dxc.end(), t.ax_c.begin(), t.ax_c.end()); dxs.insert(dxs.end(), t.ax_s.begin(), t.ax_s.end());
-        }
-        TRY(upload(urc, &sl_up_rc)); TRY(upload(urs, &sl_up_rs)); TRY(upload(uxc, &sl_up_xc)); TRY(upload(uxs, &sl_up_xs));
-        TRY(upload(drc, &sl_dn_rc)); TRY(upload(drs, &sl_dn_rs)); TRY(upload(dxc, &sl_dn_xc)); TRY(upload(dxs, &sl_dn_xs));
+        for (int q = 1; q <= kShiftLanesPmax; ++q) { sl_rot_off[q] = ot.sl_rot_off[q]; sl_ax_off[q] = ot.sl_ax_off[q]; }
+        TRY(upload(ot.urc, &sl_up_rc)); TRY(upload(ot.urs, &sl_up_rs)); TRY(upload(ot.uxc, &sl_up_xc)); TRY(upload(ot.uxs, &sl_up_xs));
+        TRY(upload(ot.drc, &sl_dn_rc)); TRY(upload(ot.drs, &sl_dn_rs)); TRY(upload(ot.dxc, &sl_dn_xc)); TRY(upload(ot.dxs, &sl_dn_xs));
         if (const char* e = std::getenv("FMMBEM_SHIFT_LANES")) shift_lanes = std::atoi(e) != 0;
         if (const char* e = std::getenv("FMMBEM_SHIFT_LANES_MAX")) shift_lanes_max = std::atoi(e);
       }
@@ -752,12 +808,15 @@ int fmmbem_plan::to_device() {
     d.n_m2l_tgt = (int)tgt.size(); d.n_mh = (int)mh.size();
     TRY(upload(tgt, &d.m2l_tgt)); TRY(upload(mh, &d.mh_box));
     TRY(upload(hp.m2l_ptr, &d.m2l_ptr)); TRY(upload(hp.m2l_src, &d.m2l_src)); TRY(upload(hp.m2l_cls, &d.m2l_cls));
+    mark("m2l lists upload");
     n_classes = (int64_t)hp.m2l_class_rep.size() / 2;
     const int R = 2 * pm;
     d.g_max = m2l_entries(pm);
     std::vector<double> gtab((size_t)n_classes * d.g_max);
-    std::vector<cplx> ztab((size_t)n_classes * pm), h;
-    for (int64_t c = 0; c < n_classes; ++c) {
+    std::vector<cplx> ztab((size_t)n_classes * pm);
+    parallel_rows(n_classes, 64, [&](int64_t c_begin, int64_t c_end) {
+    std::vector<cplx> h;
+    for (int64_t c = c_begin; c < c_end; ++c) {
       // translation = c_target - c_source (executor/M2L.hpp:40), rebuilt from the exact integer class
       // vector (half-cell units) so that the table does not depend on which pair was seen first
       // (shards of one operator must produce bit-identical rows).
@@ -773,27 +832,34 @@ int fmmbem_plan::to_device() {
           out[r * (r + 1) / 2 + cc] = h[(size_t)r * (r + 1) / 2 + cc].real() * kEps / T.A[r * r + r + cc];
       for (int m = 0; m < pm; ++m) ztab[(size_t)c * pm + m] = i_pow(m) * std::exp(cplx(0, 1) * double(m * sp.beta));
     }
+    });
     const cplx* pz = nullptr;
     TRY(upload(gtab, &d.m2l_g));
     TRY(upload(ztab, &pz));
     d.m2l_z = reinterpret_cast<const double2*>(pz);
     // lane -> output maps and table -> LDS scatter maps of the M2L kernel, every order up to p_max
-    std::vector<int32_t> lanes, scat, one;
-    for (int p = 1; p <= kPmax; ++p) {
-      if (!m2l_lane_map(p, one)) return fail(FMMBEM_ERR_INVALID, "internal: M2L lane dealing failed");
-      lanes.insert(lanes.end(), one.begin(), one.end());
-      m2l_scatter_map(p, one);
-      d.m2l_scat_off[p - 1] = (int)scat.size();
-      scat.insert(scat.end(), one.begin(), one.end());
-    }
-    TRY(upload(lanes, &d.m2l_lane)); TRY(upload(scat, &d.m2l_scat));
+    const std::shared_ptr<const OrderTables> otp = order_tables().get();
+    if (!otp->lanes_ok) return fail(FMMBEM_ERR_INVALID, "internal: M2L lane dealing failed");
+    for (int p = 1; p <= kPmax; ++p) d.m2l_scat_off[p - 1] = otp->scat_off[p - 1];
+    TRY(upload(otp->lanes, &d.m2l_lane)); TRY(upload(otp->scat, &d.m2l_scat));
   }
 
+  mark("m2l class tables");
   // M2L by rotation (kernels_m2l_rot.hip): the owned pairs in CSR order by target, cut into items; class records; constants
   {
     d.n_rot_items = (int)hp.rot_item_ptr.size() - 1;
     d.n_rot_empty = (int)hp.rot_empty.size();
-    TRY(upload(hp.rot_src, &d.rot_src)); TRY(upload(hp.rot_cls, &d.rot_cls)); TRY(upload(hp.rot_tgt, &d.rot_tgt));
+    if (hp.rot_alias) {
+      // one pair list for both M2L kernels; the target of pair i is the box whose CSR range holds i (written on the device)
+      d.rot_src = d.m2l_src; d.rot_cls = d.m2l_cls;
+      int* tgt = nullptr;
+      TRY(alloc(hp.m2l_src.size(), &tgt, false));
+      if (nb > 0) hipLaunchKernelGGL(expand_csr_targets_kernel, dim3((nb + 255) / 256), dim3(256), 0, own_stream, d.m2l_ptr, nb, tgt);
+      HIP_TRY(hipGetLastError());
+      d.rot_tgt = tgt;
+    } else {
+      TRY(upload(hp.rot_src, &d.rot_src)); TRY(upload(hp.rot_cls, &d.rot_cls)); TRY(upload(hp.rot_tgt, &d.rot_tgt));
+    }
     TRY(upload(hp.rot_item_ptr, &d.rot_item_ptr)); TRY(upload(hp.rot_empty, &d.rot_empty));
     d.n_rot_items_long = (int)hp.rot_item_ptr_long.size() - 1;
     TRY(upload(hp.rot_item_ptr_long, &d.rot_item_ptr_long));
@@ -804,16 +870,12 @@ int fmmbem_plan::to_device() {
       rot_record(tr, rec.data() + (size_t)c * 8);
     }
     TRY(upload(rec, &d.rot_cls_rec));
-    std::vector<double> all, one;
-    for (int p = 1; p <= kRotPmax; ++p) {
-      d.rot_tab_off[p - 1] = (int)all.size();
-      build_rot_stream(p, one);
-      all.insert(all.end(), one.begin(), one.end());
-    }
-    TRY(upload(all, &d.rot_tab));
+    const std::shared_ptr<const OrderTables> otp = order_tables().get();
+    for (int p = 1; p <= kRotPmax; ++p) d.rot_tab_off[p - 1] = otp->rot_off[p - 1];
+    TRY(upload(otp->rot_all, &d.rot_tab));
   }
 
-  mark("m2l class tables");
+  mark("rotation lists");
   shared->on_device = true;
   shared->device = opts.device;
   return to_device_bc_end();
@@ -1567,6 +1629,7 @@ int fmmbem_plan_create(const fmmbem_options* opts, size_t n_panels, const double
       return multi_create(opts, devices, n_panels, vertices, bc, out);
     }
   }
+  if (!opts->host_only) (void)order_tables();             // the order tables start building now, beside the tree
   uint64_t fp[2] = {0, 0};
   const bool share_on = !opts->host_only && !(std::getenv("FMMBEM_PLAN_SHARE") && std::atoi(std::getenv("FMMBEM_PLAN_SHARE")) == 0);
   if (share_on) {
@@ -1902,7 +1965,13 @@ int fmmbem_plan_get_pairs(const fmmbem_plan* plan, int which, int32_t* out, int6
         for (int c = h.box_child_begin[par]; c < h.box_child_end[par]; ++c) { flat.push_back(c); flat.push_back(par); }
       break;
     case 3: for (int c : h.l2l_children) { flat.push_back(h.box_parent[c]); flat.push_back(c); } break;
-    case 4: for (size_t i = 0; i < h.rot_src.size(); ++i) { flat.push_back(h.rot_src[i]); flat.push_back(h.rot_tgt[i]); } break;
+    case 4:
+      if (h.rot_alias) {
+        for (int b = 0; b < h.nboxes; ++b)
+          for (int i = h.m2l_ptr[b]; i < h.m2l_ptr[b + 1]; ++i) { flat.push_back(h.m2l_src[i]); flat.push_back(b); }
+      } else
+        for (size_t i = 0; i < h.rot_src.size(); ++i) { flat.push_back(h.rot_src[i]); flat.push_back(h.rot_tgt[i]); }
+      break;
     case 5: for (size_t i = 0; i + 1 < h.rot_item_ptr.size(); ++i) { flat.push_back(h.rot_item_ptr[i]); flat.push_back(h.rot_item_ptr[i + 1]); } break;
     case 6: for (size_t i = 0; i + 1 < h.rot_item_ptr_long.size(); ++i) { flat.push_back(h.rot_item_ptr_long[i]); flat.push_back(h.rot_item_ptr_long[i + 1]); } break;
     default: return fail(FMMBEM_ERR_INVALID, "which must be 0..6");

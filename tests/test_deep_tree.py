@@ -87,3 +87,36 @@ def test_deep_tree_stokes_and_shards(fb, oracle_mod):
         part.close()
     assert np.array_equal(total, y)
     plan.close()
+
+
+@pytest.mark.parametrize("case", ["two_spheres", "random", "deep"])
+def test_threaded_tree_build_equals_the_serial_one(fb, case, monkeypatch):
+    """From 32 768 panels up the octree is built by a few threads (one stable sort by Morton code, the boxes read off the sorted
+    codes level by level, every leaf's bodies put back in their original order: csrc/host_plan.cpp build_tree); below that, and
+    with FMMBEM_TREE_SERIAL=1, by the reference's breadth-first bucketing (include/tree/Octree.hpp:617-692).  Same permutation,
+    same boxes, same numbering -- both coders, degenerate inputs included (coincident centroids, one crowded octant)."""
+    rng = np.random.default_rng(11)
+    ncrit = 64
+    if case == "two_spheres":
+        v = np.concatenate([fb.unit_sphere(7), fb.unit_sphere(7, center=(2.5, 0.3, 0.1))])
+    elif case == "random":
+        c = rng.random((40000, 1, 3)) ** 3                                # crowded towards one corner: a ragged, adaptive tree
+        v = c + 1e-3 * rng.standard_normal((40000, 3, 3))
+        v[1000:1040] = v[1000]                                            # forty coincident panels: one finest cell, within ncrit
+    else:
+        v = cells_in_a_big_box(fb, recursions=5, cells=40)               # 64-bit keys
+        ncrit = 32
+    assert len(v) >= 32768
+    opts = fb.FMMOptions()
+    opts.set_max_per_box(ncrit)
+    K = fb.LaplaceSphericalBEM(4, 3)
+    a = fb.FMM_plan(K, v, opts, host_only=True)
+    monkeypatch.setenv("FMMBEM_TREE_SERIAL", "1")
+    b = fb.FMM_plan(K, v, opts, host_only=True)
+    if case == "deep":
+        assert a.stats()["n_levels"] > 11
+    assert np.array_equal(a.perm(), b.perm())
+    ba, bb = a.boxes(), b.boxes()
+    for k in ba:
+        assert np.array_equal(ba[k], bb[k]), k
+    assert np.array_equal(a.pairs("m2l"), b.pairs("m2l")) and np.array_equal(a.pairs("p2p"), b.pairs("p2p"))
