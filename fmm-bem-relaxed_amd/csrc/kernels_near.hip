@@ -1904,8 +1904,7 @@ hipError_t launch_near_spmv(const DevicePlan& d, hipStream_t s) {
   // The grid is exactly what is resident at once (kSpmvOcc workgroups per CU): with one more per CU the stragglers
   // start when the others finish (0.98 ms instead of 0.79 at N = 1M); occupancy 6 (80 VGPRs) and 2x2 loads at
   // occupancy 8 measure within 3 % of this.
-  static const int near_cus = std::getenv("FMMBEM_NEAR_CUS") ? std::atoi(std::getenv("FMMBEM_NEAR_CUS")) : 256;   // EXPERIMENT (FMMBEM_CU_SPLIT)
-  const dim3 g(std::min(d.near_nitems, near_cus * kSpmvOcc)), b(kSpmvWaves * kWave);
+  const dim3 g(std::min(d.near_nitems, 256 * kSpmvOcc)), b(kSpmvWaves * kWave);
   if (d.dof == 1 && d.max_runs <= kSpmvWaves * kWave) {               // the pipelined form; a leaf with more runs than threads (never seen) takes the plain one
     const size_t lds2 = 2 * (size_t)kSpmvPipeChunk * sizeof(double) + 4 * (size_t)d.max_runs * sizeof(int);
     hipLaunchKernelGGL((near_spmv_pipe_kernel<2, 4>), g, b, lds2, s, d);

@@ -242,9 +242,6 @@ struct fmmbem_plan {
   double *stage_x = nullptr, *stage_y = nullptr;               // device staging for host-pointer execute
   fmmbem::SolverWs* solver_ws = nullptr;                       // workspace of fmmbem_gmres* on this plan (krylov.hip), kept between solves
   hipStream_t own_stream = nullptr;
-  // EXPERIMENT (FMMBEM_CU_SPLIT=k): the near field on k compute units of every 32, the far field on the others, side by side
-  hipStream_t split_near = nullptr, split_far = nullptr;
-  hipEvent_t split_fork = nullptr, split_near_done = nullptr, split_far_done = nullptr;
 
   template <class T, class A>
   int upload(const std::vector<T, A>& v, const T** out) {
@@ -312,16 +309,6 @@ int fmmbem_plan::to_device() {
   DEVICE_SCOPE(opts.device);
   on_device = true;
   HIP_TRY(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
-  if (const char* e = std::getenv("FMMBEM_CU_SPLIT")) {
-    const int k = std::atoi(e);
-    if (k > 0 && k < 32) {
-      uint32_t mn[8], mf[8];
-      for (int w = 0; w < 8; ++w) { mn[w] = (1u << k) - 1u; mf[w] = ~mn[w]; }
-      HIP_TRY(hipExtStreamCreateWithCUMask(&split_near, 8, mn));
-      HIP_TRY(hipExtStreamCreateWithCUMask(&split_far, 8, mf));
-      for (hipEvent_t* evp : {&split_fork, &split_near_done, &split_far_done}) HIP_TRY(hipEventCreateWithFlags(evp, hipEventDisableTiming));
-    }
-  }
   ev.assign((size_t)kRing * 2 * kStages, nullptr);
   for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
 
@@ -1227,34 +1214,6 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
     TRY(near_field(s));
     pending_mask = mask;
     pending_near = true;
-    return FMMBEM_OK;
-  }
-  if (split_near && phase == 0 && !near_only && !hybrid) {
-    HIP_TRY(hipEventRecord(split_fork, s));
-    HIP_TRY(hipStreamWaitEvent(split_near, split_fork, 0));
-    HIP_TRY(hipStreamWaitEvent(split_far, split_fork, 0));
-    TRY(near_field(split_near));
-    HIP_TRY(hipEventRecord(split_near_done, split_near));
-    hipStream_t f = split_far;
-    HIP_TRY(begin(3, f));
-    if (d.kernel == FMMBEM_KERNEL_STOKES_BEM) HIP_TRY(launch_p2m_stokes(d, p, f)); else HIP_TRY(launch_p2m(d, p, f));
-    HIP_TRY(end(3, f));
-    HIP_TRY(begin(4, f)); TRY(m2m_pass(p, false, f)); HIP_TRY(end(4, f));
-    const bool rot = use_rot(p);
-    HIP_TRY(begin(5, f)); if (!rot) HIP_TRY(launch_mh_prep(d, p, f)); HIP_TRY(end(5, f));
-    HIP_TRY(begin(6, f));
-    if (rot) HIP_TRY(launch_m2l_rot(d, d_dev, p, f)); else HIP_TRY(launch_m2l(d, d_dev, p, f));
-    HIP_TRY(end(6, f));
-    HIP_TRY(begin(7, f)); TRY(l2l_pass(p, f)); HIP_TRY(end(7, f));
-    HIP_TRY(hipStreamWaitEvent(f, split_near_done, 0));            // L2P adds to what the near field left in y_tree
-    HIP_TRY(begin(8, f));
-    if (d.kernel == FMMBEM_KERNEL_STOKES_BEM) HIP_TRY(launch_l2p_stokes(d, p, d.yt, f)); else HIP_TRY(launch_l2p(d, p, d.yt, f));
-    HIP_TRY(end(8, f));
-    HIP_TRY(hipEventRecord(split_far_done, f));
-    HIP_TRY(hipStreamWaitEvent(s, split_far_done, 0));
-    TRY(deliver(s));
-    last_p = p;
-    if (tm) { ev_mask[ring] = mask; ++ev_count; }
     return FMMBEM_OK;
   }
   const bool near_here = !(phase == 2 && pending_near);
