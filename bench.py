@@ -447,7 +447,10 @@ def main():
         import hashlib
         sha = hashlib.sha256(open(os.path.join(ROOT, "fmm-bem-relaxed_amd", "csrc", "kernels_near.hip"), "rb").read()).hexdigest()
         # a figure measured on another build of the near-field kernels is stale: report none rather than that
-        if prof.get("n_panels") == n and prof.get("n_gpus") == world and prof.get("kernels_near_sha256") == sha:
+        # ... and so is one measured on another configuration of the near field (the committed passes are the streamed plans of
+        # the laplace and stokes_rbc workloads: tools/round_profile.sh, tools/stokes_profile.sh)
+        if (prof.get("n_panels") == n and prof.get("n_gpus") == world and prof.get("kernels_near_sha256") == sha and not hybrid
+                and not traction and not args.matrix_free):
             traffic = prof.get("hbm_bytes_per_launch")
     except Exception:
         pass
