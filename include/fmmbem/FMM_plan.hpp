@@ -263,6 +263,40 @@ class LaplaceSphericalBEM {
     fmmbem::check(fmmbem_ops_p2m(ops_.handle(FMMBEM_KERNEL_LAPLACE_BEM, K, 1.0, device), P, 1, v, &bc, &charge, c, m.data()));
     fmmbem::SingleOperators::unpack(m, ptrs(M), P);
   }
+  // the vectorised forms (kernel/LaplaceSpherical.hpp:214-232; ExpansionTraits::has_vector_P2M / has_vector_L2P): one device call
+  // for all the sources of a box / all the targets of a box
+  template <typename SourceIter, typename ChargeIter>
+  void P2M(SourceIter first, SourceIter last, ChargeIter c_first, const point_type& center, multipole_type& M) const {
+    std::vector<double> v, q;
+    std::vector<uint8_t> bc;
+    for (; first != last; ++first, ++c_first) {
+      double one[9];
+      fmmbem::SingleOperators::vertices_of(*first, one);
+      v.insert(v.end(), one, one + 9);
+      bc.push_back((*first).BC == Panel::NORMAL_DERIV ? FMMBEM_BC_NORMAL_DERIV : FMMBEM_BC_POTENTIAL);
+      q.push_back(*c_first);
+    }
+    const double c[3] = {center[0], center[1], center[2]};
+    std::vector<double> m = fmmbem::SingleOperators::pack(cptrs(M), P);
+    fmmbem::check(fmmbem_ops_p2m(ops_.handle(FMMBEM_KERNEL_LAPLACE_BEM, K, 1.0, device), P, bc.size(), v.data(), bc.data(), q.data(), c, m.data()));
+    fmmbem::SingleOperators::unpack(m, ptrs(M), P);
+  }
+  template <typename TargetIter, typename ResultIter>
+  void L2P(const local_type& L, const point_type& center, TargetIter first, TargetIter last, ResultIter r_first) const {
+    std::vector<double> v;
+    std::vector<uint8_t> bc;
+    for (TargetIter it = first; it != last; ++it) {
+      double one[9];
+      fmmbem::SingleOperators::vertices_of(*it, one);
+      v.insert(v.end(), one, one + 9);
+      bc.push_back((*it).BC == Panel::NORMAL_DERIV ? FMMBEM_BC_NORMAL_DERIV : FMMBEM_BC_POTENTIAL);
+    }
+    const double c[3] = {center[0], center[1], center[2]};
+    const std::vector<double> l = fmmbem::SingleOperators::pack(cptrs(L), P);
+    std::vector<double> r(bc.size(), 0.0);
+    fmmbem::check(fmmbem_ops_l2p(ops_.handle(FMMBEM_KERNEL_LAPLACE_BEM, K, 1.0, device), P, l.data(), c, bc.size(), v.data(), bc.data(), r.data()));
+    for (size_t i = 0; i < r.size(); ++i, ++r_first) *r_first += r[i];
+  }
   void M2M(const multipole_type& source, multipole_type& target, const point_type& translation) const {
     ops_.shift(fmmbem_ops_m2m, ops_.handle(FMMBEM_KERNEL_LAPLACE_BEM, K, 1.0, device), P, cptrs(source), ptrs(target), translation);
   }
@@ -366,6 +400,39 @@ class StokesSphericalBEM {
     std::vector<double> m = fmmbem::SingleOperators::pack(cptrs(M, 1), P);
     fmmbem::check(fmmbem_ops_p2m(ops_.handle(FMMBEM_KERNEL_STOKES_BEM, K, Mu, device), P, 1, v, &bc, f, c, m.data()));
     fmmbem::SingleOperators::unpack(m, ptrs(M, 1), P);
+  }
+  template <typename SourceIter, typename ChargeIter>
+  void P2M(SourceIter first, SourceIter last, ChargeIter c_first, const point_type& center, multipole_type& M) const {
+    std::vector<double> v, q;
+    std::vector<uint8_t> bc;
+    for (; first != last; ++first, ++c_first) {
+      double one[9];
+      fmmbem::SingleOperators::vertices_of(*first, one);
+      v.insert(v.end(), one, one + 9);
+      bc.push_back((*first).BC == Panel::TRACTION);
+      for (int k = 0; k < 3; ++k) q.push_back((*c_first)[k]);
+    }
+    const double c[3] = {center[0], center[1], center[2]};
+    std::vector<double> m = fmmbem::SingleOperators::pack(cptrs(M, 1), P);
+    fmmbem::check(fmmbem_ops_p2m(ops_.handle(FMMBEM_KERNEL_STOKES_BEM, K, Mu, device), P, bc.size(), v.data(), bc.data(), q.data(), c, m.data()));
+    fmmbem::SingleOperators::unpack(m, ptrs(M, 1), P);
+  }
+  template <typename TargetIter, typename ResultIter>
+  void L2P(const local_type& L, const point_type& center, TargetIter first, TargetIter last, ResultIter r_first) const {
+    std::vector<double> v;
+    std::vector<uint8_t> bc;
+    for (TargetIter it = first; it != last; ++it) {
+      double one[9];
+      fmmbem::SingleOperators::vertices_of(*it, one);
+      v.insert(v.end(), one, one + 9);
+      bc.push_back((*it).BC == Panel::TRACTION);
+    }
+    const double c[3] = {center[0], center[1], center[2]};
+    const std::vector<double> l = fmmbem::SingleOperators::pack(cptrs(L, 1), P);
+    std::vector<double> r(3 * bc.size(), 0.0);
+    fmmbem::check(fmmbem_ops_l2p(ops_.handle(FMMBEM_KERNEL_STOKES_BEM, K, Mu, device), P, l.data(), c, bc.size(), v.data(), bc.data(), r.data()));
+    for (size_t i = 0; i < bc.size(); ++i, ++r_first)
+      for (int k = 0; k < 3; ++k) (*r_first)[k] += r[3 * i + k];
   }
   void M2M(const multipole_type& source, multipole_type& target, const point_type& translation) const {
     ops_.shift(fmmbem_ops_m2m, ops_.handle(FMMBEM_KERNEL_STOKES_BEM, K, Mu, device), P, cptrs(source, 2), ptrs(target, 2), translation);

@@ -19,6 +19,8 @@ static_assert(ExpansionTraits<StokesSphericalBEM>::is_valid_fmm, "StokesSpherica
 static_assert(ExpansionTraits<LaplaceSphericalBEM>::has_init_multipole && ExpansionTraits<LaplaceSphericalBEM>::has_init_local, "initialisers");
 static_assert(ExpansionTraits<StokesSphericalBEM>::has_init_multipole && ExpansionTraits<StokesSphericalBEM>::has_init_local, "initialisers");
 static_assert(!ExpansionTraits<LaplaceSphericalBEM>::has_M2P, "the treecode's operator is not offered");
+static_assert(ExpansionTraits<LaplaceSphericalBEM>::has_vector_P2M && ExpansionTraits<LaplaceSphericalBEM>::has_vector_L2P, "the vectorised forms");
+static_assert(ExpansionTraits<StokesSphericalBEM>::has_vector_P2M && ExpansionTraits<StokesSphericalBEM>::has_vector_L2P, "the vectorised forms");
 #endif
 
 template <class Kernel>
@@ -76,13 +78,33 @@ static double chain(const Kernel& K) {
   K.M2M(M1, M2, c_src - c_src_child);
   K.M2L(M2, L1, c_tgt - c_src);
   K.L2L(L1, L2, c_tgt_child - c_tgt);
-  double worst = 0, scale = 0;
+  // the vectorised forms: all sources in one P2M, all targets in one L2P -- the same numbers as one at a time
+  typename Kernel::multipole_type M1v;
+  init_m(K, M1v, ext);
+  K.P2M(src.begin(), src.end(), q.begin(), c_src_child, M1v);
+  std::vector<result> rv(tgt.size(), result());
+  K.L2P(L2, c_tgt_child, tgt.begin(), tgt.end(), rv.begin());
+  double worst = 0, scale = 0, vec_diff = 0;
   for (size_t i = 0; i < tgt.size(); ++i) {
     result r = result(), want = result();
     K.L2P(L2, c_tgt_child, tgt[i], r);
     for (size_t j = 0; j < src.size(); ++j) want += K(tgt[i], src[j]) * q[j];
     worst = std::max(worst, mag(r - want));
     scale = std::max(scale, mag(want));
+    vec_diff = std::max(vec_diff, mag(r - rv[i]));
+  }
+  if (vec_diff > 1e-14 * scale) return 1.0;            // the vector L2P disagrees with the single one
+  {
+    typename Kernel::multipole_type Mp1, Mp2;
+    init_m(K, Mp1, ext); init_m(K, Mp2, ext);
+    K.M2M(M1, Mp1, c_src - c_src_child);
+    K.M2M(M1v, Mp2, c_src - c_src_child);
+    typename Kernel::local_type La, Lb;
+    init_l(K, La, ext); init_l(K, Lb, ext);
+    K.M2L(Mp1, La, c_tgt_child - c_src); K.M2L(Mp2, Lb, c_tgt_child - c_src);
+    result ra = result(), rb = result();
+    K.L2P(La, c_tgt_child, tgt[0], ra); K.L2P(Lb, c_tgt_child, tgt[0], rb);
+    if (mag(ra - rb) > 1e-12 * scale) return 1.0;        // the vector P2M disagrees with the sum of single ones
   }
   return worst / scale;
 }
