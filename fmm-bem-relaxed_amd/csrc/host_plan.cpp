@@ -9,12 +9,107 @@
 #include <cstdlib>
 #include <cstdio>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <pthread.h>
 #include <cstring>
 #include <deque>
 #include <numeric>
 #include <unordered_map>
 
 namespace fmmbem {
+
+// ---- host_parallel: a small persistent pool (host_plan.hpp) ----
+namespace {
+class HostPool {
+ public:
+  // heap-allocated and never destroyed: in a forked child the condition variables still count the parent's waiting workers, and
+  // destroying one (pthread_cond_destroy) would wait for them for ever.  The workers are stopped and joined at exit instead.
+  static HostPool& instance() {
+    static HostPool* p = [] { HostPool* q = new HostPool; std::atexit([] { instance().shutdown(); }); return q; }();
+    return *p;
+  }
+  void run(int nt, const std::function<void(int)>& body) {
+    if (nt <= 1) { body(0); return; }
+    std::unique_lock<std::mutex> own(busy_, std::try_to_lock);
+    if (!own.owns_lock() || dead_.load() || !start(nt)) { spawn(nt, body); return; }
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      body_ = &body; nt_ = nt; next_.store(1);
+      ++epoch_;
+    }
+    cv_.notify_all();
+    body(0);
+    for (;;) {                                           // the caller takes shares too
+      const int t = next_.fetch_add(1);
+      if (t >= nt) break;
+      body(t);
+    }
+    // every share has been taken; wait for the workers that are still inside one.  (A worker that wakes up after this finds no
+    // job: body_ is cleared under the lock it reads it under.)
+    std::unique_lock<std::mutex> lk(m_);
+    done_.wait(lk, [&] { return active_ == 0; });
+    body_ = nullptr;
+  }
+  void shutdown() {
+    if (dead_.load()) return;                            // a forked child: the threads these objects name are not in this process
+    { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+    cv_.notify_all();
+    for (auto& w : workers_) if (w.joinable()) w.join();
+  }
+
+ private:
+  HostPool() { pthread_atfork(nullptr, nullptr, [] { instance().dead_.store(true); }); }
+  static void spawn(int nt, const std::function<void(int)>& body) {
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back([&body, t] { body(t); });
+    body(0);
+    for (auto& th : pool) th.join();
+  }
+  bool start(int nt) {                                   // workers on demand, at most 15
+    const int want = std::min(nt - 1, 15);
+    try {
+      while ((int)workers_.size() < want) workers_.emplace_back([this] { work(); });
+    } catch (...) { return !workers_.empty(); }
+    return true;
+  }
+  void work() {
+    uint64_t seen = 0;
+    for (;;) {
+      const std::function<void(int)>* body;
+      int nt;
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return stop_ || epoch_ != seen; });
+        if (stop_) return;
+        seen = epoch_; body = body_; nt = nt_;
+        if (!body) continue;
+        ++active_;
+      }
+      for (;;) {
+        const int t = next_.fetch_add(1);
+        if (t >= nt) break;
+        (*body)(t);
+      }
+      {
+        std::lock_guard<std::mutex> lk(m_);
+        --active_;
+      }
+      done_.notify_all();
+    }
+  }
+  std::mutex busy_, m_;
+  std::condition_variable cv_, done_;
+  std::vector<std::thread> workers_;
+  const std::function<void(int)>* body_ = nullptr;       // under m_, like nt_, epoch_, active_, stop_
+  int nt_ = 0, active_ = 0;
+  std::atomic<int> next_{0};
+  uint64_t epoch_ = 0;
+  bool stop_ = false;
+  std::atomic<bool> dead_{false};
+};
+}  // namespace
+void host_parallel(int nt, const std::function<void(int)>& body) { HostPool::instance().run(nt, body); }
 
 // ------------------------------------------------------------------------------------------
 // Quadrature rules (numeric data of examples/BEM/GaussQuadrature.hpp:19-185).
@@ -187,9 +282,7 @@ inline int host_threads(int64_t n, int64_t grain) {
 template <class F>
 void par_shares(int nt, int64_t n, F&& body) {
   if (nt <= 1) { body((int64_t)0, n, 0); return; }
-  std::vector<std::thread> pool;
-  for (int t = 0; t < nt; ++t) pool.emplace_back([&, t] { body(n * t / nt, n * (t + 1) / nt, t); });
-  for (auto& th : pool) th.join();
+  host_parallel(nt, [&](int t) { body(n * t / nt, n * (t + 1) / nt, t); });
 }
 
 // Octree.hpp:617-692 on codes of L bits per dimension: BFS construction with stable 8-way bucketing per box, then the box
@@ -525,17 +618,21 @@ std::string HostPlan::build(const HostOptions& o, int64_t n_panels, const double
       outs.assign(nt, Out{});
       if (nt == 1) walk(cur.data(), cur.data() + cur.size(), outs[0]);
       else {
-        std::vector<std::thread> pool;
-        for (int k = 0; k < nt; ++k)
-          pool.emplace_back(walk, cur.data() + cur.size() * k / nt, cur.data() + cur.size() * (k + 1) / nt, std::ref(outs[k]));
-        for (auto& th : pool) th.join();
+        host_parallel(nt, [&](int k) { walk(cur.data() + cur.size() * k / nt, cur.data() + cur.size() * (k + 1) / nt, outs[k]); });
       }
-      next.clear();
-      for (const Out& o_ : outs) {
-        next.insert(next.end(), o_.next.begin(), o_.next.end());
-        for (const Pair& q : o_.p2p) { p2p_src.push_back(q.first); p2p_tgt.push_back(q.second); }
-        for (const Pair& q : o_.lr) { lr_src.push_back(q.first); lr_tgt.push_back(q.second); }
-      }
+      // the shares' finds, concatenated in share order (= the serial walk's order): sizes first, then every share copies its own
+      std::vector<size_t> on(nt + 1, 0), op(nt + 1, p2p_src.size()), ol(nt + 1, lr_src.size());
+      for (int k = 0; k < nt; ++k) { on[k + 1] = on[k] + outs[k].next.size(); op[k + 1] = op[k] + outs[k].p2p.size(); ol[k + 1] = ol[k] + outs[k].lr.size(); }
+      next.resize(on[nt]);
+      p2p_src.resize(op[nt]); p2p_tgt.resize(op[nt]);
+      lr_src.resize(ol[nt]); lr_tgt.resize(ol[nt]);
+      auto place = [&](int k) {
+        const Out& o_ = outs[k];
+        std::copy(o_.next.begin(), o_.next.end(), next.begin() + on[k]);
+        for (size_t i = 0; i < o_.p2p.size(); ++i) { p2p_src[op[k] + i] = o_.p2p[i].first; p2p_tgt[op[k] + i] = o_.p2p[i].second; }
+        for (size_t i = 0; i < o_.lr.size(); ++i) { lr_src[ol[k] + i] = o_.lr[i].first; lr_tgt[ol[k] + i] = o_.lr[i].second; }
+      };
+      if (nt == 1) place(0); else host_parallel(nt, place);
       cur.swap(next);
     }
   }
@@ -742,9 +839,7 @@ std::string HostPlan::build(const HostOptions& o, int64_t n_panels, const double
     };
     auto run = [&](auto&& fn) {
       if (nt == 1) { fn(0); return; }
-      std::vector<std::thread> pool;
-      for (int k = 0; k < nt; ++k) pool.emplace_back(fn, k);
-      for (auto& th : pool) th.join();
+      host_parallel(nt, [&](int k) { fn(k); });
     };
     run(scan);
     std::unordered_map<IVec3, int, IVec3Hash> cls_of;
@@ -799,9 +894,7 @@ std::string HostPlan::build(const HostOptions& o, int64_t n_panels, const double
   };
   if (nthreads == 1) fill_range(0, 0, n);
   else {
-    std::vector<std::thread> pool;
-    for (int t = 0; t < nthreads; ++t) pool.emplace_back(fill_range, t, n * t / nthreads, n * (t + 1) / nthreads);
-    for (auto& th : pool) th.join();
+    host_parallel(nthreads, [&](int t) { fill_range(t, n * t / nthreads, n * (t + 1) / nthreads); });
   }
   for (int t = 0; t < nthreads; ++t) { has_bc[0] = has_bc[0] || seen_bc[t][0]; has_bc[1] = has_bc[1] || seen_bc[t][1]; }
   mark("panels SoA");

@@ -11,6 +11,7 @@
 // tree-order panel index, grouped by TARGET so that one wavefront owns one target.
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 #include <utility>
@@ -20,6 +21,12 @@ namespace fmmbem {
 
 constexpr int kPmax = 16;
 constexpr int kMaxQuad = 79;       // FMMBEM_MAX_QUAD: the largest rule of examples/BEM/GaussQuadrature.hpp
+
+// Fan-out of the plan builder's host work: body(t) for t = 0 .. nt - 1, t = 0 on the caller.  A few worker threads are kept for
+// the life of the process (a plan build fans out ~40 times; starting sixteen threads each time cost more than some of the phases
+// they shared: the octree 14 -> 8 ms at N = 1M); when the pool is busy (plans built concurrently by the shards of a device list),
+// after a fork(), or for nt beyond the pool, plain threads are started as before.
+void host_parallel(int nt, const std::function<void(int)>& body);
 
 struct QuadRule {            // triangle Gauss rule: barycentric points + weights
   int n = 0;

@@ -85,9 +85,7 @@ template <class F>
 static void parallel_rows(int64_t n, int64_t min_per_thread, F&& body) {
   const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency())), n / std::max<int64_t>(1, min_per_thread)));
   if (nt <= 1) { body((int64_t)0, n); return; }
-  std::vector<std::thread> pool;
-  for (int t = 0; t < nt; ++t) pool.emplace_back([&, t] { body(n * t / nt, n * (t + 1) / nt); });
-  for (auto& th : pool) th.join();
+  host_parallel(nt, [&](int t) { body(n * t / nt, n * (t + 1) / nt); });
 }
 
 // Tables that depend on the expansion ORDER alone -- the constant streams of the three rotation kernels, the lanes' tables of the
@@ -1294,9 +1292,7 @@ static void fingerprint_vertices(const double* v, size_t n_panels, uint64_t out[
   };
   if (nt == 1) work(0);
   else {
-    std::vector<std::thread> pool;
-    for (int t = 0; t < nt; ++t) pool.emplace_back(work, t);
-    for (auto& th : pool) th.join();
+    host_parallel(nt, [&](int t) { work(t); });
   }
   uint64_t a = n_panels, b = ~(uint64_t)n_panels;
   for (int t = 0; t < nt; ++t) { a = (a ^ part[2 * t]) * 0x100000001B3ull; b = (b + part[2 * t + 1]) * 0xC4CEB9FE1A85EC53ull; b ^= b >> 31; }

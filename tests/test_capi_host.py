@@ -4,6 +4,8 @@ no CPU execution path."""
 import ctypes
 import os
 import re
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -197,3 +199,33 @@ def test_selective_exchange_lists_cover_what_a_shard_reads(world):
     assert max(int(c[1].sum()) for c in counts) < gather
     for pl in plans:
         pl.close()
+
+
+def test_plan_builder_threads_survive_concurrent_builds_and_fork():
+    """The plan builder keeps a few worker threads for the life of the process (csrc/host_plan.cpp host_parallel).  Plans built
+    from several threads at once (the shards of a device list are), in a forked child (no workers there: plain threads), and a
+    child that exits normally (static state that names the parent's threads must not be torn down) all give the serial result."""
+    code = r"""
+import os, sys, threading, numpy as np
+sys.path.insert(0, %r)
+import fmm_bem_relaxed_amd as fb
+v = fb.unit_sphere(7)
+K = fb.LaplaceSphericalBEM(6, 3)
+base = fb.FMM_plan(K, v, host_only=True).perm()
+out = [None] * 4
+def work(i): out[i] = fb.FMM_plan(K, v, host_only=True).perm()
+th = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+[t.start() for t in th]; [t.join() for t in th]
+assert all(np.array_equal(o, base) for o in out)
+for how in ("_exit", "exit"):
+    sys.stdout.flush()
+    pid = os.fork()
+    if pid == 0:
+        ok = np.array_equal(fb.FMM_plan(K, v, host_only=True).perm(), base)
+        (os._exit if how == "_exit" else sys.exit)(0 if ok else 1)
+    _, st = os.waitpid(pid, 0)
+    assert os.WIFEXITED(st) and os.WEXITSTATUS(st) == 0, (how, st)
+print("ok")
+""" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
