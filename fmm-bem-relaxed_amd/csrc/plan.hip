@@ -384,6 +384,7 @@ int fmmbem_plan::to_device() {
     TRY(upload(P.area, &d.area)); TRY(upload(P.quad, &d.quad)); TRY(upload(P.vert, &d.vert));
   }
 
+  mark("panels: upload + geometry");
   // leaves and the near block structure
   std::vector<int> leaf_row0(nl), leaf_nrows(nl), near_stride(nl), run_row0, run_off;
   std::vector<int64_t> near_off(nl, 0), run_ptr(nl + 1, 0);
@@ -587,6 +588,7 @@ int fmmbem_plan::to_device() {
   near_rec_host = rec;
   near_off_host = near_off;
 
+  mark("near lists + items");
   // boxes, expansions, tables
   TRY(upload(hp.box_center, &d.box_center));
   TRY(upload(T.A, &d.tabA)); TRY(upload(T.invA, &d.tabInvA)); TRY(upload(T.pref, &d.tabPref));
@@ -607,7 +609,7 @@ int fmmbem_plan::to_device() {
     TRY(upload(st, &d.tabStep));
   }
 
-  mark("panels + near lists upload");
+  mark("boxes + harmonic tables");
   TRY(to_device_bc_begin(hp.panels.bc.data()));        // the near-matrix assembly runs on the GPU from here, under the host work below
   alloc_list = &shared->allocs;
   // far-field lists
