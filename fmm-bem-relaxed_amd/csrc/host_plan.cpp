@@ -31,6 +31,8 @@ class HostPool {
   }
   void run(int nt, const std::function<void(int)>& body) {
     if (nt <= 1) { body(0); return; }
+    if (inside_) { for (int t = 0; t < nt; ++t) body(t); return; }      // a fan-out inside a share runs in place
+    struct Inside { Inside() { inside_ = true; } ~Inside() { inside_ = false; } } mark_inside;
     std::unique_lock<std::mutex> own(busy_, std::try_to_lock);
     if (!own.owns_lock() || dead_.load() || !start(nt)) { spawn(nt, body); return; }
     {
@@ -62,7 +64,7 @@ class HostPool {
   HostPool() { pthread_atfork(nullptr, nullptr, [] { instance().dead_.store(true); }); }
   static void spawn(int nt, const std::function<void(int)>& body) {
     std::vector<std::thread> pool;
-    for (int t = 1; t < nt; ++t) pool.emplace_back([&body, t] { body(t); });
+    for (int t = 1; t < nt; ++t) pool.emplace_back([&body, t] { inside_ = true; body(t); });
     body(0);
     for (auto& th : pool) th.join();
   }
@@ -86,6 +88,7 @@ class HostPool {
         if (!body) continue;
         ++active_;
       }
+      inside_ = true;
       for (;;) {
         const int t = next_.fetch_add(1);
         if (t >= nt) break;
@@ -98,6 +101,7 @@ class HostPool {
       done_.notify_all();
     }
   }
+  static thread_local bool inside_;
   std::mutex busy_, m_;
   std::condition_variable cv_, done_;
   std::vector<std::thread> workers_;
@@ -108,6 +112,7 @@ class HostPool {
   bool stop_ = false;
   std::atomic<bool> dead_{false};
 };
+thread_local bool HostPool::inside_ = false;
 }  // namespace
 void host_parallel(int nt, const std::function<void(int)>& body) { HostPool::instance().run(nt, body); }
 
