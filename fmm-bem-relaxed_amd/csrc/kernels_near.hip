@@ -115,34 +115,39 @@ __constant__ double kFine[16][4] = {
 // In two parts, so that the assembly can run the expensive regime with full wavefronts: laplace_entry_far gives the entry of a
 // pair in the far regime (the K stored Gauss points; also the 2 pi of a NORMAL_DERIV self pair) or says `deferred`;
 // laplace_entry_near gives the near regime (semi-analytic G, :166-178; the 16-point rule for dG/dn, :222-243).
-__device__ inline double laplace_entry_far(const DevicePlan& d, V3 t, int tbc, int64_t j, bool& deferred) {
-  const int64_t N = d.n;
-  const V3 c = {d.cx[j], d.cy[j], d.cz[j]};
-  const double A = d.area[j];
+// the far regime's arithmetic on a source panel held in registers (one text for both callers: the bits must not depend on who asks)
+template <class Quad>
+__device__ __forceinline__ double laplace_far_from(V3 t, int tbc, V3 c, double A, V3 nrm, int nq, const double* qw, Quad&& quad, bool& deferred) {
   const double dist = norm(sub(t, c));
   const bool nearby = sqrt(2 * A) / dist >= 0.5;
   deferred = false;
   if (tbc == 0) {                                   // POTENTIAL target: int G
     if (nearby) { deferred = true; return 0; }
     double r = 0;
-    for (int q = 0; q < d.nq; ++q) {
-      const V3 qp = {d.quad[(q * 3 + 0) * N + j], d.quad[(q * 3 + 1) * N + j], d.quad[(q * 3 + 2) * N + j]};
-      r += d.qw[q] * A / norm(sub(t, qp));
+    for (int q = 0; q < nq; ++q) {
+      const V3 qp = quad(q);
+      r += qw[q] * A / norm(sub(t, qp));
     }
     return r;
   }
   // NORMAL_DERIV target: int dG/dn
   if (dist < 1e-8) return 2 * M_PI;
   if (nearby) { deferred = true; return 0; }
-  const V3 nrm = {d.nx[j], d.ny[j], d.nz[j]};
   double r = 0;
-  for (int q = 0; q < d.nq; ++q) {
-    const V3 qp = {d.quad[(q * 3 + 0) * N + j], d.quad[(q * 3 + 1) * N + j], d.quad[(q * 3 + 2) * N + j]};
+  for (int q = 0; q < nq; ++q) {
+    const V3 qp = quad(q);
     const V3 dx = sub(qp, t);
     const double r2 = dx.x * dx.x + dx.y * dx.y + dx.z * dx.z;
-    r += d.qw[q] * A * (dx.x * nrm.x + dx.y * nrm.y + dx.z * nrm.z) / (r2 * sqrt(r2));
+    r += qw[q] * A * (dx.x * nrm.x + dx.y * nrm.y + dx.z * nrm.z) / (r2 * sqrt(r2));
   }
   return r;
+}
+__device__ inline double laplace_entry_far(const DevicePlan& d, V3 t, int tbc, int64_t j, bool& deferred) {
+  const int64_t N = d.n;
+  const V3 c = {d.cx[j], d.cy[j], d.cz[j]};
+  const V3 nrm = tbc ? V3{d.nx[j], d.ny[j], d.nz[j]} : V3{0, 0, 0};
+  return laplace_far_from(t, tbc, c, d.area[j], nrm, d.nq, d.qw,
+                          [&](int q) { return V3{d.quad[(q * 3 + 0) * N + j], d.quad[(q * 3 + 1) * N + j], d.quad[(q * 3 + 2) * N + j]}; }, deferred);
 }
 __device__ inline double laplace_entry_near(const DevicePlan& d, V3 t, int tbc, int64_t j) {
   const int64_t N = d.n;
@@ -252,6 +257,85 @@ __global__ __launch_bounds__(256) void near_assemble_kernel(DevicePlan d) {
         }
         if (threadIdx.x == 0) queued = 0;              // (read by all before the barrier above; written again only after the one below)
         __syncthreads();
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// The same assembly with a thread per COLUMN: the source panel (centroid, area, normal, the K <= 4 Gauss points: 20 doubles) is read
+// once and kept in registers down the rows of the block; the rows' centroids come from LDS.  Same entry functions, same values;
+// one load per entry instead of fourteen.  Rules of more than four points take the entry-per-thread kernel above.
+template <int NQ>
+__global__ __launch_bounds__(256) void near_assemble_cols_kernel(DevicePlan d) {
+  extern __shared__ int lds_i[];
+  __shared__ int queue[256 * (kAsmBatch + 1)];
+  __shared__ int queued;
+  __shared__ double trow[64][4];                     // centroid and flag of the rows of a row block
+  int* colmap = lds_i;                               // [kAsmChunk]
+  int* run_row0 = lds_i + kAsmChunk;                 // [max_runs]
+  int* run_off = run_row0 + d.max_runs;              // [max_runs]
+  const int64_t N = d.n;
+  for (int t = d.leaf_begin + blockIdx.x; t < d.leaf_end; t += gridDim.x) {
+    if (d.near_rec && d.near_rec[t]) continue;
+    const int ncols = d.near_ncols[t], stride = d.near_stride[t], nrows = d.leaf_nrows[t];
+    const int row0 = d.leaf_row0[t];
+    const Runs runs = load_runs(d, t, run_row0, run_off);
+    double* blk = d.near_val + d.near_off[t];
+    for (int c0 = 0; c0 < stride; c0 += kAsmChunk) {
+      const int cw = stride - c0 < kAsmChunk ? stride - c0 : kAsmChunk;
+      if (c0) __syncthreads();
+      for (int c = threadIdx.x; c < cw; c += blockDim.x) colmap[c] = c0 + c < ncols ? column_to_row(runs, c0 + c) : -1;
+      if (threadIdx.x == 0) queued = 0;
+      __syncthreads();
+      // the queue holds entries as row * cw + column of this chunk; drained when a round of 256 has gathered and at the chunk's end
+      auto drain = [&](bool last) {
+        __syncthreads();
+        const int nq = queued;
+        __syncthreads();
+        if (nq < 256 && !last) return;
+        for (int k = threadIdx.x; k < nq; k += 256) {
+          const int e = queue[k];
+          const int r = e / cw, c = e - r * cw;
+          const int64_t i = row0 + r;
+          blk[(int64_t)r * stride + c0 + c] = laplace_entry_near(d, V3{d.cx[i], d.cy[i], d.cz[i]}, d.bc[i], colmap[c]);
+        }
+        if (threadIdx.x == 0) queued = 0;
+        __syncthreads();
+      };
+      for (int rb = 0; rb < nrows; rb += 64) {
+        const int nr = nrows - rb < 64 ? nrows - rb : 64;
+        if ((int)threadIdx.x < nr) {
+          const int64_t i = row0 + rb + threadIdx.x;
+          trow[threadIdx.x][0] = d.cx[i]; trow[threadIdx.x][1] = d.cy[i]; trow[threadIdx.x][2] = d.cz[i]; trow[threadIdx.x][3] = (double)d.bc[i];
+        }
+        __syncthreads();
+        for (int cb = 0; cb < cw; cb += 256) {
+          const int c = cb + (int)threadIdx.x;
+          const int j = c < cw ? colmap[c] : -1;
+          V3 sc = {0, 0, 0}, sn = {0, 0, 0};
+          double A = 0, qx[NQ], qy[NQ], qz[NQ];
+          if (j >= 0) {
+            sc = {d.cx[j], d.cy[j], d.cz[j]}; sn = {d.nx[j], d.ny[j], d.nz[j]}; A = d.area[j];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) { qx[q] = d.quad[(q * 3 + 0) * N + j]; qy[q] = d.quad[(q * 3 + 1) * N + j]; qz[q] = d.quad[(q * 3 + 2) * N + j]; }
+          }
+          for (int r8 = 0; r8 < nr; r8 += kAsmBatch) {
+            const int rend = r8 + kAsmBatch < nr ? r8 + kAsmBatch : nr;
+            if (c < cw)
+              for (int r = r8; r < rend; ++r) {
+                double v = 0;                           // padding column (odd ncols) stays zero
+                bool deferred = false;
+                if (j >= 0)
+                  v = laplace_far_from(V3{trow[r][0], trow[r][1], trow[r][2]}, (int)trow[r][3], sc, A, sn, NQ, d.qw,
+                                       [&](int q) { return V3{qx[q], qy[q], qz[q]}; }, deferred);
+                if (deferred) queue[atomicAdd(&queued, 1)] = (rb + r) * cw + c;
+                else blk[(int64_t)(rb + r) * stride + c0 + c] = v;
+              }
+            drain(false);
+          }
+        }
+        drain(rb + 64 >= nrows);
       }
     }
     __syncthreads();
@@ -1782,8 +1866,14 @@ hipError_t launch_near_diag(const DevicePlan& d, const int* selfcol, double* out
 hipError_t launch_near_assemble(const DevicePlan& d, hipStream_t s) {
   const int nb = d.leaf_end - d.leaf_begin;
   if (nb <= 0) return hipSuccess;
-  hipLaunchKernelGGL(near_assemble_kernel, dim3(nb < 256 * 8 ? nb : 256 * 8), dim3(256),
-                     ((size_t)kAsmChunk + 2 * (size_t)d.max_runs) * sizeof(int), s, d);
+  const size_t lds = ((size_t)kAsmChunk + 2 * (size_t)d.max_runs) * sizeof(int);
+  const dim3 g(nb < 256 * 8 ? nb : 256 * 8), b(256);
+  // FMMBEM_ASM_COLS=0: the entry-per-thread kernel at every rule (A/B: the two give the same bits)
+  const bool cols = !(std::getenv("FMMBEM_ASM_COLS") && std::atoi(std::getenv("FMMBEM_ASM_COLS")) == 0);
+  if (cols && d.nq == 1) hipLaunchKernelGGL(near_assemble_cols_kernel<1>, g, b, lds, s, d);
+  else if (cols && d.nq == 3) hipLaunchKernelGGL(near_assemble_cols_kernel<3>, g, b, lds, s, d);
+  else if (cols && d.nq == 4) hipLaunchKernelGGL(near_assemble_cols_kernel<4>, g, b, lds, s, d);
+  else hipLaunchKernelGGL(near_assemble_kernel, g, b, lds, s, d);
   return hipGetLastError();
 }
 

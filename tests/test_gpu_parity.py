@@ -286,6 +286,31 @@ def test_alternative_paths_match_oracle(fb, oracle_mod, monkeypatch, env):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("k,ncrit", [(3, 64), (3, 200), (4, 300), (1, 130), (7, 64)])
+def test_assembly_kernels_give_the_same_bits(fb, monkeypatch, k, ncrit):
+    """The near matrix by a thread per column (the source panel in registers down the rows of a leaf, near-regime entries queued
+    and taken by full wavefronts; rules of up to four points) and by a thread per entry (FMMBEM_ASM_COLS=0; what rules of more
+    points take): the same entry functions, the same matrix bit for bit -- leaves of more rows than one row block (ncrit > 64),
+    mixed flags, every rule the column kernel is instantiated for."""
+    monkeypatch.setenv("FMMBEM_PLAN_SHARE", "0")
+    rng = np.random.default_rng(5)
+    v = fb.unit_sphere(6)
+    bc = (rng.random(len(v)) < 0.5).astype(np.uint8)
+    x = rng.standard_normal(len(v))
+    opts = fb.FMMOptions()
+    opts.set_max_per_box(ncrit)
+    got = []
+    for cols in ("1", "0"):
+        monkeypatch.setenv("FMMBEM_ASM_COLS", cols)
+        pl = fb.FMM_plan(fb.LaplaceSphericalBEM(4, k), v, opts, bc=bc)
+        rows = [pl.near_row(int(r)) for r in (0, 17, len(v) // 2, len(v) - 1)]
+        got.append((pl.execute(x), rows))
+    assert np.array_equal(got[0][0], got[1][0])
+    for (ca, va), (cb, vb) in zip(got[0][1], got[1][1]):
+        assert np.array_equal(ca, cb) and np.array_equal(va, vb)
+
+
+@pytest.mark.gpu
 def test_graph_replay_is_bitwise_the_launch_chain(fb, oracle_mod):
     """fmmbem_plan_set_graphs: from its second execute at an order on, the chain between gather and delivery is a captured
     hipGraph launched on the caller's stream -- the same kernels in the same order, so the same bits as launch by launch, for
