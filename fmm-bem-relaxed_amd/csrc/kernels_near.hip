@@ -438,59 +438,72 @@ __device__ inline void stresslet_point(double* res, double wA, V3 t, V3 pnt, V3 
 
 // tbc = the TARGET's flag (kernel/StokesSphericalBEM.hpp:377-389): 0 VELOCITY -> eval_velocity_integral (:260-375),
 // 1 TRACTION -> eval_traction_integral (:160-258): self 2 pi I, near K_fine, far K points, times -3, no 1/(2 mu)
-__device__ inline void stokes_entry(const DevicePlan& d, V3 t, int tbc, int64_t j, double* out) {
+// In two parts like laplace_entry: stokes_far_from gives the block of a pair in the far regime (the K stored Gauss points; the
+// 2 pi I of a TRACTION self pair) from a source panel held in registers, or says `deferred`; stokes_entry_near the near regime
+// (the K_fine rule on the vertices, the closed form of the self pair).  One text for the arithmetic, whoever asks.
+template <class Quad>
+__device__ __forceinline__ bool stokes_far_from(const DevicePlan& d, V3 t, int tbc, V3 c, double A, V3 nrm, Quad&& quad, double* out) {
+  const double dist = norm(sub(t, c));
+#pragma unroll
+  for (int i = 0; i < 9; ++i) out[i] = 0;
+  if (tbc) {
+    if (fabs(dist) < 1e-8) { out[0] = out[4] = out[8] = 2 * M_PI; return false; }
+    if (sqrt(2 * A) / dist >= 0.5) return true;
+    for (int q = 0; q < d.nq; ++q) stresslet_point(out, d.qw[q] * A, t, quad(q), nrm);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) out[i] *= -3.;
+    return false;
+  }
+  if (sqrt(2 * A) / dist >= 0.5) return true;
+  for (int q = 0; q < d.nq; ++q) stokeslet_point(out, d.qw[q] * A, t, quad(q));
+  const double sc = 1. / 2 / d.mu;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) out[i] *= sc;
+  return false;
+}
+__device__ inline void stokes_entry_near(const DevicePlan& d, V3 t, int tbc, int64_t j, double* out) {
   const int64_t N = d.n;
   const V3 c = {d.cx[j], d.cy[j], d.cz[j]};
   const double A = d.area[j];
   const double dist = norm(sub(t, c));
 #pragma unroll
   for (int i = 0; i < 9; ++i) out[i] = 0;
+  const V3 v0 = {d.vert[0 * N + j], d.vert[1 * N + j], d.vert[2 * N + j]};
+  const V3 v1 = {d.vert[3 * N + j], d.vert[4 * N + j], d.vert[5 * N + j]};
+  const V3 v2 = {d.vert[6 * N + j], d.vert[7 * N + j], d.vert[8 * N + j]};
   if (tbc) {
-    if (fabs(dist) < 1e-8) { out[0] = out[4] = out[8] = 2 * M_PI; return; }
     const V3 nrm = {d.nx[j], d.ny[j], d.nz[j]};
-    if (sqrt(2 * A) / dist >= 0.5) {
-      const V3 v0 = {d.vert[0 * N + j], d.vert[1 * N + j], d.vert[2 * N + j]};
-      const V3 v1 = {d.vert[3 * N + j], d.vert[4 * N + j], d.vert[5 * N + j]};
-      const V3 v2 = {d.vert[6 * N + j], d.vert[7 * N + j], d.vert[8 * N + j]};
-      for (int q = 0; q < d.nqf; ++q) {
-        const V3 pt = {v0.x * d.qf[4 * q + 0] + v1.x * d.qf[4 * q + 1] + v2.x * d.qf[4 * q + 2],
-                       v0.y * d.qf[4 * q + 0] + v1.y * d.qf[4 * q + 1] + v2.y * d.qf[4 * q + 2],
-                       v0.z * d.qf[4 * q + 0] + v1.z * d.qf[4 * q + 1] + v2.z * d.qf[4 * q + 2]};
-        stresslet_point(out, d.qf[4 * q + 3] * A, t, pt, nrm);
-      }
-    } else {
-      for (int q = 0; q < d.nq; ++q) {
-        const V3 qp = {d.quad[(q * 3 + 0) * N + j], d.quad[(q * 3 + 1) * N + j], d.quad[(q * 3 + 2) * N + j]};
-        stresslet_point(out, d.qw[q] * A, t, qp, nrm);
-      }
+    for (int q = 0; q < d.nqf; ++q) {
+      const V3 pt = {v0.x * d.qf[4 * q + 0] + v1.x * d.qf[4 * q + 1] + v2.x * d.qf[4 * q + 2],
+                     v0.y * d.qf[4 * q + 0] + v1.y * d.qf[4 * q + 1] + v2.y * d.qf[4 * q + 2],
+                     v0.z * d.qf[4 * q + 0] + v1.z * d.qf[4 * q + 1] + v2.z * d.qf[4 * q + 2]};
+      stresslet_point(out, d.qf[4 * q + 3] * A, t, pt, nrm);
     }
 #pragma unroll
     for (int i = 0; i < 9; ++i) out[i] *= -3.;
     return;
   }
-  if (sqrt(2 * A) / dist >= 0.5) {
-    const V3 v0 = {d.vert[0 * N + j], d.vert[1 * N + j], d.vert[2 * N + j]};
-    const V3 v1 = {d.vert[3 * N + j], d.vert[4 * N + j], d.vert[5 * N + j]};
-    const V3 v2 = {d.vert[6 * N + j], d.vert[7 * N + j], d.vert[8 * N + j]};
-    if (dist < 1e-8) {
-      stokes_self(v0, v1, v2, t, out);
-    } else {
-      for (int q = 0; q < d.nqf; ++q) {
-        const V3 pt = {v0.x * d.qf[4 * q + 0] + v1.x * d.qf[4 * q + 1] + v2.x * d.qf[4 * q + 2],
-                       v0.y * d.qf[4 * q + 0] + v1.y * d.qf[4 * q + 1] + v2.y * d.qf[4 * q + 2],
-                       v0.z * d.qf[4 * q + 0] + v1.z * d.qf[4 * q + 1] + v2.z * d.qf[4 * q + 2]};
-        stokeslet_point(out, d.qf[4 * q + 3] * A, t, pt);
-      }
-    }
+  if (dist < 1e-8) {
+    stokes_self(v0, v1, v2, t, out);
   } else {
-    for (int q = 0; q < d.nq; ++q) {
-      const V3 qp = {d.quad[(q * 3 + 0) * N + j], d.quad[(q * 3 + 1) * N + j], d.quad[(q * 3 + 2) * N + j]};
-      stokeslet_point(out, d.qw[q] * A, t, qp);
+    for (int q = 0; q < d.nqf; ++q) {
+      const V3 pt = {v0.x * d.qf[4 * q + 0] + v1.x * d.qf[4 * q + 1] + v2.x * d.qf[4 * q + 2],
+                     v0.y * d.qf[4 * q + 0] + v1.y * d.qf[4 * q + 1] + v2.y * d.qf[4 * q + 2],
+                     v0.z * d.qf[4 * q + 0] + v1.z * d.qf[4 * q + 1] + v2.z * d.qf[4 * q + 2]};
+      stokeslet_point(out, d.qf[4 * q + 3] * A, t, pt);
     }
   }
   const double sc = 1. / 2 / d.mu;
 #pragma unroll
   for (int i = 0; i < 9; ++i) out[i] *= sc;
+}
+__device__ inline void stokes_entry(const DevicePlan& d, V3 t, int tbc, int64_t j, double* out) {
+  const int64_t N = d.n;
+  const V3 c = {d.cx[j], d.cy[j], d.cz[j]};
+  const V3 nrm = tbc ? V3{d.nx[j], d.ny[j], d.nz[j]} : V3{0, 0, 0};
+  if (stokes_far_from(d, t, tbc, c, d.area[j], nrm,
+                      [&](int q) { return V3{d.quad[(q * 3 + 0) * N + j], d.quad[(q * 3 + 1) * N + j], d.quad[(q * 3 + 2) * N + j]}; }, out))
+    stokes_entry_near(d, t, tbc, j, out);
 }
 
 // one thread per (target panel, source panel) pair of the leaf block; writes its 3x3 block into the
@@ -531,6 +544,102 @@ __global__ __launch_bounds__(256) void near_assemble_stokes_kernel(DevicePlan d)
 #pragma unroll
             for (int b = 0; b < 3; ++b) blk[(int64_t)(3 * r + a) * stride + 3 * (c0 + c) + b] = m[3 * a + b];
         }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// The Stokes assembly with a thread per column (cf. near_assemble_cols_kernel): the source panel's centroid, area, normal and K <= 4
+// Gauss points in registers down the rows of the block, near-regime pairs (the K_fine rule: five times the work; the self pair)
+// queued in LDS and taken by full wavefronts.  Same entry functions, same values.
+__device__ __forceinline__ void stokes_store_block(const DevicePlan& d, double* blk, dvec2* sym, int r, int cg, int ncols, int stride, const double* m) {
+  if (sym) {                                           // the six entries (a <= b) of the symmetric block, three planes per panel row
+    dvec2* row = sym + (int64_t)r * 3 * ncols + cg;
+    row[0] = dvec2{m[0], m[1]};
+    row[ncols] = dvec2{m[2], m[4]};
+    row[2 * ncols] = dvec2{m[5], m[8]};
+  } else {
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) blk[(int64_t)(3 * r + a) * stride + 3 * cg + b] = m[3 * a + b];
+  }
+}
+template <int NQ>
+__global__ __launch_bounds__(256) void near_assemble_stokes_cols_kernel(DevicePlan d) {
+  extern __shared__ int lds_i[];
+  __shared__ int queue[256 * (kAsmBatch + 1)];
+  __shared__ int queued;
+  __shared__ double trow[64][4];
+  int* colmap = lds_i;                               // [kAsmChunk] panel columns
+  int* run_row0 = lds_i + kAsmChunk;
+  int* run_off = run_row0 + d.max_runs;
+  const int64_t N = d.n;
+  for (int t = d.leaf_begin + blockIdx.x; t < d.leaf_end; t += gridDim.x) {
+    if (d.near_rec && d.near_rec[t]) continue;
+    const int ncols = d.near_ncols[t], stride = d.near_stride[t], nrows = d.leaf_nrows[t];
+    const int row0 = d.leaf_row0[t];
+    const Runs runs = load_runs(d, t, run_row0, run_off);
+    double* blk = d.near_sym ? nullptr : d.near_val + d.near_off[t];
+    dvec2* sym = d.near_sym ? reinterpret_cast<dvec2*>(d.near_sym + d.near_sym_off[t]) : nullptr;
+    if (blk && stride > 3 * ncols)                    // padding column (odd number of unknowns per row)
+      for (int r = threadIdx.x; r < 3 * nrows; r += blockDim.x) blk[(int64_t)r * stride + 3 * ncols] = 0.0;
+    for (int c0 = 0; c0 < ncols; c0 += kAsmChunk) {
+      const int cw = ncols - c0 < kAsmChunk ? ncols - c0 : kAsmChunk;
+      if (c0) __syncthreads();
+      for (int c = threadIdx.x; c < cw; c += blockDim.x) colmap[c] = column_to_row(runs, c0 + c);
+      if (threadIdx.x == 0) queued = 0;
+      __syncthreads();
+      auto drain = [&](bool last) {
+        __syncthreads();
+        const int nq = queued;
+        __syncthreads();
+        if (nq < 256 && !last) return;
+        for (int k = threadIdx.x; k < nq; k += 256) {
+          const int e = queue[k];
+          const int r = e / cw, c = e - r * cw;
+          const int64_t i = row0 + r;
+          double m[9];
+          stokes_entry_near(d, V3{d.cx[i], d.cy[i], d.cz[i]}, d.bc[i], colmap[c], m);
+          stokes_store_block(d, blk, sym, r, c0 + c, ncols, stride, m);
+        }
+        if (threadIdx.x == 0) queued = 0;
+        __syncthreads();
+      };
+      for (int rb = 0; rb < nrows; rb += 64) {
+        const int nr = nrows - rb < 64 ? nrows - rb : 64;
+        if ((int)threadIdx.x < nr) {
+          const int64_t i = row0 + rb + threadIdx.x;
+          trow[threadIdx.x][0] = d.cx[i]; trow[threadIdx.x][1] = d.cy[i]; trow[threadIdx.x][2] = d.cz[i]; trow[threadIdx.x][3] = (double)d.bc[i];
+        }
+        __syncthreads();
+        for (int cb = 0; cb < cw; cb += 256) {
+          const int c = cb + (int)threadIdx.x;
+          const bool live = c < cw;
+          V3 sc = {0, 0, 0}, sn = {0, 0, 0};
+          double A = 0, qx[NQ], qy[NQ], qz[NQ];
+          if (live) {
+            const int j = colmap[c];
+            sc = {d.cx[j], d.cy[j], d.cz[j]}; sn = {d.nx[j], d.ny[j], d.nz[j]}; A = d.area[j];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) { qx[q] = d.quad[(q * 3 + 0) * N + j]; qy[q] = d.quad[(q * 3 + 1) * N + j]; qz[q] = d.quad[(q * 3 + 2) * N + j]; }
+          }
+          for (int r8 = 0; r8 < nr; r8 += kAsmBatch) {
+            const int rend = r8 + kAsmBatch < nr ? r8 + kAsmBatch : nr;
+            if (live)
+              for (int r = r8; r < rend; ++r) {
+                double m[9];
+                const int tbc = (int)trow[r][3];
+                const bool deferred = stokes_far_from(d, V3{trow[r][0], trow[r][1], trow[r][2]}, tbc, sc, A, tbc ? sn : V3{0, 0, 0},
+                                                      [&](int q) { return V3{qx[q], qy[q], qz[q]}; }, m);
+                if (deferred) queue[atomicAdd(&queued, 1)] = (rb + r) * cw + c;
+                else stokes_store_block(d, blk, sym, rb + r, c0 + c, ncols, stride, m);
+              }
+            drain(false);
+          }
+        }
+        drain(rb + 64 >= nrows);
       }
     }
     __syncthreads();
@@ -1880,8 +1989,13 @@ hipError_t launch_near_assemble(const DevicePlan& d, hipStream_t s) {
 hipError_t launch_near_assemble_stokes(const DevicePlan& d, hipStream_t s) {
   const int nb = d.leaf_end - d.leaf_begin;
   if (nb <= 0) return hipSuccess;
-  hipLaunchKernelGGL(near_assemble_stokes_kernel, dim3(nb < 256 * 8 ? nb : 256 * 8), dim3(256),
-                     ((size_t)kAsmChunk + 2 * (size_t)d.max_runs) * sizeof(int), s, d);
+  const size_t lds = ((size_t)kAsmChunk + 2 * (size_t)d.max_runs) * sizeof(int);
+  const dim3 g(nb < 256 * 8 ? nb : 256 * 8), b(256);
+  const bool cols = !(std::getenv("FMMBEM_ASM_COLS") && std::atoi(std::getenv("FMMBEM_ASM_COLS")) == 0);
+  if (cols && d.nq == 1) hipLaunchKernelGGL(near_assemble_stokes_cols_kernel<1>, g, b, lds, s, d);
+  else if (cols && d.nq == 3) hipLaunchKernelGGL(near_assemble_stokes_cols_kernel<3>, g, b, lds, s, d);
+  else if (cols && d.nq == 4) hipLaunchKernelGGL(near_assemble_stokes_cols_kernel<4>, g, b, lds, s, d);
+  else hipLaunchKernelGGL(near_assemble_stokes_kernel, g, b, lds, s, d);
   return hipGetLastError();
 }
 

@@ -311,6 +311,33 @@ def test_assembly_kernels_give_the_same_bits(fb, monkeypatch, k, ncrit):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", ["velocity_sym", "mixed_rows9", "mixed_big_leaves", "traction_k1"])
+def test_stokes_assembly_kernels_give_the_same_bits(fb, monkeypatch, case):
+    """The same for the Stokes blocks (`near_assemble_stokes_cols_kernel` against the pair-per-thread kernel): the symmetric
+    6-value form and the 9-value rows, VELOCITY and TRACTION targets, leaves of more rows than one row block."""
+    monkeypatch.setenv("FMMBEM_PLAN_SHARE", "0")
+    rng = np.random.default_rng(7)
+    v, k, kf, ncrit, sym = {"velocity_sym": (fb.red_blood_cell(5), 4, 19, 64, "1"), "mixed_rows9": (fb.red_blood_cell(5), 4, 19, 64, "0"),
+                            "mixed_big_leaves": (fb.unit_sphere(5), 3, 25, 200, "1"), "traction_k1": (fb.unit_sphere(4), 1, 7, 64, "1")}[case]
+    n = len(v)
+    bc = None if case == "velocity_sym" else np.ones(n, dtype=np.uint8) if case == "traction_k1" else (rng.random(n) < 0.4).astype(np.uint8)
+    monkeypatch.setenv("FMMBEM_STOKES_SYM", sym)
+    x = rng.standard_normal((n, 3))
+    opts = fb.FMMOptions()
+    opts.set_max_per_box(ncrit)
+    got = []
+    for cols in ("1", "0"):
+        monkeypatch.setenv("FMMBEM_ASM_COLS", cols)
+        K = fb.StokesSphericalBEM(4, k, 1e-3)
+        K.set_Kfine(kf)
+        pl = fb.FMM_plan(K, v, opts, bc=bc)
+        got.append((pl.execute(x), [pl.near_row(int(r)) for r in (0, 7, 3 * n - 1)]))
+    assert np.array_equal(got[0][0], got[1][0])
+    for (ca, va), (cb, vb) in zip(got[0][1], got[1][1]):
+        assert np.array_equal(ca, cb) and np.array_equal(va, vb)
+
+
+@pytest.mark.gpu
 def test_graph_replay_is_bitwise_the_launch_chain(fb, oracle_mod):
     """fmmbem_plan_set_graphs: from its second execute at an order on, the chain between gather and delivery is a captured
     hipGraph launched on the caller's stream -- the same kernels in the same order, so the same bits as launch by launch, for
