@@ -292,6 +292,24 @@ struct fmmbem_plan {
 
 #define TRY(expr) do { int rc_ = (expr); if (rc_ != FMMBEM_OK) return rc_; } while (0)
 
+// Work items largest first, equal ones in their given order: a stable radix sort on the (descending) key -- the comparison
+// sort of 60 000 items took 4-5 ms of every plan build
+template <class T, class KeyFn>
+static void stable_sort_largest_first(std::vector<T>& v, KeyFn key) {
+  if (v.size() < 2) return;
+  uint64_t kmax = 0;
+  for (const T& x : v) kmax = std::max<uint64_t>(kmax, (uint64_t)key(x));
+  std::vector<T> tmp(v.size());
+  constexpr int kBits = 11, kB = 1 << kBits;
+  for (int shift = 0; shift < 64 && (kmax >> shift) != 0; shift += kBits) {
+    size_t count[kB + 1] = {0};
+    for (const T& x : v) ++count[(((kmax - (uint64_t)key(x)) >> shift) & (kB - 1)) + 1];
+    for (int b = 0; b < kB; ++b) count[b + 1] += count[b];
+    for (const T& x : v) tmp[count[((kmax - (uint64_t)key(x)) >> shift) & (kB - 1)]++] = x;
+    v.swap(tmp);
+  }
+}
+
 // rot_tgt of a plan whose rotation pairs are its CSR lists: pair i belongs to the box b with m2l_ptr[b] <= i < m2l_ptr[b + 1]
 __global__ void expand_csr_targets_kernel(const int* __restrict__ ptr, int nboxes, int* __restrict__ tgt) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -486,7 +504,7 @@ int fmmbem_plan::to_device() {
       if (per >= 8) per = (per + 7) & ~7;
       for (int r0 = 0; r0 < nr; r0 += per) { const int k = std::min(per, nr - r0); items.push_back({l, r0, k, k * row_bytes}); }
     }
-    std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.bytes > b.bytes; });
+    stable_sort_largest_first(items, [](const Item& a) { return a.bytes; });
     std::vector<int4> packed(items.size());
     for (size_t i = 0; i < items.size(); ++i) packed[i] = make_int4(items[i].leaf, items[i].r0, items[i].nr, items[i].nr < 8);
     d.near_nitems = (int)packed.size();
@@ -533,7 +551,7 @@ int fmmbem_plan::to_device() {
         if (per >= 8) per = (per + 7) & ~7;
         for (int r0 = 0; r0 < nr; r0 += per) { const int k = std::min(per, nr - r0); items.push_back({l, r0, k, k * row_bytes}); }
       }
-      std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.bytes > b.bytes; });
+      stable_sort_largest_first(items, [](const Item& a) { return a.bytes; });
       std::vector<int4> packed(items.size());
       for (size_t i = 0; i < items.size(); ++i) packed[i] = make_int4(items[i].leaf, items[i].r0, items[i].nr, items[i].nr < 8);
       d.sym_nitems = (int)packed.size();
@@ -559,7 +577,7 @@ int fmmbem_plan::to_device() {
       const int per = (nr + cnt - 1) / cnt;          // dealt evenly: the kernel gives a wavefront ceil(rows / 4) of an item's rows
       for (int r0 = 0; r0 < nr; r0 += per) { const int k = std::min(per, nr - r0); ritems.push_back({l, r0, k, (int64_t)k * ncp}); }
     }
-    std::stable_sort(ritems.begin(), ritems.end(), [](const RItem& a, const RItem& b) { return a.pairs > b.pairs; });
+    stable_sort_largest_first(ritems, [](const RItem& a) { return a.pairs; });
     // the side listing (mf_sweep COUNT / FILL) walks d.near_items: the recompute items, panel rows
     std::vector<int4> rpacked(ritems.size());
     std::vector<RcItem> rrecs(ritems.size());
