@@ -147,3 +147,23 @@ def test_config4_stokes_full_vector_vs_oracle(fb, oracle_mod):
     g, r = rel_l2(y[rows], d), rel_l2(yo[rows], d)
     assert abs(g - r) <= 1e-3 * r, (g, r)
     assert g < 5e-5, g                                         # the reference's level at p = 8 is 1.4e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("r", [7, 9])
+def test_unit_density_on_two_spheres_reproduces_the_analytic_potential(fb, r):
+    """A check that needs no oracle and holds at any size (profiles/r05t: run at 16.8 M panels): sigma = 1 on two unit spheres.  A
+    uniformly charged sphere is a point charge at its centre for points outside it and 4 pi R on itself, so the single-layer
+    potential at a collocation point is 4 pi (1 + 1 / d), d = its distance to the OTHER sphere's centre -- up to the O(h^2) of flat
+    panels inscribed in the sphere and the FMM's own error.  The deviation must fall with the discretisation."""
+    c2 = np.array([2.5, 0.0, 0.0])
+    v = np.concatenate([fb.unit_sphere(r), fb.unit_sphere(r, center=tuple(c2))])
+    n = len(v)
+    plan = fb.FMM_plan(fb.LaplaceSphericalBEM(10, 3), v, fb.FMMOptions())
+    y = plan.execute(np.ones(n))
+    cen = v.mean(axis=1)
+    other = np.where(np.arange(n) < n // 2, 1, 0)[:, None] * c2
+    want = 4 * np.pi * (1.0 + 1.0 / np.linalg.norm(cen - other, axis=1))
+    rel = np.abs(y - want) / want
+    h2 = 4 * np.pi / (n / 2)                                            # a panel's area on the unit sphere
+    assert np.median(rel) < 0.5 * h2 and rel.max() < 2e-3, (np.median(rel), rel.max(), h2)
