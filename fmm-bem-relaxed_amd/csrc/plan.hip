@@ -423,13 +423,19 @@ int fmmbem_plan::to_device() {
     bool rule_ok = hp.rule.n <= (dof == 3 ? 4 : 3);               // the far-regime points of a source live in registers
     for (int q = 2; q < hp.rule.n; ++q) rule_ok = rule_ok && hp.rule.w[q] == hp.rule.w[1];      // K = 1, 3, 4: two distinct weights at most
     const bool stokes_sym_on = !(std::getenv("FMMBEM_STOKES_SYM") && std::atoi(std::getenv("FMMBEM_STOKES_SYM")) == 0);
-    // runs of consecutive source rows per leaf (the pipelined kernels prefetch an item's run descriptors one per thread)
+    // runs of consecutive source rows per leaf (the pipelined kernels prefetch an item's run descriptors one per thread): counted
+    // by the shares of a few threads, as the runs themselves are filled in below
     std::vector<int> nruns_of(nl, 0);
     int max_runs_owned = 1;
-    for (int l = 0; l < nl; ++l) {
-      for (int64_t i = hp.near_ptr[l]; i < hp.near_ptr[l + 1]; ++i) nruns_of[l] += i == hp.near_ptr[l] || hp.near_src[i - 1] + 1 != hp.near_src[i];
-      if (l >= hp.leaf_begin && l < hp.leaf_end) max_runs_owned = std::max(max_runs_owned, nruns_of[l]);
-    }
+    parallel_rows(nl, 4096, [&](int64_t l0, int64_t l1) {
+      for (int64_t l = l0; l < l1; ++l) {
+        int c = 0;
+        for (int64_t i = hp.near_ptr[l]; i < hp.near_ptr[l + 1]; ++i) c += i == hp.near_ptr[l] || hp.near_src[i - 1] + 1 != hp.near_src[i];
+        nruns_of[l] = c;
+      }
+    });
+    for (int l = hp.leaf_begin; l < hp.leaf_end; ++l) max_runs_owned = std::max(max_runs_owned, nruns_of[l]);
+    for (int l = 0; l < nl; ++l) run_ptr[l + 1] = run_ptr[l] + nruns_of[l];
     hybrid = f < 1.0 && opts.sparse_local && hp.opt.evaluator == 0 && rule_ok && (dof == 3 ? stokes_sym_on : max_runs_owned <= 256);
     if (hybrid) {
       if (!(f >= 0.0)) f = 0.0;
@@ -450,28 +456,31 @@ int fmmbem_plan::to_device() {
       for (int l = hp.leaf_begin; l < hp.leaf_end; ++l) if (rec[l]) near_recomputed_pairs += (int64_t)leaf_nrows[l] * hp.near_ncols[l];
     }
   }
-  for (int l = 0; l < nl; ++l) {
-    const int b = hp.leaf_box[l];
-    leaf_row0[l] = hp.box_body_begin[b];
-    near_stride[l] = (dof * hp.near_ncols[l] + 1) & ~1;      // in unknowns (dof per panel), rows 16-B aligned
-    // source leaves are ascending; leaves with consecutive indices own adjacent rows -> one run
-    int col = 0, runs = 0;
-    for (int64_t i = hp.near_ptr[l]; i < hp.near_ptr[l + 1]; ++i) {
-      const int sl = hp.near_src[i], sb = hp.leaf_box[sl];
-      if (i == hp.near_ptr[l] || hp.near_src[i - 1] + 1 != sl) {
-        run_row0.push_back(hp.box_body_begin[sb]);
-        run_off.push_back(col);
-        ++runs;
+  run_row0.resize((size_t)run_ptr[nl]); run_off.resize((size_t)run_ptr[nl]);
+  parallel_rows(nl, 4096, [&](int64_t l0, int64_t l1) {
+    for (int64_t l = l0; l < l1; ++l) {
+      const int b = hp.leaf_box[l];
+      leaf_row0[l] = hp.box_body_begin[b];
+      near_stride[l] = (dof * hp.near_ncols[l] + 1) & ~1;      // in unknowns (dof per panel), rows 16-B aligned
+      // source leaves are ascending; leaves with consecutive indices own adjacent rows -> one run
+      int col = 0;
+      int64_t k = run_ptr[l];
+      for (int64_t i = hp.near_ptr[l]; i < hp.near_ptr[l + 1]; ++i) {
+        const int sl = hp.near_src[i], sb = hp.leaf_box[sl];
+        if (i == hp.near_ptr[l] || hp.near_src[i - 1] + 1 != sl) {
+          run_row0[(size_t)k] = hp.box_body_begin[sb];
+          run_off[(size_t)k] = col;
+          ++k;
+        }
+        col += hp.box_body_end[sb] - hp.box_body_begin[sb];
       }
-      col += hp.box_body_end[sb] - hp.box_body_begin[sb];
     }
-    run_ptr[l + 1] = (int64_t)run_row0.size();
-    if (l >= hp.leaf_begin && l < hp.leaf_end) {
-      near_off[l] = total;
-      if (!rec[l]) total += (int64_t)dof * leaf_nrows[l] * near_stride[l];
-      max_cols = std::max(max_cols, near_stride[l]);
-      max_runs = std::max(max_runs, runs);
-    }
+  });
+  for (int l = hp.leaf_begin; l < hp.leaf_end; ++l) {
+    near_off[l] = total;
+    if (!rec[l]) total += (int64_t)dof * leaf_nrows[l] * near_stride[l];
+    max_cols = std::max(max_cols, near_stride[l]);
+    max_runs = std::max(max_runs, (int)(run_ptr[l + 1] - run_ptr[l]));
   }
   d.max_runs = max_runs;
   if (const char* e = getenv("FMMBEM_M2L_ROT")) { if (atoi(e) == 0) rot_max = 0; }
