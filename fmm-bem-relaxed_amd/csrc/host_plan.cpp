@@ -663,16 +663,20 @@ std::string HostPlan::build(const HostOptions& o, int64_t n_panels, const double
   }
   near_ncols.assign(nl, 0);
   near_nnz_total = 0;
-  for (int t = 0; t < nl; ++t) {
-    std::sort(near_src.begin() + near_ptr[t], near_src.begin() + near_ptr[t + 1]);   // leaf index order == body order
-    int cols = 0;
-    for (int64_t i = near_ptr[t]; i < near_ptr[t + 1]; ++i) {
-      const int sb = leaf_box[near_src[i]];
-      cols += box_body_end[sb] - box_body_begin[sb];
+  par_shares(host_threads(nl, 4096), nl, [&](int64_t t0, int64_t t1, int) {      // every leaf sorts and counts its own columns
+    for (int64_t t = t0; t < t1; ++t) {
+      std::sort(near_src.begin() + near_ptr[t], near_src.begin() + near_ptr[t + 1]);   // leaf index order == body order
+      int cols = 0;
+      for (int64_t i = near_ptr[t]; i < near_ptr[t + 1]; ++i) {
+        const int sb = leaf_box[near_src[i]];
+        cols += box_body_end[sb] - box_body_begin[sb];
+      }
+      near_ncols[t] = cols;
     }
-    near_ncols[t] = cols;
+  });
+  for (int t = 0; t < nl; ++t) {
     const int tb = leaf_box[t];
-    near_nnz_total += int64_t(cols) * (box_body_end[tb] - box_body_begin[tb]);
+    near_nnz_total += int64_t(near_ncols[t]) * (box_body_end[tb] - box_body_begin[tb]);
   }
 
   mark("near lists");
@@ -815,11 +819,23 @@ std::string HostPlan::build(const HostOptions& o, int64_t n_panels, const double
 
   mark("operator lists");
   // ---- M2L grouped by target, traversal order kept within a target; translation classes ----
+  // (a stable counting sort by target, the list's chunks counted and placed by a few threads: chunk k's pairs of a target go
+  // behind those of the chunks before it, which is the serial order)
   m2l_ptr.assign(nboxes + 1, 0);
   m2l_pairs_owned = 0;
-  for (size_t i = 0; i < lr_tgt.size(); ++i)
-    if (owned_L[lr_tgt[i]]) { ++m2l_ptr[lr_tgt[i] + 1]; ++m2l_pairs_owned; }
-  for (int b = 0; b < nboxes; ++b) m2l_ptr[b + 1] += m2l_ptr[b];
+  const int nt_csr = lr_tgt.size() < (1u << 16) ? 1 : host_threads((int64_t)lr_tgt.size(), 1 << 15);
+  std::vector<std::vector<int>> csr_at(nt_csr, std::vector<int>((size_t)nboxes, 0));      // [chunk][box]: count, then first slot
+  par_shares(nt_csr, (int64_t)lr_tgt.size(), [&](int64_t i0, int64_t i1, int k) {
+    std::vector<int>& c = csr_at[k];
+    for (int64_t i = i0; i < i1; ++i)
+      if (owned_L[lr_tgt[i]]) ++c[lr_tgt[i]];
+  });
+  for (int b = 0; b < nboxes; ++b) {
+    int run = m2l_ptr[b];
+    for (int k = 0; k < nt_csr; ++k) { const int c = csr_at[k][b]; csr_at[k][b] = run; run += c; }
+    m2l_ptr[b + 1] = run;
+  }
+  m2l_pairs_owned = m2l_ptr[nboxes];
   m2l_src.resize(m2l_pairs_owned);
   m2l_cls.resize(m2l_pairs_owned);
   {
@@ -859,14 +875,16 @@ std::string HostPlan::build(const HostOptions& o, int64_t n_panels, const double
       for (size_t i = np * k / nt; i < np * (k + 1) / nt; ++i)
         if (owned_L[lr_tgt[i]]) cls_pair[i] = cls_of.find(vec_of(i))->second;
     });
-    std::vector<int> at(m2l_ptr.begin(), m2l_ptr.end() - 1);
-    for (size_t i = 0; i < np; ++i) {
-      const int t = lr_tgt[i];
-      if (!owned_L[t]) continue;
-      const int slot = at[t]++;
-      m2l_src[slot] = lr_src[i];
-      m2l_cls[slot] = cls_pair[i];
-    }
+    par_shares(nt_csr, (int64_t)np, [&](int64_t i0, int64_t i1, int k) {
+      std::vector<int>& at = csr_at[k];
+      for (int64_t i = i0; i < i1; ++i) {
+        const int t = lr_tgt[i];
+        if (!owned_L[t]) continue;
+        const int slot = at[t]++;
+        m2l_src[slot] = lr_src[i];
+        m2l_cls[slot] = cls_pair[i];
+      }
+    });
   }
 
   build_rot_items();
