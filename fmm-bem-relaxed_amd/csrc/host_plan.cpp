@@ -278,6 +278,41 @@ inline uint64_t compact3(uint64_t x) {
 inline int level_of_key(uint32_t key) { return (31 - __builtin_clz(key)) / 3; }
 inline int level_of_key(uint64_t key) { return (63 - __builtin_clzll(key)) / 3; }
 
+// translation vector -> class number: open addressing, a few thousand entries that stay in the cache (std::unordered_map's two
+// lookups per M2L pair were most of the class numbering's time)
+class ClassMap {
+ public:
+  ClassMap() : slots_(1 << 13, Slot{{0, 0, 0}, -1}) {}
+  // the class of `key`, -1 if it has none
+  int find(const IVec3& key) const {
+    for (size_t h = IVec3Hash()(key) & (slots_.size() - 1);; h = (h + 1) & (slots_.size() - 1)) {
+      const Slot& q = slots_[h];
+      if (q.val < 0) return -1;
+      if (q.key == key) return q.val;
+    }
+  }
+  // true if `key` was new (it then has the value `val`)
+  bool insert(const IVec3& key, int val) {
+    if (2 * (used_ + 1) > slots_.size()) grow();
+    for (size_t h = IVec3Hash()(key) & (slots_.size() - 1);; h = (h + 1) & (slots_.size() - 1)) {
+      Slot& q = slots_[h];
+      if (q.val < 0) { q.key = key; q.val = val; ++used_; return true; }
+      if (q.key == key) return false;
+    }
+  }
+
+ private:
+  struct Slot { IVec3 key; int val; };
+  void grow() {
+    std::vector<Slot> old(slots_.size() * 2, Slot{{0, 0, 0}, -1});
+    old.swap(slots_);
+    used_ = 0;
+    for (const Slot& q : old) if (q.val >= 0) insert(q.key, q.val);
+  }
+  std::vector<Slot> slots_;
+  size_t used_ = 0;
+};
+
 template <class Code> struct CodedT { Code code; uint32_t idx; };
 
 // a few host threads over [0, n) in contiguous shares: body(begin, end, share)
@@ -851,11 +886,11 @@ std::string HostPlan::build(const HostOptions& o, int64_t n_panels, const double
     struct Found { IVec3 key; int s, t; };
     std::vector<std::vector<Found>> found(nt);
     auto scan = [&](int k) {
-      std::unordered_map<IVec3, int, IVec3Hash> mine;
+      ClassMap mine;
       for (size_t i = np * k / nt; i < np * (k + 1) / nt; ++i) {
         if (!owned_L[lr_tgt[i]]) continue;
         const IVec3 key = vec_of(i);                        // exact: half-cells of the finest level (up to 2^22 on a deep tree)
-        if (mine.try_emplace(key, 0).second) found[k].push_back({key, lr_src[i], lr_tgt[i]});
+        if (mine.insert(key, 0)) found[k].push_back({key, lr_src[i], lr_tgt[i]});
       }
     };
     auto run = [&](auto&& fn) {
@@ -863,17 +898,17 @@ std::string HostPlan::build(const HostOptions& o, int64_t n_panels, const double
       host_parallel(nt, [&](int k) { fn(k); });
     };
     run(scan);
-    std::unordered_map<IVec3, int, IVec3Hash> cls_of;
+    ClassMap cls_of;
     for (int k = 0; k < nt; ++k)
       for (const Found& f : found[k])
-        if (cls_of.try_emplace(f.key, (int)m2l_class_rep.size() / 2).second) {
+        if (cls_of.insert(f.key, (int)m2l_class_rep.size() / 2)) {
           m2l_class_vec.insert(m2l_class_vec.end(), {f.key.x, f.key.y, f.key.z});
           m2l_class_rep.insert(m2l_class_rep.end(), {f.s, f.t});
         }
     std::vector<int> cls_pair(np, -1);
     run([&](int k) {
       for (size_t i = np * k / nt; i < np * (k + 1) / nt; ++i)
-        if (owned_L[lr_tgt[i]]) cls_pair[i] = cls_of.find(vec_of(i))->second;
+        if (owned_L[lr_tgt[i]]) cls_pair[i] = cls_of.find(vec_of(i));
     });
     par_shares(nt_csr, (int64_t)np, [&](int64_t i0, int64_t i1, int k) {
       std::vector<int>& at = csr_at[k];
