@@ -789,6 +789,23 @@ std::string HostPlan::build(const HostOptions& o, int64_t n_panels, const double
   }
 
   mark("shard");
+  has_bc[0] = has_bc[1] = false;
+  if (o.panels_on_device) {
+    // the flags in tree order (the panels' derived geometry is computed on the device from the caller's vertices: 0.2 GB written by
+    // the host and uploaded, 60-80 ms at N = 1M, otherwise), and everything the near field needs is final: hand it over
+    panels.bc.resize(n);
+    for (int64_t i = 0; i < n; ++i) {
+      const uint8_t flag = bc ? (bc[perm[i]] ? 1 : 0) : 0;
+      panels.bc[i] = flag;
+      has_bc[flag] = true;
+    }
+    mark("flags");
+    if (o.after_near_lists) {
+      const std::string err = o.after_near_lists();
+      if (!err.empty()) return err;
+      mark("(caller: near field to the device)");
+    }
+  }
   // ---- operator lists ----
   const bool su = o.shard_upward && o.shard_world > 1;
   for (int b = 0; b < nboxes; ++b) {
@@ -927,18 +944,7 @@ std::string HostPlan::build(const HostOptions& o, int64_t n_panels, const double
   // ---- panels in tree order, SoA (LaplaceSphericalBEM.hpp:64-97) ----
   PanelSoA& P = panels;
   const int nq = rule.n;
-  has_bc[0] = has_bc[1] = false;
-  if (o.panels_on_device) {
-    // the derived geometry is computed where it is used (0.2 GB written by the host and uploaded, 60-80 ms at N = 1M, otherwise)
-    P.bc.resize(n);
-    for (int64_t i = 0; i < n; ++i) {
-      const uint8_t flag = bc ? (bc[perm[i]] ? 1 : 0) : 0;
-      P.bc[i] = flag;
-      has_bc[flag] = true;
-    }
-    mark("flags");
-    return {};
-  }
+  if (o.panels_on_device) return {};                  // (the flags were set above, ahead of the hand-over)
   alloc_panels(P, n, nq);
   // independent per panel: cut into ranges for a few host threads (half of this function's time at N = 1M when serial)
   const int nthreads = n < (1 << 16) ? 1 : (int)std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));

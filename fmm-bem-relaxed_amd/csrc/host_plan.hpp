@@ -51,6 +51,10 @@ struct IVec3Hash {
 };
 
 struct HostOptions {
+  // called by HostPlan::build once the tree, the leaves, the near lists, the shard's ranges and the flags (panels_on_device)
+  // are final and before the far-field lists are built: the caller uploads them and starts the near-matrix assembly on the GPU
+  // while the host goes on.  A non-empty string aborts the build with that text.
+  std::function<std::string()> after_near_lists;
   int p_max = 10;
   int quad_k = 3;
   double theta = 0.5;

@@ -267,7 +267,9 @@ struct fmmbem_plan {
   int rot_max = kRotPmax;
   bool use_rot(int p) const { return p <= rot_max && m2l_rot_supported(p); }
   const double* create_vertices = nullptr;                   // fmmbem_plan_create: the caller's vertices while to_device runs (panel set-up on the device)
-  int to_device();                                           // the geometry's share (-> shared), then to_device_bc
+  // part 0: everything.  part 1: the near field's share -- panels, leaves, near lists, the assembly LAUNCHED -- as soon as the
+  // host plan holds them (HostOptions::after_near_lists); part 2: the rest, when the host plan is complete
+  int to_device(int part = 0);                               // the geometry's share (-> shared), then to_device_bc
   int to_device_bc(const uint8_t* bc_tree);
   int to_device_bc_begin(const uint8_t* bc_tree);
   int to_device_bc_end();
@@ -317,16 +319,18 @@ __global__ void expand_csr_targets_kernel(const int* __restrict__ ptr, int nboxe
   for (int i = ptr[b]; i < ptr[b + 1]; ++i) tgt[i] = b;
 }
 
-int fmmbem_plan::to_device() {
+int fmmbem_plan::to_device(int part) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(FMMBEM_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU execution path)");
   if (opts.device < 0 || opts.device >= ndev) return fail(FMMBEM_ERR_INVALID, "device ordinal out of range");
   DEVICE_SCOPE(opts.device);
-  on_device = true;
-  HIP_TRY(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
-  ev.assign((size_t)kRing * 2 * kStages, nullptr);
-  for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+  if (part != 2) {
+    on_device = true;
+    HIP_TRY(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
+    ev.assign((size_t)kRing * 2 * kStages, nullptr);
+    for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+  }
 
   const bool trace = std::getenv("FMMBEM_BUILD_TRACE") != nullptr;     // phase times on stderr (tuning aid)
   double t_last = now_ms();
@@ -339,6 +343,7 @@ int fmmbem_plan::to_device() {
   };
   const HarmonicTables T;
   const int nl = hp.nleaves(), nb = hp.nboxes, pm = hp.opt.p_max;
+  if (part != 2) {                                     // ======== the near field's share ========
   mark("streams, events, tables");
   d = DevicePlan{};
   d.n = hp.n; d.nq = hp.rule.n; d.nboxes = nb; d.nleaves = nl;
@@ -638,6 +643,8 @@ int fmmbem_plan::to_device() {
 
   mark("boxes + harmonic tables");
   TRY(to_device_bc_begin(hp.panels.bc.data()));        // the near-matrix assembly runs on the GPU from here, under the host work below
+  }                                                    // ======== the rest ========
+  if (part == 1) return FMMBEM_OK;
   alloc_list = &shared->allocs;
   // far-field lists
   std::vector<int> p2m_leaf, l2p_leaf;
@@ -1682,19 +1689,41 @@ int fmmbem_plan_create(const fmmbem_options* opts, size_t n_panels, const double
   ho.reference_l2l = opts->l2l_rule == FMMBEM_L2L_REFERENCE;
   ho.panels_on_device = !opts->host_only && !(std::getenv("FMMBEM_PANELS_ON_HOST") && std::atoi(std::getenv("FMMBEM_PANELS_ON_HOST")) != 0);
   const double t0 = now_ms();
+  // The near field goes to the device as soon as the host plan holds what it needs -- the panels' geometry, the leaves, the
+  // near lists -- and its assembly runs on the GPU while the host builds the far-field lists (FMMBEM_BUILD_TWO_PHASE=0: after them)
+  int near_rc = FMMBEM_OK;
+  bool near_done = false;
+  double near_ms = 0;
+  if (!opts->host_only && ho.panels_on_device && !(std::getenv("FMMBEM_BUILD_TWO_PHASE") && std::atoi(std::getenv("FMMBEM_BUILD_TWO_PHASE")) == 0))
+    ho.after_near_lists = [&]() -> std::string {
+      const double t = now_ms();
+      pl->has_bc[0] = pl->hp.has_bc[0]; pl->has_bc[1] = pl->hp.has_bc[1];
+      pl->create_vertices = vertices;
+      try {
+        near_rc = pl->to_device(1);
+      } catch (const std::bad_alloc&) {
+        near_rc = fail(FMMBEM_ERR_ALLOC, "host allocation failed while tabulating operators");
+      }
+      pl->create_vertices = nullptr;
+      near_done = true;
+      near_ms = now_ms() - t;
+      return near_rc == FMMBEM_OK ? std::string() : std::string("device");
+    };
   std::string err;
   try {
     err = pl->hp.build(ho, (int64_t)n_panels, vertices, bc);
   } catch (const std::bad_alloc&) {
     return fail(FMMBEM_ERR_ALLOC, "host allocation failed while building the plan");
   }
+  pl->hp.opt.after_near_lists = nullptr;                // (it refers to this frame)
+  if (near_rc != FMMBEM_OK) return near_rc;
   if (!err.empty()) return fail(err.find("octree") != std::string::npos ? FMMBEM_ERR_TREE : FMMBEM_ERR_INVALID, err);
-  pl->build_host_ms = now_ms() - t0;
+  pl->build_host_ms = now_ms() - t0 - near_ms;
   pl->has_bc[0] = pl->hp.has_bc[0]; pl->has_bc[1] = pl->hp.has_bc[1];
   if (!opts->host_only) {
     try {
       pl->create_vertices = ho.panels_on_device ? vertices : nullptr;
-      const int rc = pl->to_device();
+      const int rc = pl->to_device(near_done ? 2 : 0);
       pl->create_vertices = nullptr;
       if (rc != FMMBEM_OK) return rc;
     } catch (const std::bad_alloc&) {
