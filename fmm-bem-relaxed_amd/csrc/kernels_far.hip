@@ -363,6 +363,109 @@ __global__ __launch_bounds__(kWave) void p2m_table_kernel(DevicePlan d, double2*
   }
 }
 
+// The same table with the quadrature points INNERMOST (rules of up to four points): the recurrences of a panel's K points run side
+// by side, a coefficient's K contributions are added in registers in the order q = 0 .. K - 1 -- the order the kernel above adds them
+// in memory: the same record up to the compiler's choice of fused multiply-adds (measured: identical, or different by <= 4e-16
+// relative) -- and every record entry is written once instead of read and rewritten K times (Stokes config 4: the table 11.3 -> 2 ms,
+// the plan 0.061 -> 0.046 s; the stride between two threads' records is 3 KB, every one of those accesses a line of its own).
+template <int NT, int NQ>
+__global__ __launch_bounds__(kWave) void p2m_table_points_kernel(DevicePlan d, double2* __restrict__ tab) {
+  const int P = d.p_max, SM = d.p2m_stride;
+  const ConstD4* steptab = reinterpret_cast<const ConstD4*>(reinterpret_cast<uintptr_t>(d.tabStep + (size_t)(P - 1) * (kSmax + 1) * 4));
+  const int64_t N = d.n;
+  for (int li = blockIdx.x; li < d.n_p2m; li += gridDim.x) {
+    const int leaf = d.p2m_leaf[li], box = d.leaf_box[leaf];
+    const int row0 = d.leaf_row0[leaf], nrows = d.leaf_nrows[leaf];
+    const double c0 = d.box_center[3 * box], c1 = d.box_center[3 * box + 1], c2 = d.box_center[3 * box + 2];
+    for (int r = threadIdx.x; r < nrows; r += blockDim.x) {
+      const int64_t i = row0 + r;
+      double2* out = tab + (size_t)(i - d.p2m_tab_row0) * NT * SM;
+      const bool deriv = (NT == 1 && d.bc[i] != 0) || NT == 3;
+      const double n0 = d.nx[i], n1 = d.ny[i], n2 = d.nz[i];
+      Sph s[NQ];
+      double qx[NQ], qy[NQ], qz[NQ], aw[NQ], pn[NQ], rhom[NQ], er[NQ], ei[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        qx[q] = d.quad[(q * 3 + 0) * N + i]; qy[q] = d.quad[(q * 3 + 1) * N + i]; qz[q] = d.quad[(q * 3 + 2) * N + i];
+        aw[q] = d.area[i] * d.qw[q];
+        s[q] = cart2sph(qx[q] - c0, qy[q] - c1, qz[q] - c2);
+        pn[q] = 1; rhom[q] = 1; er[q] = 1; ei[q] = 0;
+      }
+      double fact = 1;
+      int step = 0;
+#pragma nounroll
+      for (int m = 0; m < P; ++m) {
+        double p[NQ], p1[NQ], rhon[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) { p[q] = pn[q]; p1[q] = p[q]; rhon[q] = rhom[q]; }
+#pragma nounroll
+        for (int n = m; n < P; ++n, ++step) {
+          const double pref = steptab[step].x, cy = steptab[step].y, cz = steptab[step].z;
+          double2 acc[NT == 3 ? 3 : NT];
+#pragma unroll
+          for (int e = 0; e < (NT == 3 ? 3 : NT); ++e) acc[e] = double2{0, 0};
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) {
+            const double mag = rhon[q] * p[q] * pref;
+            const double yr = mag * er[q], yi = -mag * ei[q];
+            const double pcur = p[q];
+            const double pnext = cy * s[q].ca * pcur - cz * p1[q];
+            double vr = yr, vi = yi;
+            if (deriv) {
+              double tmag;
+              if (n == m) tmag = rhon[q] * (pnext - (m + 1) * s[q].ca * pcur) / s[q].sa * pref;
+              else tmag = rhon[q] * ((n - m + 1) * pnext - (n + 1) * s[q].ca * pcur) / s[q].sa * pref;
+              const double tr = tmag * er[q], ti = -tmag * ei[q];
+              const double rho = s[q].rho, sa = s[q].sa, ca = s[q].ca, cb = s[q].cb, sb = s[q].sb;
+              const double brr = (double)n / rho * yr, bri = (double)n / rho * yi;
+              const double ber = (double)m * yi, bei = -(double)m * yr;
+              const double gxr = sa * cb * brr + ca * cb / rho * tr - sb / rho / sa * ber;
+              const double gxi = sa * cb * bri + ca * cb / rho * ti - sb / rho / sa * bei;
+              const double gyr = sa * sb * brr + ca * sb / rho * tr + cb / rho / sa * ber;
+              const double gyi = sa * sb * bri + ca * sb / rho * ti + cb / rho / sa * bei;
+              const double gzr = ca * brr - sa / rho * tr;
+              const double gzi = ca * bri - sa / rho * ti;
+              vr = n0 * gxr + n1 * gyr + n2 * gzr;
+              vi = n0 * gxi + n1 * gyi + n2 * gzi;
+              if constexpr (NT == 3) {
+                const double gr[3] = {gxr, gyr, gzr}, gi[3] = {gxi, gyi, gzi};
+#pragma unroll
+                for (int e = 0; e < 3; ++e) { acc[e].x += aw[q] * gr[e]; acc[e].y += aw[q] * gi[e]; }
+              }
+            }
+            if constexpr (NT == 1) { acc[0].x += aw[q] * vr; acc[0].y += aw[q] * vi; }
+            else if constexpr (NT != 3) {
+              const double wt[4] = {aw[q], aw[q] * qx[q], aw[q] * qy[q], aw[q] * qz[q]};
+#pragma unroll
+              for (int e = 0; e < NT; ++e) { acc[e].x += wt[e] * vr; acc[e].y += wt[e] * vi; }
+            }
+            p1[q] = pcur; p[q] = pnext;
+            rhon[q] *= s[q].rho;
+          }
+          const int idx = n * (n + 1) / 2 + m;
+          if constexpr (NT == 1) {
+            if (d.p2m_packed) {
+              if (m) out[packed_cpos(n, m)] = acc[0];
+              else reinterpret_cast<double*>(out + d.p2m_real_off)[n] = acc[0].x;
+            } else out[idx] = acc[0];
+          } else {
+#pragma unroll
+            for (int e = 0; e < (NT == 3 ? 3 : NT); ++e) out[(size_t)e * SM + idx] = acc[e];
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          pn[q] = -pn[q] * fact * s[q].sa;
+          rhom[q] *= s[q].rho;
+          const double nr = er[q] * s[q].cb - ei[q] * s[q].sb, ni = er[q] * s[q].sb + ei[q] * s[q].cb;
+          er[q] = nr; ei[q] = ni;
+        }
+        fact += 2;
+      }
+    }
+  }
+}
+
 #ifndef FMMBEM_P2M_INFLIGHT
 #define FMMBEM_P2M_INFLIGHT 4
 #endif
@@ -1020,8 +1123,14 @@ hipError_t launch_p2m_table(const DevicePlan& d, double2* tab, hipStream_t s) {
   if (hipError_t e = upload_constants_once(); e != hipSuccess) return e;
   if (d.n_p2m <= 0) return hipSuccess;
   const dim3 g(d.n_p2m < 256 * 32 ? d.n_p2m : 256 * 32), b(kWave);
-  if (d.kernel == 1) hipLaunchKernelGGL((p2m_table_kernel<4>), g, b, 0, s, d, tab);
-  else hipLaunchKernelGGL((p2m_table_kernel<1>), g, b, 0, s, d, tab);
+  // FMMBEM_P2M_TABLE_POINTS=0: the point-by-point kernel at every rule (A/B: the same records to <= 4e-16)
+  const bool pts = !(std::getenv("FMMBEM_P2M_TABLE_POINTS") && std::atoi(std::getenv("FMMBEM_P2M_TABLE_POINTS")) == 0);
+#define P2M_TABLE_CASE(NTV)                                                                             \
+  if (pts && d.nq == 1) hipLaunchKernelGGL((p2m_table_points_kernel<NTV, 1>), g, b, 0, s, d, tab);       \
+  else if (pts && d.nq == 3) hipLaunchKernelGGL((p2m_table_points_kernel<NTV, 3>), g, b, 0, s, d, tab);  \
+  else if (pts && d.nq == 4) hipLaunchKernelGGL((p2m_table_points_kernel<NTV, 4>), g, b, 0, s, d, tab);  \
+  else hipLaunchKernelGGL((p2m_table_kernel<NTV>), g, b, 0, s, d, tab)
+  if (d.kernel == 1) { P2M_TABLE_CASE(4); } else { P2M_TABLE_CASE(1); }
   return hipGetLastError();
 }
 
@@ -1029,7 +1138,9 @@ hipError_t launch_p2m_table_grad(const DevicePlan& d, double2* tab, hipStream_t 
   if (hipError_t e = upload_constants_once(); e != hipSuccess) return e;
   if (d.n_p2m <= 0) return hipSuccess;
   const dim3 g(d.n_p2m < 256 * 32 ? d.n_p2m : 256 * 32), b(kWave);
-  hipLaunchKernelGGL((p2m_table_kernel<3>), g, b, 0, s, d, tab);
+  const bool pts = !(std::getenv("FMMBEM_P2M_TABLE_POINTS") && std::atoi(std::getenv("FMMBEM_P2M_TABLE_POINTS")) == 0);
+  P2M_TABLE_CASE(3);
+#undef P2M_TABLE_CASE
   return hipGetLastError();
 }
 
