@@ -1189,6 +1189,10 @@ int fmmbem_plan::run(int p, const double* d_x, double* d_y, hipStream_t s, bool 
     if (!ge) { graphs.push_back(GraphEntry{region, p, buf, 0, nullptr}); ge = &graphs.back(); }
     if (++ge->runs == 1) return body(s);
     if (!ge->exec) {
+      // one capture at a time in the process: the shards of a device list are issued by threads of their own, and a capture on one
+      // thread made another thread's hipStreamWaitEvent fail ("dependency created on uncaptured work in another stream")
+      static std::mutex capture_mu;
+      std::lock_guard<std::mutex> capture_lock(capture_mu);
       HIP_TRY(hipStreamBeginCapture(own_stream, hipStreamCaptureModeThreadLocal));
       const int rc = body(own_stream);
       hipGraph_t g = nullptr;
@@ -1585,7 +1589,22 @@ static int multi_execute_device(fmmbem_plan* h, int p, const double* d_x, double
   if (m.split) TRY(multi_xch(h, p, &xc));
   HIP_TRY(hipSetDevice(m.dev[0]));
   HIP_TRY(hipEventRecord(m.ev_x, s0));
-  for (int r = 0; r < W; ++r) {                        // x to every device; the owners' upward pass
+  // Every device's share of a phase is ISSUED by a thread of its own (host_parallel): one thread took 0.43 ms to issue a matvec
+  // over eight devices -- as long as a shard's share of the work runs (FMMBEM_MULTI_ISSUE_THREADS=0: the one thread).  A phase's
+  // events are all recorded when its fan-out returns, which is what the next phase waits on.
+  const bool threads = W > 1 && !(std::getenv("FMMBEM_MULTI_ISSUE_THREADS") && std::atoi(std::getenv("FMMBEM_MULTI_ISSUE_THREADS")) == 0);
+  std::vector<int> rcs((size_t)W, FMMBEM_OK);
+  std::vector<std::string> errs((size_t)W);
+  auto fan_out = [&](auto&& body) -> int {
+    auto one = [&](int r) {
+      rcs[(size_t)r] = body(r);
+      if (rcs[(size_t)r] != FMMBEM_OK) errs[(size_t)r] = fmmbem_last_error();     // (the text is the issuing thread's own)
+    };
+    if (threads) host_parallel(W, one); else for (int r = 0; r < W; ++r) one(r);
+    for (int r = 0; r < W; ++r) if (rcs[(size_t)r] != FMMBEM_OK) return fail(rcs[(size_t)r], errs[(size_t)r]);
+    return FMMBEM_OK;
+  };
+  TRY(fan_out([&](int r) -> int {                      // x to every device; the owners' upward pass
     fmmbem_plan& sh = *m.shards[r];
     HIP_TRY(hipSetDevice(m.dev[r]));
     HIP_TRY(hipStreamWaitEvent(sh.own_stream, m.ev_x, 0));
@@ -1594,11 +1613,14 @@ static int multi_execute_device(fmmbem_plan* h, int p, const double* d_x, double
       TRY(sh.run(p, m.x[r], nullptr, sh.own_stream, false, 1, xc->send[r]));
       HIP_TRY(hipEventRecord(m.ev_up[r], sh.own_stream));
     }
-  }
-  for (int q = 0; q < W; ++q) {                        // the multipoles q's lists read, its downward pass and near field, its slice home
-    fmmbem_plan& sh = *m.shards[q];
-    HIP_TRY(hipSetDevice(m.dev[q]));
-    if (m.split) {
+    return FMMBEM_OK;
+  }));
+  // (the waits on the other shards' events in a fan-out of their own: a shard whose downward pass is being CAPTURED into a graph
+  // on one thread makes another thread's wait on an event of that stream fail -- "dependency created on uncaptured work")
+  if (m.split)
+    TRY(fan_out([&](int q) -> int {                    // the multipoles q's lists read
+      fmmbem_plan& sh = *m.shards[q];
+      HIP_TRY(hipSetDevice(m.dev[q]));
       int64_t roff = 0;
       for (int r = 0; r < W; ++r) {
         const int64_t cnt = xc->rc[q][r];
@@ -1610,14 +1632,18 @@ static int multi_execute_device(fmmbem_plan* h, int p, const double* d_x, double
         }
         roff += cnt;
       }
-      TRY(sh.run(p, nullptr, m.slice[q], sh.own_stream, false, 2, xc->recv[q]));
-    } else {
-      TRY(sh.run(p, m.x[q], m.slice[q], sh.own_stream, false));
-    }
+      return FMMBEM_OK;
+    }));
+  TRY(fan_out([&](int q) -> int {                      // q's downward pass and near field, its slice home
+    fmmbem_plan& sh = *m.shards[q];
+    HIP_TRY(hipSetDevice(m.dev[q]));
+    if (m.split) TRY(sh.run(p, nullptr, m.slice[q], sh.own_stream, false, 2, xc->recv[q]));
+    else TRY(sh.run(p, m.x[q], m.slice[q], sh.own_stream, false));
     const size_t rows = (size_t)(m.cut[q + 1] - m.cut[q]) * h->d.dof;
     if (rows) HIP_TRY(hipMemcpyPeerAsync(m.gathered + (size_t)q * m.chunk, m.dev[0], m.slice[q], m.dev[q], sizeof(double) * rows, sh.own_stream));
     HIP_TRY(hipEventRecord(m.ev_done[q], sh.own_stream));
-  }
+    return FMMBEM_OK;
+  }));
   HIP_TRY(hipSetDevice(m.dev[0]));
   for (int q = 0; q < W; ++q) HIP_TRY(hipStreamWaitEvent(s0, m.ev_done[q], 0));
   TRY(fmmbem_plan_assemble_slices_device(m.shards[0].get(), m.gathered, m.chunk, d_y, s0));
